@@ -1,0 +1,142 @@
+"""Model configuration records for the two hot-path model families.
+
+The reference keeps these numbers in un-vendored upstream config files
+(BigVGAN ``config.json`` read at /root/reference BigVGAN/Export_BigVGAN.py:53,
+F5 ``F5TTS_v1_Base.yaml`` read at F5_TTS/Export_F5.py:207, Vocos ``config.yaml``
+read at F5_TTS/Export_F5.py:389) and in module-level constants
+(F5_TTS/Export_F5.py:43-59).  Here they are explicit dataclasses; the C-ABI
+receives them as flat int arrays (see include/mi355tts.h).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field, asdict
+from typing import List, Tuple
+
+
+@dataclass
+class BigVGANConfig:
+    """BigVGAN-v2 generator hyper-parameters (bigvgan_v2_24khz_100band_256x defaults).
+
+    Mirrors the fields the reference generator reads from ``h``
+    (BigVGAN/modeling_modified/bigvgan.py:260-382).
+    """
+    num_mels: int = 100
+    upsample_initial_channel: int = 1536
+    upsample_rates: Tuple[int, ...] = (4, 4, 2, 2, 2, 2)
+    upsample_kernel_sizes: Tuple[int, ...] = (8, 8, 4, 4, 4, 4)
+    resblock_kernel_sizes: Tuple[int, ...] = (3, 7, 11)
+    resblock_dilation_sizes: Tuple[Tuple[int, ...], ...] = ((1, 3, 5), (1, 3, 5), (1, 3, 5))
+    use_bias_at_final: bool = False      # v2 checkpoints: conv_post has no bias
+    use_tanh_at_final: bool = True       # forced on by Export_BigVGAN.py:21,41
+    snake_logscale: bool = True
+    sampling_rate: int = 24000
+
+    @property
+    def num_upsamples(self) -> int:
+        return len(self.upsample_rates)
+
+    @property
+    def num_kernels(self) -> int:
+        return len(self.resblock_kernel_sizes)
+
+    @property
+    def hop(self) -> int:
+        h = 1
+        for u in self.upsample_rates:
+            h *= u
+        return h
+
+    def stage_channels(self, i: int) -> int:
+        return self.upsample_initial_channel // (2 ** (i + 1))
+
+    def out_len(self, frames: int) -> int:
+        # post activation pads 15 on each side of both FIRs => +30 samples
+        # (BigVGAN/modeling_modified/bigvgan.py:370,381-382)
+        return frames * self.hop + 30
+
+    def to_int_array(self) -> List[int]:
+        """Flat encoding consumed by mi_bigvgan_create (include/mi355tts.h)."""
+        out = [self.num_mels, self.upsample_initial_channel, self.num_upsamples, self.num_kernels,
+               int(self.use_bias_at_final), int(self.use_tanh_at_final), int(self.snake_logscale)]
+        out += list(self.upsample_rates)
+        out += list(self.upsample_kernel_sizes)
+        out += list(self.resblock_kernel_sizes)
+        nd = len(self.resblock_dilation_sizes[0])
+        out.append(nd)
+        for d in self.resblock_dilation_sizes:
+            assert len(d) == nd
+            out += list(d)
+        return out
+
+    @staticmethod
+    def small() -> "BigVGANConfig":
+        """Tiny 2-stage generator used by the golden fixtures."""
+        return BigVGANConfig(num_mels=16, upsample_initial_channel=32, upsample_rates=(4, 2),
+                             upsample_kernel_sizes=(8, 4), use_bias_at_final=True)
+
+
+@dataclass
+class F5Config:
+    """F5-TTS v1 Base (DiT) + Vocos-mel-24khz + STFT constants.
+
+    DiT arch numbers are *not* in the reference tree; they are
+    corroborated by F5_TTS/Optimize_ONNX.py:53-54 (heads 16, hidden 1024) and
+    F5_TTS/Export_F5.py:65 (text dim 512).
+    """
+    # DiT
+    dim: int = 1024
+    depth: int = 22
+    heads: int = 16
+    dim_head: int = 64
+    ff_mult: int = 2
+    mel_dim: int = 100
+    text_dim: int = 512
+    text_num_embeds: int = 2545          # vocab.txt lines; embedding has +1 rows
+    conv_layers: int = 4
+    conv_mult: int = 2
+    pos_conv_kernel: int = 31
+    pos_conv_groups: int = 16
+    freq_embed_dim: int = 256
+    # sampler (F5_TTS/Export_F5.py:43-59)
+    nfe_step: int = 32
+    cfg_strength: float = 2.0
+    sway_coef: float = -1.0
+    max_signal_length: int = 4096
+    # STFT / mel
+    n_fft: int = 1024
+    hop_length: int = 256
+    sample_rate: int = 24000
+    # Vocos
+    vocos_dim: int = 512
+    vocos_intermediate: int = 1536
+    vocos_layers: int = 8
+
+    @property
+    def ff_dim(self) -> int:
+        return self.dim * self.ff_mult
+
+    @property
+    def n_freq(self) -> int:
+        return self.n_fft // 2 + 1
+
+    def to_int_array(self) -> List[int]:
+        return [self.dim, self.depth, self.heads, self.dim_head, self.ff_mult, self.mel_dim, self.text_dim,
+                self.text_num_embeds, self.conv_layers, self.conv_mult, self.pos_conv_kernel,
+                self.pos_conv_groups, self.freq_embed_dim, self.nfe_step, self.max_signal_length,
+                self.n_fft, self.hop_length, self.sample_rate, self.vocos_dim, self.vocos_intermediate,
+                self.vocos_layers]
+
+    def to_float_array(self) -> List[float]:
+        return [self.cfg_strength, self.sway_coef]
+
+    @staticmethod
+    def small() -> "F5Config":
+        """Reduced-depth model for golden fixtures.  dim/heads stay 1024/16 because the
+        reference hard-wires ``.view(2, -1, heads, head_dim)`` shapes only through these."""
+        return F5Config(dim=128, depth=2, heads=2, dim_head=64, text_dim=64, text_num_embeds=40,
+                        conv_layers=2, pos_conv_groups=2, vocos_dim=64, vocos_intermediate=128,
+                        vocos_layers=2, nfe_step=6)
+
+
+def as_dict(cfg) -> dict:
+    return asdict(cfg)

@@ -1,0 +1,265 @@
+"""Weight specs, deterministic synthetic weights and the blob packer.
+
+There are no checkpoints in the reference tree and no network, so
+parity and benchmarks run on *synthetic seeded weights*.  Tensor names and shapes follow the
+upstream ``state_dict`` names after ``remove_weight_norm`` (BigVGAN/Export_BigVGAN.py:54) so
+the same dict loads into the reference modules (tests/golden/make_golden.py) and into this
+engine (``pack_bigvgan`` / ``pack_f5`` -> flat fp32 blob in the canonical order documented in
+include/mi355tts.h).
+
+The packer also applies the reference's export-time folds:
+  * q/k weight+bias * head_dim**-0.25          (F5_TTS/Export_F5.py:321-333)
+  * Vocos LayerNorm weight * sqrt(C)            (F5_TTS/Export_F5.py:390-398)
+  * Vocos layer-scale gamma folded into pwconv2 (F5_TTS/Export_F5.py:401-402)
+"""
+from __future__ import annotations
+
+import hashlib
+import math
+from collections import OrderedDict
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+from .config import BigVGANConfig, F5Config
+
+Spec = List[Tuple[str, Tuple[int, ...], str]]   # (name, shape, kind)
+
+
+# --------------------------------------------------------------------------------------
+# deterministic, platform-independent normal generator (counter-based: splitmix64 + Box-Muller)
+# --------------------------------------------------------------------------------------
+def _splitmix64(x: np.ndarray) -> np.ndarray:
+    x = (x + np.uint64(0x9E3779B97F4A7C15)) & np.uint64(0xFFFFFFFFFFFFFFFF)
+    z = x
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def synth_normal(seed: int, name: str, shape, std: float = 1.0, mean: float = 0.0) -> np.ndarray:
+    """N(mean, std^2) float32 tensor that depends only on (seed, name, shape)."""
+    n = int(np.prod(shape)) if len(shape) else 1
+    h = int.from_bytes(hashlib.sha256(f"{seed}:{name}".encode()).digest()[:8], "little")
+    with np.errstate(over="ignore"):
+        ctr = np.arange(n, dtype=np.uint64) * np.uint64(2) + np.uint64(h)
+        a = _splitmix64(ctr)
+        b = _splitmix64(ctr + np.uint64(1))
+    u1 = ((a >> np.uint64(11)).astype(np.float64) + 1.0) / 9007199254740993.0   # (0,1)
+    u2 = (b >> np.uint64(11)).astype(np.float64) / 9007199254740992.0           # [0,1)
+    z = np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * math.pi * u2)
+    return (mean + std * z).astype(np.float32).reshape(shape)
+
+
+# --------------------------------------------------------------------------------------
+# BigVGAN
+# --------------------------------------------------------------------------------------
+def bigvgan_spec(cfg: BigVGANConfig) -> Spec:
+    """Canonical tensor order == order of the fp32 blob given to mi_bigvgan_create.
+
+    Layouts are PyTorch-native: Conv1d (Cout, Cin, k); ConvTranspose1d (Cin, Cout, k).
+    """
+    s: Spec = []
+    c0 = cfg.upsample_initial_channel
+    s.append(("conv_pre.weight", (c0, cfg.num_mels, 7), "conv_pre"))
+    s.append(("conv_pre.bias", (c0,), "bias"))
+    for i, (u, k) in enumerate(zip(cfg.upsample_rates, cfg.upsample_kernel_sizes)):
+        cin, cout = c0 // (2 ** i), c0 // (2 ** (i + 1))
+        s.append((f"ups.{i}.0.weight", (cin, cout, k), "convt"))
+        s.append((f"ups.{i}.0.bias", (cout,), "bias"))
+        for j, (rk, dil) in enumerate(zip(cfg.resblock_kernel_sizes, cfg.resblock_dilation_sizes)):
+            n = i * cfg.num_kernels + j
+            for l in range(len(dil)):
+                s.append((f"resblocks.{n}.convs1.{l}.weight", (cout, cout, rk), "conv"))
+                s.append((f"resblocks.{n}.convs1.{l}.bias", (cout,), "bias"))
+                s.append((f"resblocks.{n}.convs2.{l}.weight", (cout, cout, rk), "conv_res"))
+                s.append((f"resblocks.{n}.convs2.{l}.bias", (cout,), "bias"))
+            for m in range(2 * len(dil)):
+                s.append((f"resblocks.{n}.activations.{m}.act.alpha", (cout,), "snake"))
+                s.append((f"resblocks.{n}.activations.{m}.act.beta", (cout,), "snake"))
+    cl = cfg.stage_channels(cfg.num_upsamples - 1)
+    s.append(("activation_post.act.alpha", (cl,), "snake"))
+    s.append(("activation_post.act.beta", (cl,), "snake"))
+    s.append(("conv_post.weight", (1, cl, 7), "conv_post"))
+    if cfg.use_bias_at_final:
+        s.append(("conv_post.bias", (1,), "bias"))
+    return s
+
+
+# gains keep activations O(1) through the stack and the pre-tanh signal well inside (-1, 1)
+_GAIN = {"conv": 1.0, "convt": 1.0, "linear": 1.0, "conv_pre": 0.35, "conv_res": 0.4, "conv_post": 0.3}
+
+
+def _fan_in(shape, kind: str) -> int:
+    if kind in ("conv", "conv_pre", "conv_res", "conv_post"):
+        return shape[1] * shape[2]
+    if kind == "convt":      # each output sample sees Cin * k/stride taps; k = 2*stride here
+        return shape[0] * 2
+    if kind in ("linear",):
+        return shape[1]
+    return 1
+
+
+def synth_tensor(seed: int, name: str, shape, kind: str) -> np.ndarray:
+    """Fan-in scaled init so activations stay O(1) through the stack (so the int16
+    output is neither silent nor saturated; see DESIGN.md 'synthetic weights')."""
+    if kind in _GAIN:
+        return synth_normal(seed, name, shape, std=_GAIN[kind] / math.sqrt(_fan_in(shape, kind)))
+    if kind == "bias":
+        return synth_normal(seed, name, shape, std=0.02)
+    if kind == "snake":
+        return synth_normal(seed, name, shape, std=0.3)
+    if kind == "embed":
+        return synth_normal(seed, name, shape, std=1.0)
+    if kind == "norm_w":
+        return synth_normal(seed, name, shape, std=0.1, mean=1.0)
+    if kind == "mod":        # AdaLN modulation linears (upstream zero-inits these: dit.py:156-166)
+        return synth_normal(seed, name, shape, std=0.5 / math.sqrt(shape[1]))
+    if kind == "gamma":      # layer-scale / GRN gamma
+        return synth_normal(seed, name, shape, std=0.1, mean=0.5)
+    raise ValueError(kind)
+
+
+def synth_state(spec: Spec, seed: int = 9527) -> "OrderedDict[str, np.ndarray]":
+    return OrderedDict((name, synth_tensor(seed, name, shape, kind)) for name, shape, kind in spec)
+
+
+def pack_state(spec: Spec, state: Dict[str, np.ndarray]) -> np.ndarray:
+    parts = []
+    for name, shape, _ in spec:
+        t = np.asarray(state[name], dtype=np.float32)
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError(f"{name}: shape {t.shape} != spec {shape}")
+        parts.append(t.reshape(-1))
+    return np.ascontiguousarray(np.concatenate(parts))
+
+
+def pack_bigvgan(cfg: BigVGANConfig, state: Dict[str, np.ndarray]) -> np.ndarray:
+    """state_dict (weight-norm already removed) -> canonical fp32 blob."""
+    return pack_state(bigvgan_spec(cfg), state)
+
+
+def remove_weight_norm_state(state: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    """weight_g / weight_v pairs -> plain weights (what ``remove_weight_norm`` does,
+    BigVGAN/modeling_modified/bigvgan.py:412-424; dim=0 norm over the remaining axes)."""
+    out = {}
+    for k, v in state.items():
+        if k.endswith(".weight_g"):
+            base = k[: -len("_g")]
+            vv = np.asarray(state[base + "_v"], dtype=np.float64)
+            g = np.asarray(v, dtype=np.float64)
+            nrm = np.sqrt((vv ** 2).sum(axis=tuple(range(1, vv.ndim)), keepdims=True))
+            out[base] = (vv * (g / nrm)).astype(np.float32)
+        elif k.endswith(".weight_v"):
+            continue
+        else:
+            out[k] = np.asarray(v)
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# F5 (DiT + text embedding + Vocos)
+# --------------------------------------------------------------------------------------
+def f5_spec(cfg: F5Config) -> Spec:
+    """Canonical order of the F5 blob (names = upstream f5_tts / vocos state_dict keys)."""
+    d, td, ff = cfg.dim, cfg.text_dim, cfg.ff_dim
+    s: Spec = []
+    # --- time embedding (F5_TTS/modeling_modified/F5/modules.py:687-698)
+    s += [("transformer.time_embed.time_mlp.0.weight", (d, cfg.freq_embed_dim), "linear"),
+          ("transformer.time_embed.time_mlp.0.bias", (d,), "bias"),
+          ("transformer.time_embed.time_mlp.2.weight", (d, d), "linear"),
+          ("transformer.time_embed.time_mlp.2.bias", (d,), "bias")]
+    # --- text embedding (dit.py:33-73)
+    s.append(("transformer.text_embed.text_embed.weight", (cfg.text_num_embeds + 1, td), "embed"))
+    for l in range(cfg.conv_layers):
+        p = f"transformer.text_embed.text_blocks.{l}."
+        s += [(p + "dwconv.weight", (td, 1, 7), "conv"), (p + "dwconv.bias", (td,), "bias"),
+              (p + "norm.weight", (td,), "norm_w"), (p + "norm.bias", (td,), "bias"),
+              (p + "pwconv1.weight", (td * cfg.conv_mult, td), "linear"),
+              (p + "pwconv1.bias", (td * cfg.conv_mult,), "bias"),
+              (p + "grn.gamma", (1, 1, td * cfg.conv_mult), "gamma"),
+              (p + "grn.beta", (1, 1, td * cfg.conv_mult), "bias"),
+              (p + "pwconv2.weight", (td, td * cfg.conv_mult), "linear"),
+              (p + "pwconv2.bias", (td,), "bias")]
+    # --- input embedding (dit.py:79-87, modules.py:167-190)
+    cin = cfg.mel_dim * 2 + td
+    g = cfg.pos_conv_groups
+    s += [("transformer.input_embed.proj.weight", (d, cin), "linear"),
+          ("transformer.input_embed.proj.bias", (d,), "bias"),
+          ("transformer.input_embed.conv_pos_embed.conv1d.0.weight", (d, d // g, cfg.pos_conv_kernel), "conv"),
+          ("transformer.input_embed.conv_pos_embed.conv1d.0.bias", (d,), "bias"),
+          ("transformer.input_embed.conv_pos_embed.conv1d.2.weight", (d, d // g, cfg.pos_conv_kernel), "conv"),
+          ("transformer.input_embed.conv_pos_embed.conv1d.2.bias", (d,), "bias")]
+    # --- DiT blocks (modules.py:575-613)
+    for i in range(cfg.depth):
+        p = f"transformer.transformer_blocks.{i}."
+        s += [(p + "attn_norm.linear.weight", (6 * d, d), "mod"), (p + "attn_norm.linear.bias", (6 * d,), "bias"),
+              (p + "attn.to_q.weight", (d, d), "linear"), (p + "attn.to_q.bias", (d,), "bias"),
+              (p + "attn.to_k.weight", (d, d), "linear"), (p + "attn.to_k.bias", (d,), "bias"),
+              (p + "attn.to_v.weight", (d, d), "linear"), (p + "attn.to_v.bias", (d,), "bias"),
+              (p + "attn.to_out.0.weight", (d, d), "linear"), (p + "attn.to_out.0.bias", (d,), "bias"),
+              (p + "ff.ff.0.0.weight", (ff, d), "linear"), (p + "ff.ff.0.0.bias", (ff,), "bias"),
+              (p + "ff.ff.2.weight", (d, ff), "linear"), (p + "ff.ff.2.bias", (d,), "bias")]
+    s += [("transformer.norm_out.linear.weight", (2 * d, d), "mod"),
+          ("transformer.norm_out.linear.bias", (2 * d,), "bias"),
+          ("transformer.proj_out.weight", (cfg.mel_dim, d), "linear"),
+          ("transformer.proj_out.bias", (cfg.mel_dim,), "bias")]
+    # --- Vocos (vocos/models.py:44-83, modules.py:20-51, heads.py:39-59)
+    vd, vi = cfg.vocos_dim, cfg.vocos_intermediate
+    s += [("vocos.backbone.embed.weight", (vd, cfg.mel_dim, 7), "conv"), ("vocos.backbone.embed.bias", (vd,), "bias"),
+          ("vocos.backbone.norm.weight", (vd,), "norm_w"), ("vocos.backbone.norm.bias", (vd,), "bias")]
+    for l in range(cfg.vocos_layers):
+        p = f"vocos.backbone.convnext.{l}."
+        s += [(p + "dwconv.weight", (vd, 1, 7), "conv"), (p + "dwconv.bias", (vd,), "bias"),
+              (p + "norm.weight", (vd,), "norm_w"), (p + "norm.bias", (vd,), "bias"),
+              (p + "pwconv1.weight", (vi, vd), "linear"), (p + "pwconv1.bias", (vi,), "bias"),
+              (p + "pwconv2.weight", (vd, vi), "linear"), (p + "pwconv2.bias", (vd,), "bias"),
+              (p + "gamma", (vd,), "gamma")]
+    s += [("vocos.backbone.final_layer_norm.weight", (vd,), "norm_w"),
+          ("vocos.backbone.final_layer_norm.bias", (vd,), "bias"),
+          ("vocos.head.out.weight", (cfg.n_fft + 2, vd), "linear"),
+          ("vocos.head.out.bias", (cfg.n_fft + 2,), "bias")]
+    return s
+
+
+def f5_packed_spec(cfg: F5Config) -> Spec:
+    """Blob order after folding: vocos gammas are folded away."""
+    return [e for e in f5_spec(cfg) if not (e[0].startswith("vocos.") and e[0].endswith(".gamma"))]
+
+
+def fold_f5(cfg: F5Config, state: Dict[str, np.ndarray]) -> "OrderedDict[str, np.ndarray]":
+    """Apply the export-time folds (see module docstring) and return a new dict whose
+    keys are those of ``f5_packed_spec``."""
+    st = OrderedDict((k, np.array(v, dtype=np.float32, copy=True)) for k, v in state.items())
+    sf = np.float32(math.pow(cfg.dim_head, -0.25))
+    for i in range(cfg.depth):
+        p = f"transformer.transformer_blocks.{i}.attn."
+        for nm in ("to_q", "to_k"):
+            st[p + nm + ".weight"] = st[p + nm + ".weight"] * sf
+            st[p + nm + ".bias"] = st[p + nm + ".bias"] * sf
+    rt = np.float32(math.sqrt(cfg.vocos_dim))
+    st["vocos.backbone.norm.weight"] = st["vocos.backbone.norm.weight"] * rt
+    st["vocos.backbone.final_layer_norm.weight"] = st["vocos.backbone.final_layer_norm.weight"] * rt
+    for l in range(cfg.vocos_layers):
+        p = f"vocos.backbone.convnext.{l}."
+        st[p + "norm.weight"] = st[p + "norm.weight"] * rt
+        gamma = st.pop(p + "gamma")
+        st[p + "pwconv2.weight"] = gamma[:, None] * st[p + "pwconv2.weight"]
+        st[p + "pwconv2.bias"] = gamma * st[p + "pwconv2.bias"]
+    return st
+
+
+def pack_f5(cfg: F5Config, state: Dict[str, np.ndarray]) -> np.ndarray:
+    """Unfolded upstream-style state dict -> folded canonical fp32 blob."""
+    return pack_state(f5_packed_spec(cfg), fold_f5(cfg, state))
+
+
+def synth_vocab(n: int = 2545) -> Dict[str, int]:
+    """Synthetic vocab.txt stand-in: line i holds one character (F5-TTS-ONNX-Inference.py:88-92
+    maps ``char[:-1] -> line index``).  Index 0 is the space, like upstream's vocab."""
+    chars = [" "] + [chr(c) for c in range(33, 127)]
+    i = 0x4E00
+    while len(chars) < n:
+        chars.append(chr(i))
+        i += 1
+    return {c: k for k, c in enumerate(chars[:n])}
