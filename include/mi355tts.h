@@ -1,0 +1,91 @@
+/*
+ * mi355tts.h — C-ABI of libmi355tts.so, the MI355X (gfx950) engine that stands in for the
+ * reference's onnxruntime.InferenceSession.run() hot path.
+ *
+ * Each entry point names the reference interface it replaces (paths relative to the
+ * reference repo DakeQQ/Text-to-Speech-TTS-ONNX):
+ *
+ *   mi_bigvgan_forward      ort_session_A.run_with_ort_values([generated_wav], {mel_features})
+ *                           BigVGAN/Export_BigVGAN.py:170   (graph = BIGVGAN.forward, :44-49)
+ *   mi_f5_preprocess        ort_session_A.run(...)   F5_TTS/F5-TTS-ONNX-Inference.py:247-253
+ *                           (graph = F5Preprocess.forward, F5_TTS/Export_F5.py:117-141)
+ *   mi_f5_transformer_step  ort_session_B.run(...)   F5_TTS/F5-TTS-ONNX-Inference.py:292-303
+ *                           (graph = F5Transformer.forward, F5_TTS/Export_F5.py:167-182)
+ *   mi_f5_sample            the whole `for i in range(0, NFE_STEP - 1, FUSE_NFE)` loop, :291-304,
+ *                           kept on device (no per-step host round trip)
+ *   mi_f5_decode            ort_session_C.run(...)   F5_TTS/F5-TTS-ONNX-Inference.py:306-311
+ *                           (graph = F5Decode.forward, F5_TTS/Export_F5.py:193-203)
+ *
+ * Conventions
+ *   - plain pointers + sizes, no C++/torch types; tensors are row-major contiguous with exactly
+ *     the ONNX graph layouts.
+ *   - `mem` says where caller buffers live: MI_HOST (copied by the engine) or MI_DEVICE (HIP
+ *     device pointers on the handle's device, e.g. torch tensor.data_ptr()).
+ *   - every function returns 0 on success, a negative MI_E* code on failure; mi_last_error()
+ *     gives the message (thread-local).  Constructors return NULL on failure.
+ *   - a handle owns its weights, workspace and one HIP stream; calls on one handle are
+ *     serialised; different handles may be used concurrently from different threads.
+ *   - weights are one flat fp32 blob in the canonical tensor order of
+ *     mi355tts/weights.py (bigvgan_spec / f5_packed_spec), PyTorch-native layouts, with the
+ *     reference's export-time folds already applied by the packer.
+ */
+#ifndef MI355TTS_H
+#define MI355TTS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { MI_F32 = 0, MI_F16 = 1, MI_BF16 = 2 };          /* activation / matmul-operand dtype   */
+enum { MI_HOST = 0, MI_DEVICE = 1 };                    /* where caller buffers live           */
+enum { MI_OK = 0, MI_EINVAL = -1, MI_EHIP = -2, MI_ENOMEM = -3, MI_ESTATE = -4 };
+
+typedef struct mi_bigvgan mi_bigvgan;
+typedef struct mi_f5 mi_f5;
+
+/* ---- process-level ------------------------------------------------------------------------ */
+int         mi_init(int device);            /* hipSetDevice + context warm-up                  */
+int         mi_device_count(void);
+const char* mi_last_error(void);
+const char* mi_version(void);
+
+/* ---- BigVGAN-v2 vocoder ---------------------------------------------------------------------
+ * cfg: int32 array = BigVGANConfig.to_int_array():
+ *   [num_mels, initial_channel, n_up, n_kernels, bias_at_final, tanh_at_final, snake_logscale,
+ *    rates[n_up], up_kernels[n_up], res_kernels[n_kernels], n_dil, dil[n_kernels][n_dil]]      */
+int64_t     mi_bigvgan_param_count(const int32_t* cfg, int n_cfg);
+mi_bigvgan* mi_bigvgan_create(const int32_t* cfg, int n_cfg, const float* weights, int64_t n_weights,
+                              int dtype, int device);
+void        mi_bigvgan_destroy(mi_bigvgan* h);
+int64_t     mi_bigvgan_out_len(const mi_bigvgan* h, int frames);      /* frames*hop + 30 */
+/* mel: (B, num_mels, frames) fp32 channels-first (the ONNX `mel_features` layout; B>1 is this
+ * engine's extension).  out: (B, 1, out_len) int16 = trunc(clamp(32767*tanh(.)))               */
+int         mi_bigvgan_forward(mi_bigvgan* h, const float* mel, int B, int frames, int16_t* out, int mem);
+/* same, but the float waveform before the int16 conversion (tests)                            */
+int         mi_bigvgan_forward_f32(mi_bigvgan* h, const float* mel, int B, int frames, float* out, int mem);
+/* unit-level entry (tests): one anti-aliased SnakeBeta Activation1d on x (B,C,T) fp32
+ * channels-first host memory; post!=0 selects the pad-15 variant (out T+30).                   */
+int         mi_aa_activation1d(const float* x, int B, int C, int T, const float* alpha_log,
+                               const float* beta_log, int logscale, int post, int dtype, float* y);
+/* unit-level entry (tests): Conv1d / ConvTranspose1d on fp32 channels-first host tensors,
+ * executed by the implicit-GEMM MFMA kernel in `dtype`.                                       */
+int         mi_conv1d(const float* x, int B, int Cin, int T, const float* w, const float* bias, int Cout,
+                      int k, int dilation, int padding, int groups, int dtype, float* y);
+int         mi_conv_transpose1d(const float* x, int B, int Cin, int T, const float* w, const float* bias,
+                                int Cout, int k, int stride, int padding, int dtype, float* y);
+
+/* ---- profiling hooks (bench.py roofline leg) -------------------------------------------------
+ * family_mask: bit i enables family i (0 = off, -1 = all).  Every launch of an enabled kernel
+ * family is bracketed by HIP events on the handle's own stream; mi_prof_get returns accumulated
+ * milliseconds, launches and algorithmic bytes / flops since the last reset.
+ * Families (bit): "conv_gemm"(0) "aa_act"(1) "conv_post"(2) "attn"(3) "norm"(4) "other"(5).    */
+int         mi_prof_enable(int family_mask);
+int         mi_prof_reset(void);
+int         mi_prof_get(const char* family, double* ms, int64_t* launches, double* bytes, double* flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355TTS_H */

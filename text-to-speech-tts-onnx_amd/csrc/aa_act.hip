@@ -1,0 +1,196 @@
+// aa_act.hip — fused anti-aliased SnakeBeta activation (one reference Activation1d) for gfx950.
+//
+// Reference: Activation1d.forward (BigVGAN/modeling_modified/act.py:25-29) =
+//   UpSample1d (resample.py:30-34: zero-pad 5, depthwise conv_transpose stride 2 with the 12-tap
+//   kaiser-sinc filter, x2, crop 15/15) -> SnakeBeta -> DownSample1d (filter.py:94-98: zero-pad 5/6,
+//   depthwise 12-tap conv stride 2).  The pad-15 "post" variant (bigvgan.py:370,381-382) returns
+//   T+30 samples.
+//
+// Polyphase form used here (derivation in DESIGN.md §K-AA), centred index i' / output m':
+//   U[2a]   = 2 * sum_e h[2e+1] * x[a+2-e]        U[2a+1] = 2 * sum_e h[2e] * x[a+3-e]   (e = 0..5)
+//   S[i']   = U + inv_beta_c * sin^2(alpha_c * U)   for -ext <= i' < 2T+ext, else 0
+//   y[m']   = sum_t h[t] * S[2m' - 5 + t]           for -shift <= m' < T+shift
+// with (shift, ext) = (0, 0) in the residual blocks and (15, 20) for activation_post.
+// x is zero outside [0, T).  Everything is computed in fp32 whatever the storage type.
+//
+// Memory plan: HBM-bound.  A workgroup stages a (TT+10) x CT tile of channels-last activations into
+// LDS with 16-byte coalesced loads (the tile is one contiguous HBM span when CT == C), each thread
+// then slides an R-long run down the time axis in registers (18 inputs -> 8 outputs), and the
+// result goes back through LDS so the HBM store is again 16-byte coalesced.
+#include "common.h"
+
+namespace mi {
+
+static float g_taps[12];
+static bool g_taps_init = false;
+__constant__ float c_h[12];
+
+static double bessel_i0(double x) {
+    double sum = 1.0, term = 1.0;
+    for (int k = 1; k < 64; ++k) {
+        term *= (x / (2.0 * k)) * (x / (2.0 * k));
+        sum += term;
+        if (term < 1e-18 * sum) break;
+    }
+    return sum;
+}
+
+// kaiser_sinc_filter1d(cutoff 0.25, half_width 0.3, kernel 12) — filter.py:30-62
+const float* aa_filter_host() {
+    if (!g_taps_init) {
+        const int K = 12, half = 6;
+        const double cutoff = 0.25, half_width = 0.3;
+        const double delta_f = 4 * half_width;
+        const double A = 2.285 * (half - 1) * M_PI * delta_f + 7.95;
+        double beta;
+        if (A > 50.0) beta = 0.1102 * (A - 8.7);
+        else if (A >= 21.0) beta = 0.5842 * std::pow(A - 21.0, 0.4) + 0.07886 * (A - 21.0);
+        else beta = 0.0;
+        double f[12], sum = 0.0;
+        for (int n = 0; n < K; ++n) {
+            const double r = (n - (K - 1) / 2.0) / ((K - 1) / 2.0);
+            const double win = bessel_i0(beta * std::sqrt(std::max(0.0, 1.0 - r * r))) / bessel_i0(beta);
+            const double t = (n - half) + 0.5;
+            const double a = 2 * cutoff * t;
+            const double sinc = a == 0.0 ? 1.0 : std::sin(M_PI * a) / (M_PI * a);
+            f[n] = 2 * cutoff * win * sinc;
+            sum += f[n];
+        }
+        for (int n = 0; n < K; ++n) g_taps[n] = (float)(f[n] / sum);
+        g_taps_init = true;
+    }
+    return g_taps;
+}
+
+template <typename T, int R>
+__global__ __launch_bounds__(256) void aa_act_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                     const float* __restrict__ alpha,
+                                                     const float* __restrict__ inv_beta, int Tlen, int C, int CT,
+                                                     int TT, int shift, int ext) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* xs = lds;                          // (TT+10) x CT fp32
+    T* ys = reinterpret_cast<T*>(lds + (TT + 10) * CT);   // TT x CT
+
+    const int tid = threadIdx.x;
+    const int o0 = blockIdx.x * TT;           // first output row of the tile
+    const int c0 = blockIdx.y * CT;
+    const int b = blockIdx.z;
+    const int Tout = Tlen + 2 * shift;
+    const int mp0 = o0 - shift;               // centred index m' of the first output row
+    const T* xb = x + (long)b * Tlen * C;
+    T* yb = y + (long)b * Tout * C;
+
+    // ---- stage x rows [mp0-5, mp0+TT+5) ------------------------------------------------------
+    const int cvn = CT / VEC;
+    const int nvec = (TT + 10) * cvn;
+    for (int v = tid; v < nvec; v += 256) {
+        const int row = v / cvn, cv = v - row * cvn;
+        const int t = mp0 - 5 + row;
+        float f[VEC];
+        if (t >= 0 && t < Tlen) {
+            const uint4 raw = *reinterpret_cast<const uint4*>(xb + (long)t * C + c0 + cv * VEC);
+            const T* e = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) f[k] = to_f32(e[k]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) f[k] = 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) xs[row * CT + cv * VEC + k] = f[k];
+    }
+    __syncthreads();
+
+    // ---- sliding-window compute ---------------------------------------------------------------
+    const int nitems = CT * (TT / R);
+    for (int it = tid; it < nitems; it += 256) {
+        const int run = it / CT, c = it - run * CT;
+        const int ml = run * R;               // local output row
+        const float al = alpha[c0 + c], ib = inv_beta[c0 + c];
+        float xv[R + 10];
+#pragma unroll
+        for (int j = 0; j < R + 10; ++j) xv[j] = xs[(ml + j) * CT + c];
+        float acc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = 0.f;
+        const int mp = mp0 + ml;              // centred m' of acc[0]
+#pragma unroll
+        for (int e = 0; e < R + 5; ++e) {
+            float ue = 0.f, uo = 0.f;
+#pragma unroll
+            for (int ee = 0; ee < 6; ++ee) {
+                ue = fmaf(c_h[2 * ee + 1], xv[e + 5 - ee], ue);
+                uo = fmaf(c_h[2 * ee], xv[e + 5 - ee], uo);
+            }
+            ue *= 2.f; uo *= 2.f;
+            const int ie = 2 * (mp + e - 2);          // i' of the even sample
+            const int io = 2 * (mp + e - 3) + 1;      // i' of the odd sample
+            float se = sinf(al * ue), so = sinf(al * uo);
+            se = ue + ib * (se * se);
+            so = uo + ib * (so * so);
+            if (ie < -ext || ie >= 2 * Tlen + ext) se = 0.f;
+            if (io < -ext || io >= 2 * Tlen + ext) so = 0.f;
+#pragma unroll
+            for (int tt = 0; tt < 6; ++tt) {
+                const int r = e - tt;
+                if (r >= 0 && r < R) acc[r] = fmaf(c_h[2 * tt], so, fmaf(c_h[2 * tt + 1], se, acc[r]));
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) ys[(ml + r) * CT + c] = from_f32<T>(acc[r]);
+    }
+    __syncthreads();
+
+    // ---- coalesced store ----------------------------------------------------------------------
+    const int nout = TT * cvn;
+    for (int v = tid; v < nout; v += 256) {
+        const int row = v / cvn, cv = v - row * cvn;
+        const int o = o0 + row;
+        if (o < Tout)
+            *reinterpret_cast<uint4*>(yb + (long)o * C + c0 + cv * VEC) =
+                *reinterpret_cast<const uint4*>(ys + row * CT + cv * VEC);
+    }
+}
+
+template <typename T>
+static void launch_t(const AAAct& p, hipStream_t s) {
+    constexpr int R = 8;
+    constexpr int VEC = 16 / (int)sizeof(T);
+    MI_REQUIRE(p.C % VEC == 0, "aa_act: C must be a multiple of the 16-byte vector");
+    int CT = p.C;
+    if (p.C > 96) {
+        CT = 0;
+        for (int cand : {64, 48, 32, 24, 16, 8})
+            if (p.C % cand == 0 && cand % VEC == 0) { CT = cand; break; }
+        MI_REQUIRE(CT > 0, "aa_act: unsupported channel count");
+    }
+    int TT = (4096 / CT) / R * R;
+    if (TT < R) TT = R;
+    if (TT > 512) TT = 512;
+    const int shift = p.post ? 15 : 0, ext = p.post ? 20 : 0;
+    const int Tout = p.T + 2 * shift;
+    dim3 grid((Tout + TT - 1) / TT, p.C / CT, p.B);
+    const size_t lds = (size_t)(TT + 10) * CT * 4 + (size_t)TT * CT * sizeof(T);
+    const double bytes = (double)p.B * p.C * ((double)p.T + Tout) * sizeof(T);
+    const double flops = (double)p.B * p.C * Tout * 60.0;
+    ProfScope ps(FAM_AA, s, bytes, flops);
+    hipLaunchKernelGGL((aa_act_kernel<T, R>), grid, dim3(256), lds, s, (const T*)p.x, (T*)p.y, p.alpha, p.inv_beta,
+                       p.T, p.C, CT, TT, shift, ext);
+    MI_HIP(hipGetLastError());
+}
+
+void launch_aa_act(const AAAct& p, hipStream_t s) {
+    static bool uploaded[64] = {false};
+    int dev = 0;
+    MI_HIP(hipGetDevice(&dev));
+    if (!uploaded[dev & 63]) {
+        MI_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_h), aa_filter_host(), sizeof(float) * 12));
+        uploaded[dev & 63] = true;
+    }
+    if (p.dtype == MI_F32) launch_t<float>(p, s);
+    else if (p.dtype == MI_F16) launch_t<f16>(p, s);
+    else launch_t<bf16>(p, s);
+}
+
+}  // namespace mi

@@ -1,0 +1,58 @@
+// bigvgan.h — BigVGAN-v2 engine object (see bigvgan.hip).
+#pragma once
+#include "common.h"
+
+namespace mi {
+
+struct BigVGANCfg {
+    int num_mels = 0, c0 = 0, n_up = 0, n_kernels = 0, bias_final = 0, tanh_final = 1, logscale = 1, n_dil = 0;
+    int hop = 1;
+    std::vector<int> rates, up_k, res_k;
+    std::vector<std::vector<int>> dil;
+};
+BigVGANCfg parse_bigvgan_cfg(const int32_t* c, int n);
+int64_t bigvgan_param_count(const BigVGANCfg& g);
+
+struct ConvW { DevBuf w, b; };
+struct SnakeP { DevBuf alpha, inv_beta; };
+struct AmpBlock { int k = 3; std::vector<ConvW> c1, c2; std::vector<SnakeP> acts; };
+struct Stage { int cin = 0, cout = 0, u = 1; ConvW up; std::vector<AmpBlock> blocks; };
+
+struct BigVGAN {
+    BigVGANCfg cfg;
+    int dtype, device;
+    hipStream_t stream = nullptr;
+    int mel_pad = 0;
+    ConvW pre;
+    std::vector<Stage> stages;
+    SnakeP post_act;
+    DevBuf post_w;
+    float post_bias = 0.f;
+    // workspace
+    int ws_B = 0, ws_F = 0;
+    DevBuf bIN, bX, bT1, bT2, bP, bQ, d_mel, d_out_f32, d_out_i16;
+
+    BigVGAN(const BigVGANCfg& g, const float* w, int64_t nw, int dt, int dev);
+    ~BigVGAN();
+    void ensure_workspace(int B, int F);
+    void conv(const ConvW& cw, const void* x, void* out, int B, int T, int Cin, int Cout, int k, int dil,
+              const void* res, float alpha, int accumulate);
+    void aa(const SnakeP& sp, const void* x, void* y, int B, int T, int C, int post);
+    void run(const float* mel, int B, int F, float* out_f32, int16_t* out_i16, int mem);
+};
+
+void unit_aa_activation1d(const float* x, int B, int C, int T, const float* alpha_log, const float* beta_log,
+                          int logscale, int post, int dtype, float* y);
+void unit_conv1d(const float* x, int B, int Cin, int T, const float* w, const float* bias, int Cout, int k, int dil,
+                 int padding, int groups, int dtype, float* y);
+void unit_conv_transpose1d(const float* x, int B, int Cin, int T, const float* w, const float* bias, int Cout, int k,
+                           int stride, int padding, int dtype, float* y);
+
+// runtime.hip
+const std::string& last_error();
+void prof_enable(unsigned mask);
+void prof_reset();
+int prof_family(const char* name);
+void prof_get(int fam, double* ms, int64_t* launches, double* bytes, double* flops);
+
+}  // namespace mi

@@ -1,0 +1,336 @@
+// bigvgan.hip — BigVGAN-v2 generator on gfx950: weight re-layout + the forward launch sequence.
+//
+// Reference: BigVGAN.forward (BigVGAN/modeling_modified/bigvgan.py:384-410), AMPBlock1.forward
+// (:132-140), BIGVGAN.forward int16 tail (BigVGAN/Export_BigVGAN.py:44-49).
+//
+// HBM plan (channels-last activations, dtype = engine dtype):
+//   IN/XS ping-pong : stage input / stage output (mean of the 3 AMP blocks)
+//   X               : ConvTranspose1d output = input of all three AMP blocks of the stage
+//   T1, T2          : AA-activation / conv1 temporaries
+//   P, Q            : running residual stream of the current AMP block
+// all sized for the largest stage (B * 1536*F*2 elements) and reused; nothing is re-allocated
+// between calls with the same (B, frames).
+#include "common.h"
+#include "bigvgan.h"
+
+namespace mi {
+
+static int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+BigVGANCfg parse_bigvgan_cfg(const int32_t* c, int n) {
+    MI_REQUIRE(c && n >= 7, "bigvgan cfg too short");
+    BigVGANCfg g;
+    int i = 0;
+    g.num_mels = c[i++]; g.c0 = c[i++]; g.n_up = c[i++]; g.n_kernels = c[i++];
+    g.bias_final = c[i++]; g.tanh_final = c[i++]; g.logscale = c[i++];
+    MI_REQUIRE(g.n_up > 0 && g.n_up <= 8 && g.n_kernels > 0 && g.n_kernels <= 4, "bigvgan cfg: bad counts");
+    MI_REQUIRE(n >= 7 + 2 * g.n_up + g.n_kernels + 1, "bigvgan cfg too short");
+    for (int k = 0; k < g.n_up; ++k) g.rates.push_back(c[i++]);
+    for (int k = 0; k < g.n_up; ++k) g.up_k.push_back(c[i++]);
+    for (int k = 0; k < g.n_kernels; ++k) g.res_k.push_back(c[i++]);
+    g.n_dil = c[i++];
+    MI_REQUIRE(g.n_dil > 0 && g.n_dil <= 4 && n == i + g.n_kernels * g.n_dil, "bigvgan cfg: dilation table");
+    for (int k = 0; k < g.n_kernels; ++k) {
+        std::vector<int> d;
+        for (int l = 0; l < g.n_dil; ++l) d.push_back(c[i++]);
+        g.dil.push_back(d);
+    }
+    g.hop = 1;
+    for (int k = 0; k < g.n_up; ++k) {
+        MI_REQUIRE(g.up_k[k] == 2 * g.rates[k] && g.rates[k] % 2 == 0,
+                   "bigvgan: ConvTranspose1d needs kernel == 2*stride and an even stride");
+        g.hop *= g.rates[k];
+    }
+    MI_REQUIRE(g.c0 % (1 << g.n_up) == 0, "bigvgan: initial channel not divisible");
+    return g;
+}
+
+int64_t bigvgan_param_count(const BigVGANCfg& g) {
+    int64_t n = (int64_t)g.c0 * g.num_mels * 7 + g.c0;
+    for (int i = 0; i < g.n_up; ++i) {
+        const int64_t cin = g.c0 >> i, cout = g.c0 >> (i + 1);
+        n += cin * cout * g.up_k[i] + cout;
+        for (int j = 0; j < g.n_kernels; ++j)
+            n += (int64_t)g.n_dil * 2 * (cout * cout * g.res_k[j] + cout) + (int64_t)2 * g.n_dil * 2 * cout;
+    }
+    const int64_t cl = g.c0 >> g.n_up;
+    n += 2 * cl + cl * 7 + (g.bias_final ? 1 : 0);
+    return n;
+}
+
+// Conv1d weight (Co,Ci,k) fp32 -> [co][tap][ci_pad]
+static void relayout_conv(const float* w, int Co, int Ci, int k, int Cip, std::vector<float>& out) {
+    out.assign((size_t)Co * k * Cip, 0.f);
+    for (int co = 0; co < Co; ++co)
+        for (int ci = 0; ci < Ci; ++ci)
+            for (int j = 0; j < k; ++j) out[((size_t)co * k + j) * Cip + ci] = w[((size_t)co * Ci + ci) * k + j];
+}
+// ConvTranspose1d weight (Ci,Co,k=2u) -> [n = r*Co + co][tap][ci]; tap0 <-> x[q-1] uses j = r+u, tap1 <-> x[q] uses j = r
+static void relayout_convt(const float* w, int Ci, int Co, int u, std::vector<float>& out) {
+    const int k = 2 * u;
+    out.assign((size_t)u * Co * 2 * Ci, 0.f);
+    for (int r = 0; r < u; ++r)
+        for (int co = 0; co < Co; ++co)
+            for (int ci = 0; ci < Ci; ++ci) {
+                const size_t n = (size_t)r * Co + co;
+                out[(n * 2 + 0) * Ci + ci] = w[((size_t)ci * Co + co) * k + r + u];
+                out[(n * 2 + 1) * Ci + ci] = w[((size_t)ci * Co + co) * k + r];
+            }
+}
+
+static void make_snake(const float* a, const float* b, int C, bool logscale, DevBuf& d_alpha, DevBuf& d_ib, hipStream_t s) {
+    std::vector<float> al(C), ib(C);
+    for (int c = 0; c < C; ++c) {
+        const float av = logscale ? expf(a[c]) : a[c];
+        const float bv = logscale ? expf(b[c]) : b[c];
+        al[c] = av;
+        ib[c] = 1.0f / (bv + 1e-9f);
+    }
+    upload_f32(d_alpha, al.data(), C, s);
+    upload_f32(d_ib, ib.data(), C, s);
+}
+
+BigVGAN::BigVGAN(const BigVGANCfg& g, const float* w, int64_t nw, int dt, int dev) : cfg(g), dtype(dt), device(dev) {
+    MI_REQUIRE(dt == MI_F32 || dt == MI_F16 || dt == MI_BF16, "bigvgan: bad dtype");
+    MI_REQUIRE(nw == bigvgan_param_count(g), "bigvgan: weight blob size does not match the config");
+    MI_HIP(hipSetDevice(dev));
+    MI_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    const int vec = 16 / (int)dtype_size(dt);
+    MI_REQUIRE((g.c0 >> g.n_up) % vec == 0, "bigvgan: last-stage channels must be a multiple of the 16-byte vector");
+    mel_pad = round_up(g.num_mels, vec);
+    std::vector<float> tmp;
+    const float* p = w;
+    relayout_conv(p, g.c0, g.num_mels, 7, mel_pad, tmp);
+    upload_as(pre.w, tmp.data(), tmp.size(), dt, stream);
+    p += (size_t)g.c0 * g.num_mels * 7;
+    upload_f32(pre.b, p, g.c0, stream);
+    p += g.c0;
+    stages.resize(g.n_up);
+    for (int i = 0; i < g.n_up; ++i) {
+        Stage& st = stages[i];
+        st.cin = g.c0 >> i; st.cout = g.c0 >> (i + 1); st.u = g.rates[i];
+        relayout_convt(p, st.cin, st.cout, st.u, tmp);
+        upload_as(st.up.w, tmp.data(), tmp.size(), dt, stream);
+        p += (size_t)st.cin * st.cout * g.up_k[i];
+        upload_f32(st.up.b, p, st.cout, stream);
+        p += st.cout;
+        st.blocks.resize(g.n_kernels);
+        for (int j = 0; j < g.n_kernels; ++j) {
+            AmpBlock& bk = st.blocks[j];
+            bk.k = g.res_k[j];
+            bk.c1.resize(g.n_dil); bk.c2.resize(g.n_dil); bk.acts.resize(2 * g.n_dil);
+            const int C = st.cout;
+            for (int l = 0; l < g.n_dil; ++l) {
+                relayout_conv(p, C, C, bk.k, C, tmp);
+                upload_as(bk.c1[l].w, tmp.data(), tmp.size(), dt, stream);
+                p += (size_t)C * C * bk.k;
+                upload_f32(bk.c1[l].b, p, C, stream); p += C;
+                relayout_conv(p, C, C, bk.k, C, tmp);
+                upload_as(bk.c2[l].w, tmp.data(), tmp.size(), dt, stream);
+                p += (size_t)C * C * bk.k;
+                upload_f32(bk.c2[l].b, p, C, stream); p += C;
+            }
+            for (int m = 0; m < 2 * g.n_dil; ++m) {
+                make_snake(p, p + C, C, g.logscale, bk.acts[m].alpha, bk.acts[m].inv_beta, stream);
+                p += 2 * C;
+            }
+        }
+    }
+    const int cl = g.c0 >> g.n_up;
+    make_snake(p, p + cl, cl, g.logscale, post_act.alpha, post_act.inv_beta, stream);
+    p += 2 * cl;
+    // conv_post (1, C, 7) -> [7][C] fp32
+    tmp.assign((size_t)7 * cl, 0.f);
+    for (int c = 0; c < cl; ++c)
+        for (int j = 0; j < 7; ++j) tmp[(size_t)j * cl + c] = p[(size_t)c * 7 + j];
+    upload_f32(post_w, tmp.data(), tmp.size(), stream);
+    p += (size_t)cl * 7;
+    post_bias = g.bias_final ? *p++ : 0.f;
+    MI_REQUIRE(p - w == nw, "bigvgan: weight walk mismatch");
+}
+
+BigVGAN::~BigVGAN() {
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+void BigVGAN::ensure_workspace(int B, int F) {
+    if (B == ws_B && F == ws_F) return;
+    const size_t es = dtype_size(dtype);
+    size_t max_elems = (size_t)B * F * std::max(cfg.c0, mel_pad);
+    long T = F;
+    for (int i = 0; i < cfg.n_up; ++i) {
+        T *= cfg.rates[i];
+        max_elems = std::max(max_elems, (size_t)B * (size_t)(T + 30) * (size_t)(cfg.c0 >> (i + 1)));
+    }
+    for (DevBuf* b : {&bIN, &bX, &bT1, &bT2, &bP, &bQ}) b->ensure(max_elems * es);
+    d_mel.ensure((size_t)B * cfg.num_mels * F * 4);
+    d_out_f32.ensure((size_t)B * (T + 30) * 4);
+    d_out_i16.ensure((size_t)B * (T + 30) * 2);
+    ws_B = B; ws_F = F;
+}
+
+void BigVGAN::conv(const ConvW& cw, const void* x, void* out, int B, int T, int Cin, int Cout, int k, int dil,
+                   const void* res, float alpha, int accumulate) {
+    ConvGemm p;
+    p.dtype = dtype; p.x = x; p.w = cw.w.p; p.bias = cw.b.as<float>(); p.out = out; p.res = res;
+    p.B = B; p.T_in = T; p.M = T; p.N = Cout; p.Cin = Cin; p.taps = k; p.dil = dil; p.pad = (k * dil - dil) / 2;
+    p.x_bstride = (long)T * Cin; p.x_rstride = Cin; p.out_bstride = (long)T * Cout; p.out_rstride = Cout;
+    p.alpha = alpha; p.accumulate = accumulate;
+    launch_conv_gemm(p, stream);
+}
+
+void BigVGAN::aa(const SnakeP& sp, const void* x, void* y, int B, int T, int C, int post) {
+    AAAct a;
+    a.dtype = dtype; a.x = x; a.y = y; a.alpha = sp.alpha.as<float>(); a.inv_beta = sp.inv_beta.as<float>();
+    a.B = B; a.T = T; a.C = C; a.post = post;
+    launch_aa_act(a, stream);
+}
+
+// returns the buffer holding the stage result
+void BigVGAN::run(const float* mel, int B, int F, float* out_f32, int16_t* out_i16, int mem) {
+    MI_REQUIRE(mel && B > 0 && F > 0, "bigvgan_forward: bad arguments");
+    MI_REQUIRE(out_f32 || out_i16, "bigvgan_forward: no output buffer");
+    MI_REQUIRE((long)F * cfg.hop < (1L << 30), "bigvgan_forward: too many frames");
+    MI_HIP(hipSetDevice(device));
+    ensure_workspace(B, F);
+    const long Tout = (long)F * cfg.hop + 30;
+    const float* dmel = mel;
+    if (mem == MI_HOST) {
+        MI_HIP(hipMemcpyAsync(d_mel.p, mel, (size_t)B * cfg.num_mels * F * 4, hipMemcpyHostToDevice, stream));
+        dmel = d_mel.as<float>();
+    }
+    // mel (B,100,F) -> channels-last padded (B,F,mel_pad)
+    launch_ncl_to_nlc(dmel, bT1.p, B, cfg.num_mels, F, mel_pad, dtype, stream);
+    DevBuf* IN = &bIN;     // holds the running stage input/output
+    DevBuf* X = &bX;
+    conv(pre, bT1.p, IN->p, B, F, mel_pad, cfg.c0, 7, 1, nullptr, 1.f, 0);
+    int T = F;
+    const float inv_nk = 1.0f / (float)cfg.n_kernels;
+    for (int i = 0; i < cfg.n_up; ++i) {
+        Stage& st = stages[i];
+        const int Tn = T * st.u, C = st.cout;
+        {   // ConvTranspose1d as a 2-tap conv producing u*Cout phase-major channels
+            ConvGemm p;
+            p.dtype = dtype; p.x = IN->p; p.w = st.up.w.p; p.bias = st.up.b.as<float>(); p.out = X->p;
+            p.B = B; p.T_in = T; p.M = T + 1; p.N = st.u * C; p.Cin = st.cin; p.taps = 2; p.dil = 1; p.pad = 1;
+            p.x_bstride = (long)T * st.cin; p.x_rstride = st.cin; p.out_bstride = (long)Tn * C; p.out_rstride = C;
+            p.epi = EPI_CONVT; p.u = st.u; p.Cout = C; p.padT = st.u / 2; p.T_out = Tn;
+            launch_conv_gemm(p, stream);
+        }
+        // AMP blocks: XS(=IN) = 1/3 * sum_j block_j(X)
+        for (int j = 0; j < cfg.n_kernels; ++j) {
+            AmpBlock& bk = st.blocks[j];
+            const void* cur = X->p;
+            for (int l = 0; l < cfg.n_dil; ++l) {
+                aa(bk.acts[2 * l], cur, bT1.p, B, Tn, C, 0);
+                conv(bk.c1[l], bT1.p, bT2.p, B, Tn, C, C, bk.k, cfg.dil[j][l], nullptr, 1.f, 0);
+                aa(bk.acts[2 * l + 1], bT2.p, bT1.p, B, Tn, C, 0);
+                const bool last = l == cfg.n_dil - 1;
+                void* dst = last ? IN->p : ((l & 1) ? bQ.p : bP.p);
+                conv(bk.c2[l], bT1.p, dst, B, Tn, C, C, bk.k, 1, cur, last ? inv_nk : 1.f, last && j > 0);
+                cur = dst;
+            }
+        }
+        T = Tn;
+    }
+    const int cl = cfg.c0 >> cfg.n_up;
+    aa(post_act, IN->p, bT1.p, B, T, cl, 1);
+    float* of = out_f32 ? (mem == MI_DEVICE ? out_f32 : d_out_f32.as<float>()) : nullptr;
+    int16_t* oi = out_i16 ? (mem == MI_DEVICE ? out_i16 : d_out_i16.as<int16_t>()) : nullptr;
+    launch_conv_post(bT1.p, post_w.as<float>(), post_bias, B, (int)Tout, cl, dtype, cfg.tanh_final, of, oi, stream);
+    if (mem == MI_HOST) {
+        if (out_f32) MI_HIP(hipMemcpyAsync(out_f32, of, (size_t)B * Tout * 4, hipMemcpyDeviceToHost, stream));
+        if (out_i16) MI_HIP(hipMemcpyAsync(out_i16, oi, (size_t)B * Tout * 2, hipMemcpyDeviceToHost, stream));
+    }
+    MI_HIP(hipStreamSynchronize(stream));
+}
+
+// ---------------------------------------------------------------------------------------------
+// unit-level entries (tests): fp32 channels-first host tensors in/out
+// ---------------------------------------------------------------------------------------------
+struct TmpStream {
+    hipStream_t s = nullptr;
+    TmpStream() { MI_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); }
+    ~TmpStream() { if (s) (void)hipStreamDestroy(s); }
+};
+
+void unit_aa_activation1d(const float* x, int B, int C, int T, const float* alpha_log, const float* beta_log,
+                          int logscale, int post, int dtype, float* y) {
+    TmpStream ts;
+    DevBuf dx, dxl, dyl, dy, da, db;
+    const size_t es = dtype_size(dtype);
+    const int To = T + (post ? 30 : 0);
+    upload_f32(dx, x, (size_t)B * C * T, ts.s);
+    dxl.ensure((size_t)B * C * T * es); dyl.ensure((size_t)B * C * To * es); dy.ensure((size_t)B * C * To * 4);
+    make_snake(alpha_log, beta_log, C, logscale, da, db, ts.s);
+    launch_ncl_to_nlc(dx.as<float>(), dxl.p, B, C, T, C, dtype, ts.s);
+    AAAct a;
+    a.dtype = dtype; a.x = dxl.p; a.y = dyl.p; a.alpha = da.as<float>(); a.inv_beta = db.as<float>();
+    a.B = B; a.T = T; a.C = C; a.post = post;
+    launch_aa_act(a, ts.s);
+    launch_nlc_to_ncl(dyl.p, dy.as<float>(), B, C, To, dtype, ts.s);
+    MI_HIP(hipMemcpyAsync(y, dy.p, (size_t)B * C * To * 4, hipMemcpyDeviceToHost, ts.s));
+    MI_HIP(hipStreamSynchronize(ts.s));
+}
+
+void unit_conv1d(const float* x, int B, int Cin, int T, const float* w, const float* bias, int Cout, int k, int dil,
+                 int padding, int groups, int dtype, float* y) {
+    MI_REQUIRE(Cin % groups == 0 && Cout % groups == 0, "conv1d: groups");
+    TmpStream ts;
+    const int vec = 16 / (int)dtype_size(dtype);
+    const int cig = Cin / groups, cog = Cout / groups;
+    MI_REQUIRE(groups == 1 || cig % vec == 0, "conv1d: grouped conv needs Cin/groups % vec == 0");
+    const int Cp = groups == 1 ? round_up(Cin, vec) : Cin;
+    const int cigp = groups == 1 ? Cp : cig;
+    const int To = T + 2 * padding - dil * (k - 1);
+    MI_REQUIRE(To > 0, "conv1d: empty output");
+    DevBuf dx, dxl, dw, db, dyl, dy;
+    const size_t es = dtype_size(dtype);
+    upload_f32(dx, x, (size_t)B * Cin * T, ts.s);
+    dxl.ensure((size_t)B * T * Cp * es);
+    launch_ncl_to_nlc(dx.as<float>(), dxl.p, B, Cin, T, Cp, dtype, ts.s);
+    std::vector<float> wl;
+    relayout_conv(w, Cout, cig, k, cigp, wl);       // (Cout, Cin/g, k) -> [co][tap][ci]
+    upload_as(dw, wl.data(), wl.size(), dtype, ts.s);
+    if (bias) upload_f32(db, bias, Cout, ts.s);
+    dyl.ensure((size_t)B * To * Cout * es); dy.ensure((size_t)B * To * Cout * 4);
+    ConvGemm p;
+    p.dtype = dtype; p.x = dxl.p; p.w = dw.p; p.bias = bias ? db.as<float>() : nullptr; p.out = dyl.p;
+    p.B = B; p.G = groups; p.T_in = T; p.M = To; p.N = cog; p.Cin = cigp; p.taps = k; p.dil = dil; p.pad = padding;
+    p.x_bstride = (long)T * Cp; p.x_rstride = Cp; p.x_goff = cigp; p.out_bstride = (long)To * Cout; p.out_rstride = Cout;
+    launch_conv_gemm(p, ts.s);
+    launch_nlc_to_ncl(dyl.p, dy.as<float>(), B, Cout, To, dtype, ts.s);
+    MI_HIP(hipMemcpyAsync(y, dy.p, (size_t)B * Cout * To * 4, hipMemcpyDeviceToHost, ts.s));
+    MI_HIP(hipStreamSynchronize(ts.s));
+}
+
+void unit_conv_transpose1d(const float* x, int B, int Cin, int T, const float* w, const float* bias, int Cout, int k,
+                           int stride, int padding, int dtype, float* y) {
+    MI_REQUIRE(k == 2 * stride && stride % 2 == 0 && padding == (k - stride) / 2,
+               "conv_transpose1d: only k == 2*stride, padding == stride/2 (the BigVGAN upsamplers)");
+    const int vec = 16 / (int)dtype_size(dtype);
+    MI_REQUIRE(Cin % vec == 0, "conv_transpose1d: Cin % vec");
+    TmpStream ts;
+    const int To = T * stride;
+    DevBuf dx, dxl, dw, db, dyl, dy;
+    const size_t es = dtype_size(dtype);
+    upload_f32(dx, x, (size_t)B * Cin * T, ts.s);
+    dxl.ensure((size_t)B * T * Cin * es);
+    launch_ncl_to_nlc(dx.as<float>(), dxl.p, B, Cin, T, Cin, dtype, ts.s);
+    std::vector<float> wl;
+    relayout_convt(w, Cin, Cout, stride, wl);
+    upload_as(dw, wl.data(), wl.size(), dtype, ts.s);
+    if (bias) upload_f32(db, bias, Cout, ts.s);
+    dyl.ensure((size_t)B * To * Cout * es); dy.ensure((size_t)B * To * Cout * 4);
+    ConvGemm p;
+    p.dtype = dtype; p.x = dxl.p; p.w = dw.p; p.bias = bias ? db.as<float>() : nullptr; p.out = dyl.p;
+    p.B = B; p.T_in = T; p.M = T + 1; p.N = stride * Cout; p.Cin = Cin; p.taps = 2; p.dil = 1; p.pad = 1;
+    p.x_bstride = (long)T * Cin; p.x_rstride = Cin; p.out_bstride = (long)To * Cout; p.out_rstride = Cout;
+    p.epi = EPI_CONVT; p.u = stride; p.Cout = Cout; p.padT = stride / 2; p.T_out = To;
+    launch_conv_gemm(p, ts.s);
+    launch_nlc_to_ncl(dyl.p, dy.as<float>(), B, Cout, To, dtype, ts.s);
+    MI_HIP(hipMemcpyAsync(y, dy.p, (size_t)B * Cout * To * 4, hipMemcpyDeviceToHost, ts.s));
+    MI_HIP(hipStreamSynchronize(ts.s));
+}
+
+}  // namespace mi

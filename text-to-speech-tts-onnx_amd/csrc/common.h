@@ -1,0 +1,153 @@
+// common.h — shared host/device helpers for libmi355tts (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <cmath>
+#include <string>
+#include <vector>
+#include <stdexcept>
+#include <map>
+
+#include "../../include/mi355tts.h"
+
+namespace mi {
+
+// ---------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+void set_last_error(const std::string& m);
+
+#define MI_HIP(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess)                                                                     \
+            throw mi::Error(MI_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e) + " @" +   \
+                                         __FILE__ + ":" + std::to_string(__LINE__));              \
+    } while (0)
+
+#define MI_REQUIRE(cond, msg)                                                                     \
+    do {                                                                                          \
+        if (!(cond)) throw mi::Error(MI_EINVAL, std::string(msg) + " [" #cond "]");               \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// element types.  half = _Float16 ; bf16 = __bf16 (storage) ; all math accumulates in fp32
+// ---------------------------------------------------------------------------------------------
+using f16 = _Float16;
+using bf16 = __bf16;
+
+template <typename T> struct DT;
+template <> struct DT<float> { static constexpr int id = MI_F32; };
+template <> struct DT<f16>   { static constexpr int id = MI_F16; };
+template <> struct DT<bf16>  { static constexpr int id = MI_BF16; };
+
+inline size_t dtype_size(int dt) { return dt == MI_F32 ? 4 : 2; }
+
+template <typename T> __host__ __device__ inline float to_f32(T v) { return (float)v; }
+template <typename T> __host__ __device__ inline T from_f32(float v) { return (T)v; }
+
+// ---------------------------------------------------------------------------------------------
+// device buffer (owning)
+// ---------------------------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept {
+        if (this != &o) { release(); p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; }
+        return *this;
+    }
+    ~DevBuf() { release(); }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
+    void ensure(size_t n) {           // grow-only
+        if (n <= bytes) return;
+        release();
+        MI_HIP(hipMalloc(&p, n));
+        bytes = n;
+    }
+    template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// host fp32 -> device tensor of dtype dt
+void upload_as(DevBuf& dst, const float* src, size_t n, int dt, hipStream_t s);
+void upload_f32(DevBuf& dst, const float* src, size_t n, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// profiling (bench roofline leg): HIP events around launches of a kernel family
+// ---------------------------------------------------------------------------------------------
+struct ProfScope {
+    int fam; hipStream_t s; hipEvent_t e0 = nullptr, e1 = nullptr; bool on;
+    ProfScope(int family, hipStream_t stream, double bytes, double flops);
+    ~ProfScope();
+};
+enum { FAM_CONV_GEMM = 0, FAM_AA = 1, FAM_CONV_POST = 2, FAM_ATTN = 3, FAM_NORM = 4, FAM_OTHER = 5, FAM_COUNT = 6 };
+void prof_collect();   // resolve pending events (synchronises)
+
+// ---------------------------------------------------------------------------------------------
+// implicit-GEMM convolution / linear launcher (gemm_conv.hip)
+//   out[b, m, n] = epi( sum_{tap, ci} x[b, m - pad + tap*dil, ci] * w[n, tap*Cin + ci] )
+// activations are channels-last: element (b, t, c) at  b*bstride + t*rstride + c
+// ---------------------------------------------------------------------------------------------
+enum Act { ACT_NONE = 0, ACT_GELU_TANH = 1, ACT_GELU_ERF = 2, ACT_MISH = 3, ACT_SILU = 4 };
+enum EpiMode { EPI_PLAIN = 0, EPI_CONVT = 1, EPI_QKV_ROPE = 2 };
+
+struct ConvGemm {
+    int dtype = MI_F32;           // x / w / res element type
+    int out_dtype = -1;           // -1: same as dtype ; MI_F32 allowed
+    const void* x = nullptr;
+    const void* w = nullptr;      // [G][N][K] , K = taps*Cin contiguous
+    const float* bias = nullptr;  // [G*N] (EPI_CONVT: [Cout])
+    void* out = nullptr;
+    const void* res = nullptr;    // same layout/dtype as out
+    const float* gate = nullptr;  // optional per-(b, n) multiplier applied before the residual add
+    long gate_bstride = 0;
+    int B = 1, G = 1;
+    int T_in = 0;                 // valid x rows per batch item
+    int M = 0, N = 0, Cin = 0, taps = 1, dil = 1, pad = 0;
+    long x_bstride = 0, x_rstride = 0;       // elements
+    long out_bstride = 0, out_rstride = 0;   // elements
+    long x_goff = 0;              // per-group column offset in x (elements) ; out col offset = g*N
+    int act = ACT_NONE;
+    float alpha = 1.f;            // out = alpha*(act(acc+bias)*gate + res) (+ out_prev if accumulate)
+    int accumulate = 0;
+    int epi = EPI_PLAIN;
+    // EPI_CONVT: N = u*Cout ; output row tau = m*u + n/Cout - padT, col n%Cout, valid 0<=tau<T_out
+    int u = 1, Cout = 0, padT = 0, T_out = 0;
+    // EPI_QKV_ROPE (f5): see f5.hip
+    const float* rope_cos = nullptr; const float* rope_sin = nullptr; int heads = 0, head_dim = 0;
+    void* out2 = nullptr; void* out3 = nullptr;
+};
+void launch_conv_gemm(const ConvGemm& p, hipStream_t s);
+
+// anti-aliased SnakeBeta (aa_act.hip); channels-last (B,T,C) -> (B,T+2*shift,C)
+struct AAAct {
+    int dtype = MI_F32;
+    const void* x = nullptr; void* y = nullptr;
+    const float* alpha = nullptr;      // exp(alpha_log)            [C]
+    const float* inv_beta = nullptr;   // 1/(exp(beta_log)+1e-9)    [C]
+    int B = 1, T = 0, C = 0;
+    int post = 0;                      // 1: pad-15 variant, output rows T+30
+};
+void launch_aa_act(const AAAct& p, hipStream_t s);
+const float* aa_filter_host();         // the 12 kaiser-sinc taps
+
+// layout helpers (elementwise.hip)
+// (B,C,T) fp32 channels-first -> (B,T,Cpad) dtype channels-last (zero padded channels)
+void launch_ncl_to_nlc(const float* x, void* y, int B, int C, int T, int Cpad, int dtype, hipStream_t s);
+// (B,T,C) dtype channels-last -> (B,C,T) fp32 channels-first
+void launch_nlc_to_ncl(const void* x, float* y, int B, int C, int T, int dtype, hipStream_t s);
+// conv_post: (B,T,C) -> tanh/clamp -> float (B,T) and/or int16 (B,T)
+void launch_conv_post(const void* x, const float* w /*[7][C]*/, float bias, int B, int T, int C, int dtype,
+                      int use_tanh, float* out_f32, int16_t* out_i16, hipStream_t s);
+
+}  // namespace mi

@@ -1,0 +1,113 @@
+"""ctypes binding of libmi355tts.so (C-ABI: include/mi355tts.h).
+
+The product path has NO CPU fallback: if the shared library is missing or no MI355X is visible,
+calls raise loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+MI_F32, MI_F16, MI_BF16 = 0, 1, 2
+MI_HOST, MI_DEVICE = 0, 1
+DTYPES = {"f32": MI_F32, "fp32": MI_F32, "float32": MI_F32, "f16": MI_F16, "fp16": MI_F16, "float16": MI_F16,
+          "bf16": MI_BF16, "bfloat16": MI_BF16}
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmi355tts.so")
+_lib = None
+
+
+class MiError(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def load() -> C.CDLL:
+    """dlopen the engine (no GPU needed for this step) and declare every prototype."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise MiError(f"{_LIB_PATH} is missing: build it with `python text-to-speech-tts-onnx_amd/build.py` "
+                      f"(or __graft_entry__.build()); there is no CPU fallback")
+    L = C.CDLL(_LIB_PATH)
+    i32p, f32p = C.POINTER(C.c_int32), C.POINTER(C.c_float)
+    vp = C.c_void_p
+    L.mi_init.argtypes = [C.c_int]; L.mi_init.restype = C.c_int
+    L.mi_device_count.argtypes = []; L.mi_device_count.restype = C.c_int
+    L.mi_last_error.argtypes = []; L.mi_last_error.restype = C.c_char_p
+    L.mi_version.argtypes = []; L.mi_version.restype = C.c_char_p
+    L.mi_bigvgan_param_count.argtypes = [i32p, C.c_int]; L.mi_bigvgan_param_count.restype = C.c_int64
+    L.mi_bigvgan_create.argtypes = [i32p, C.c_int, f32p, C.c_int64, C.c_int, C.c_int]
+    L.mi_bigvgan_create.restype = vp
+    L.mi_bigvgan_destroy.argtypes = [vp]; L.mi_bigvgan_destroy.restype = None
+    L.mi_bigvgan_out_len.argtypes = [vp, C.c_int]; L.mi_bigvgan_out_len.restype = C.c_int64
+    L.mi_bigvgan_forward.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int]; L.mi_bigvgan_forward.restype = C.c_int
+    L.mi_bigvgan_forward_f32.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int]
+    L.mi_bigvgan_forward_f32.restype = C.c_int
+    L.mi_aa_activation1d.argtypes = [f32p, C.c_int, C.c_int, C.c_int, f32p, f32p, C.c_int, C.c_int, C.c_int, f32p]
+    L.mi_aa_activation1d.restype = C.c_int
+    L.mi_conv1d.argtypes = [f32p, C.c_int, C.c_int, C.c_int, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                            C.c_int, f32p]
+    L.mi_conv1d.restype = C.c_int
+    L.mi_conv_transpose1d.argtypes = [f32p, C.c_int, C.c_int, C.c_int, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, f32p]
+    L.mi_conv_transpose1d.restype = C.c_int
+    L.mi_prof_enable.argtypes = [C.c_int]; L.mi_prof_enable.restype = C.c_int
+    L.mi_prof_reset.argtypes = []; L.mi_prof_reset.restype = C.c_int
+    L.mi_prof_get.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
+                              C.POINTER(C.c_double)]
+    L.mi_prof_get.restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().mi_last_error().decode("utf-8", "replace")
+        raise MiError(f"{what}: {msg} (code {rc})")
+
+
+def f32p(a: np.ndarray):
+    assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def i32p(a: np.ndarray):
+    assert a.dtype == np.int32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def init(device: int = 0) -> None:
+    check(load().mi_init(device), "mi_init")
+
+
+PROF_FAMILIES = ("conv_gemm", "aa_act", "conv_post", "attn", "norm", "other")
+
+
+def prof_enable(families=()) -> None:
+    """families: iterable of family names, or True for all, or False/() for off."""
+    if families is True:
+        mask = -1
+    elif not families:
+        mask = 0
+    else:
+        mask = 0
+        for f in families:
+            mask |= 1 << PROF_FAMILIES.index(f)
+    load().mi_prof_enable(mask)
+
+
+def prof_reset() -> None:
+    check(load().mi_prof_reset(), "mi_prof_reset")
+
+
+def prof_get(family: str) -> dict:
+    ms, n, by, fl = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+    check(load().mi_prof_get(family.encode(), C.byref(ms), C.byref(n), C.byref(by), C.byref(fl)), "mi_prof_get")
+    return {"ms": ms.value, "launches": n.value, "bytes": by.value, "flops": fl.value}
