@@ -103,10 +103,75 @@ def bigvgan_hparams(cfg) -> _AttrDict:
 def exec_lines(path: str, start: int, end: int, ns: dict, replace=()):
     """exec source lines [start, end] (1-based, inclusive) of a reference script that cannot be
     imported as a module (import-time side effects: Export_*.py)."""
+    import textwrap
     with open(path, "r", encoding="utf-8") as f:
-        src = "".join(f.readlines()[start - 1:end])
+        src = textwrap.dedent("".join(f.readlines()[start - 1:end]))
     for a, b in replace:
         assert a in src, a
         src = src.replace(a, b)
     exec(compile(src, f"{path}:{start}-{end}", "exec"), ns)
     return ns
+
+
+# ------------------------------------------------------------------------------------------
+# F5 (DiT, Vocos, STFT_Process)
+# ------------------------------------------------------------------------------------------
+def melscale_fbanks(n_freqs, f_min, f_max, n_mels, sample_rate, norm=None, mel_scale="htk"):
+    """torchaudio.functional.melscale_fbanks restated from its published definition (HTK, norm=None);
+    un-vendored in the reference (Export_F5.py:113)."""
+    assert norm is None and mel_scale == "htk"
+    all_freqs = torch.linspace(0, sample_rate // 2, n_freqs)
+    m_min = 2595.0 * math.log10(1.0 + (f_min / 700.0))
+    m_max = 2595.0 * math.log10(1.0 + (f_max / 700.0))
+    m_pts = torch.linspace(m_min, m_max, n_mels + 2)
+    f_pts = 700.0 * (10 ** (m_pts / 2595.0) - 1.0)
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts.unsqueeze(0) - all_freqs.unsqueeze(1)
+    zero = torch.zeros(1)
+    down_slopes = (-1.0 * slopes[:, :-2]) / f_diff[:-1]
+    up_slopes = slopes[:, 2:] / f_diff[1:]
+    return torch.max(zero, torch.min(down_slopes, up_slopes))
+
+
+def load_f5_ref():
+    """Returns (modules, dit, vocos_models, vocos_heads, STFT_Process) from the reference files."""
+    ort = types.ModuleType("onnxruntime")
+    sys.modules["onnxruntime"] = ort
+    ta = _pkg("torchaudio")
+    taf = _pkg("torchaudio.functional")
+    taff = _pkg("torchaudio.functional.functional")
+    taff._hz_to_mel = lambda *a, **k: 0.0
+    taff._mel_to_hz = lambda *a, **k: 0.0
+    taf.melscale_fbanks = melscale_fbanks
+    taf.functional = taff
+    ta.functional = taf
+    _pkg("librosa")
+    lf = _pkg("librosa.filters")
+    lf.mel = lambda *a, **k: None
+    _pkg("x_transformers")
+    xt = _pkg("x_transformers.x_transformers")
+    xt.apply_rotary_pos_emb = lambda *a, **k: None
+
+    class RotaryEmbedding(nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+    xt.RotaryEmbedding = RotaryEmbedding
+    _pkg("f5_tts")
+    _pkg("f5_tts.model")
+    _pkg("f5_tts.model.backbones")
+    d = REF + "/F5_TTS/modeling_modified/"
+    modules = _load("f5_tts.model.modules", d + "F5/modules.py")
+    dit = _load("f5_tts.model.backbones.dit", d + "F5/dit.py")
+    _pkg("vocos")
+    so = _pkg("vocos.spectral_ops")
+
+    class _Nop(nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+    so.ISTFT = _Nop
+    so.IMDCT = _Nop
+    vmod = _load("vocos.modules", d + "vocos/modules.py")
+    vheads = _load("vocos.heads", d + "vocos/heads.py")
+    vmodels = _load("vocos.models", d + "vocos/models.py")
+    stft = _load("STFT_Process", REF + "/F5_TTS/STFT_Process.py")
+    return modules, dit, vmodels, vheads, stft

@@ -1,0 +1,127 @@
+"""CPU: the numpy F5 oracle (oracle/f5_np.py) against golden vectors produced by the reference's own
+module + wrapper code (tests/golden/make_golden_f5.py -> f5_small.npz)."""
+import os
+
+import numpy as np
+import pytest
+
+from mi355tts.config import F5Config
+from mi355tts import weights as W
+from oracle import f5_np as O
+
+
+@pytest.fixture(scope="module")
+def g(golden_dir):
+    return np.load(os.path.join(golden_dir, "f5_small.npz"))
+
+
+@pytest.fixture(scope="module")
+def small():
+    cfg = F5Config.small()
+    st = W.fold_f5(cfg, W.synth_state(W.f5_spec(cfg), 9527))
+    return cfg, st
+
+
+def rms(a):
+    return float(np.sqrt(np.mean(np.square(np.asarray(a, dtype=np.float64)))))
+
+
+def test_stft_b(g):
+    re, im = O.stft_b(g["stft_x"])
+    assert re.shape == g["stft_re"].shape == (513, 17)
+    np.testing.assert_allclose(re, g["stft_re"], atol=2e-4)
+    np.testing.assert_allclose(im, g["stft_im"], atol=2e-4)
+
+
+def test_istft_tables_and_output(g):
+    basis = O.istft_basis()
+    rows = [0, 1, 7, 512, 513, 514, 700, 1025]
+    np.testing.assert_allclose(basis[rows], g["istft_basis_rows"], atol=2e-7)      # closed form == fp32 pinv
+    # only [n_fft/2:] is ever used (STFT_Process.py:165-166); the first samples divide by ~1e-7
+    np.testing.assert_allclose(O.window_sum_inv()[512:2048], g["wsi_head"][512:], rtol=2e-6)
+    np.testing.assert_allclose(O.window_sum_inv()[8:512], g["wsi_head"][8:512], rtol=1e-3)
+    y = O.istft_a(g["istft_mag"], g["istft_ph"])
+    assert y.shape == g["istft_y"].shape == (8 * 256,)
+    np.testing.assert_allclose(y, g["istft_y"], atol=2e-5)
+
+
+def test_fbank(g):
+    fb = O.melscale_fbanks_htk().T
+    np.testing.assert_allclose(fb[[0, 1, 50, 99]], g["fbank_rows"], atol=1e-5)   # fp64 here vs fp32 linspace in torch
+
+
+def test_preprocess(g, small):
+    cfg, st = small
+    N = int(g["pre_N"])
+    pre = O.preprocess(cfg, st, g["pre_audio"], g["pre_text_ids"], N, np.zeros((N, cfg.mel_dim), np.float32))
+    assert pre["ref_signal_len"] == int(g["pre_ref_signal_len"]) == 8192 // 256 + 1
+    assert np.array_equal(pre["rope_cos"], g["pre_rope_cos_q"])          # fp16-rounded tables: exact
+    assert np.array_equal(pre["rope_sin"], g["pre_rope_sin_q"])
+    np.testing.assert_allclose(pre["cat_mel_text"][:, :100], g["pre_cat_mel_text"][:, :100], atol=2e-3)   # log-mel
+    np.testing.assert_allclose(pre["cat_mel_text"][:, 100:], g["pre_cat_mel_text"][:, 100:], atol=2e-5)   # text embed
+    np.testing.assert_allclose(pre["cat_mel_text_drop"], g["pre_cat_mel_text_drop"], atol=2e-5)
+    assert np.all(pre["cat_mel_text"][len(g["pre_text_ids"]):, 100:] == 0)      # filler rows are masked
+    assert np.all(pre["cat_mel_text"][3, 100:] == 0)                              # pad id -1 -> filler
+
+
+def test_time_tables(g, small):
+    cfg, st = small
+    ts, delta, texp = O.time_tables(cfg, st)
+    assert len(delta) == cfg.nfe_step - 1 and abs(float(delta.sum()) - 1.0) < 1e-6
+    np.testing.assert_allclose(delta, g["delta_t"], atol=1e-7)
+    np.testing.assert_allclose(texp, g["time_expand"], atol=2e-5)
+
+
+def test_dit_forward(g, small):
+    cfg, st = small
+    _, _, texp = O.time_tables(cfg, st)
+    taps = {}
+    pred = O.dit_forward(cfg, st, g["dit_noise"], g["pre_cat_mel_text"], g["pre_cat_mel_text_drop"], texp[2],
+                         g["pre_rope_cos_q"], g["pre_rope_sin_q"], taps)
+    np.testing.assert_allclose(taps["input_embed"][0], g["dit_input_embed_c"], atol=2e-5)
+    np.testing.assert_allclose(taps["block.0"], g["dit_block0"], atol=5e-5)
+    np.testing.assert_allclose(taps["block.1"], g["dit_block1"], atol=1e-4)
+    np.testing.assert_allclose(pred, g["dit_pred_t2"], atol=1e-4)
+
+
+def test_sampling_loop(g, small):
+    cfg, st = small
+    pre = {"noise": g["dit_noise"], "cat_mel_text": g["pre_cat_mel_text"], "cat_mel_text_drop": g["pre_cat_mel_text_drop"],
+           "rope_cos": g["pre_rope_cos_q"], "rope_sin": g["pre_rope_sin_q"]}
+    tables = O.time_tables(cfg, st)
+    x1 = O.transformer_step(cfg, st, tables, pre["noise"], pre, 0)
+    np.testing.assert_allclose(x1, g["loop_step1"], atol=5e-5)
+    xf = O.sample(cfg, st, pre, tables)                      # nfe_step-1 evaluations ("NFE=32" -> 31)
+    np.testing.assert_allclose(xf, g["loop_final"], atol=5e-4)
+
+
+def test_decode(g, small):
+    cfg, st = small
+    R = int(g["pre_ref_signal_len"])
+    mag, ph = O.vocos_decode(cfg, st, g["dec_in"][R:])
+    np.testing.assert_allclose(mag, g["dec_mag"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(ph, g["dec_phase"], atol=1e-4)
+    sig = O.decode(cfg, st, g["dec_in"], R, return_float=True)
+    assert rms(sig - g["dec_float"]) < 1e-5                  # north-star bound: 1e-3 RMS
+    w = O.decode(cfg, st, g["dec_in"], R)
+    assert w.dtype == np.int16 and w.shape == g["dec_i16"].shape
+    assert np.abs(w.astype(np.int32) - g["dec_i16"].astype(np.int32)).max() <= 2
+
+
+def test_end_to_end_waveform(g, small):
+    """preprocess -> sampler -> decode, against the reference chain; gate = 1e-3 RMS on [-1,1] scale."""
+    cfg, st = small
+    R = int(g["pre_ref_signal_len"])
+    pre = {"noise": g["dit_noise"], "cat_mel_text": g["pre_cat_mel_text"], "cat_mel_text_drop": g["pre_cat_mel_text_drop"],
+           "rope_cos": g["pre_rope_cos_q"], "rope_sin": g["pre_rope_sin_q"]}
+    w = O.decode(cfg, st, O.sample(cfg, st, pre), R)
+    err = rms((w.astype(np.float64) - g["e2e_i16"].astype(np.float64)) / 32767.0)
+    assert err < 1e-3, err
+    assert rms(g["e2e_i16"]) > 500
+
+
+def test_host_text_helpers():
+    vocab = W.synth_vocab(100)
+    ids = O.list_str_to_idx(list("ab é"), vocab)
+    assert ids.dtype == np.int32 and ids[2] == vocab[" "] == 0 and ids[3] == 0        # OOV -> 0
+    assert O.max_duration(144000, "a" * 80, "b" * 80) == 563 + 563
