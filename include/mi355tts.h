@@ -76,6 +76,47 @@ int         mi_conv1d(const float* x, int B, int Cin, int T, const float* w, con
 int         mi_conv_transpose1d(const float* x, int B, int Cin, int T, const float* w, const float* bias,
                                 int Cout, int k, int stride, int padding, int dtype, float* y);
 
+/* ---- F5-TTS (DiT CFM sampler + text/mel front end + Vocos/ISTFT back end) ---------------------
+ * cfg_i = F5Config.to_int_array() (21 ints: dim, depth, heads, dim_head, ff_mult, mel_dim, text_dim,
+ *   text_num_embeds, conv_layers, conv_mult, pos_conv_kernel, pos_conv_groups, freq_embed_dim, nfe_step,
+ *   max_signal_length, n_fft, hop_length, sample_rate, vocos_dim, vocos_intermediate, vocos_layers);
+ * cfg_f = [cfg_strength, sway_coef].  `dtype` selects the DiT operand type (fp32 residual stream and
+ * fp32 softmax/norm statistics always); the front end and the vocoder always run in fp32, like the
+ * reference's CPU-pinned graphs A and C (F5-TTS-ONNX-Inference.py:173,214).
+ * Batching extension: U utterances of equal max_duration N; tensors gain a leading U axis.        */
+int64_t     mi_f5_param_count(const int32_t* cfg_i, int n_i, const float* cfg_f, int n_f);
+mi_f5*      mi_f5_create(const int32_t* cfg_i, int n_i, const float* cfg_f, int n_f, const float* weights,
+                         int64_t n_weights, int dtype, int device);
+void        mi_f5_destroy(mi_f5* h);
+/* load-time tables (tests): time_expand (nfe, dim), delta_t (nfe-1)   Export_F5.py:153-164          */
+int         mi_f5_tables(mi_f5* h, float* time_expand, float* delta_t);
+/* graph A.  audio (L) int16, text_ids (T) int32 (pad value -1 allowed), max_duration N.
+ * noise_in != NULL injects the initial noise (N,100); else it is drawn from `seed`.
+ * Outputs (any may be NULL): noise (N,100), rope_cos/rope_sin (N,64) [the ONNX graph broadcasts these
+ * to (2,16,N,64) and a transposed K copy], cat_mel_text / cat_mel_text_drop (N,612), ref_signal_len.   */
+int         mi_f5_preprocess(mi_f5* h, const int16_t* audio, int64_t L, const int32_t* text_ids, int64_t T,
+                             int64_t max_duration, const float* noise_in, uint64_t seed, float* noise,
+                             float* rope_cos, float* rope_sin, float* cat_mel_text, float* cat_mel_text_drop,
+                             int64_t* ref_signal_len, int mem);
+/* graph B, one call = `fuse` Euler/CFG steps starting at *time_step (host int); noise (U,N,100) is
+ * updated in place, *time_step += fuse.  cat_mel_text(_drop): (U,N,612).                              */
+int         mi_f5_transformer_step(mi_f5* h, float* noise, const float* cat_mel_text, const float* cat_mel_text_drop,
+                                   int U, int64_t N, int32_t* time_step, int fuse, int mem);
+/* the whole NFE loop on device: steps k0 .. k0+n_steps-1 (reference: k0 = 0, n_steps = nfe_step-1)   */
+int         mi_f5_sample(mi_f5* h, float* noise, const float* cat_mel_text, const float* cat_mel_text_drop, int U,
+                         int64_t N, int k0, int n_steps, int mem);
+/* tests: one DiT evaluation at grid index k -> pred (2U, N, 100) (cond branch first)                 */
+int         mi_f5_dit_eval(mi_f5* h, const float* noise, const float* cat_mel_text, const float* cat_mel_text_drop,
+                           int U, int64_t N, int k, float* pred, int mem);
+/* graph C.  denoised (U,N,100), ref_signal_len R -> int16 (U, (N-R-1)*hop); out_f32 (optional) is the
+ * float signal before clamp/int16.  *out_len receives the per-utterance sample count.                 */
+int         mi_f5_decode(mi_f5* h, const float* denoised, int U, int64_t N, int64_t ref_signal_len, int16_t* out,
+                         float* out_f32, int64_t* out_len, int mem);
+/* A -> loop -> C without leaving the device.  audio (U,L), text_ids (U,T), noise_in (U,N,100) or NULL. */
+int         mi_f5_synthesize(mi_f5* h, int U, const int16_t* audio, int64_t L, const int32_t* text_ids, int64_t T,
+                             int64_t max_duration, const float* noise_in, uint64_t seed, int16_t* out,
+                             int64_t* out_len, int mem);
+
 /* ---- profiling hooks (bench.py roofline leg) -------------------------------------------------
  * family_mask: bit i enables family i (0 = off, -1 = all).  Every launch of an enabled kernel
  * family is bracketed by HIP events on the handle's own stream; mi_prof_get returns accumulated

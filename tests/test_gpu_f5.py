@@ -1,0 +1,159 @@
+"""GPU parity: the HIP F5-TTS path (through the C-ABI) against golden vectors from the reference's own
+module/wrapper code and against the numpy oracle.
+
+Tolerances (fp32 engine: exact-fp32 MFMA, fp32 softmax / norm statistics):
+  tables / single ops      <= 1e-4 abs (summation order + libm vs torch transcendental differences)
+  31-step sampler output   <= 2e-3 abs on O(2) values
+  waveform                 <= 1e-3 RMS on the [-1,1] scale  (the north-star gate), asserted with headroom
+bf16 / f16 engines: DiT operands rounded to 16 bit, fp32 residual stream -> waveform RMS gate 3e-2 (stated).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from mi355tts.config import F5Config
+from mi355tts import weights as W
+from mi355tts.f5 import F5Engine
+from oracle import f5_np as O
+
+pytestmark = pytest.mark.gpu
+
+
+def rms(a):
+    return float(np.sqrt(np.mean(np.square(np.asarray(a, dtype=np.float64)))))
+
+
+@pytest.fixture(scope="module")
+def g(golden_dir):
+    return np.load(os.path.join(golden_dir, "f5_small.npz"))
+
+
+@pytest.fixture(scope="module")
+def small():
+    cfg = F5Config.small()
+    raw = W.synth_state(W.f5_spec(cfg), 9527)
+    eng = F5Engine(cfg, raw, dtype="f32")
+    yield cfg, W.fold_f5(cfg, raw), eng
+    eng.close()
+
+
+def test_param_count_and_tables(g, small):
+    cfg, st, eng = small
+    te, dt = eng.tables()
+    np.testing.assert_allclose(dt, g["delta_t"], atol=2e-7)
+    np.testing.assert_allclose(te, g["time_expand"], atol=5e-5)
+    assert abs(float(dt.sum()) - 1.0) < 1e-6 and len(dt) == cfg.nfe_step - 1
+
+
+def test_preprocess_golden(g, small):
+    cfg, st, eng = small
+    N = int(g["pre_N"])
+    noise = g["dit_noise"]
+    o = eng.preprocess(g["pre_audio"].reshape(1, 1, -1), g["pre_text_ids"].reshape(1, -1), np.array([N]), noise=noise)
+    assert int(o["ref_signal_len"]) == int(g["pre_ref_signal_len"])
+    assert o["rope_cos_q"].shape == (2, cfg.heads, N, 64) and o["rope_cos_k"].shape == (2, cfg.heads, 64, N)
+    np.testing.assert_allclose(o["rope_cos_q"][1, 1], g["pre_rope_cos_q"], atol=1e-3)    # fp16-rounded tables (1 ulp_fp16)
+    np.testing.assert_allclose(o["rope_sin_q"][0, 0], g["pre_rope_sin_q"], atol=1e-3)
+    assert np.array_equal(o["noise"][0], noise)
+    np.testing.assert_allclose(o["cat_mel_text"][0, :, :100], g["pre_cat_mel_text"][:, :100], atol=3e-3)
+    np.testing.assert_allclose(o["cat_mel_text"][0, :, 100:], g["pre_cat_mel_text"][:, 100:], atol=5e-5)
+    np.testing.assert_allclose(o["cat_mel_text_drop"][0], g["pre_cat_mel_text_drop"], atol=5e-5)
+
+
+def test_dit_eval_golden(g, small):
+    cfg, st, eng = small
+    pred = eng.dit_eval(g["dit_noise"][None], g["pre_cat_mel_text"][None], g["pre_cat_mel_text_drop"][None], 2)
+    assert pred.shape == g["dit_pred_t2"].shape
+    np.testing.assert_allclose(pred, g["dit_pred_t2"], atol=3e-4)
+
+
+def test_step_and_loop_golden(g, small):
+    cfg, st, eng = small
+    x0, cmt, cmtd = g["dit_noise"][None], g["pre_cat_mel_text"][None], g["pre_cat_mel_text_drop"][None]
+    x1, ts = eng.transformer_step(x0, cmt, cmtd, np.array([0], np.int32))
+    assert int(ts[0]) == 1 and np.array_equal(x0[0], g["dit_noise"])          # inputs untouched
+    np.testing.assert_allclose(x1[0], g["loop_step1"], atol=2e-4)
+    # the reference loop: nfe_step - 1 calls, each feeding the previous output back
+    x, t = x0, np.array([0], np.int32)
+    for _ in range(cfg.nfe_step - 1):
+        x, t = eng.transformer_step(x, cmt, cmtd, t)
+    assert int(t[0]) == cfg.nfe_step - 1
+    np.testing.assert_allclose(x[0], g["loop_final"], atol=2e-3)
+    xs = eng.sample(x0, cmt, cmtd)                                               # device-resident loop == stepwise
+    assert np.array_equal(xs, x)
+    with pytest.raises(Exception):
+        eng.transformer_step(x, cmt, cmtd, t)                                    # past the end of the grid
+
+
+def test_batched_utterances_equal_single(g, small):
+    cfg, st, eng = small
+    x0, cmt, cmtd = g["dit_noise"][None], g["pre_cat_mel_text"][None], g["pre_cat_mel_text_drop"][None]
+    x2 = np.concatenate([x0, x0[:, ::-1].copy()], 0)
+    c2 = np.concatenate([cmt, cmt], 0)
+    d2 = np.concatenate([cmtd, cmtd], 0)
+    a = eng.sample(x2, c2, d2, n_steps=2)
+    b0 = eng.sample(x0, cmt, cmtd, n_steps=2)
+    b1 = eng.sample(x0[:, ::-1].copy(), cmt, cmtd, n_steps=2)
+    assert np.array_equal(a[0], b0[0]) and np.array_equal(a[1], b1[0])
+
+
+def test_decode_golden(g, small):
+    cfg, st, eng = small
+    R = int(g["pre_ref_signal_len"])
+    w, wf = eng.decode(g["dec_in"][None], R, return_float=True)
+    assert w.shape == (1, 1, g["dec_i16"].shape[0]) and w.dtype == np.int16
+    assert rms(wf[0, 0] - g["dec_float"]) < 2e-5
+    assert np.abs(w[0, 0].astype(np.int32) - g["dec_i16"].astype(np.int32)).max() <= 3
+
+
+def test_end_to_end_golden_waveform(g, small):
+    """audio + text in, waveform out, against the reference chain (noise injected)."""
+    cfg, st, eng = small
+    N = int(g["pre_N"])
+    w = eng.synthesize(g["pre_audio"][None], g["pre_text_ids"][None], N, noise=g["dit_noise"][None])
+    assert w.shape == (1, 1, g["e2e_i16"].shape[0])
+    err = rms((w[0, 0].astype(np.float64) - g["e2e_i16"].astype(np.float64)) / 32767.0)
+    assert err < 5e-4, err                                                      # north-star gate: 1e-3
+    assert rms(g["e2e_i16"]) > 500
+
+
+@pytest.mark.parametrize("dtype,gate", [("bf16", 3e-2), ("f16", 1e-2)])
+def test_end_to_end_lowp(g, dtype, gate):
+    cfg = F5Config.small()
+    eng = F5Engine(cfg, W.synth_state(W.f5_spec(cfg), 9527), dtype=dtype)
+    N = int(g["pre_N"])
+    w = eng.synthesize(g["pre_audio"][None], g["pre_text_ids"][None], N, noise=g["dit_noise"][None])
+    err = rms((w[0, 0].astype(np.float64) - g["e2e_i16"].astype(np.float64)) / 32767.0)
+    assert err < gate, err
+    eng.close()
+
+
+def test_attention_against_oracle_ragged_lengths(small):
+    """N not a multiple of the 64-key stage / 128-query tile; heads > 2 via a wider reduced model."""
+    cfg = F5Config(dim=256, depth=1, heads=4, dim_head=64, text_dim=64, text_num_embeds=40, conv_layers=1,
+                   pos_conv_groups=4, vocos_dim=64, vocos_intermediate=128, vocos_layers=1, nfe_step=4)
+    raw = W.synth_state(W.f5_spec(cfg), 7)
+    st = W.fold_f5(cfg, raw)
+    eng = F5Engine(cfg, raw, dtype="f32")
+    tables = O.time_tables(cfg, st)
+    for N in (67, 130, 257):
+        noise = W.synth_normal(3, f"n{N}", (N, cfg.mel_dim))
+        cmt = W.synth_normal(4, f"c{N}", (N, cfg.mel_dim + cfg.text_dim), std=0.7)
+        cmtd = W.synth_normal(5, f"d{N}", (N, cfg.mel_dim + cfg.text_dim), std=0.7)
+        cos, sin = O.rope_tables(N, 64)
+        ref = O.dit_forward(cfg, st, noise, cmt, cmtd, tables[2][1], cos, sin)
+        pred = eng.dit_eval(noise[None], cmt[None], cmtd[None], 1)
+        np.testing.assert_allclose(pred, ref, atol=3e-4)
+    eng.close()
+
+
+def test_bad_arguments(small):
+    cfg, st, eng = small
+    with pytest.raises(ValueError):
+        eng.decode(np.zeros((1, 10, cfg.mel_dim + 1), np.float32), 3)
+    from mi355tts._lib import MiError
+    with pytest.raises(MiError):                       # max_duration shorter than the reference audio
+        eng.preprocess(np.zeros(8192, np.int16), np.zeros(4, np.int32), 8)
+    with pytest.raises(MiError):                       # text id outside the embedding table
+        eng.preprocess(np.zeros(8192, np.int16), np.full(4, 10 ** 6, np.int32), 60)

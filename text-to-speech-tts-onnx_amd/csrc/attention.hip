@@ -1,0 +1,208 @@
+// attention.hip — flash-style attention for the DiT blocks on gfx950 MFMA.
+//
+// Reference: AttnProcessor.__call__ (F5_TTS/modeling_modified/F5/modules.py:467):
+//     softmax(q @ k, dim=-1, dtype=float32) @ v      — no mask, no 1/sqrt(d) (folded into W_q, W_k).
+// The reference materialises the (2,16,N,N) logits; here K/V stream through LDS in 64-key stages and
+// the softmax is online (running max / sum in fp32), so HBM traffic is q,k,v,o only.
+//
+// Tiling (wave64, 32x32 MFMA tiles, head_dim = 64):
+//   workgroup = 4 waves = 128 queries of one (batch, head); each wave owns 32 queries.
+//   S^T = K Q^T   (rows = keys, cols = queries): lane l holds query (l&31) and 16 of the 32 keys
+//                 [key kappa(r) = (r&3) + 8*(r>>2) + 4*(l>>5)], so a query's softmax statistics are
+//                 per-lane: 16 in-register values + ONE cross-lane exchange with lane^32.
+//   O^T = V^T P^T (rows = head-dim, cols = queries): the probabilities a lane holds are already in the
+//                 MFMA B-operand position (k = key, j = query) — keys are simply consumed in kappa
+//                 order, and V is fetched in that same order — no LDS round trip for P, and the
+//                 rescale factor exp(m_old - m_new) is again per-lane.
+//   fp32 : v_mfma_f32_32x32x2_f32 (exact fp32 products, K = 2 keys per instruction)
+//   f16/bf16 : v_mfma_f32_32x32x16 — V is staged transposed ([d][key]) so that the 8 keys a lane feeds
+//                 per instruction are two contiguous 8-byte LDS reads.
+#include "common.h"
+#include "mfma.h"
+#include "f5_kernels.h"
+
+namespace mi {
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                   const T* __restrict__ v, T* __restrict__ o, int H, int N) {
+    using MF = Mfma<T>;
+    constexpr int KP = MF::KP;
+    constexpr int D = 64, KT = 64;
+    constexpr int VEC = 16 / (int)sizeof(T);
+    constexpr int KS = D / (2 * KP);                       // MFMA k-steps over head_dim for S^T
+    constexpr int LDK = D + (sizeof(T) == 4 ? 1 : 8);
+    constexpr int LDV = sizeof(T) == 4 ? D : KT + 4;       // fp32: Vs[key][d] ; 16-bit: Vt[d][key]
+    constexpr int NV = KT * D / VEC / 256;                 // 16-byte vectors per thread per tile
+    __shared__ __attribute__((aligned(16))) T smem[KT * LDK + (sizeof(T) == 4 ? KT * D : D * LDV)];
+    T* Ks = smem;
+    T* Vs = smem + KT * LDK;
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, hi = lane >> 5;
+    const int bh = blockIdx.y;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const T* qb = q + (long)bh * N * D;
+    const T* kb = k + (long)bh * N * D;
+    const T* vb = v + (long)bh * N * D;
+
+    // ---- Q fragments (B operand of S^T): Q[q = q0+lr][d = ks*2KP + hi*KP ..] ------------------
+    typename MF::Frag qf[KS];
+    {
+        const int qr = q0 + lr;
+        const bool ok = qr < N;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if constexpr (KP == 1) {
+                qf[ks] = ok ? qb[(long)qr * D + 2 * ks + hi] : 0.f;
+            } else {
+                uint4 raw = make_uint4(0, 0, 0, 0);
+                if (ok) raw = *reinterpret_cast<const uint4*>(qb + (long)qr * D + ks * 16 + hi * 8);
+                qf[ks] = *reinterpret_cast<const typename MF::Frag*>(&raw);
+            }
+        }
+    }
+
+    uint4 kreg[NV], vreg[NV];
+    auto load_regs = [&](int key0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int vi = tid + i * 256;
+            const int key = vi / (D / VEC), dv = vi - key * (D / VEC);
+            uint4 a = make_uint4(0, 0, 0, 0), b = make_uint4(0, 0, 0, 0);
+            if (key0 + key < N) {
+                a = *reinterpret_cast<const uint4*>(kb + (long)(key0 + key) * D + dv * VEC);
+                b = *reinterpret_cast<const uint4*>(vb + (long)(key0 + key) * D + dv * VEC);
+            }
+            kreg[i] = a; vreg[i] = b;
+        }
+    };
+    auto store_lds = [&]() {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int vi = tid + i * 256;
+            const int key = vi / (D / VEC), dv = vi - key * (D / VEC);
+            if constexpr (sizeof(T) == 4) {
+                float* d = reinterpret_cast<float*>(Ks) + key * LDK + dv * VEC;
+                d[0] = __uint_as_float(kreg[i].x); d[1] = __uint_as_float(kreg[i].y);
+                d[2] = __uint_as_float(kreg[i].z); d[3] = __uint_as_float(kreg[i].w);
+                *reinterpret_cast<uint4*>(Vs + key * LDV + dv * VEC) = vreg[i];
+            } else {
+                *reinterpret_cast<uint4*>(Ks + key * LDK + dv * VEC) = kreg[i];
+                const T* e = reinterpret_cast<const T*>(&vreg[i]);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) Vs[(dv * VEC + j) * LDV + key] = e[j];      // transpose: Vt[d][key]
+            }
+        }
+    };
+
+    f32x16 oacc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.f; oacc[1][r] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int nstage = (N + KT - 1) / KT;
+    load_regs(0);
+    store_lds();
+    __syncthreads();
+    for (int st = 0; st < nstage; ++st) {
+        if (st + 1 < nstage) load_regs((st + 1) * KT);
+#pragma unroll
+        for (int kt = 0; kt < KT / 32; ++kt) {
+            const int key0 = st * KT + kt * 32;
+            if (key0 < N) {                                            // wave-uniform
+                // ---- S^T tile: 32 keys x 32 queries ----------------------------------------------
+                f32x16 sacc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const typename MF::Frag a =
+                        *reinterpret_cast<const typename MF::Frag*>(Ks + (kt * 32 + lr) * LDK + ks * 2 * KP + hi * KP);
+                    sacc = MF::mma(a, qf[ks], sacc);
+                }
+                // ---- online softmax (per lane = per query) -----------------------------------------
+                float mloc = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (key >= N) sacc[r] = -INFINITY;
+                    mloc = fmaxf(mloc, sacc[r]);
+                }
+                mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+                const float m_new = fmaxf(m_run, mloc);
+                const float alpha = expf(m_run - m_new);
+                float p[16], lsum = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { p[r] = expf(sacc[r] - m_new); lsum += p[r]; }
+                lsum += __shfl_xor(lsum, 32);
+                l_run = l_run * alpha + lsum;
+                m_run = m_new;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
+                // ---- O^T += V^T P^T ------------------------------------------------------------------
+                if constexpr (KP == 1) {
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) {
+                        const int kk = kt * 32 + (s & 3) + 8 * (s >> 2) + 4 * hi;
+#pragma unroll
+                        for (int dt = 0; dt < 2; ++dt)
+                            oacc[dt] = MF::mma(reinterpret_cast<const float*>(Vs)[kk * LDV + dt * 32 + lr], p[s], oacc[dt]);
+                    }
+                } else {
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        T pb[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) pb[e] = from_f32<T>(p[8 * s2 + e]);
+                        const typename MF::Frag bfrag = *reinterpret_cast<const typename MF::Frag*>(pb);
+#pragma unroll
+                        for (int dt = 0; dt < 2; ++dt) {
+                            const T* row = Vs + (dt * 32 + lr) * LDV + kt * 32 + 16 * s2 + 4 * hi;
+                            uint2 a2[2];
+                            a2[0] = *reinterpret_cast<const uint2*>(row);
+                            a2[1] = *reinterpret_cast<const uint2*>(row + 8);
+                            oacc[dt] = MF::mma(*reinterpret_cast<const typename MF::Frag*>(a2), bfrag, oacc[dt]);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (st + 1 < nstage) {
+            store_lds();
+            __syncthreads();
+        }
+    }
+
+    // ---- normalise + store o[b][n][h*64 + d] ---------------------------------------------------------
+    const int qr = q0 + lr;
+    if (qr < N) {
+        const float inv = 1.0f / l_run;
+        const int b = bh / H, h = bh - b * H;
+        T* ob = o + ((long)b * N + qr) * H * D + h * D;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                T vals[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) vals[e] = from_f32<T>(oacc[dt][g * 4 + e] * inv);
+                T* dst = ob + dt * 32 + 8 * g + 4 * hi;
+                if constexpr (sizeof(T) == 4) *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(vals);
+                else *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(vals);
+            }
+    }
+}
+
+void launch_attention(const void* q, const void* k, const void* v, void* o, int BH, int H, int N, int dtype, hipStream_t s) {
+    MI_REQUIRE(BH % H == 0 && N > 0, "attention: bad shape");
+    dim3 grid((N + 127) / 128, BH);
+    const double esz = (double)dtype_size(dtype);
+    ProfScope ps(FAM_ATTN, s, 4.0 * BH * N * 64.0 * esz, 4.0 * BH * (double)N * N * 64.0);
+    if (dtype == MI_F32) hipLaunchKernelGGL(attn_kernel<float>, grid, dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N);
+    else if (dtype == MI_F16) hipLaunchKernelGGL(attn_kernel<f16>, grid, dim3(256), 0, s, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)o, H, N);
+    else hipLaunchKernelGGL(attn_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, H, N);
+    MI_HIP(hipGetLastError());
+}
+
+}  // namespace mi

@@ -1,10 +1,12 @@
 // capi.hip — extern "C" boundary of libmi355tts.so (declarations: include/mi355tts.h).
 #include "common.h"
 #include "bigvgan.h"
+#include "f5.h"
 
 using namespace mi;
 
 struct mi_bigvgan { BigVGAN* impl; };
+struct mi_f5 { F5* impl; };
 
 template <typename F> static int guard(F&& f) {
     try {
@@ -112,6 +114,150 @@ int mi_conv_transpose1d(const float* x, int B, int Cin, int T, const float* w, c
     return guard([&] {
         MI_REQUIRE(x && w && y && B > 0 && Cin > 0 && Cout > 0 && T > 0, "mi_conv_transpose1d: bad arguments");
         unit_conv_transpose1d(x, B, Cin, T, w, bias, Cout, k, stride, padding, dtype, y);
+    });
+}
+
+// ---------------------------------------------------------------------------------------------------
+// F5-TTS
+// ---------------------------------------------------------------------------------------------------
+int64_t mi_f5_param_count(const int32_t* cfg_i, int n_i, const float* cfg_f, int n_f) {
+    int64_t n = -1;
+    int rc = guard([&] { n = f5_param_count(parse_f5_cfg(cfg_i, n_i, cfg_f, n_f)); });
+    return rc == MI_OK ? n : (int64_t)rc;
+}
+
+mi_f5* mi_f5_create(const int32_t* cfg_i, int n_i, const float* cfg_f, int n_f, const float* weights, int64_t n_weights,
+                    int dtype, int device) {
+    mi_f5* h = nullptr;
+    int rc = guard([&] {
+        MI_REQUIRE(weights != nullptr, "mi_f5_create: null weights");
+        F5Cfg c = parse_f5_cfg(cfg_i, n_i, cfg_f, n_f);
+        h = new mi_f5{new F5(c, weights, n_weights, dtype, device)};
+    });
+    return rc == MI_OK ? h : nullptr;
+}
+
+void mi_f5_destroy(mi_f5* h) {
+    if (!h) return;
+    delete h->impl;
+    delete h;
+}
+
+#define F5_CHECK(h, mem, name)                                                     \
+    MI_REQUIRE((h) && (h)->impl, name ": null handle");                            \
+    MI_REQUIRE((mem) == MI_HOST || (mem) == MI_DEVICE, name ": bad mem kind")
+
+static void copy_out(void* dst, const void* src, size_t bytes, int mem, hipStream_t s) {
+    if (!dst) return;
+    MI_HIP(hipMemcpyAsync(dst, src, bytes, mem == MI_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, s));
+}
+
+int mi_f5_tables(mi_f5* h, float* time_expand, float* delta_t) {
+    return guard([&] {
+        MI_REQUIRE(h && h->impl, "mi_f5_tables: null handle");
+        F5& e = *h->impl;
+        if (time_expand) std::memcpy(time_expand, e.h_time_expand.data(), e.h_time_expand.size() * 4);
+        if (delta_t) std::memcpy(delta_t, e.h_delta.data(), e.h_delta.size() * 4);
+    });
+}
+
+int mi_f5_preprocess(mi_f5* h, const int16_t* audio, int64_t L, const int32_t* text_ids, int64_t T, int64_t max_duration,
+                     const float* noise_in, uint64_t seed, float* noise, float* rope_cos, float* rope_sin,
+                     float* cat_mel_text, float* cat_mel_text_drop, int64_t* ref_signal_len, int mem) {
+    return guard([&] {
+        F5_CHECK(h, mem, "mi_f5_preprocess");
+        F5& e = *h->impl;
+        MI_REQUIRE(max_duration > 0 && max_duration <= e.cfg.max_len && T >= 0 && T < (1 << 20) && L > 0 && L < (1L << 31),
+                   "mi_f5_preprocess: sizes");
+        const int N = (int)max_duration;
+        const int R = e.preprocess(0, 1, audio, L, text_ids, (int)T, N, noise_in, seed, mem);
+        hipStream_t s = e.stream;
+        const size_t cd = e.cfg.cond_dim(), D = e.cfg.dim_head;
+        copy_out(noise, e.d_noise.p, (size_t)N * e.cfg.mel * 4, mem, s);
+        copy_out(rope_cos, e.rope_cos.p, (size_t)N * D * 4, mem, s);
+        copy_out(rope_sin, e.rope_sin.p, (size_t)N * D * 4, mem, s);
+        copy_out(cat_mel_text, e.d_cmt.p, (size_t)N * cd * 4, mem, s);
+        copy_out(cat_mel_text_drop, e.d_cmtd.p, (size_t)N * cd * 4, mem, s);
+        MI_HIP(hipStreamSynchronize(s));
+        if (ref_signal_len) *ref_signal_len = R;
+    });
+}
+
+int mi_f5_transformer_step(mi_f5* h, float* noise, const float* cmt, const float* cmtd, int U, int64_t N,
+                           int32_t* time_step, int fuse, int mem) {
+    return guard([&] {
+        F5_CHECK(h, mem, "mi_f5_transformer_step");
+        MI_REQUIRE(noise && cmt && cmtd && time_step && fuse >= 1 && U >= 1 && N > 0, "mi_f5_transformer_step: bad arguments");
+        F5& e = *h->impl;
+        e.load_cond(noise, cmt, cmtd, U, (int)N, mem);
+        e.build_cat_cond(U, (int)N);
+        e.steps(U, (int)N, *time_step, fuse);
+        copy_out(noise, e.d_noise.p, (size_t)U * N * e.cfg.mel * 4, mem, e.stream);
+        MI_HIP(hipStreamSynchronize(e.stream));
+        *time_step += fuse;
+    });
+}
+
+int mi_f5_sample(mi_f5* h, float* noise, const float* cmt, const float* cmtd, int U, int64_t N, int k0, int n_steps, int mem) {
+    return guard([&] {
+        F5_CHECK(h, mem, "mi_f5_sample");
+        MI_REQUIRE(noise && cmt && cmtd && U >= 1 && N > 0, "mi_f5_sample: bad arguments");
+        F5& e = *h->impl;
+        e.load_cond(noise, cmt, cmtd, U, (int)N, mem);
+        e.build_cat_cond(U, (int)N);
+        e.steps(U, (int)N, k0, n_steps);
+        copy_out(noise, e.d_noise.p, (size_t)U * N * e.cfg.mel * 4, mem, e.stream);
+        MI_HIP(hipStreamSynchronize(e.stream));
+    });
+}
+
+int mi_f5_dit_eval(mi_f5* h, const float* noise, const float* cmt, const float* cmtd, int U, int64_t N, int k, float* pred, int mem) {
+    return guard([&] {
+        F5_CHECK(h, mem, "mi_f5_dit_eval");
+        MI_REQUIRE(noise && cmt && cmtd && pred && U >= 1 && N > 0, "mi_f5_dit_eval: bad arguments");
+        F5& e = *h->impl;
+        e.load_cond(noise, cmt, cmtd, U, (int)N, mem);
+        e.build_cat_cond(U, (int)N);
+        e.dit_eval(U, (int)N, k);
+        copy_out(pred, e.pred.p, (size_t)2 * U * N * e.cfg.mel * 4, mem, e.stream);
+        MI_HIP(hipStreamSynchronize(e.stream));
+    });
+}
+
+int mi_f5_decode(mi_f5* h, const float* denoised, int U, int64_t N, int64_t ref_signal_len, int16_t* out, float* out_f32,
+                 int64_t* out_len, int mem) {
+    return guard([&] {
+        F5_CHECK(h, mem, "mi_f5_decode");
+        MI_REQUIRE(denoised && (out || out_f32) && U >= 1 && N > 0 && ref_signal_len >= 0 && ref_signal_len < N,
+                   "mi_f5_decode: bad arguments");
+        F5& e = *h->impl;
+        e.load_cond(denoised, nullptr, nullptr, U, (int)N, mem);
+        const long len = e.decode(e.d_noise.as<float>(), U, (int)N, (int)ref_signal_len, out_f32 ? e.v_outf.as<float>() : nullptr,
+                                  out ? e.v_outi.as<int16_t>() : nullptr);
+        copy_out(out, e.v_outi.p, (size_t)U * len * 2, mem, e.stream);
+        copy_out(out_f32, e.v_outf.p, (size_t)U * len * 4, mem, e.stream);
+        MI_HIP(hipStreamSynchronize(e.stream));
+        if (out_len) *out_len = len;
+    });
+}
+
+int mi_f5_synthesize(mi_f5* h, int U, const int16_t* audio, int64_t L, const int32_t* text_ids, int64_t T,
+                     int64_t max_duration, const float* noise_in, uint64_t seed, int16_t* out, int64_t* out_len, int mem) {
+    return guard([&] {
+        F5_CHECK(h, mem, "mi_f5_synthesize");
+        MI_REQUIRE(audio && text_ids && out && U >= 1 && max_duration > 0, "mi_f5_synthesize: bad arguments");
+        F5& e = *h->impl;
+        const int N = (int)max_duration;
+        int R = 0;
+        for (int u = 0; u < U; ++u)
+            R = e.preprocess(u, U, audio + (size_t)u * L, L, text_ids + (size_t)u * T, (int)T, N,
+                             noise_in ? noise_in + (size_t)u * N * e.cfg.mel : nullptr, seed, mem);
+        e.build_cat_cond(U, N);
+        e.steps(U, N, 0, e.cfg.nfe - 1);
+        const long len = e.decode(e.d_noise.as<float>(), U, N, R, nullptr, e.v_outi.as<int16_t>());
+        copy_out(out, e.v_outi.p, (size_t)U * len * 2, mem, e.stream);
+        MI_HIP(hipStreamSynchronize(e.stream));
+        if (out_len) *out_len = len;
     });
 }
 

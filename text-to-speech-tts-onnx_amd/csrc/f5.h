@@ -1,0 +1,69 @@
+// f5.h — F5-TTS engine object: DiT flow-matching sampler + text/mel front-end + Vocos/ISTFT back-end.
+#pragma once
+#include "common.h"
+#include "f5_kernels.h"
+
+namespace mi {
+
+struct F5Cfg {
+    int dim, depth, heads, dim_head, ff_mult, mel, text_dim, vocab, conv_layers, conv_mult, pos_k, pos_g, freq_dim,
+        nfe, max_len, n_fft, hop, sr, vd, vi, vlayers;
+    float cfg_strength, sway;
+    int ff() const { return dim * ff_mult; }
+    int nb() const { return n_fft / 2 + 1; }
+    int cat_dim() const { return 2 * mel + text_dim; }     // x | mel | text
+    int cond_dim() const { return mel + text_dim; }        // cat_mel_text width
+};
+F5Cfg parse_f5_cfg(const int32_t* ci, int ni, const float* cf, int nf);
+int64_t f5_param_count(const F5Cfg& c);
+
+struct Lin { DevBuf w, b; int n = 0, k = 0; };
+
+struct F5 {
+    F5Cfg cfg;
+    int dtype, device;
+    hipStream_t stream = nullptr;
+
+    // ---- DiT (engine dtype) ----
+    Lin in_proj, gconv1, gconv2, proj_out;
+    struct Block { Lin qkv, o, ff1, ff2; };
+    std::vector<Block> blocks;
+    DevBuf mod;             // fp32 [nfe][depth*6d + 2d]  AdaLN modulation, hoisted out of the loop
+    long mod_ld = 0;
+    DevBuf delta_t;         // fp32 [nfe-1]
+    DevBuf rope_cos, rope_sin;   // fp32 [max_len][dim_head] (rounded through fp16 like the export)
+    std::vector<float> h_time_expand, h_delta;
+
+    // ---- front end (fp32) ----
+    DevBuf text_emb, text_pos, stft_w, fbank;
+    struct TextBlock { DevBuf dw_w, dw_b, ln_w, ln_b, grn_g, grn_b; Lin pw1, pw2; };
+    std::vector<TextBlock> tblocks;
+
+    // ---- Vocos + ISTFT (fp32) ----
+    Lin v_embed, v_head, istft;
+    DevBuf v_norm_w, v_norm_b, v_fnorm_w, v_fnorm_b, wsi;
+    struct VBlock { DevBuf dw_w, dw_b, n_w, n_b; Lin pw1, pw2; };
+    std::vector<VBlock> vblocks;
+
+    // ---- workspace ----
+    int ws_U = 0, ws_N = 0;
+    DevBuf d_noise, d_cmt, d_cmtd, cat, h32, hT, c1, X, Ub, qb, kb, vb, Ob, Hff, pred;
+    DevBuf p_audio, p_pad, p_spec, p_mag, p_mel, p_ids, p_tx, p_ty, p_ty2, p_ss;
+    DevBuf v_h, v_z, v_z2, v_s, v_c, v_fr, v_outf, v_outi;
+
+    F5(const F5Cfg& c, const float* w, int64_t nw, int dt, int dev);
+    ~F5();
+    void ensure_workspace(int U, int N);
+    void gemm(int dt, const void* x, long xb, long xr, int K, const Lin& L, void* out, int odt, long ob, long orr,
+              int B, int M, int act = ACT_NONE, const void* res = nullptr, const float* gate = nullptr);
+    // fills d_noise[u], d_cmt[u], d_cmtd[u]; returns ref_signal_len
+    int preprocess(int u, int U, const int16_t* audio, long L, const int32_t* text_ids, int T, int N,
+                   const float* noise_in, uint64_t seed, int mem);
+    void load_cond(const float* noise, const float* cmt, const float* cmtd, int U, int N, int mem);
+    void build_cat_cond(int U, int N);
+    void dit_eval(int U, int N, int k);                 // pred <- DiT(noise, cond, t_k)
+    void steps(int U, int N, int k0, int nsteps);       // Euler/CFG updates k0 .. k0+nsteps-1 (in d_noise)
+    long decode(const float* denoised_dev, int U, int N, int R, float* out_f, int16_t* out_i);  // device outputs
+};
+
+}  // namespace mi

@@ -1,0 +1,536 @@
+// f5.hip — F5-TTS on gfx950: weight packing, load-time tables and the three launch sequences
+// (preprocess / sampler / decode) that stand in for the reference's three ONNX graphs.
+//
+//   preprocess  = F5Preprocess.forward   F5_TTS/Export_F5.py:117-141
+//   dit_eval    = DiT.forward            F5_TTS/modeling_modified/F5/dit.py:205-220
+//   steps       = F5Transformer.forward  F5_TTS/Export_F5.py:167-182   (x nfe-1, all on device)
+//   decode      = F5Decode.forward       F5_TTS/Export_F5.py:193-203
+//
+// Device-resident state: noise (fp32), conditioning (fp32 master + dtype copy inside the `cat`
+// GEMM operand), the residual stream X (always fp32), and per-layer operands in the engine dtype.
+// Everything that does not depend on the sample is hoisted to load time: time-MLP table, AdaLN
+// modulation for all (step, block) pairs, RoPE tables, STFT / mel / ISTFT bases.
+// Batching: U utterances of equal length N are laid out as batch 2U (2u = cond, 2u+1 = uncond).
+#include "f5.h"
+
+namespace mi {
+
+static int rup(int a, int b) { return (a + b - 1) / b * b; }
+
+F5Cfg parse_f5_cfg(const int32_t* ci, int ni, const float* cf, int nf) {
+    MI_REQUIRE(ci && ni == 21 && cf && nf == 2, "f5 cfg: expected 21 ints + 2 floats");
+    F5Cfg c;
+    int i = 0;
+    c.dim = ci[i++]; c.depth = ci[i++]; c.heads = ci[i++]; c.dim_head = ci[i++]; c.ff_mult = ci[i++]; c.mel = ci[i++];
+    c.text_dim = ci[i++]; c.vocab = ci[i++]; c.conv_layers = ci[i++]; c.conv_mult = ci[i++]; c.pos_k = ci[i++];
+    c.pos_g = ci[i++]; c.freq_dim = ci[i++]; c.nfe = ci[i++]; c.max_len = ci[i++]; c.n_fft = ci[i++]; c.hop = ci[i++];
+    c.sr = ci[i++]; c.vd = ci[i++]; c.vi = ci[i++]; c.vlayers = ci[i++];
+    c.cfg_strength = cf[0]; c.sway = cf[1];
+    MI_REQUIRE(c.dim == c.heads * c.dim_head, "f5 cfg: dim != heads*dim_head");
+    MI_REQUIRE(c.dim_head == 64, "f5: the attention kernel is built for head_dim 64");
+    MI_REQUIRE(c.dim % 32 == 0 && c.dim <= 2048 && c.text_dim % 8 == 0 && c.mel % 4 == 0, "f5 cfg: widths");
+    MI_REQUIRE(c.dim % c.pos_g == 0 && (c.dim / c.pos_g) % 8 == 0 && c.pos_k % 2 == 1, "f5 cfg: pos conv");
+    MI_REQUIRE(c.nfe >= 2 && c.nfe <= 1024 && c.max_len >= 16 && c.depth > 0, "f5 cfg: sampler");
+    MI_REQUIRE(c.n_fft % 8 == 0 && c.n_fft % c.hop == 0 && c.vd % 4 == 0 && c.vi % 4 == 0 && c.vd <= 2048, "f5 cfg: vocoder");
+    MI_REQUIRE(c.freq_dim % 2 == 0 && c.conv_mult >= 1 && c.text_dim * c.conv_mult <= 4096, "f5 cfg: text");
+    return c;
+}
+
+int64_t f5_param_count(const F5Cfg& c) {
+    const int64_t d = c.dim, td = c.text_dim, ff = c.ff(), ti = td * c.conv_mult, cin = c.cat_dim();
+    int64_t n = d * c.freq_dim + d + d * d + d;
+    n += (int64_t)(c.vocab + 1) * td;
+    n += (int64_t)c.conv_layers * (td * 7 + td + td + td + ti * td + ti + ti + ti + td * ti + td);
+    n += d * cin + d + 2 * (d * (d / c.pos_g) * c.pos_k + d);
+    n += (int64_t)c.depth * (6 * d * d + 6 * d + 4 * (d * d + d) + ff * d + ff + d * ff + d);
+    n += 2 * d * d + 2 * d + (int64_t)c.mel * d + c.mel;
+    const int64_t vd = c.vd, vi = c.vi;
+    n += vd * c.mel * 7 + vd + 2 * vd;
+    n += (int64_t)c.vlayers * (vd * 7 + vd + 2 * vd + vi * vd + vi + vd * vi + vd);
+    n += 2 * vd + (int64_t)(c.n_fft + 2) * vd + (c.n_fft + 2);
+    return n;
+}
+
+static void up_lin(Lin& L, const float* w, const float* b, int n, int k, int dt, hipStream_t s) {
+    L.n = n; L.k = k;
+    upload_as(L.w, w, (size_t)n * k, dt, s);
+    if (b) upload_f32(L.b, b, n, s);
+}
+// Conv1d weight (Co, Ci, k) -> [co][tap][ci]
+static std::vector<float> relayout(const float* w, int Co, int Ci, int k) {
+    std::vector<float> o((size_t)Co * k * Ci);
+    for (int co = 0; co < Co; ++co)
+        for (int ci = 0; ci < Ci; ++ci)
+            for (int j = 0; j < k; ++j) o[((size_t)co * k + j) * Ci + ci] = w[((size_t)co * Ci + ci) * k + j];
+    return o;
+}
+static inline float siluf(float v) { return v / (1.f + expf(-v)); }
+static inline float round_f16(float v) { return (float)(f16)v; }
+
+F5::F5(const F5Cfg& c, const float* w, int64_t nw, int dt, int dev) : cfg(c), dtype(dt), device(dev) {
+    MI_REQUIRE(dt == MI_F32 || dt == MI_F16 || dt == MI_BF16, "f5: bad dtype");
+    MI_REQUIRE(nw == f5_param_count(c), "f5: weight blob size does not match the config");
+    MI_HIP(hipSetDevice(dev));
+    MI_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    hipStream_t s = stream;
+    const int d = c.dim, td = c.text_dim, ff = c.ff(), ti = td * c.conv_mult, cin = c.cat_dim();
+    const float* p = w;
+    auto take = [&](size_t n) { const float* r = p; p += n; return r; };
+
+    // ---- time MLP table (Export_F5.py:145-165), host fp32 -------------------------------------------
+    const float* tw0 = take((size_t)d * c.freq_dim); const float* tb0 = take(d);
+    const float* tw2 = take((size_t)d * d); const float* tb2 = take(d);
+    const int steps = c.nfe, half = c.freq_dim / 2;
+    std::vector<float> ts(steps);
+    for (int i = 0; i < steps; ++i) {
+        const float t = (float)i / (float)(steps - 1);
+        ts[i] = t + c.sway * (cosf(3.14159265358979323846f * 0.5f * t) - 1.f + t);
+    }
+    h_delta.resize(steps - 1);
+    for (int i = 0; i + 1 < steps; ++i) h_delta[i] = ts[i + 1] - ts[i];
+    upload_f32(delta_t, h_delta.data(), steps - 1, s);
+    h_time_expand.assign((size_t)steps * d, 0.f);
+    {
+        const float ef = logf(10000.f) / (float)(half - 1);
+        std::vector<float> emb(c.freq_dim), hid(d);
+        for (int i = 0; i < steps; ++i) {
+            for (int j = 0; j < half; ++j) {
+                const float a = ts[i] * (1000.0f * expf((float)j * -ef));
+                emb[j] = sinf(a); emb[half + j] = cosf(a);
+            }
+            for (int o = 0; o < d; ++o) {
+                float acc = tb0[o];
+                for (int j = 0; j < c.freq_dim; ++j) acc += tw0[(size_t)o * c.freq_dim + j] * emb[j];
+                hid[o] = siluf(acc);
+            }
+            for (int o = 0; o < d; ++o) {
+                float acc = tb2[o];
+                for (int j = 0; j < d; ++j) acc += tw2[(size_t)o * d + j] * hid[j];
+                h_time_expand[(size_t)i * d + o] = acc;
+            }
+        }
+    }
+    // ---- text embedding -----------------------------------------------------------------------------
+    upload_f32(text_emb, take((size_t)(c.vocab + 1) * td), (size_t)(c.vocab + 1) * td, s);
+    {   // precompute_freqs_cis(text_dim, max_len) (modules.py:196-207)
+        std::vector<float> pos((size_t)c.max_len * td);
+        std::vector<float> fr(td / 2);
+        for (int j = 0; j < td / 2; ++j) fr[j] = 1.0f / powf(10000.0f, (float)(2 * j) / (float)td);
+        for (int n = 0; n < c.max_len; ++n)
+            for (int j = 0; j < td / 2; ++j) {
+                const float a = (float)n * fr[j];
+                pos[(size_t)n * td + j] = cosf(a); pos[(size_t)n * td + td / 2 + j] = sinf(a);
+            }
+        upload_f32(text_pos, pos.data(), pos.size(), s);
+    }
+    tblocks.resize(c.conv_layers);
+    for (auto& tb : tblocks) {
+        upload_f32(tb.dw_w, take((size_t)td * 7), (size_t)td * 7, s);
+        upload_f32(tb.dw_b, take(td), td, s);
+        upload_f32(tb.ln_w, take(td), td, s);
+        upload_f32(tb.ln_b, take(td), td, s);
+        const float* w1 = take((size_t)ti * td); const float* b1 = take(ti);
+        up_lin(tb.pw1, w1, b1, ti, td, MI_F32, s);
+        upload_f32(tb.grn_g, take(ti), ti, s);
+        upload_f32(tb.grn_b, take(ti), ti, s);
+        const float* w2 = take((size_t)td * ti); const float* b2 = take(td);
+        up_lin(tb.pw2, w2, b2, td, ti, MI_F32, s);
+    }
+    // ---- input embedding -------------------------------------------------------------------------------
+    {
+        const float* pw = take((size_t)d * cin); const float* pb = take(d);
+        up_lin(in_proj, pw, pb, d, cin, dt, s);
+        const int cg = d / c.pos_g;
+        const float* w1 = take((size_t)d * cg * c.pos_k); const float* b1 = take(d);
+        auto r1 = relayout(w1, d, cg, c.pos_k);
+        up_lin(gconv1, r1.data(), b1, d, cg * c.pos_k, dt, s);
+        const float* w2 = take((size_t)d * cg * c.pos_k); const float* b2 = take(d);
+        auto r2 = relayout(w2, d, cg, c.pos_k);
+        up_lin(gconv2, r2.data(), b2, d, cg * c.pos_k, dt, s);
+    }
+    // ---- DiT blocks + hoisted AdaLN modulation table -------------------------------------------------
+    mod_ld = (long)c.depth * 6 * d + 2 * d;
+    mod.ensure((size_t)steps * mod_ld * 4);
+    DevBuf d_silu_t, d_tmpw, d_tmpb;
+    {
+        std::vector<float> st(h_time_expand.size());
+        for (size_t i = 0; i < st.size(); ++i) st[i] = siluf(h_time_expand[i]);
+        upload_f32(d_silu_t, st.data(), st.size(), s);
+    }
+    auto mod_gemm = [&](const float* mw, const float* mb, int n, long col) {
+        upload_f32(d_tmpw, mw, (size_t)n * d, s);
+        upload_f32(d_tmpb, mb, n, s);
+        ConvGemm g;
+        g.dtype = MI_F32; g.x = d_silu_t.p; g.w = d_tmpw.p; g.bias = d_tmpb.as<float>(); g.out = mod.as<float>() + col;
+        g.B = 1; g.T_in = steps; g.M = steps; g.N = n; g.Cin = d; g.x_rstride = d; g.x_bstride = (long)steps * d;
+        g.out_rstride = mod_ld; g.out_bstride = (long)steps * mod_ld;
+        launch_conv_gemm(g, s);
+        MI_HIP(hipStreamSynchronize(s));
+    };
+    blocks.resize(c.depth);
+    for (int i = 0; i < c.depth; ++i) {
+        Block& bk = blocks[i];
+        const float* mw = take((size_t)6 * d * d); const float* mb = take((size_t)6 * d);
+        mod_gemm(mw, mb, 6 * d, (long)i * 6 * d);
+        std::vector<float> wq((size_t)3 * d * d), bq((size_t)3 * d);
+        for (int t3 = 0; t3 < 3; ++t3) {
+            std::memcpy(&wq[(size_t)t3 * d * d], take((size_t)d * d), (size_t)d * d * 4);
+            std::memcpy(&bq[(size_t)t3 * d], take(d), (size_t)d * 4);
+        }
+        up_lin(bk.qkv, wq.data(), bq.data(), 3 * d, d, dt, s);
+        const float* wo = take((size_t)d * d); const float* bo = take(d);
+        up_lin(bk.o, wo, bo, d, d, dt, s);
+        const float* w1 = take((size_t)ff * d); const float* b1 = take(ff);
+        up_lin(bk.ff1, w1, b1, ff, d, dt, s);
+        const float* w2 = take((size_t)d * ff); const float* b2 = take(d);
+        up_lin(bk.ff2, w2, b2, d, ff, dt, s);
+    }
+    {
+        const float* mw = take((size_t)2 * d * d); const float* mb = take((size_t)2 * d);
+        mod_gemm(mw, mb, 2 * d, (long)c.depth * 6 * d);
+        const float* pw = take((size_t)c.mel * d); const float* pb = take(c.mel);
+        up_lin(proj_out, pw, pb, c.mel, d, dt, s);
+    }
+    // ---- RoPE tables, rounded through fp16 (Export_F5.py:107-112) --------------------------------------
+    {
+        const int D = c.dim_head;
+        std::vector<float> rc((size_t)c.max_len * D), rs((size_t)c.max_len * D);
+        for (int n = 0; n < c.max_len; ++n)
+            for (int j = 0; j < D / 2; ++j) {
+                const float inv = 1.0f / powf(10000.0f, (float)(2 * j) / (float)D);
+                const float a = (float)n * inv;
+                const float cc = round_f16(cosf(a)), ss = round_f16(sinf(a));
+                rc[(size_t)n * D + 2 * j] = rc[(size_t)n * D + 2 * j + 1] = cc;
+                rs[(size_t)n * D + 2 * j] = rs[(size_t)n * D + 2 * j + 1] = ss;
+            }
+        upload_f32(rope_cos, rc.data(), rc.size(), s);
+        upload_f32(rope_sin, rs.data(), rs.size(), s);
+    }
+    // ---- STFT kernels (STFT_Process.py:86-98; fp32 evaluation order of torch) + HTK mel fbank ---------
+    {
+        const int nf = c.n_fft, nb = c.nb();
+        std::vector<float> win(nf);
+        const float wstep = (float)(2.0 * M_PI / nf);
+        for (int n = 0; n < nf; ++n) win[n] = cosf((float)n * wstep) * -0.5f + 0.5f;      // torch.hann_window (periodic)
+        std::vector<float> sw((size_t)2 * nb * nf);
+        const float two_pi = (float)(2.0 * M_PI);
+        for (int f = 0; f < nb; ++f)
+            for (int t = 0; t < nf; ++t) {
+                const float om = ((two_pi * (float)f) * (float)t) / (float)nf;
+                sw[(size_t)f * nf + t] = cosf(om) * win[t];
+                sw[(size_t)(nb + f) * nf + t] = -sinf(om) * win[t];
+            }
+        upload_f32(stft_w, sw.data(), sw.size(), s);
+        // melscale_fbanks(nb, 0, sr/2, mel, sr, None, 'htk') -> stored [mel][ldm] zero padded
+        const int ldm = rup(nb, 8);
+        std::vector<float> fb((size_t)c.mel * ldm, 0.f);
+        const double m_min = 0.0, m_max = 2595.0 * std::log10(1.0 + (c.sr / 2) / 700.0);
+        std::vector<double> fpts(c.mel + 2);
+        for (int i = 0; i < c.mel + 2; ++i) {
+            const double m = m_min + (m_max - m_min) * i / (c.mel + 1);
+            fpts[i] = 700.0 * (std::pow(10.0, m / 2595.0) - 1.0);
+        }
+        for (int k = 0; k < nb; ++k) {
+            const double fr = (double)(c.sr / 2) * k / (nb - 1);
+            for (int m = 0; m < c.mel; ++m) {
+                const double down = (fr - fpts[m]) / (fpts[m + 1] - fpts[m]);
+                const double up = (fpts[m + 2] - fr) / (fpts[m + 2] - fpts[m + 1]);
+                fb[(size_t)m * ldm + k] = (float)std::max(0.0, std::min(down, up));
+            }
+        }
+        upload_f32(fbank, fb.data(), fb.size(), s);
+        // ISTFT basis, closed form of window * pinv(fourier_basis*n_fft/hop).T (STFT_Process.py:100-112):
+        // stored as GEMM weight [n = sample][r = coefficient], K padded to a multiple of 4.
+        const int kp = rup(2 * nb, 4);
+        std::vector<float> ib((size_t)nf * kp, 0.f);
+        for (int n = 0; n < nf; ++n)
+            for (int k = 0; k < nb; ++k) {
+                const double sc = ((k == 0 || k == nb - 1) ? 1.0 : 2.0) / nf * ((double)c.hop / nf) * (double)win[n];
+                const double ang = 2.0 * M_PI * (double)k * (double)n / nf;
+                ib[(size_t)n * kp + k] = (float)(sc * std::cos(ang));
+                ib[(size_t)n * kp + nb + k] = (float)(sc * -std::sin(ang));
+            }
+        istft.n = nf; istft.k = kp;
+        upload_f32(istft.w, ib.data(), ib.size(), s);
+        // window_sum_inv for max_len frames (STFT_Process.py:114-133), same fp32 accumulation order
+        const size_t wl = (size_t)nf + (size_t)c.hop * (c.max_len - 1);
+        std::vector<float> ws(wl, 0.f);
+        float wmax = 0.f;
+        for (int n = 0; n < nf; ++n) wmax = std::max(wmax, fabsf(win[n]));
+        std::vector<float> wsq(nf);
+        for (int n = 0; n < nf; ++n) { const float wn = win[n] / wmax; wsq[n] = wn * wn; }
+        for (int i = 0; i < c.max_len; ++i)
+            for (int n = 0; n < nf; ++n) ws[(size_t)i * c.hop + n] += wsq[n];
+        for (size_t i = 0; i < wl; ++i) ws[i] = (float)nf / (ws[i] * (float)c.hop + 1e-7f);
+        upload_f32(wsi, ws.data(), wl, s);
+    }
+    // ---- Vocos ----------------------------------------------------------------------------------------------
+    {
+        const int vd = c.vd, vi = c.vi;
+        const float* ew = take((size_t)vd * c.mel * 7); const float* eb = take(vd);
+        auto re = relayout(ew, vd, c.mel, 7);
+        up_lin(v_embed, re.data(), eb, vd, c.mel * 7, MI_F32, s);
+        upload_f32(v_norm_w, take(vd), vd, s); upload_f32(v_norm_b, take(vd), vd, s);
+        vblocks.resize(c.vlayers);
+        for (auto& vb_ : vblocks) {
+            upload_f32(vb_.dw_w, take((size_t)vd * 7), (size_t)vd * 7, s); upload_f32(vb_.dw_b, take(vd), vd, s);
+            upload_f32(vb_.n_w, take(vd), vd, s); upload_f32(vb_.n_b, take(vd), vd, s);
+            const float* w1 = take((size_t)vi * vd); const float* b1 = take(vi);
+            up_lin(vb_.pw1, w1, b1, vi, vd, MI_F32, s);
+            const float* w2 = take((size_t)vd * vi); const float* b2 = take(vd);
+            up_lin(vb_.pw2, w2, b2, vd, vi, MI_F32, s);
+        }
+        upload_f32(v_fnorm_w, take(vd), vd, s); upload_f32(v_fnorm_b, take(vd), vd, s);
+        const float* hw = take((size_t)(c.n_fft + 2) * vd); const float* hb = take(c.n_fft + 2);
+        up_lin(v_head, hw, hb, c.n_fft + 2, vd, MI_F32, s);
+    }
+    MI_REQUIRE(p - w == nw, "f5: weight walk mismatch");
+}
+
+F5::~F5() {
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+void F5::ensure_workspace(int U, int N) {
+    if (U <= ws_U && N <= ws_N) return;
+    const int Um = std::max(U, ws_U), Nm = std::max(N, ws_N);
+    const F5Cfg& c = cfg;
+    const size_t es = dtype_size(dtype);
+    const size_t rows = (size_t)2 * Um * Nm;
+    d_noise.ensure((size_t)Um * Nm * c.mel * 4);
+    d_cmt.ensure((size_t)Um * Nm * c.cond_dim() * 4);
+    d_cmtd.ensure((size_t)Um * Nm * c.cond_dim() * 4);
+    cat.ensure(rows * c.cat_dim() * es);
+    h32.ensure(rows * c.dim * 4); hT.ensure(rows * c.dim * es); c1.ensure(rows * c.dim * es);
+    X.ensure(rows * c.dim * 4); Ub.ensure(rows * c.dim * es);
+    qb.ensure(rows * c.dim * es); kb.ensure(rows * c.dim * es); vb.ensure(rows * c.dim * es); Ob.ensure(rows * c.dim * es);
+    Hff.ensure(rows * c.ff() * es);
+    pred.ensure(rows * c.mel * 4);
+    // preprocess temporaries (one utterance at a time)
+    const int ti = c.text_dim * c.conv_mult;
+    p_ids.ensure((size_t)Nm * 4);
+    p_tx.ensure((size_t)2 * Nm * c.text_dim * 4); p_ty.ensure((size_t)2 * Nm * c.text_dim * 4);
+    p_ty2.ensure((size_t)2 * Nm * ti * 4); p_ss.ensure((size_t)2 * ti * 4);
+    // decode temporaries
+    const size_t fr = (size_t)Um * Nm;
+    v_h.ensure(fr * c.vd * 4); v_z.ensure(fr * c.vd * 4); v_z2.ensure(fr * c.vi * 4);
+    v_s.ensure(fr * (c.n_fft + 2) * 4); v_c.ensure(fr * istft.k * 4); v_fr.ensure(fr * c.n_fft * 4);
+    v_outf.ensure(fr * c.hop * 4); v_outi.ensure(fr * c.hop * 2);
+    ws_U = Um; ws_N = Nm;
+}
+
+void F5::gemm(int dt, const void* x, long xb, long xr, int K, const Lin& L, void* out, int odt, long ob, long orr, int B,
+              int M, int act, const void* res, const float* gate) {
+    ConvGemm g;
+    g.dtype = dt; g.out_dtype = odt; g.x = x; g.w = L.w.p; g.bias = L.b.p ? L.b.as<float>() : nullptr; g.out = out;
+    g.res = res; g.gate = gate; g.gate_bstride = 0;
+    g.B = B; g.T_in = M; g.M = M; g.N = L.n; g.Cin = K; g.taps = 1;
+    g.x_bstride = xb; g.x_rstride = xr; g.out_bstride = ob; g.out_rstride = orr; g.act = act;
+    launch_conv_gemm(g, stream);
+}
+
+// counter-based N(0,1) for the case where the caller does not inject noise (the reference draws it inside
+// ORT graph A, Export_F5.py:131, which cannot be reproduced outside ORT anyway)
+static inline uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    uint64_t z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static void host_normal(float* out, size_t n, uint64_t seed) {
+    for (size_t i = 0; i < n; ++i) {
+        const uint64_t a = splitmix64(seed * 0x2545F4914F6CDD1Dull + 2 * i), b = splitmix64(seed * 0x2545F4914F6CDD1Dull + 2 * i + 1);
+        const double u1 = ((double)(a >> 11) + 1.0) / 9007199254740993.0, u2 = (double)(b >> 11) / 9007199254740992.0;
+        out[i] = (float)(std::sqrt(-2.0 * std::log(u1)) * std::cos(2.0 * M_PI * u2));
+    }
+}
+
+int F5::preprocess(int u, int U, const int16_t* audio, long L, const int32_t* text_ids, int T, int N,
+                   const float* noise_in, uint64_t seed, int mem) {
+    const F5Cfg& c = cfg;
+    MI_REQUIRE(audio && text_ids && L >= c.n_fft / 2 + 1 && T >= 0, "f5_preprocess: bad arguments");
+    const int R = (int)(L / c.hop) + 1;
+    MI_REQUIRE(N >= R && N >= T && N <= c.max_len, "f5_preprocess: max_duration must be >= ref frames, >= text length and <= max_signal_length");
+    MI_HIP(hipSetDevice(device));
+    ensure_workspace(U, N);
+    hipStream_t s = stream;
+    const int nf = c.n_fft, nb = c.nb(), ldm = rup(nb, 8), cd = c.cond_dim();
+    float* cmt = d_cmt.as<float>() + (size_t)u * N * cd;
+    float* cmtd = d_cmtd.as<float>() + (size_t)u * N * cd;
+    // ---- audio -> STFT -> |.| -> mel -> log ---------------------------------------------------------------
+    p_audio.ensure((size_t)L * 2); p_pad.ensure((size_t)(L + nf) * 4);
+    p_spec.ensure((size_t)R * 2 * nb * 4); p_mag.ensure((size_t)R * ldm * 4); p_mel.ensure((size_t)R * c.mel * 4);
+    const int16_t* da = audio;
+    if (mem == MI_HOST) {
+        MI_HIP(hipMemcpyAsync(p_audio.p, audio, (size_t)L * 2, hipMemcpyHostToDevice, s));
+        da = p_audio.as<int16_t>();
+    }
+    launch_pad_reflect(da, p_pad.as<float>(), L, nf / 2, s);
+    {
+        ConvGemm g;      // framed GEMM: row f = padded[f*hop : f*hop + n_fft]
+        g.dtype = MI_F32; g.x = p_pad.p; g.w = stft_w.p; g.out = p_spec.p;
+        g.B = 1; g.T_in = R; g.M = R; g.N = 2 * nb; g.Cin = nf; g.x_rstride = c.hop; g.x_bstride = 0;
+        g.out_rstride = 2 * nb; g.out_bstride = 0;
+        launch_conv_gemm(g, s);
+    }
+    launch_spec_mag(p_spec.as<float>(), p_mag.as<float>(), R, nb, ldm, s);
+    {
+        ConvGemm g;
+        g.dtype = MI_F32; g.x = p_mag.p; g.w = fbank.p; g.out = p_mel.p;
+        g.B = 1; g.T_in = R; g.M = R; g.N = c.mel; g.Cin = ldm; g.x_rstride = ldm; g.out_rstride = c.mel;
+        launch_conv_gemm(g, s);
+    }
+    launch_logmel(p_mel.as<float>(), cmt, cmtd, N, R, c.mel, cd, s);
+    // ---- text ids (+1, zero = filler) -> embedding + pos -> ConvNeXtV2 blocks (both branches as batch 2) ----
+    {
+        std::vector<int> ids(N, 0);
+        std::vector<int32_t> hti(T);
+        if (mem == MI_HOST) std::memcpy(hti.data(), text_ids, (size_t)T * 4);
+        else MI_HIP(hipMemcpy(hti.data(), text_ids, (size_t)T * 4, hipMemcpyDeviceToHost));
+        for (int i = 0; i < T; ++i) {
+            const long id = (long)hti[i] + 1;
+            MI_REQUIRE(id >= 0 && id <= c.vocab, "f5_preprocess: text id out of range");
+            ids[i] = (int)id;
+        }
+        MI_HIP(hipMemcpyAsync(p_ids.p, ids.data(), (size_t)N * 4, hipMemcpyHostToDevice, s));
+        MI_HIP(hipStreamSynchronize(s));
+    }
+    const int td = c.text_dim, ti = td * c.conv_mult;
+    const int* dids = p_ids.as<int>();
+    float* tx = p_tx.as<float>(); float* ty = p_ty.as<float>(); float* ty2 = p_ty2.as<float>();
+    launch_text_gather(dids, text_emb.as<float>(), text_pos.as<float>(), tx, N, td, s);
+    for (auto& tb : tblocks) {
+        launch_dwconv7(tx, ty, tb.dw_w.as<float>(), tb.dw_b.as<float>(), 2, N, td, s);
+        launch_rownorm(NORM_LN_AFFINE, ty, ty, MI_F32, tb.ln_w.as<float>(), tb.ln_b.as<float>(), 2L * N, td, 1e-6f, s);
+        gemm(MI_F32, ty, (long)N * td, td, td, tb.pw1, ty2, MI_F32, (long)N * ti, ti, 2, N, ACT_GELU_ERF);
+        launch_grn(ty2, p_ss.as<float>(), tb.grn_g.as<float>(), tb.grn_b.as<float>(), 2, N, ti, s);
+        gemm(MI_F32, ty2, (long)N * ti, ti, ti, tb.pw2, tx, MI_F32, (long)N * td, td, 2, N, ACT_NONE, tx);
+        launch_mask_rows(dids, tx, 2, N, td, s);
+    }
+    launch_copy2d(tx, td, cmt + c.mel, cd, N, td, MI_F32, s);
+    launch_copy2d(tx + (size_t)N * td, td, cmtd + c.mel, cd, N, td, MI_F32, s);
+    // ---- noise ------------------------------------------------------------------------------------------------
+    float* dn = d_noise.as<float>() + (size_t)u * N * c.mel;
+    if (noise_in) {
+        MI_HIP(hipMemcpyAsync(dn, noise_in, (size_t)N * c.mel * 4, mem == MI_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, s));
+    } else {
+        std::vector<float> hn((size_t)N * c.mel);
+        host_normal(hn.data(), hn.size(), seed + (uint64_t)u);
+        MI_HIP(hipMemcpyAsync(dn, hn.data(), hn.size() * 4, hipMemcpyHostToDevice, s));
+        MI_HIP(hipStreamSynchronize(s));
+    }
+    MI_HIP(hipStreamSynchronize(s));
+    return R;
+}
+
+void F5::load_cond(const float* noise, const float* cmt, const float* cmtd, int U, int N, int mem) {
+    const F5Cfg& c = cfg;
+    MI_REQUIRE(U > 0 && N > 0 && N <= c.max_len, "f5: bad batch / length");
+    MI_HIP(hipSetDevice(device));
+    ensure_workspace(U, N);
+    const hipMemcpyKind kind = mem == MI_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+    if (noise && noise != d_noise.p) MI_HIP(hipMemcpyAsync(d_noise.p, noise, (size_t)U * N * c.mel * 4, kind, stream));
+    if (cmt && cmt != d_cmt.p) MI_HIP(hipMemcpyAsync(d_cmt.p, cmt, (size_t)U * N * c.cond_dim() * 4, kind, stream));
+    if (cmtd && cmtd != d_cmtd.p) MI_HIP(hipMemcpyAsync(d_cmtd.p, cmtd, (size_t)U * N * c.cond_dim() * 4, kind, stream));
+}
+
+// cat[(2u+br), n, mel:] = (br == 0 ? cat_mel_text : cat_mel_text_drop)[u, n, :]   (engine dtype)
+void F5::build_cat_cond(int U, int N) {
+    const F5Cfg& c = cfg;
+    const size_t es = dtype_size(dtype);
+    const int cd = c.cond_dim(), ld = c.cat_dim();
+    for (int u = 0; u < U; ++u)
+        for (int br = 0; br < 2; ++br) {
+            const float* src = (br == 0 ? d_cmt.as<float>() : d_cmtd.as<float>()) + (size_t)u * N * cd;
+            char* dst = (char*)cat.p + ((size_t)(2 * u + br) * N * ld + c.mel) * es;
+            launch_copy2d(src, cd, dst, ld, N, cd, dtype, stream);
+        }
+}
+
+void F5::dit_eval(int U, int N, int k) {
+    const F5Cfg& c = cfg;
+    MI_REQUIRE(k >= 0 && k < c.nfe, "f5: time step out of range");
+    hipStream_t s = stream;
+    const int B = 2 * U, d = c.dim, ld = c.cat_dim(), ff = c.ff(), H = c.heads, D = c.dim_head;
+    const long rows = (long)B * N;
+    const float* modk = mod.as<float>() + (size_t)k * mod_ld;
+    // ---- input embedding: proj(cat(x, cond)) ; + Mish(GConv(Mish(GConv(.)))) ---------------------------
+    launch_cat_noise(d_noise.as<float>(), cat.p, U, N, c.mel, ld, dtype, s);
+    gemm(dtype, cat.p, (long)N * ld, ld, ld, in_proj, h32.p, MI_F32, (long)N * d, d, B, N);
+    const void* hin = h32.p;
+    if (dtype != MI_F32) { launch_copy2d(h32.as<float>(), d, hT.p, d, rows, d, dtype, s); hin = hT.p; }
+    {
+        ConvGemm g;
+        g.dtype = dtype; g.x = hin; g.w = gconv1.w.p; g.bias = gconv1.b.as<float>(); g.out = c1.p;
+        g.B = B; g.G = c.pos_g; g.T_in = N; g.M = N; g.N = d / c.pos_g; g.Cin = d / c.pos_g; g.taps = c.pos_k; g.pad = c.pos_k / 2;
+        g.x_bstride = (long)N * d; g.x_rstride = d; g.x_goff = d / c.pos_g; g.out_bstride = (long)N * d; g.out_rstride = d;
+        g.act = ACT_MISH;
+        launch_conv_gemm(g, s);
+        g.x = c1.p; g.w = gconv2.w.p; g.bias = gconv2.b.as<float>(); g.out = X.p; g.out_dtype = MI_F32; g.res = h32.p;
+        launch_conv_gemm(g, s);
+    }
+    // ---- transformer blocks ----------------------------------------------------------------------------------
+    for (int i = 0; i < c.depth; ++i) {
+        const Block& bk = blocks[i];
+        const float* m = modk + (size_t)i * 6 * d;       // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
+        launch_rownorm(NORM_LN_MOD, X.as<float>(), Ub.p, dtype, m + d, m, rows, d, 1e-6f, s);
+        {
+            ConvGemm g;
+            g.dtype = dtype; g.x = Ub.p; g.w = bk.qkv.w.p; g.bias = bk.qkv.b.as<float>();
+            g.out = qb.p; g.out2 = kb.p; g.out3 = vb.p;
+            g.B = B; g.T_in = N; g.M = N; g.N = 3 * d; g.Cin = d; g.x_bstride = (long)N * d; g.x_rstride = d;
+            g.epi = EPI_QKV_ROPE; g.rope_cos = rope_cos.as<float>(); g.rope_sin = rope_sin.as<float>(); g.heads = H; g.head_dim = D;
+            launch_conv_gemm(g, s);
+        }
+        launch_attention(qb.p, kb.p, vb.p, Ob.p, B * H, H, N, dtype, s);
+        gemm(dtype, Ob.p, (long)N * d, d, d, bk.o, X.p, MI_F32, (long)N * d, d, B, N, ACT_NONE, X.p, m + 2 * d);
+        launch_rownorm(NORM_LN_MOD, X.as<float>(), Ub.p, dtype, m + 4 * d, m + 3 * d, rows, d, 1e-6f, s);
+        gemm(dtype, Ub.p, (long)N * d, d, d, bk.ff1, Hff.p, dtype, (long)N * ff, ff, B, N, ACT_GELU_TANH);
+        gemm(dtype, Hff.p, (long)N * ff, ff, ff, bk.ff2, X.p, MI_F32, (long)N * d, d, B, N, ACT_NONE, X.p, m + 5 * d);
+    }
+    // ---- AdaLN-final (scale, shift order: modules.py:323) + proj_out ------------------------------------------
+    const float* mf = modk + (size_t)c.depth * 6 * d;
+    launch_rownorm(NORM_LN_MOD, X.as<float>(), Ub.p, dtype, mf, mf + d, rows, d, 1e-6f, s);
+    gemm(dtype, Ub.p, (long)N * d, d, d, proj_out, pred.p, MI_F32, (long)N * c.mel, c.mel, B, N);
+}
+
+void F5::steps(int U, int N, int k0, int nsteps) {
+    MI_REQUIRE(k0 >= 0 && nsteps >= 0 && k0 + nsteps <= cfg.nfe - 1, "f5: step range exceeds the NFE grid");
+    for (int k = k0; k < k0 + nsteps; ++k) {
+        dit_eval(U, N, k);
+        launch_cfg_update(d_noise.as<float>(), pred.as<float>(), U, N, cfg.mel, cfg.cfg_strength, delta_t.as<float>(), k, stream);
+    }
+}
+
+long F5::decode(const float* den, int U, int N, int R, float* out_f, int16_t* out_i) {
+    const F5Cfg& c = cfg;
+    const int F = N - R;
+    MI_REQUIRE(R >= 0 && F >= 2, "f5_decode: need at least 2 generated frames");
+    hipStream_t s = stream;
+    const int vd = c.vd, vi = c.vi, nf = c.n_fft, nb = c.nb();
+    const long rows = (long)U * F;
+    float* h = v_h.as<float>(); float* z = v_z.as<float>(); float* z2 = v_z2.as<float>();
+    {   // embed: Conv1d(mel -> vd, k7, pad 3) over the generated frames only (zero padded at the slice edges)
+        ConvGemm g;
+        g.dtype = MI_F32; g.x = den + (size_t)R * c.mel; g.w = v_embed.w.p; g.bias = v_embed.b.as<float>(); g.out = h;
+        g.B = U; g.T_in = F; g.M = F; g.N = vd; g.Cin = c.mel; g.taps = 7; g.pad = 3;
+        g.x_bstride = (long)N * c.mel; g.x_rstride = c.mel; g.out_bstride = (long)F * vd; g.out_rstride = vd;
+        launch_conv_gemm(g, s);
+    }
+    launch_rownorm(NORM_L2, h, h, MI_F32, v_norm_w.as<float>(), v_norm_b.as<float>(), rows, vd, 0.f, s);
+    for (auto& vbk : vblocks) {
+        launch_dwconv7(h, z, vbk.dw_w.as<float>(), vbk.dw_b.as<float>(), U, F, vd, s);
+        launch_rownorm(NORM_L2, z, z, MI_F32, vbk.n_w.as<float>(), vbk.n_b.as<float>(), rows, vd, 0.f, s);
+        gemm(MI_F32, z, (long)F * vd, vd, vd, vbk.pw1, z2, MI_F32, (long)F * vi, vi, U, F, ACT_GELU_ERF);
+        gemm(MI_F32, z2, (long)F * vi, vi, vi, vbk.pw2, h, MI_F32, (long)F * vd, vd, U, F, ACT_NONE, h);
+    }
+    launch_rownorm(NORM_L2, h, z, MI_F32, v_fnorm_w.as<float>(), v_fnorm_b.as<float>(), rows, vd, 0.f, s);
+    gemm(MI_F32, z, (long)F * vd, vd, vd, v_head, v_s.p, MI_F32, (long)F * 2 * nb, 2 * nb, U, F);
+    launch_vocos_head(v_s.as<float>(), v_c.as<float>(), rows, nb, istft.k, s);
+    gemm(MI_F32, v_c.p, (long)F * istft.k, istft.k, istft.k, istft, v_fr.p, MI_F32, (long)F * nf, nf, U, F);
+    launch_istft_ola(v_fr.as<float>(), wsi.as<float>(), U, F, nf, c.hop, out_f, out_i, s);
+    return (long)(F - 1) * c.hop;
+}
+
+}  // namespace mi

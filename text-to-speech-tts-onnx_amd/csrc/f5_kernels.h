@@ -1,0 +1,29 @@
+// f5_kernels.h — launchers of the non-GEMM F5 kernels (f5_kernels.hip, attention.hip).
+#pragma once
+#include "common.h"
+
+namespace mi {
+
+enum { NORM_LN_MOD = 0, NORM_LN_AFFINE = 1, NORM_L2 = 2 };
+// x fp32 [rows][D] -> y (out_dtype) ; LN_MOD: LN(x)*(1+a)+b ; LN_AFFINE: LN(x)*a+b ; L2: a*x/||x||+b
+void launch_rownorm(int mode, const float* x, void* y, int out_dtype, const float* a, const float* b, long rows, int D,
+                    float eps, hipStream_t s);
+void launch_dwconv7(const float* x, float* y, const float* w, const float* bias, int B, int T, int C, hipStream_t s);
+void launch_grn(float* y, float* ss_scratch, const float* gamma, const float* beta, int B, int T, int C, hipStream_t s);
+void launch_text_gather(const int* ids, const float* emb, const float* pos, float* out, int N, int C, hipStream_t s);
+void launch_mask_rows(const int* ids, float* x, int V, int N, int C, hipStream_t s);
+void launch_copy2d(const float* src, long lds_, void* dst, long ldd, long rows, int cols, int out_dtype, hipStream_t s);
+void launch_pad_reflect(const int16_t* a, float* out, long L, int half, hipStream_t s);
+void launch_spec_mag(const float* spec, float* mag, int F, int nb, int ldm, hipStream_t s);
+void launch_logmel(const float* melraw, float* cmt, float* cmtd, int N, int R, int M, int ld, hipStream_t s);
+void launch_vocos_head(const float* sp, float* c, long rows, int nb, int ldc, hipStream_t s);
+void launch_istft_ola(const float* frames, const float* wsi, int U, int F, int nfft, int hop, float* out_f,
+                      int16_t* out_i, hipStream_t s);
+void launch_cat_noise(const float* noise, void* cat, int U, int N, int M, int ldc, int dtype, hipStream_t s);
+void launch_cfg_update(float* noise, const float* pred, int U, int N, int M, float cfg, const float* dt, int k, hipStream_t s);
+
+// attention.hip: softmax_fp32(q k^T) v, no mask, no scale (q/k are pre-scaled): modules.py:467
+//   q,k,v [BH][N][64] (dtype) -> o [B][N][H*64] (dtype), B = BH / H
+void launch_attention(const void* q, const void* k, const void* v, void* o, int BH, int H, int N, int dtype, hipStream_t s);
+
+}  // namespace mi

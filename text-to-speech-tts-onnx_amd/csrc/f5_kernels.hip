@@ -1,0 +1,382 @@
+// f5_kernels.hip — the HBM-bound (non-GEMM) kernels of the F5-TTS path, gfx950.
+//
+//   row norms        AdaLayerNorm / LayerNorm / Vocos L2 "norm"   modules.py:301-305, 321-325, 609
+//                                                                 vocos/models.py:80,83, vocos/modules.py:46
+//   dwconv7          depthwise Conv1d k7 (ConvNeXt blocks)        modules.py:242-244, vocos/modules.py:28
+//   GRN              global response norm over the SEQUENCE axis  modules.py:217-226
+//   text gather      Embedding + sinus pos-emb + filler mask      dit.py:49-73
+//   STFT helpers     int16->f32 reflect pad, |.|, log-mel         Export_F5.py:122-125, STFT_Process.py:144-157
+//   Vocos head       exp/clip magnitude, phase -> re/im           vocos/heads.py:55-59, STFT_Process.py:160-163
+//   ISTFT OLA        overlap-add + envelope + clamp + int16       STFT_Process.py:164-166, Export_F5.py:203
+//   CFG/Euler        x += (p + (p - p1)*cfg) * dt[k]              Export_F5.py:179-180
+#include "common.h"
+#include "f5_kernels.h"
+
+namespace mi {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// -----------------------------------------------------------------------------------------------
+// row norm: one 64-lane wave per row, row cached in registers (D <= 64*4*MAXV), two-pass statistics
+// -----------------------------------------------------------------------------------------------
+template <typename TO, int MAXV>
+__global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ x, TO* __restrict__ y,
+                                                      const float* __restrict__ a, const float* __restrict__ b,
+                                                      long rows, int D, int mode, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * D;
+    float4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        v[i] = c < D ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0, 0, 0, 0);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    float mean = 0.f, inv;
+    if (mode == NORM_L2) {
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) q += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+        inv = 1.0f / sqrtf(wave_sum(q));                  // no epsilon (vocos/models.py:80)
+    } else {
+        mean = wave_sum(s) / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < D) {
+                const float d0 = v[i].x - mean, d1 = v[i].y - mean, d2 = v[i].z - mean, d3 = v[i].w - mean;
+                q += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+            }
+        }
+        inv = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);   // biased variance
+    }
+    TO* yr = y + row * D;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < D) {
+            const float4 av = *reinterpret_cast<const float4*>(a + c);
+            const float4 bv = *reinterpret_cast<const float4*>(b + c);
+            float o[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+            const float aa[4] = {av.x, av.y, av.z, av.w}, bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float n = (o[k] - mean) * inv;
+                o[k] = mode == NORM_LN_MOD ? n * (1.f + aa[k]) + bb[k] : n * aa[k] + bb[k];
+            }
+            if constexpr (sizeof(TO) == 4) {
+                *reinterpret_cast<float4*>(yr + c) = make_float4(o[0], o[1], o[2], o[3]);
+            } else {
+                TO h[4] = {from_f32<TO>(o[0]), from_f32<TO>(o[1]), from_f32<TO>(o[2]), from_f32<TO>(o[3])};
+                *reinterpret_cast<uint2*>(yr + c) = *reinterpret_cast<const uint2*>(h);
+            }
+        }
+    }
+}
+
+void launch_rownorm(int mode, const float* x, void* y, int out_dtype, const float* a, const float* b, long rows, int D,
+                    float eps, hipStream_t s) {
+    MI_REQUIRE(D % 4 == 0 && D <= 2048, "rownorm: D must be a multiple of 4 and <= 2048");
+    dim3 grid((unsigned)((rows + 3) / 4));
+    ProfScope ps(FAM_NORM, s, (double)rows * D * (4.0 + (double)dtype_size(out_dtype)), 8.0 * rows * D);
+#define RN(TO, MV) hipLaunchKernelGGL((rownorm_kernel<TO, MV>), grid, dim3(256), 0, s, x, (TO*)y, a, b, rows, D, mode, eps)
+    const int mv = D <= 256 ? 1 : D <= 512 ? 2 : D <= 1024 ? 4 : 8;
+    if (out_dtype == MI_F32) { if (mv == 1) RN(float, 1); else if (mv == 2) RN(float, 2); else if (mv == 4) RN(float, 4); else RN(float, 8); }
+    else if (out_dtype == MI_F16) { if (mv == 1) RN(f16, 1); else if (mv == 2) RN(f16, 2); else if (mv == 4) RN(f16, 4); else RN(f16, 8); }
+    else { if (mv == 1) RN(bf16, 1); else if (mv == 2) RN(bf16, 2); else if (mv == 4) RN(bf16, 4); else RN(bf16, 8); }
+#undef RN
+    MI_HIP(hipGetLastError());
+}
+
+// -----------------------------------------------------------------------------------------------
+// depthwise conv k7 pad 3 over time, channels-last fp32: y[b,t,c] = sum_j w[c,j] x[b,t-3+j,c] + bias[c]
+// -----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dwconv7_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                      const float* __restrict__ w, const float* __restrict__ bias,
+                                                      int T, int C) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;       // over (b, t, c/4)
+    const int c4n = C / 4;
+    const long total = (long)gridDim.y * T * c4n;
+    (void)total;
+    const int b = blockIdx.y;
+    if (i >= (long)T * c4n) return;
+    const int t = (int)(i / c4n), c = (int)(i - (long)t * c4n) * 4;
+    const float* xb = x + (long)b * T * C;
+    float acc[4] = {bias[c], bias[c + 1], bias[c + 2], bias[c + 3]};
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        const int tt = t - 3 + j;
+        if (tt < 0 || tt >= T) continue;
+        const float4 xv = *reinterpret_cast<const float4*>(xb + (long)tt * C + c);
+        acc[0] = fmaf(w[(c + 0) * 7 + j], xv.x, acc[0]);
+        acc[1] = fmaf(w[(c + 1) * 7 + j], xv.y, acc[1]);
+        acc[2] = fmaf(w[(c + 2) * 7 + j], xv.z, acc[2]);
+        acc[3] = fmaf(w[(c + 3) * 7 + j], xv.w, acc[3]);
+    }
+    *reinterpret_cast<float4*>(y + ((long)b * T + t) * C + c) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+}
+
+void launch_dwconv7(const float* x, float* y, const float* w, const float* bias, int B, int T, int C, hipStream_t s) {
+    MI_REQUIRE(C % 4 == 0, "dwconv7: C % 4");
+    const long n = (long)T * (C / 4);
+    dim3 grid((unsigned)((n + 255) / 256), B);
+    ProfScope ps(FAM_OTHER, s, 8.0 * B * T * C, 14.0 * B * T * C);
+    hipLaunchKernelGGL(dwconv7_kernel, grid, dim3(256), 0, s, x, y, w, bias, T, C);
+    MI_HIP(hipGetLastError());
+}
+
+// -----------------------------------------------------------------------------------------------
+// GRN (modules.py:217-226): Gx[c] = ||y[:, c]||_2 over the sequence; Nx = Gx / (mean_c Gx + 1e-6);
+// out = gamma * (y * Nx) + beta + y.   Kernel 1: per-(b,c) sum of squares (fp32, fixed order);
+// kernel 2: each workgroup re-derives mean_c Gx (C <= 4096) and applies the elementwise map.
+// -----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void grn_sumsq_kernel(const float* __restrict__ y, float* __restrict__ ss, int T, int C) {
+    __shared__ float red[4][64];
+    const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+    float acc = 0.f;
+    if (c < C) {
+        const float* yb = y + (long)b * T * C + c;
+        for (int t = part; t < T; t += 4) { const float v = yb[(long)t * C]; acc = fmaf(v, v, acc); }
+    }
+    red[part][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (part == 0 && c < C) ss[(long)b * C + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void grn_apply_kernel(float* __restrict__ y, const float* __restrict__ ss,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        int T, int C) {
+    __shared__ float red[4];
+    __shared__ float s_mean;
+    const int b = blockIdx.y;
+    float part = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) part += sqrtf(ss[(long)b * C + c]);
+    part = wave_sum(part);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) s_mean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)C;
+    __syncthreads();
+    const float denom = s_mean + 1e-6f;
+    const long n = (long)T * C;
+    float* yb = y + (long)b * n;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const float v = yb[i];
+        const float nx = sqrtf(ss[(long)b * C + c]) / denom;
+        yb[i] = gamma[c] * (v * nx) + beta[c] + v;
+    }
+}
+
+void launch_grn(float* y, float* ss_scratch, const float* gamma, const float* beta, int B, int T, int C, hipStream_t s) {
+    ProfScope ps(FAM_OTHER, s, 12.0 * B * T * C, 6.0 * B * T * C);
+    hipLaunchKernelGGL(grn_sumsq_kernel, dim3((C + 63) / 64, B), dim3(256), 0, s, y, ss_scratch, T, C);
+    const long n = (long)T * C;
+    const int blocks = (int)std::min<long>((n + 255) / 256, 1024);
+    hipLaunchKernelGGL(grn_apply_kernel, dim3(blocks, B), dim3(256), 0, s, y, ss_scratch, gamma, beta, T, C);
+    MI_HIP(hipGetLastError());
+}
+
+// -----------------------------------------------------------------------------------------------
+// text embedding gather: out[v, n, :] = filler(n) ? 0 : Emb[v == 0 ? id : 0] + pos[n]
+// -----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void text_gather_kernel(const int* __restrict__ ids, const float* __restrict__ emb,
+                                                          const float* __restrict__ pos, float* __restrict__ out,
+                                                          int N, int C) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int v = blockIdx.y;
+    if (i >= (long)N * C) return;
+    const int n = (int)(i / C), c = (int)(i - (long)n * C);
+    const int id = ids[n];
+    float r = 0.f;
+    if (id != 0) r = emb[(long)(v == 0 ? id : 0) * C + c] + pos[(long)n * C + c];
+    out[((long)v * N + n) * C + c] = r;
+}
+void launch_text_gather(const int* ids, const float* emb, const float* pos, float* out, int N, int C, hipStream_t s) {
+    const long n = (long)N * C;
+    hipLaunchKernelGGL(text_gather_kernel, dim3((unsigned)((n + 255) / 256), 2), dim3(256), 0, s, ids, emb, pos, out, N, C);
+    MI_HIP(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void mask_rows_kernel(const int* __restrict__ ids, float* __restrict__ x, int N, int C) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)N * C) return;
+    const int n = (int)(i / C);
+    if (ids[n] == 0) x[(long)blockIdx.y * N * C + i] = 0.f;
+}
+void launch_mask_rows(const int* ids, float* x, int V, int N, int C, hipStream_t s) {
+    const long n = (long)N * C;
+    hipLaunchKernelGGL(mask_rows_kernel, dim3((unsigned)((n + 255) / 256), V), dim3(256), 0, s, ids, x, N, C);
+    MI_HIP(hipGetLastError());
+}
+
+// -----------------------------------------------------------------------------------------------
+// generic strided copy/cast: dst[r*ldd + c] = (TO) src[r*lds + c]   (fp32 source)
+// -----------------------------------------------------------------------------------------------
+template <typename TO>
+__global__ __launch_bounds__(256) void copy2d_kernel(const float* __restrict__ src, long lds_, TO* __restrict__ dst,
+                                                     long ldd, long rows, int cols) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * cols) return;
+    const long r = i / cols;
+    const int c = (int)(i - r * cols);
+    dst[r * ldd + c] = from_f32<TO>(src[r * lds_ + c]);
+}
+void launch_copy2d(const float* src, long lds_, void* dst, long ldd, long rows, int cols, int out_dtype, hipStream_t s) {
+    const long n = rows * cols;
+    if (n == 0) return;
+    dim3 grid((unsigned)((n + 255) / 256));
+    if (out_dtype == MI_F32) hipLaunchKernelGGL(copy2d_kernel<float>, grid, dim3(256), 0, s, src, lds_, (float*)dst, ldd, rows, cols);
+    else if (out_dtype == MI_F16) hipLaunchKernelGGL(copy2d_kernel<f16>, grid, dim3(256), 0, s, src, lds_, (f16*)dst, ldd, rows, cols);
+    else hipLaunchKernelGGL(copy2d_kernel<bf16>, grid, dim3(256), 0, s, src, lds_, (bf16*)dst, ldd, rows, cols);
+    MI_HIP(hipGetLastError());
+}
+
+// -----------------------------------------------------------------------------------------------
+// STFT helpers
+// -----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pad_reflect_kernel(const int16_t* __restrict__ a, float* __restrict__ out, long L, int half) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= L + 2 * half) return;
+    long j = i - half;
+    if (j < 0) j = -j;
+    if (j >= L) j = 2 * (L - 1) - j;
+    out[i] = (float)a[j] * (1.0f / 32768.0f);
+}
+void launch_pad_reflect(const int16_t* a, float* out, long L, int half, hipStream_t s) {
+    hipLaunchKernelGGL(pad_reflect_kernel, dim3((unsigned)((L + 2 * half + 255) / 256)), dim3(256), 0, s, a, out, L, half);
+    MI_HIP(hipGetLastError());
+}
+
+// spec [F][2*nb] (re | im) -> mag [F][ldm] (zero padded columns)
+__global__ __launch_bounds__(256) void spec_mag_kernel(const float* __restrict__ spec, float* __restrict__ mag, int F, int nb, int ldm) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)F * ldm) return;
+    const int f = (int)(i / ldm), k = (int)(i - (long)f * ldm);
+    float v = 0.f;
+    if (k < nb) { const float re = spec[(long)f * 2 * nb + k], im = spec[(long)f * 2 * nb + nb + k]; v = sqrtf(re * re + im * im); }
+    mag[i] = v;
+}
+void launch_spec_mag(const float* spec, float* mag, int F, int nb, int ldm, hipStream_t s) {
+    const long n = (long)F * ldm;
+    hipLaunchKernelGGL(spec_mag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, spec, mag, F, nb, ldm);
+    MI_HIP(hipGetLastError());
+}
+
+// cat_mel_text[n, 0:M] = n < R ? log(max(melraw[n], 1e-5)) : 0 ;  cat_mel_text_drop[n, 0:M] = 0
+__global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ melraw, float* __restrict__ cmt,
+                                                     float* __restrict__ cmtd, int N, int R, int M, int ld) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)N * M) return;
+    const int n = (int)(i / M), m = (int)(i - (long)n * M);
+    cmt[(long)n * ld + m] = n < R ? logf(fmaxf(melraw[(long)n * M + m], 1e-5f)) : 0.f;
+    cmtd[(long)n * ld + m] = 0.f;
+}
+void launch_logmel(const float* melraw, float* cmt, float* cmtd, int N, int R, int M, int ld, hipStream_t s) {
+    const long n = (long)N * M;
+    hipLaunchKernelGGL(logmel_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, melraw, cmt, cmtd, N, R, M, ld);
+    MI_HIP(hipGetLastError());
+}
+
+// -----------------------------------------------------------------------------------------------
+// Vocos head: s [rows][2*nb] -> c [rows][ldc] = [min(exp(s_mag),100)*cos(ph) | ...*sin(ph) | 0 pad]
+// -----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vocos_head_kernel(const float* __restrict__ sp, float* __restrict__ c, long rows, int nb, int ldc) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * ldc) return;
+    const long r = i / ldc;
+    const int k = (int)(i - r * ldc);
+    float v = 0.f;
+    if (k < 2 * nb) {
+        const int kk = k < nb ? k : k - nb;
+        const float mag = fminf(expf(sp[r * 2 * nb + kk]), 100.0f);
+        const float ph = sp[r * 2 * nb + nb + kk];
+        v = k < nb ? mag * cosf(ph) : mag * sinf(ph);
+    }
+    c[i] = v;
+}
+void launch_vocos_head(const float* sp, float* c, long rows, int nb, int ldc, hipStream_t s) {
+    const long n = rows * ldc;
+    hipLaunchKernelGGL(vocos_head_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, sp, c, rows, nb, ldc);
+    MI_HIP(hipGetLastError());
+}
+
+// frames [U][F][n_fft] -> out[u][i], i in [0,(F-1)*hop): sum of the <= n_fft/hop overlapping frames at
+// t = i + n_fft/2, times window_sum_inv[t]; then clamp +-1, *32767, truncate (Export_F5.py:203).
+__global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict__ fr, const float* __restrict__ wsi,
+                                                        int F, int nfft, int hop, float* __restrict__ out_f,
+                                                        int16_t* __restrict__ out_i) {
+    const long len = (long)(F - 1) * hop;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int u = blockIdx.y;
+    if (i >= len) return;
+    const long t = i + nfft / 2;
+    long f1 = t / hop;
+    if (f1 > F - 1) f1 = F - 1;
+    long f0 = (t - nfft + hop) / hop;            // ceil((t - nfft + 1) / hop)
+    if (t - nfft + 1 <= 0) f0 = 0;
+    const float* fb = fr + (long)u * F * nfft;
+    float acc = 0.f;
+    for (long f = f0; f <= f1; ++f) acc += fb[f * nfft + (t - f * hop)];     // ascending frame order == conv_transpose
+    float v = acc * wsi[t];
+    if (out_f) out_f[(long)u * len + i] = v;
+    if (out_i) {
+        v = fminf(fmaxf(v, -1.0f), 1.0f) * 32767.0f;
+        out_i[(long)u * len + i] = (int16_t)v;
+    }
+}
+void launch_istft_ola(const float* frames, const float* wsi, int U, int F, int nfft, int hop, float* out_f,
+                      int16_t* out_i, hipStream_t s) {
+    const long len = (long)(F - 1) * hop;
+    if (len <= 0) return;
+    hipLaunchKernelGGL(istft_ola_kernel, dim3((unsigned)((len + 255) / 256), U), dim3(256), 0, s, frames, wsi, F, nfft, hop, out_f, out_i);
+    MI_HIP(hipGetLastError());
+}
+
+// -----------------------------------------------------------------------------------------------
+// sampler glue
+// -----------------------------------------------------------------------------------------------
+// cat[(2u+br), n, 0:M] = noise[u, n, :]   (both CFG branches see the same x)
+template <typename T>
+__global__ __launch_bounds__(256) void cat_noise_kernel(const float* __restrict__ noise, T* __restrict__ cat, long UN, int M, int ldc, int N) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= UN * M) return;
+    const long un = i / M;
+    const int m = (int)(i - un * M);
+    const long u = un / N, n = un - u * N;
+    const T v = from_f32<T>(noise[i]);
+    cat[((2 * u) * N + n) * ldc + m] = v;
+    cat[((2 * u + 1) * N + n) * ldc + m] = v;
+}
+void launch_cat_noise(const float* noise, void* cat, int U, int N, int M, int ldc, int dtype, hipStream_t s) {
+    const long n = (long)U * N * M;
+    dim3 grid((unsigned)((n + 255) / 256));
+    if (dtype == MI_F32) hipLaunchKernelGGL(cat_noise_kernel<float>, grid, dim3(256), 0, s, noise, (float*)cat, (long)U * N, M, ldc, N);
+    else if (dtype == MI_F16) hipLaunchKernelGGL(cat_noise_kernel<f16>, grid, dim3(256), 0, s, noise, (f16*)cat, (long)U * N, M, ldc, N);
+    else hipLaunchKernelGGL(cat_noise_kernel<bf16>, grid, dim3(256), 0, s, noise, (bf16*)cat, (long)U * N, M, ldc, N);
+    MI_HIP(hipGetLastError());
+}
+
+// noise[u,n,m] += (p_c + (p_c - p_u) * cfg) * dt ; pred layout [(2u+br)][N][M]
+__global__ __launch_bounds__(256) void cfg_update_kernel(float* __restrict__ noise, const float* __restrict__ pred,
+                                                         long NM, long total, float cfg, const float* __restrict__ dt, int k) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const long u = i / NM, r = i - u * NM;
+    const float pc = pred[(2 * u) * NM + r], pu = pred[(2 * u + 1) * NM + r];
+    noise[i] += (pc + (pc - pu) * cfg) * dt[k];
+}
+void launch_cfg_update(float* noise, const float* pred, int U, int N, int M, float cfg, const float* dt, int k, hipStream_t s) {
+    const long total = (long)U * N * M;
+    hipLaunchKernelGGL(cfg_update_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, noise, pred, (long)N * M, total, cfg, dt, k);
+    MI_HIP(hipGetLastError());
+}
+
+}  // namespace mi

@@ -20,35 +20,9 @@
 // tiles.  K is streamed in KC-wide chunks: global -> registers (next chunk, issued before the
 // MFMAs of the current one) -> LDS -> fragments.
 #include "common.h"
+#include "mfma.h"
 
 namespace mi {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-template <typename T> struct Mfma;
-template <> struct Mfma<float> {
-    static constexpr int KP = 1;
-    using Frag = float;
-    static __device__ __forceinline__ f32x16 mma(Frag a, Frag b, f32x16 c) {
-        return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
-    }
-};
-template <> struct Mfma<f16> {
-    static constexpr int KP = 8;
-    using Frag = f16x8;
-    static __device__ __forceinline__ f32x16 mma(Frag a, Frag b, f32x16 c) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-    }
-};
-template <> struct Mfma<bf16> {
-    static constexpr int KP = 8;
-    using Frag = bf16x8;
-    static __device__ __forceinline__ f32x16 mma(Frag a, Frag b, f32x16 c) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-    }
-};
 
 __device__ __forceinline__ float act_apply(float v, int act) {
     switch (act) {
@@ -199,6 +173,39 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmDev p) {
     }
 
     // ---- epilogue -------------------------------------------------------------------------
+    if (p.epi == EPI_QKV_ROPE) {
+        // fused bias + interleaved-pair RoPE + head scatter (AttnProcessor, modules.py:459-466, 421-438):
+        //   column n -> (which = q|k|v, head, d) ; q,k: z*cos + rot(z)*sin with rot(z)[2j] = -z[2j+1],
+        //   rot(z)[2j+1] = z[2j] (the pair partner lives in lane^1 of the accumulator tile) ;
+        //   destination layout [b*H + head][token][head_dim] for the attention kernel.
+        const int dm = p.heads * p.head_dim;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * WN + j * 32 + lr;        // N % 32 == 0 is required: no lane drops out
+            const int which = n / dm;
+            const int rem = n - which * dm;
+            const int hh = rem / p.head_dim, dd = rem - hh * p.head_dim;
+            const float bv = p.bias ? p.bias[n] : 0.f;
+            TO* dst = (TO*)(which == 0 ? p.out : which == 1 ? p.out2 : p.out3) + ((long)b * p.heads + hh) * p.M * p.head_dim + dd;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                    float v = acc[i][j][r] + bv;
+                    const float partner = __shfl_xor(v, 1);
+                    if (m < p.M) {
+                        if (which < 2) {
+                            const float c = p.rope_cos[(long)m * p.head_dim + dd], sn = p.rope_sin[(long)m * p.head_dim + dd];
+                            v = v * c + ((dd & 1) ? partner : -partner) * sn;
+                        }
+                        dst[(long)m * p.head_dim] = from_f32<TO>(v);
+                    }
+                }
+            }
+        }
+        return;
+    }
     TO* outp = (TO*)p.out + (long)b * p.out_bstride;
     const TO* resp = p.res ? (const TO*)p.res + (long)b * p.out_bstride : nullptr;
 #pragma unroll
@@ -276,6 +283,9 @@ void launch_conv_gemm(const ConvGemm& p, hipStream_t s) {
     d.rope_cos = p.rope_cos; d.rope_sin = p.rope_sin; d.heads = p.heads; d.head_dim = p.head_dim;
     d.out2 = p.out2; d.out3 = p.out3;
     if (p.epi == EPI_CONVT) MI_REQUIRE(p.Cout > 0 && p.N == p.u * p.Cout, "conv_gemm: convT shape");
+    if (p.epi == EPI_QKV_ROPE)
+        MI_REQUIRE(p.G == 1 && p.heads > 0 && p.head_dim % 2 == 0 && p.N == 3 * p.heads * p.head_dim && p.N % 32 == 0 &&
+                       p.rope_cos && p.rope_sin && p.out2 && p.out3, "conv_gemm: qkv-rope epilogue arguments");
 
     const double esz = (double)dtype_size(p.dtype), osz = (double)dtype_size(odt);
     // algorithmic traffic: read x once, weights once, write out once (+ residual / accumulate reads)

@@ -58,6 +58,26 @@ def load() -> C.CDLL:
     L.mi_conv_transpose1d.argtypes = [f32p, C.c_int, C.c_int, C.c_int, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_int, f32p]
     L.mi_conv_transpose1d.restype = C.c_int
+    i16p, i64p = C.POINTER(C.c_int16), C.POINTER(C.c_int64)
+    L.mi_f5_param_count.argtypes = [i32p, C.c_int, f32p, C.c_int]; L.mi_f5_param_count.restype = C.c_int64
+    L.mi_f5_create.argtypes = [i32p, C.c_int, f32p, C.c_int, f32p, C.c_int64, C.c_int, C.c_int]
+    L.mi_f5_create.restype = vp
+    L.mi_f5_destroy.argtypes = [vp]; L.mi_f5_destroy.restype = None
+    L.mi_f5_tables.argtypes = [vp, f32p, f32p]; L.mi_f5_tables.restype = C.c_int
+    L.mi_f5_preprocess.argtypes = [vp, vp, C.c_int64, vp, C.c_int64, C.c_int64, vp, C.c_uint64, vp, vp, vp, vp, vp,
+                                   i64p, C.c_int]
+    L.mi_f5_preprocess.restype = C.c_int
+    L.mi_f5_transformer_step.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int64, i32p, C.c_int, C.c_int]
+    L.mi_f5_transformer_step.restype = C.c_int
+    L.mi_f5_sample.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int]
+    L.mi_f5_sample.restype = C.c_int
+    L.mi_f5_dit_eval.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int64, C.c_int, vp, C.c_int]
+    L.mi_f5_dit_eval.restype = C.c_int
+    L.mi_f5_decode.argtypes = [vp, vp, C.c_int, C.c_int64, C.c_int64, vp, vp, i64p, C.c_int]
+    L.mi_f5_decode.restype = C.c_int
+    L.mi_f5_synthesize.argtypes = [vp, C.c_int, vp, C.c_int64, vp, C.c_int64, C.c_int64, vp, C.c_uint64, vp, i64p,
+                                   C.c_int]
+    L.mi_f5_synthesize.restype = C.c_int
     L.mi_prof_enable.argtypes = [C.c_int]; L.mi_prof_enable.restype = C.c_int
     L.mi_prof_reset.argtypes = []; L.mi_prof_reset.restype = C.c_int
     L.mi_prof_get.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
