@@ -71,14 +71,154 @@ def cpu_baseline_bigvgan(cfg, state, frames: int):
             "sample": f"numpy oracle, BigVGAN-v2 fp32, mel (1,{cfg.num_mels},{frames}) = {secs:.2f} s audio in {dt:.1f} s"}
 
 
+def f5_flops_per_eval(cfg, N: int) -> float:
+    """Algorithmic FLOPs of one DiT CFG evaluation: tokens = 2N,
+    MAC/token = depth*(4d^2 + 2*d*ff + 2*N*d) + (cat*d + 2*d*(d/g)*k + d*mel)."""
+    d, ff = cfg.dim, cfg.ff_dim
+    mac = cfg.depth * (4 * d * d + 2 * d * ff + 2 * N * d) + ((2 * cfg.mel_dim + cfg.text_dim) * d +
+                                                               2 * d * (d // cfg.pos_conv_groups) * cfg.pos_conv_kernel + d * cfg.mel_dim)
+    return 2.0 * (2 * N) * mac
+
+
+def f5_synthetic_inputs(cfg, U: int, rank: int):
+    """6.0 s reference audio (144000 samples -> 563 frames), equal-length
+    ~15-word ASCII ref/gen texts (-> N = 1126), char-level ids against a synthetic vocab."""
+    from mi355tts import weights as W
+    L = 144000
+    ref_text = "Some call me nature, others call me mother nature, I am the breeze and rain. "
+    gen_text = "The quick brown fox jumps over the lazy dog while seven wizards brew a potion"
+    gen_text = (gen_text + " " * len(ref_text))[:len(ref_text)]
+    vocab = W.synth_vocab(cfg.text_num_embeds)
+    ids = np.asarray([vocab.get(c, 0) for c in (ref_text + gen_text)], dtype=np.int32)
+    ref_frames = L // cfg.hop_length + 1
+    N = ref_frames + int(ref_frames / len(ref_text.encode()) * len(gen_text.encode()) / 1.0)
+    audio = np.empty((U, L), np.int16)
+    tt = np.arange(L) / cfg.sample_rate
+    for u in range(U):
+        a = 0.1 * 32767 * np.sin(2 * np.pi * 220 * tt) + W.synth_normal(9527 + 64 * rank + u, "audio", (L,), std=500.0)
+        audio[u] = np.clip(np.round(a), -32768, 32767).astype(np.int16)
+    noise = np.stack([W.synth_normal(9527 + 64 * rank + u, "noise", (N, cfg.mel_dim)) for u in range(U)])
+    return audio, np.tile(ids[None], (U, 1)), N, noise
+
+
+def cpu_baseline_f5(cfg, raw_state, audio, ids, N, noise):
+    """numpy oracle (kind 'port'): preprocess + ONE of the 31 DiT evaluations + decode, extrapolated to the
+    full 31-evaluation utterance (every evaluation costs the same)."""
+    from oracle import f5_np as O
+    from mi355tts import weights as W
+    st = W.fold_f5(cfg, raw_state)
+    t0 = time.perf_counter()
+    pre = O.preprocess(cfg, st, audio, ids, N, noise)
+    tables = O.time_tables(cfg, st)
+    t1 = time.perf_counter()
+    x = O.transformer_step(cfg, st, tables, pre["noise"], pre, 0)
+    t2 = time.perf_counter()
+    w = O.decode(cfg, st, x, pre["ref_signal_len"])
+    t3 = time.perf_counter()
+    total = (t1 - t0) + (t2 - t1) * (cfg.nfe_step - 1) + (t3 - t2)
+    secs = w.shape[-1] / cfg.sample_rate
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    return {"value": secs / total, "unit": "audio_seconds_per_second", "cores": int(cores), "kind": "port",
+            "sample": f"numpy oracle fp32: preprocess {t1 - t0:.1f} s + 1 of {cfg.nfe_step - 1} DiT evaluations "
+                      f"{t2 - t1:.1f} s (x{cfg.nfe_step - 1} extrapolated) + decode {t3 - t2:.1f} s for one {secs:.2f} s utterance"}
+
+
+def run_f5(args, world, rank, local, dev, dist, torch):
+    from mi355tts.config import F5Config
+    from mi355tts import weights as W
+    from mi355tts import _lib
+    from mi355tts.f5 import F5Engine
+    cfg = F5Config()
+    spec = W.f5_spec(cfg)
+    raw = None
+    nparam = sum(int(np.prod(sh)) for _, sh, _ in W.f5_packed_spec(cfg))
+    if rank == 0:
+        raw = W.synth_state(spec, 9527)
+        blob_t = torch.from_numpy(W.pack_f5(cfg, raw)).to(dev)
+    else:
+        blob_t = torch.empty(nparam, dtype=torch.float32, device=dev)
+    bcast_ms = 0.0
+    if world > 1:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dist.broadcast(blob_t, src=0)
+        torch.cuda.synchronize()
+        bcast_ms = (time.perf_counter() - t0) * 1e3
+    eng = F5Engine(cfg, blob=blob_t.cpu().numpy(), dtype=args.dtype, device=local)
+    del blob_t
+    U = args.batch
+    audio, ids, N, noise = f5_synthetic_inputs(cfg, U, rank)
+    R = audio.shape[1] // cfg.hop_length + 1
+    t_audio, t_ids, t_noise = torch.from_numpy(audio).to(dev), torch.from_numpy(ids).to(dev), torch.from_numpy(noise).to(dev)
+    out = torch.empty((U, 1, (N - R - 1) * cfg.hop_length), dtype=torch.int16, device=dev)
+    audio_s = U * out.shape[-1] / cfg.sample_rate
+    for _ in range(args.warmup):
+        eng.synthesize_torch(t_audio, t_ids, N, noise=t_noise, out=out)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    _lib.prof_reset()
+    _lib.prof_enable(["conv_gemm", "attn"])
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.synthesize_torch(t_audio, t_ids, N, noise=t_noise, out=out)
+    barrier()
+    dt = time.perf_counter() - t0
+    _lib.prof_enable(())
+    pg, pa = _lib.prof_get("conv_gemm"), _lib.prof_get("attn")
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank != 0:
+        eng.close()
+        return
+    peak = MFMA_F32_PEAK_TF if args.dtype == "f32" else MFMA_F16_PEAK_TF
+    achieved = pg["flops"] / (pg["ms"] * 1e-3) / 1e12 if pg["ms"] > 0 else 0.0
+    value = world * audio_s * args.steps / dt
+    alg_flops = f5_flops_per_eval(cfg, N) * (cfg.nfe_step - 1) * U
+    line = {
+        "metric": "audio_seconds_per_second", "value": value, "unit": "audio-s/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"F5-TTS {args.dtype} NFE=32 (31 DiT evaluations, CFG batch 2) + Vocos/ISTFT end to end, "
+                               f"{U} utterance(s) per GPU, 6 s ref audio, N={N} frames (BASELINE configs[2]/[3])",
+                   "utterances_per_gpu": U, "frames": N, "audio_seconds_per_step_per_gpu": audio_s,
+                   "rtf": dt / args.steps / audio_s, "weights": "synthetic seeded (337 M DiT + 13.5 M Vocos params)",
+                   "weight_bcast_ms": bcast_ms, "end_to_end_TFLOPs_per_step": alg_flops / 1e12,
+                   "end_to_end_TFLOP_per_s": alg_flops / (dt / args.steps) / 1e12},
+        "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel (DiT linear layers, implicit-GEMM MFMA)", "achieved": achieved,
+                     "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                     "launches_per_step": pg["launches"] / args.steps, "avg_launch_ms": pg["ms"] / max(pg["launches"], 1),
+                     "family_ms_per_step": pg["ms"] / args.steps,
+                     "attn_ms_per_step": pa["ms"] / args.steps,
+                     "attn_tflops": pa["flops"] / (pa["ms"] * 1e-3) / 1e12 if pa["ms"] > 0 else 0.0},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        if raw is None:
+            raw = W.synth_state(spec, 9527)
+        line["cpu_baseline"] = cpu_baseline_f5(cfg, raw, audio[0], ids[0], N, noise[0])
+    print(json.dumps(line), flush=True)
+    eng.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="bigvgan", choices=["bigvgan", "f5"])
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=None, help="mel batch (bigvgan, default 8) / utterances (f5, default 1) per GPU")
     ap.add_argument("--frames", type=int, default=512)
-    ap.add_argument("--dtype", default="f16")
+    ap.add_argument("--dtype", default=None, help="bigvgan: f16 (default) | f32 | bf16 ; f5: bf16 (default) | f32 | f16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=48)
     args = ap.parse_args()
@@ -102,6 +242,18 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+
+    if args.steps is None:
+        args.steps = 20 if args.workload == "bigvgan" else 3
+    if args.batch is None:
+        args.batch = 8 if args.workload == "bigvgan" else 1
+    if args.dtype is None:
+        args.dtype = "f16" if args.workload == "bigvgan" else "bf16"
+    if args.workload == "f5":
+        run_f5(args, world, rank, local, dev, dist, torch)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     cfg = BigVGANConfig()
     spec = W.bigvgan_spec(cfg)

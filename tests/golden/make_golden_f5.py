@@ -166,6 +166,13 @@ def gen_f5():
     # ---- G9: end to end: preprocess -> loop -> decode --------------------------------------------------
     out["e2e_i16"] = dec(t(traj[-1])[None].clone(), torch.tensor(R_len, dtype=torch.long))[0, 0].numpy()
 
+    # ---- G10: list_str_to_idx (F5-TTS-ONNX-Inference.py:140-148 exec'ed where it lies): OOV -> 0, pad -1 ----
+    ns4 = {"torch": torch}
+    R.exec_lines(R.REF + "/F5_TTS/F5-TTS-ONNX-Inference.py", 140, 148, ns4)
+    vocab = W.synth_vocab(2545)
+    cases = [list("ab c!"), list("Z"), ["a", "\u00e9", "zhong1", " ", "b"]]
+    out["g10_ids"] = ns4["list_str_to_idx"](cases, vocab).numpy()
+
     np.savez_compressed(os.path.join(HERE, "f5_small.npz"), **out)
     print("f5_small.npz:", {k: np.asarray(v).shape for k, v in out.items()})
     for k in ("dit_pred_t2", "loop_final", "dec_float", "dec_mag"):

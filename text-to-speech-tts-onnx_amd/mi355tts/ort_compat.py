@@ -1,0 +1,303 @@
+"""Drop-in stand-in for the slice of the ``onnxruntime`` Python API the reference drivers use.
+
+    import mi355tts.ort_compat as onnxruntime
+
+then the bodies of /root/reference F5_TTS/F5-TTS-ONNX-Inference.py (:152-311) and
+BigVGAN/Export_BigVGAN.py (:77-177) run unchanged with model paths pointing at ``*.mi355.json``
+manifests written by :func:`save_model`.  Surface mirrored:
+
+    set_seed, SessionOptions (+add_session_config_entry), GraphOptimizationLevel, ExecutionMode,
+    InferenceSession(path, sess_options=, providers=, provider_options=)
+        .get_inputs() / .get_outputs() -> objects with .name/.type/.shape ; ._inputs_meta ; .get_providers()
+        .run(output_names, {name: ndarray}) -> [ndarray]
+        .run_with_ort_values(output_names, {name: OrtValue}) -> [OrtValue]
+        .io_binding() / .run_with_iobinding(binding)
+    OrtValue.ortvalue_from_numpy(arr, device_type, device_id) / .numpy()
+
+Graph tensor names, dtypes and dynamic axes are those of the exports (F5_TTS/Export_F5.py:294-305,
+354-365, 409-414; BigVGAN/Export_BigVGAN.py:65-70).  Errors raise (InvalidArgument / Fail), like ORT.
+Execution is always the MI355X engine ("MI355XExecutionProvider"); there is no CPU provider.
+"""
+from __future__ import annotations
+
+import json
+import os
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from .config import BigVGANConfig, F5Config
+
+_SEED = [9527]
+PROVIDER = "MI355XExecutionProvider"
+
+
+class InvalidArgument(ValueError):
+    pass
+
+
+class Fail(RuntimeError):
+    pass
+
+
+def set_seed(seed: int) -> None:
+    _SEED[0] = int(seed)
+
+
+def get_available_providers() -> List[str]:
+    return [PROVIDER]
+
+
+class GraphOptimizationLevel:
+    ORT_DISABLE_ALL, ORT_ENABLE_BASIC, ORT_ENABLE_EXTENDED, ORT_ENABLE_ALL = 0, 1, 2, 99
+
+
+class ExecutionMode:
+    ORT_SEQUENTIAL, ORT_PARALLEL = 0, 1
+
+
+class SessionOptions:
+    """Attribute bag: the engine has no graph optimiser or thread pools to configure."""
+
+    def __init__(self):
+        self.log_severity_level = 2
+        self.log_verbosity_level = 0
+        self.inter_op_num_threads = 0
+        self.intra_op_num_threads = 0
+        self.enable_cpu_mem_arena = True
+        self.execution_mode = ExecutionMode.ORT_SEQUENTIAL
+        self.graph_optimization_level = GraphOptimizationLevel.ORT_ENABLE_ALL
+        self.config_entries: Dict[str, str] = {}
+
+    def add_session_config_entry(self, key: str, value: str) -> None:
+        if not isinstance(key, str) or not isinstance(value, str):
+            raise InvalidArgument("session config entries are (str, str)")
+        self.config_entries[key] = value
+
+
+class NodeArg:
+    def __init__(self, name: str, type_: str, shape):
+        self.name, self.type, self.shape = name, type_, list(shape)
+
+    def __repr__(self):
+        return f"NodeArg(name='{self.name}', type='{self.type}', shape={self.shape})"
+
+
+class OrtValue:
+    def __init__(self, arr: np.ndarray, device_type: str = "cpu", device_id: int = 0):
+        self._arr, self._device, self._device_id = arr, device_type, device_id
+
+    @staticmethod
+    def ortvalue_from_numpy(arr, device_type: str = "cpu", device_id: int = 0) -> "OrtValue":
+        return OrtValue(np.asarray(arr), device_type or "cpu", device_id)
+
+    def numpy(self) -> np.ndarray:
+        return self._arr
+
+    def shape(self):
+        return list(self._arr.shape)
+
+    def device_name(self) -> str:
+        return self._device
+
+
+class IOBinding:
+    def __init__(self, session):
+        self._s, self._in, self._out, self._results = session, {}, {}, []
+
+    def bind_ortvalue_input(self, name: str, ortvalue: OrtValue):
+        self._in[name] = ortvalue
+
+    def bind_ortvalue_output(self, name: str, ortvalue: OrtValue):
+        self._out[name] = ortvalue
+
+    def get_outputs(self):
+        return self._results
+
+
+# ---------------------------------------------------------------------------------------------------
+# model manifests
+# ---------------------------------------------------------------------------------------------------
+def save_model(path: str, graph: str, cfg, weights_file: str, dtype: str = "f32") -> str:
+    """Write a ``*.mi355.json`` manifest.  `weights_file` is a ``.npy`` holding the canonical fp32 blob
+    (mi355tts.weights.pack_bigvgan / pack_f5); several graphs may share one file."""
+    from dataclasses import asdict
+    if graph not in _GRAPHS:
+        raise InvalidArgument(f"unknown graph {graph}")
+    man = {"format": "mi355tts-1", "graph": graph, "dtype": dtype, "config": asdict(cfg),
+           "weights": os.path.relpath(weights_file, os.path.dirname(os.path.abspath(path)))}
+    with open(path, "w") as f:
+        json.dump(man, f, indent=1)
+    return path
+
+
+_ENGINES: Dict[tuple, object] = {}
+
+
+def _engine(kind: str, cfg, wfile: str, dtype: str, device: int):
+    key = (kind, os.path.abspath(wfile), dtype, device)
+    if key not in _ENGINES:
+        blob = np.load(wfile, mmap_mode="r")
+        if kind == "f5":
+            from .f5 import F5Engine
+            _ENGINES[key] = F5Engine(cfg, blob=np.asarray(blob), dtype=dtype, device=device)
+        else:
+            from .bigvgan import BigVGANVocoder
+            _ENGINES[key] = BigVGANVocoder(cfg, blob=np.asarray(blob), dtype=dtype, device=device)
+    return _ENGINES[key]
+
+
+def _tname(dtype: str) -> str:
+    return {"f32": "tensor(float)", "f16": "tensor(float16)", "bf16": "tensor(bfloat16)"}[dtype]
+
+
+def _graph_io(graph: str, cfg, dtype: str):
+    """(inputs, outputs) as NodeArg lists, names/ranks/dynamic axes as in the reference's exports."""
+    if graph == "BigVGAN":
+        return ([NodeArg("mel_features", "tensor(float)", [1, cfg.num_mels, "mel_features_len"])],
+                [NodeArg("generated_wav", "tensor(int16)", [1, 1, "generated_len"])])
+    H, D, M, cd = cfg.heads, cfg.dim_head, cfg.mel_dim, cfg.mel_dim + cfg.text_dim
+    ft = "tensor(float)"          # the engine keeps graph I/O in fp32 whatever the DiT operand dtype
+    cond = [NodeArg("noise", ft, [1, "max_duration", M]), NodeArg("rope_cos_q", ft, [2, H, "max_duration", D]),
+            NodeArg("rope_sin_q", ft, [2, H, "max_duration", D]), NodeArg("rope_cos_k", ft, [2, H, D, "max_duration"]),
+            NodeArg("rope_sin_k", ft, [2, H, D, "max_duration"]), NodeArg("cat_mel_text", ft, [1, "max_duration", cd]),
+            NodeArg("cat_mel_text_drop", ft, [1, "max_duration", cd])]
+    if graph == "F5_Preprocess":
+        return ([NodeArg("audio", "tensor(int16)", [1, 1, "audio_len"]), NodeArg("text_ids", "tensor(int32)", [1, "text_ids_len"]),
+                 NodeArg("max_duration", "tensor(int64)", [1])], cond + [NodeArg("ref_signal_len", "tensor(int64)", [])])
+    if graph == "F5_Transformer":
+        return (cond + [NodeArg("time_step", "tensor(int32)", [1])],
+                [NodeArg("denoised", ft, [1, "max_duration", M]), NodeArg("time_step", "tensor(int32)", [1])])
+    if graph == "F5_Decode":
+        return ([NodeArg("denoised", ft, [1, "max_duration", M]), NodeArg("ref_signal_len", "tensor(int64)", [])],
+                [NodeArg("output_audio", "tensor(int16)", [1, 1, "generated_len"])])
+    raise InvalidArgument(graph)
+
+
+_GRAPHS = ("BigVGAN", "F5_Preprocess", "F5_Transformer", "F5_Decode")
+
+
+class InferenceSession:
+    def __init__(self, path_or_bytes, sess_options: Optional[SessionOptions] = None, providers: Optional[Sequence] = None,
+                 provider_options: Optional[Sequence[dict]] = None, **kwargs):
+        if not isinstance(path_or_bytes, (str, os.PathLike)) or not os.path.exists(path_or_bytes):
+            raise Fail(f"Load model from {path_or_bytes} failed: file does not exist (expected a *.mi355.json manifest)")
+        with open(path_or_bytes) as f:
+            man = json.load(f)
+        if man.get("format") != "mi355tts-1" or man.get("graph") not in _GRAPHS:
+            raise InvalidArgument(f"{path_or_bytes}: not an mi355tts manifest")
+        self._graph, self._dtype = man["graph"], man.get("dtype", "f32")
+        self._opts = sess_options or SessionOptions()
+        device = 0
+        for po in (provider_options or []):
+            if isinstance(po, dict) and "device_id" in po:
+                device = int(po["device_id"])
+        c = dict(man["config"])
+        if self._graph == "BigVGAN":
+            for k in ("upsample_rates", "upsample_kernel_sizes", "resblock_kernel_sizes"):
+                c[k] = tuple(c[k])
+            c["resblock_dilation_sizes"] = tuple(tuple(d) for d in c["resblock_dilation_sizes"])
+            self._cfg = BigVGANConfig(**c)
+        else:
+            self._cfg = F5Config(**c)
+        wfile = os.path.join(os.path.dirname(os.path.abspath(path_or_bytes)), man["weights"])
+        self._eng = _engine("bigvgan" if self._graph == "BigVGAN" else "f5", self._cfg, wfile, self._dtype, device)
+        self._inputs, self._outputs = _graph_io(self._graph, self._cfg, self._dtype)
+        self._inputs_meta, self._outputs_meta = self._inputs, self._outputs
+
+    # ---- metadata ---------------------------------------------------------------------------------
+    def get_inputs(self):
+        return self._inputs
+
+    def get_outputs(self):
+        return self._outputs
+
+    def get_providers(self):
+        return [PROVIDER]
+
+    def io_binding(self):
+        return IOBinding(self)
+
+    # ---- execution ----------------------------------------------------------------------------------
+    def run(self, output_names, input_feed: Dict[str, np.ndarray], run_options=None):
+        names = [o.name for o in self._outputs]
+        want = list(output_names) if output_names else names
+        for n in want:
+            if n not in names:
+                raise InvalidArgument(f"Invalid output name: {n}")
+        need = [i.name for i in self._inputs]
+        missing = [n for n in need if n not in input_feed]
+        if missing:
+            raise InvalidArgument(f"Required inputs ({missing}) are missing from input feed ({list(input_feed)}).")
+        extra = [n for n in input_feed if n not in need]
+        if extra:
+            raise InvalidArgument(f"Invalid input name: {extra[0]}")
+        res = self._run(input_feed)
+        return [res[n] for n in want]
+
+    def run_with_ort_values(self, output_names, input_feed: Dict[str, OrtValue], run_options=None):
+        outs = self.run(output_names, {k: v.numpy() for k, v in input_feed.items()})
+        return [OrtValue(o) for o in outs]
+
+    def run_with_iobinding(self, binding: IOBinding, run_options=None):
+        outs = self.run(list(binding._out) or None, {k: v.numpy() for k, v in binding._in.items()})
+        names = list(binding._out) or [o.name for o in self._outputs]
+        binding._results = []
+        for n, o in zip(names, outs):
+            if n in binding._out:                       # the reference aliases outputs onto input buffers
+                tgt = binding._out[n]._arr
+                if tgt.shape == o.shape and tgt.dtype == o.dtype:
+                    tgt[...] = o
+                    o = tgt
+                else:
+                    binding._out[n]._arr = o
+            binding._results.append(OrtValue(o))
+
+    def _chk(self, feed, name, dtype, ndim):
+        a = np.asarray(feed[name])
+        if a.dtype != dtype:
+            raise InvalidArgument(f"Unexpected input data type. Actual: ({a.dtype}) , expected: ({np.dtype(dtype)}) for input {name}")
+        if ndim is not None and a.ndim != ndim:
+            raise InvalidArgument(f"Invalid rank for input: {name} Got: {a.ndim} Expected: {ndim}")
+        return a
+
+    def _run(self, feed) -> Dict[str, np.ndarray]:
+        g, e = self._graph, self._eng
+        if g == "BigVGAN":
+            mel = np.asarray(feed["mel_features"])
+            if mel.dtype not in (np.float32, np.float16) or mel.ndim != 3:
+                raise InvalidArgument("mel_features must be a rank-3 float tensor")
+            return {"generated_wav": e.run(mel.astype(np.float32))}
+        if g == "F5_Preprocess":
+            audio = self._chk(feed, "audio", np.int16, 3)
+            ids = self._chk(feed, "text_ids", np.int32, 2)
+            md = self._chk(feed, "max_duration", np.int64, 1)
+            return e.preprocess(audio, ids, md, noise=None, seed=_SEED[0])
+        if g == "F5_Transformer":
+            noise = self._chk(feed, "noise", np.float32, 3)
+            cmt = self._chk(feed, "cat_mel_text", np.float32, 3)
+            cmtd = self._chk(feed, "cat_mel_text_drop", np.float32, 3)
+            ts = self._chk(feed, "time_step", np.int32, 1)
+            for n in ("rope_cos_q", "rope_sin_q", "rope_cos_k", "rope_sin_k"):   # tables are regenerated on device
+                if np.asarray(feed[n]).ndim != 4:
+                    raise InvalidArgument(f"Invalid rank for input: {n}")
+            x, t = e.transformer_step(noise, cmt, cmtd, ts, fuse=1)
+            return {"denoised": x, "time_step": t}
+        if g == "F5_Decode":
+            den = self._chk(feed, "denoised", np.float32, 3)
+            rsl = int(np.asarray(feed["ref_signal_len"]))
+            return {"output_audio": e.decode(den, rsl)}
+        raise Fail(g)
+
+
+# ---------------------------------------------------------------------------------------------------
+# one-call convenience: lines :223-311 of F5-TTS-ONNX-Inference.py on the device
+# ---------------------------------------------------------------------------------------------------
+def synthesize(engine, ref_audio_i16: np.ndarray, ref_text: str, gen_text: str, vocab: Dict[str, int], *,
+               speed: float = 1.0, seed: int = 9527, noise: Optional[np.ndarray] = None) -> np.ndarray:
+    """reference audio (int16 mono 24 kHz) + texts in, int16 waveform (1,1,n) out."""
+    from . import text as T
+    audio = np.ascontiguousarray(np.asarray(ref_audio_i16).reshape(-1), dtype=np.int16)
+    N = T.max_duration(audio.size, ref_text, gen_text, engine.cfg.hop_length, speed)
+    ids = T.list_str_to_idx(T.convert_char_to_pinyin([ref_text + gen_text]), vocab)
+    return engine.synthesize(audio[None], ids, N, noise=noise, seed=seed)
