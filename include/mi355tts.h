@@ -117,6 +117,11 @@ int         mi_f5_synthesize(mi_f5* h, int U, const int16_t* audio, int64_t L, c
                              int64_t max_duration, const float* noise_in, uint64_t seed, int16_t* out,
                              int64_t* out_len, int mem);
 
+/* tuning hook: time `iters` launches of the implicit-GEMM conv kernel on random device data (no host copies);
+ * returns average milliseconds per launch in *ms.  x (B,T,Cin), w (N, taps*Cin), out (B,T,N), "same" padding. */
+int         mi_bench_conv_gemm(int dtype, int B, int T, int Cin, int N, int taps, int dil, int with_res, int iters,
+                               double* ms);
+
 /* ---- profiling hooks (bench.py roofline leg) -------------------------------------------------
  * family_mask: bit i enables family i (0 = off, -1 = all).  Every launch of an enabled kernel
  * family is bracketed by HIP events on the handle's own stream; mi_prof_get returns accumulated

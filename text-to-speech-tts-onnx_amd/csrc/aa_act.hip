@@ -126,7 +126,9 @@ __global__ __launch_bounds__(256) void aa_act_kernel(const T* __restrict__ x, T*
             ue *= 2.f; uo *= 2.f;
             const int ie = 2 * (mp + e - 2);          // i' of the even sample
             const int io = 2 * (mp + e - 3) + 1;      // i' of the odd sample
-            float se = sinf(al * ue), so = sinf(al * uo);
+            float se, so;
+            if constexpr (sizeof(T) == 4) { se = sinf(al * ue); so = sinf(al * uo); }      // fp32 parity path: libm-accurate
+            else { se = __sinf(al * ue); so = __sinf(al * uo); }                            // 16-bit storage: v_sin_f32
             se = ue + ib * (se * se);
             so = uo + ib * (so * so);
             if (ie < -ext || ie >= 2 * Tlen + ext) se = 0.f;

@@ -1,0 +1,247 @@
+// aa_conv.hip — fused [anti-aliased SnakeBeta -> Conv1d(k, dilation) -> +bias (+residual) (*alpha) (+=)]
+// for the HBM-bound low-channel BigVGAN stages (C = 96 / 48 / 24 at T = 32k..131k), gfx950.
+//
+// Reference: one half of an AMPBlock1 iteration, `xt = c(a(x))` (+ `x = xt + x` on the second half),
+// BigVGAN/modeling_modified/bigvgan.py:132-140; Activation1d act.py:25-29.
+//
+// Unfused, an AMP iteration moves 9 tensor passes through HBM ([AA: R+W] [conv: R+W] [AA: R+W]
+// [conv+res: 2R+W]); fused it is 5 ([R+W] [2R+W]).  One workgroup owns BM output time steps x all C channels:
+//   1. one contiguous, 16-byte-coalesced HBM read of the x tile (+ conv halo + 5-sample AA halo) into LDS
+//   2. AA in registers (polyphase FIR x2 -> snake -> FIR /2, fp32; see aa_act.hip) -> activated tile in LDS
+//      with a bank-conflict-free row stride; rows outside [0,T) are the conv's zero padding
+//   3. implicit-GEMM on MFMA: A fragments are read from the LDS tile at row offsets tap*dilation (im2col
+//      never exists), B fragments (weights [co][tap][ci]) stream from L2
+//   4. accumulators -> LDS (fp32) -> coalesced epilogue (bias, residual, alpha, accumulate) -> HBM
+#include "common.h"
+#include "mfma.h"
+
+namespace mi {
+
+extern __constant__ float c_h_fused[12];
+__constant__ float c_h_fused[12];
+
+struct AAConvDev {
+    const void* x; const void* w; const float* bias; const float* alpha_s; const float* inv_beta; void* out; const void* res;
+    int T, C, S, k, dil, K, Kpad, halo, rows_act, rows_x;
+    float alpha; int accumulate;
+};
+
+template <typename T, int BM, int TN>
+__global__ __launch_bounds__(256) void aa_conv_kernel(const AAConvDev p) {
+    using MF = Mfma<T>;
+    constexpr int KP = MF::KP;
+    constexpr int VEC = 16 / (int)sizeof(T);
+    constexpr int R = 8;
+    constexpr int WM = BM / 4, TM = WM / 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* XS = reinterpret_cast<T*>(smem_raw);                        // rows_x   x C   raw input
+    T* AS = XS + (size_t)p.rows_x * p.C;                             // rows_act x S   activated
+    float* OUT = reinterpret_cast<float*>(smem_raw);                 // BM x C fp32 (aliases XS/AS after the MFMA loop)
+
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    const int m0 = blockIdx.x * BM;
+    const int C = p.C, S = p.S;
+    const T* xb = (const T*)p.x + (long)b * p.T * C;
+
+    // ---- 1. stage x rows [m0 - halo - 5, ...) ---------------------------------------------------------
+    {
+        const int cvn = C / VEC, nvec = p.rows_x * cvn;
+        const int t_base = m0 - p.halo - 5;
+        for (int v = tid; v < nvec; v += 256) {
+            const int row = v / cvn, cv = v - row * cvn;
+            const int t = t_base + row;
+            uint4 raw = make_uint4(0, 0, 0, 0);
+            if (t >= 0 && t < p.T) raw = *reinterpret_cast<const uint4*>(xb + (long)t * C + cv * VEC);
+            *reinterpret_cast<uint4*>(XS + row * C + cv * VEC) = raw;
+        }
+    }
+    __syncthreads();
+    // ---- 2. AA: sliding window of R outputs per (channel, run) -------------------------------------------
+    {
+        const int runs = (p.rows_act + R - 1) / R;
+        const int nitems = C * runs;
+        const int t_act0 = m0 - p.halo;                              // global time of activated row 0
+        for (int it = tid; it < nitems; it += 256) {
+            const int run = it / C, c = it - run * C;
+            const int ml = run * R;
+            const float al = p.alpha_s[c], ib = p.inv_beta[c];
+            float xv[R + 10];
+#pragma unroll
+            for (int j = 0; j < R + 10; ++j) xv[j] = to_f32(XS[(ml + j) * C + c]);
+            float acc[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] = 0.f;
+            const int mp = t_act0 + ml;
+#pragma unroll
+            for (int e = 0; e < R + 5; ++e) {
+                float ue = 0.f, uo = 0.f;
+#pragma unroll
+                for (int ee = 0; ee < 6; ++ee) {
+                    ue = fmaf(c_h_fused[2 * ee + 1], xv[e + 5 - ee], ue);
+                    uo = fmaf(c_h_fused[2 * ee], xv[e + 5 - ee], uo);
+                }
+                ue *= 2.f; uo *= 2.f;
+                const int ie = 2 * (mp + e - 2), io = 2 * (mp + e - 3) + 1;
+                float se, so;
+                if constexpr (sizeof(T) == 4) { se = sinf(al * ue); so = sinf(al * uo); }
+                else { se = __sinf(al * ue); so = __sinf(al * uo); }
+                se = ue + ib * (se * se);
+                so = uo + ib * (so * so);
+                if (ie < 0 || ie >= 2 * p.T) se = 0.f;
+                if (io < 0 || io >= 2 * p.T) so = 0.f;
+#pragma unroll
+                for (int tt = 0; tt < 6; ++tt) {
+                    const int r = e - tt;
+                    if (r >= 0 && r < R) acc[r] = fmaf(c_h_fused[2 * tt], so, fmaf(c_h_fused[2 * tt + 1], se, acc[r]));
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int row = ml + r;
+                if (row < p.rows_act) {
+                    const int t = mp + r;
+                    AS[row * S + c] = from_f32<T>((t >= 0 && t < p.T) ? acc[r] : 0.f);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- 3. implicit GEMM: out[m][n] = sum_{tap,ci} AS[m + tap*dil][ci] * W[n][tap*C + ci] -----------------
+    const int wave = tid >> 6, lane = tid & 63, lr = lane & 31, hi = lane >> 5;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    {
+        const T* wp = (const T*)p.w;
+        int kk = hi * KP;                     // this lane's K offset inside the current MFMA k-step
+        int tap = kk / C, ci = kk - tap * C;
+        const int nsteps = p.Kpad / (2 * KP);
+        for (int ks = 0; ks < nsteps; ++ks) {
+            const int tapc = tap < p.k ? tap : p.k - 1;            // padded K tail: weights are zero there
+            typename MF::Frag a[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                a[i] = *reinterpret_cast<const typename MF::Frag*>(AS + (wave * WM + i * 32 + lr + tapc * p.dil) * S + ci);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = j * 32 + lr;
+                if constexpr (KP == 1) {
+                    bf[j] = (n < C && kk < p.K) ? wp[(long)n * p.K + kk] : 0.f;
+                } else {
+                    uint4 raw = make_uint4(0, 0, 0, 0);
+                    if (n < C && kk < p.K) raw = *reinterpret_cast<const uint4*>(wp + (long)n * p.K + kk);
+                    bf[j] = *reinterpret_cast<const typename MF::Frag*>(&raw);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma(a[i], bf[j], acc[i][j]);
+            kk += 2 * KP; ci += 2 * KP;
+            while (ci >= C) { ci -= C; ++tap; }
+        }
+    }
+    __syncthreads();                          // every wave is done reading AS before OUT overwrites it
+    // ---- 4. accumulators -> LDS -> coalesced epilogue -------------------------------------------------------
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = j * 32 + lr;
+        if (n < C) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    OUT[(wave * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * C + n] = acc[i][j][r];
+        }
+    }
+    __syncthreads();
+    {
+        const int cvn = C / VEC, nvec = BM * cvn;
+        T* ob = (T*)p.out + (long)b * p.T * C;
+        const T* rb = p.res ? (const T*)p.res + (long)b * p.T * C : nullptr;
+        for (int v = tid; v < nvec; v += 256) {
+            const int row = v / cvn, cv = v - row * cvn;
+            const int t = m0 + row;
+            if (t >= p.T) continue;
+            const long gi = (long)t * C + cv * VEC;
+            float o[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) o[e] = OUT[row * C + cv * VEC + e] + p.bias[cv * VEC + e];
+            if (rb) {
+                const uint4 raw = *reinterpret_cast<const uint4*>(rb + gi);
+                const T* rv = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) o[e] += to_f32(rv[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) o[e] *= p.alpha;
+            if (p.accumulate) {
+                const uint4 raw = *reinterpret_cast<const uint4*>(ob + gi);
+                const T* pv = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) o[e] += to_f32(pv[e]);
+            }
+            T ov[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) ov[e] = from_f32<T>(o[e]);
+            *reinterpret_cast<uint4*>(ob + gi) = *reinterpret_cast<const uint4*>(ov);
+        }
+    }
+}
+
+template <typename T>
+static void launch_t(const AAConv& q, hipStream_t s) {
+    constexpr int KP = Mfma<T>::KP;
+    constexpr int VEC = 16 / (int)sizeof(T);
+    MI_REQUIRE(q.C % VEC == 0 && q.C % 8 == 0 && q.C <= 96, "aa_conv: C must be a multiple of 8 and <= 96");
+    AAConvDev d;
+    d.x = q.x; d.w = q.w; d.bias = q.bias; d.alpha_s = q.snake_alpha; d.inv_beta = q.snake_inv_beta; d.out = q.out; d.res = q.res;
+    d.T = q.T; d.C = q.C; d.k = q.k; d.dil = q.dil; d.K = q.k * q.C;
+    d.Kpad = (d.K + 2 * KP - 1) / (2 * KP) * (2 * KP);
+    d.halo = (q.k * q.dil - q.dil) / 2;
+    d.S = ((q.C / 8) & 1) ? q.C : q.C + 8;             // S/8 odd => conflict-free ds_read_b128 fragment rows
+    if (sizeof(T) == 4) d.S = (q.C % 2 == 0) ? q.C + 1 : q.C;   // fp32 fragments are ds_read_b32: odd dword stride
+    d.alpha = q.alpha; d.accumulate = q.accumulate;
+    const int BM = q.C <= 48 ? 256 : 128;
+    d.rows_act = BM + 2 * d.halo;
+    d.rows_x = (d.rows_act + 7) / 8 * 8 + 10;
+    const int TN = (q.C + 31) / 32;
+    size_t lds = (size_t)d.rows_x * q.C * sizeof(T) + (size_t)d.rows_act * d.S * sizeof(T);
+    lds = std::max(lds, (size_t)BM * q.C * 4);
+    lds = (lds + 15) / 16 * 16;
+    MI_REQUIRE(lds <= 160 * 1024, "aa_conv: tile does not fit LDS");
+    dim3 grid((q.T + BM - 1) / BM, q.B);
+    const double E = (double)q.B * q.T * q.C * sizeof(T);
+    ProfScope ps(FAM_CONV_GEMM, s, E * (2.0 + (q.res ? 1.0 : 0.0) + (q.accumulate ? 1.0 : 0.0)) + (double)d.K * q.C * sizeof(T),
+                 2.0 * q.B * (double)q.T * q.C * d.K + 60.0 * q.B * (double)q.T * q.C);
+#define LAUNCH(BMv, TNv)                                                                                         \
+    do {                                                                                                         \
+        auto kfn = aa_conv_kernel<T, BMv, TNv>;                                                                  \
+        if (lds > 64 * 1024) MI_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(kfn, grid, dim3(256), lds, s, d);                                                     \
+    } while (0)
+    if (BM == 256) { if (TN == 1) LAUNCH(256, 1); else LAUNCH(256, 2); }
+    else { if (TN == 1) LAUNCH(128, 1); else if (TN == 2) LAUNCH(128, 2); else LAUNCH(128, 3); }
+#undef LAUNCH
+    MI_HIP(hipGetLastError());
+}
+
+void launch_aa_conv(const AAConv& q, hipStream_t s) {
+    static bool uploaded[64] = {false};
+    int dev = 0;
+    MI_HIP(hipGetDevice(&dev));
+    if (!uploaded[dev & 63]) {
+        MI_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_h_fused), aa_filter_host(), sizeof(float) * 12));
+        uploaded[dev & 63] = true;
+    }
+    if (q.dtype == MI_F32) launch_t<float>(q, s);
+    else if (q.dtype == MI_F16) launch_t<f16>(q, s);
+    else launch_t<bf16>(q, s);
+}
+
+}  // namespace mi

@@ -12,6 +12,7 @@
 // between calls with the same (B, frames).
 #include "common.h"
 #include "bigvgan.h"
+#include <cstdlib>
 
 namespace mi {
 
@@ -95,6 +96,7 @@ BigVGAN::BigVGAN(const BigVGANCfg& g, const float* w, int64_t nw, int dt, int de
     MI_REQUIRE(nw == bigvgan_param_count(g), "bigvgan: weight blob size does not match the config");
     MI_HIP(hipSetDevice(dev));
     MI_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    if (const char* e = std::getenv("MI355TTS_NO_FUSED_AA")) use_fused = !(e[0] == '1');
     const int vec = 16 / (int)dtype_size(dt);
     MI_REQUIRE((g.c0 >> g.n_up) % vec == 0, "bigvgan: last-stage channels must be a multiple of the 16-byte vector");
     mel_pad = round_up(g.num_mels, vec);
@@ -179,6 +181,15 @@ void BigVGAN::conv(const ConvW& cw, const void* x, void* out, int B, int T, int 
     launch_conv_gemm(p, stream);
 }
 
+void BigVGAN::aa_conv(const SnakeP& sp, const ConvW& cw, const void* x, void* out, int B, int T, int C, int k, int dil,
+                      const void* res, float alpha, int accumulate) {
+    AAConv a;
+    a.dtype = dtype; a.x = x; a.w = cw.w.p; a.bias = cw.b.as<float>(); a.snake_alpha = sp.alpha.as<float>();
+    a.snake_inv_beta = sp.inv_beta.as<float>(); a.out = out; a.res = res; a.B = B; a.T = T; a.C = C; a.k = k; a.dil = dil;
+    a.alpha = alpha; a.accumulate = accumulate;
+    launch_aa_conv(a, stream);
+}
+
 void BigVGAN::aa(const SnakeP& sp, const void* x, void* y, int B, int T, int C, int post) {
     AAAct a;
     a.dtype = dtype; a.x = x; a.y = y; a.alpha = sp.alpha.as<float>(); a.inv_beta = sp.inv_beta.as<float>();
@@ -222,12 +233,18 @@ void BigVGAN::run(const float* mel, int B, int F, float* out_f32, int16_t* out_i
             AmpBlock& bk = st.blocks[j];
             const void* cur = X->p;
             for (int l = 0; l < cfg.n_dil; ++l) {
-                aa(bk.acts[2 * l], cur, bT1.p, B, Tn, C, 0);
-                conv(bk.c1[l], bT1.p, bT2.p, B, Tn, C, C, bk.k, cfg.dil[j][l], nullptr, 1.f, 0);
-                aa(bk.acts[2 * l + 1], bT2.p, bT1.p, B, Tn, C, 0);
                 const bool last = l == cfg.n_dil - 1;
                 void* dst = last ? IN->p : ((l & 1) ? bQ.p : bP.p);
-                conv(bk.c2[l], bT1.p, dst, B, Tn, C, C, bk.k, 1, cur, last ? inv_nk : 1.f, last && j > 0);
+                if (use_fused && C <= 96) {
+                    // HBM-bound stages: AA folded into the conv's operand staging (5 tensor passes instead of 9)
+                    aa_conv(bk.acts[2 * l], bk.c1[l], cur, bT2.p, B, Tn, C, bk.k, cfg.dil[j][l], nullptr, 1.f, 0);
+                    aa_conv(bk.acts[2 * l + 1], bk.c2[l], bT2.p, dst, B, Tn, C, bk.k, 1, cur, last ? inv_nk : 1.f, last && j > 0);
+                } else {
+                    aa(bk.acts[2 * l], cur, bT1.p, B, Tn, C, 0);
+                    conv(bk.c1[l], bT1.p, bT2.p, B, Tn, C, C, bk.k, cfg.dil[j][l], nullptr, 1.f, 0);
+                    aa(bk.acts[2 * l + 1], bT2.p, bT1.p, B, Tn, C, 0);
+                    conv(bk.c2[l], bT1.p, dst, B, Tn, C, C, bk.k, 1, cur, last ? inv_nk : 1.f, last && j > 0);
+                }
                 cur = dst;
             }
         }

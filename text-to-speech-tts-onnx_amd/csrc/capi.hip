@@ -261,6 +261,40 @@ int mi_f5_synthesize(mi_f5* h, int U, const int16_t* audio, int64_t L, const int
     });
 }
 
+int mi_bench_conv_gemm(int dtype, int B, int T, int Cin, int N, int taps, int dil, int with_res, int iters, double* ms) {
+    return guard([&] {
+        MI_REQUIRE(ms && B > 0 && T > 0 && Cin > 0 && N > 0 && taps > 0 && iters > 0, "mi_bench_conv_gemm: bad arguments");
+        hipStream_t s;
+        MI_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        const size_t es = dtype_size(dtype);
+        DevBuf x, w, o, r, bias;
+        const size_t nx = (size_t)B * T * Cin, nw = (size_t)N * taps * Cin, no = (size_t)B * T * N;
+        std::vector<float> hx(nx), hw(nw), hb(N, 0.01f);
+        uint32_t st = 12345;
+        auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 65536.0f - 0.5f; };
+        for (auto& v : hx) v = rnd();
+        for (auto& v : hw) v = rnd() * 0.1f;
+        upload_as(x, hx.data(), nx, dtype, s); upload_as(w, hw.data(), nw, dtype, s); upload_f32(bias, hb.data(), N, s);
+        o.ensure(no * es); r.ensure(no * es);
+        MI_HIP(hipMemsetAsync(r.p, 0, no * es, s));
+        ConvGemm p;
+        p.dtype = dtype; p.x = x.p; p.w = w.p; p.bias = bias.as<float>(); p.out = o.p; p.res = with_res ? r.p : nullptr;
+        p.B = B; p.T_in = T; p.M = T; p.N = N; p.Cin = Cin; p.taps = taps; p.dil = dil; p.pad = (taps * dil - dil) / 2;
+        p.x_bstride = (long)T * Cin; p.x_rstride = Cin; p.out_bstride = (long)T * N; p.out_rstride = N;
+        for (int i = 0; i < 3; ++i) launch_conv_gemm(p, s);
+        hipEvent_t e0, e1;
+        MI_HIP(hipEventCreate(&e0)); MI_HIP(hipEventCreate(&e1));
+        MI_HIP(hipEventRecord(e0, s));
+        for (int i = 0; i < iters; ++i) launch_conv_gemm(p, s);
+        MI_HIP(hipEventRecord(e1, s));
+        MI_HIP(hipEventSynchronize(e1));
+        float t = 0.f;
+        MI_HIP(hipEventElapsedTime(&t, e0, e1));
+        *ms = (double)t / iters;
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(s);
+    });
+}
+
 int mi_prof_enable(int family_mask) { prof_enable((unsigned)family_mask); return MI_OK; }
 int mi_prof_reset(void) { return guard([&] { prof_reset(); }); }
 int mi_prof_get(const char* family, double* ms, int64_t* launches, double* bytes, double* flops) {

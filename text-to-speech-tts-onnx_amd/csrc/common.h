@@ -141,6 +141,18 @@ struct AAAct {
 void launch_aa_act(const AAAct& p, hipStream_t s);
 const float* aa_filter_host();         // the 12 kaiser-sinc taps
 
+// fused AA-activation -> Conv1d for C <= 96 (aa_conv.hip); channels-last (B,T,C) -> (B,T,C)
+struct AAConv {
+    int dtype = MI_F32;
+    const void* x = nullptr; const void* w = nullptr;   // w: [co][tap][ci]
+    const float* bias = nullptr;
+    const float* snake_alpha = nullptr; const float* snake_inv_beta = nullptr;
+    void* out = nullptr; const void* res = nullptr;
+    int B = 1, T = 0, C = 0, k = 3, dil = 1;
+    float alpha = 1.f; int accumulate = 0;
+};
+void launch_aa_conv(const AAConv& p, hipStream_t s);
+
 // layout helpers (elementwise.hip)
 // (B,C,T) fp32 channels-first -> (B,T,Cpad) dtype channels-last (zero padded channels)
 void launch_ncl_to_nlc(const float* x, void* y, int B, int C, int T, int Cpad, int dtype, hipStream_t s);

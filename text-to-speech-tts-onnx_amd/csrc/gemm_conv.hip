@@ -21,6 +21,7 @@
 // MFMAs of the current one) -> LDS -> fragments.
 #include "common.h"
 #include "mfma.h"
+#include <cstdlib>
 
 namespace mi {
 
@@ -48,10 +49,117 @@ struct ConvGemmDev {
     int act; float alpha; int accumulate; int epi;
     int u, Cout, padT, T_out;
     const float* rope_cos; const float* rope_sin; int heads, head_dim; void* out2; void* out3;
+    const void* zero;      // >= 16 bytes of zeros: source for out-of-range / K-tail vectors of the LDS-DMA path
+    int dbg;               // tuning only: 1 = no DMA in the main loop, 2 = no ds_read/MFMA in the main loop
+    int Tm, Tn, RT, RC;    // XCD-aware tile order (DMA kernel): M-tiles per batch item, N-tiles, row tiles (B*Tm), rows per XCD
 };
 
+// Shared epilogue: 32x32 accumulator tiles -> bias / activation / gate / residual / alpha / accumulate -> HBM,
+// with the ConvTranspose1d index map and the fused QKV bias+RoPE+head-scatter variants.
+// All wave-uniform decisions (activation kind, residual, accumulate, index map) are taken ONCE per 32x32 tile, not
+// per element: the first version branched per element and cost ~5 us per tile (~20 us fixed per launch).
+template <int ACT>
+__device__ __forceinline__ void act16(float (&v)[16]) {
+    // four values at a time: letting the scheduler interleave all 16 transcendental expansions costs ~90 VGPRs
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[q * 4 + r] = act_apply(v[q * 4 + r], ACT);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <typename TO, int TM, int TN, int WM, int WN>
+__device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], const ConvGemmDev& p, int m0, int n0, int b, int g,
+                                              int wm, int wn, int lr, int lk) {
+    if (p.epi == EPI_QKV_ROPE) {
+        // fused bias + interleaved-pair RoPE + head scatter (AttnProcessor, modules.py:459-466, 421-438):
+        //   column n -> (which = q|k|v, head, d) ; q,k: z*cos + rot(z)*sin with rot(z)[2j] = -z[2j+1],
+        //   rot(z)[2j+1] = z[2j] (the pair partner lives in lane^1 of the accumulator tile) ;
+        //   destination layout [b*H + head][token][head_dim] for the attention kernel.
+        const int dm = p.heads * p.head_dim;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * WN + j * 32 + lr;        // N % 32 == 0 is required: no lane drops out
+            const int which = n / dm;
+            const int rem = n - which * dm;
+            const int hh = rem / p.head_dim, dd = rem - hh * p.head_dim;
+            const float bv = p.bias ? p.bias[n] : 0.f;
+            const float sgn = (dd & 1) ? 1.f : -1.f;
+            TO* dst = (TO*)(which == 0 ? p.out : which == 1 ? p.out2 : p.out3) + ((long)b * p.heads + hh) * p.M * p.head_dim + dd;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int mb = m0 + wm * WM + i * 32 + 4 * lk;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mb + (r & 3) + 8 * (r >> 2);
+                    float v = acc[i][j][r] + bv;
+                    const float partner = __shfl_xor(v, 1);
+                    const int mc = m < p.M ? m : p.M - 1;
+                    const float c = which < 2 ? p.rope_cos[(long)mc * p.head_dim + dd] : 1.f;
+                    const float sn = which < 2 ? p.rope_sin[(long)mc * p.head_dim + dd] : 0.f;
+                    v = v * c + sgn * partner * sn;
+                    if (m < p.M) dst[(long)m * p.head_dim] = from_f32<TO>(v);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        return;
+    }
+    TO* outp = (TO*)p.out + (long)b * p.out_bstride;
+    const TO* resp = p.res ? (const TO*)p.res + (long)b * p.out_bstride : nullptr;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WN + j * 32 + lr;
+        const bool nok = n < p.N;
+        const int nc = nok ? n : 0;
+        int col, ph = 0;
+        if (p.epi == EPI_CONVT) { ph = nc / p.Cout; col = nc - ph * p.Cout; }
+        else col = g * p.N + nc;
+        const float bv = p.bias ? p.bias[col] : 0.f;
+        const float gv = p.gate ? p.gate[(long)b * p.gate_bstride + col] : 1.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mb = m0 + wm * WM + i * 32 + 4 * lk;
+            float v[16];
+            // element r -> output row; recomputed where needed instead of kept in 32 registers
+            auto row_of = [&](int r, bool& o) -> long {
+                const int m = mb + (r & 3) + 8 * (r >> 2);
+                long row = m;
+                o = nok && m < p.M;
+                if (p.epi == EPI_CONVT) { row = (long)m * p.u + ph - p.padT; o = o && row >= 0 && row < p.T_out; }
+                return (o ? row : 0) * p.out_rstride + col;
+            };
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r] + bv;
+            switch (p.act) {                                  // wave-uniform, once per tile
+                case ACT_GELU_TANH: act16<ACT_GELU_TANH>(v); break;
+                case ACT_GELU_ERF: act16<ACT_GELU_ERF>(v); break;
+                case ACT_MISH: act16<ACT_MISH>(v); break;
+                case ACT_SILU: act16<ACT_SILU>(v); break;
+                default: break;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] *= gv;
+            if (resp) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { bool o; const long ix = row_of(r, o); v[r] += o ? to_f32(resp[ix]) : 0.f; }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] *= p.alpha;
+            if (p.accumulate) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { bool o; const long ix = row_of(r, o); v[r] += o ? to_f32(outp[ix]) : 0.f; }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { bool o; const long ix = row_of(r, o); if (o) outp[ix] = from_f32<TO>(v[r]); }
+            __builtin_amdgcn_sched_barrier(0);                // keep one tile's addresses live at a time
+        }
+    }
+}
+
 template <typename T, typename TO, int BM, int BN, int WGM, int WGN, int KC>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmDev p) {
+__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmDev p) {
     using MF = Mfma<T>;
     constexpr int KP = MF::KP;
     constexpr int VEC = 16 / (int)sizeof(T);
@@ -172,80 +280,239 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmDev p) {
         }
     }
 
-    // ---- epilogue -------------------------------------------------------------------------
-    if (p.epi == EPI_QKV_ROPE) {
-        // fused bias + interleaved-pair RoPE + head scatter (AttnProcessor, modules.py:459-466, 421-438):
-        //   column n -> (which = q|k|v, head, d) ; q,k: z*cos + rot(z)*sin with rot(z)[2j] = -z[2j+1],
-        //   rot(z)[2j+1] = z[2j] (the pair partner lives in lane^1 of the accumulator tile) ;
-        //   destination layout [b*H + head][token][head_dim] for the attention kernel.
-        const int dm = p.heads * p.head_dim;
+    gemm_epilogue<TO, TM, TN, WM, WN>(acc, p, m0, n0, b, g, wm, wn, lr, lk);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 16-bit main loop v2: HBM -> LDS by direct DMA (global_load_lds, 16 B per lane), two LDS buffers,
+// one barrier per 64-deep K chunk, XOR-swizzled 128-byte tile rows.
+//
+//   * a K chunk is (tap, 64 input channels): A rows are x[m + tap*dil - pad][c0 .. c0+64), B rows are
+//     w[n][tap*Cin + c0 .. +64).  Vectors that fall outside the tensor (time padding, Cin tail, N tail) are
+//     fetched from a page of zeros, so the DMA needs no predication and the MFMA loop no masking.
+//   * LDS image: row r holds its eight 16-byte k-vectors at slot (kv ^ (r & 7)).  The DMA writes lane-linear
+//     (lane l -> row R0 + l/8, slot l%8), so lane l simply FETCHES k-vector (l%8) ^ (l/8); fragment reads apply
+//     the same XOR.  8 consecutive rows then cover all 64 banks for a ds_read_b128 (2-way at worst in a
+//     16-lane group instead of 8-way for the linear image).
+//   * the loads of chunk c+1 are in flight while the 16 MFMAs per wave of chunk c run.
+// ---------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void;
+
+template <typename T, typename TO>
+__global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvGemmDev p) {
+    using MF = Mfma<T>;
+    constexpr int BM = 128, BN = 128, KC = 64, WM = 64, WN = 64, TM = 2, TN = 2;
+    constexpr int TILE = (BM + BN) * KC;                  // elements per buffer
+    __shared__ __attribute__((aligned(1024))) T smem[2 * TILE];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lk = lane >> 5;
+    // XCD-aware tile order.  Workgroup L lands on XCD (L % 8) (observed dispatch order; only speed depends on
+    // it).  Each XCD owns a contiguous range of RC row tiles (batch x M) and walks the N tiles in the OUTER loop,
+    // so the RC workgroups that run together share one weight panel in their XCD's 4 MiB L2 and the XCD's
+    // activation rows stay L2-resident across N tiles, instead of every L2 streaming every panel from MALL.
+    const int L = blockIdx.x;
+    int nt, rowt;
+    if (p.RC > 0) {
+        const int xcd = L & 7, jx = L >> 3;
+        nt = jx / p.RC; rowt = xcd * p.RC + (jx - nt * p.RC);
+        if (rowt >= p.RT) return;                         // padding workgroups (RT rounded up to 8*RC)
+    } else {                                              // plain order: row tiles fastest
+        nt = L / p.RT; rowt = L - nt * p.RT;
+    }
+    const int b = rowt / p.Tm, mt = rowt - b * p.Tm;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int g = blockIdx.y;
+    const T* xb = (const T*)p.x + (long)b * p.x_bstride + (long)g * p.x_goff;
+    const T* wg = (const T*)p.w + (long)g * p.N * p.K;
+    const T* zero = (const T*)p.zero;
+
+    const int kvl = (lane & 7) ^ (lane >> 3);             // logical k-vector this lane fetches
+    const int lrow = lane >> 3;                           // row inside an 8-row DMA group
+    const int cpt = (p.Cin + KC - 1) / KC;                // chunks per tap
+    const int nchunks = (p.K / p.Cin) * cpt;
+
+    auto issue = [&](int buf, int tap, int c0) {
+        T* base = smem + buf * TILE;
+        const int ci = c0 + kvl * 8;
+        const bool kval = ci < p.Cin;
+        const int toff = tap * p.dil - p.pad;
+        const long wk = (long)tap * p.Cin + ci;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * WN + j * 32 + lr;        // N % 32 == 0 is required: no lane drops out
-            const int which = n / dm;
-            const int rem = n - which * dm;
-            const int hh = rem / p.head_dim, dd = rem - hh * p.head_dim;
-            const float bv = p.bias ? p.bias[n] : 0.f;
-            TO* dst = (TO*)(which == 0 ? p.out : which == 1 ? p.out2 : p.out3) + ((long)b * p.heads + hh) * p.M * p.head_dim + dd;
+        for (int j = 0; j < 4; ++j) {
+            const int R0 = (wave * 4 + j) * 8;
+            const int t = m0 + R0 + lrow + toff;
+            const T* src = (kval && t >= 0 && t < p.T_in) ? xb + (long)t * p.x_rstride + ci : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (lds_void*)(base + R0 * KC), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int R0 = (wave * 4 + j) * 8;
+            const int n = n0 + R0 + lrow;
+            const T* src = (kval && n < p.N) ? wg + (long)n * p.K + wk : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (lds_void*)(base + (BM + R0) * KC), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    int tap = 0, c0 = 0;
+    issue(0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        int ntap = tap, nc0 = c0 + KC;
+        if (nc0 >= p.Cin) { nc0 = 0; ++ntap; }
+        if (c + 1 < nchunks) issue(buf ^ 1, ntap, nc0);
+        const T* As = smem + buf * TILE;
+        const T* Bs = As + BM * KC;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            typename MF::Frag a[TM], bb[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                    float v = acc[i][j][r] + bv;
-                    const float partner = __shfl_xor(v, 1);
-                    if (m < p.M) {
-                        if (which < 2) {
-                            const float c = p.rope_cos[(long)m * p.head_dim + dd], sn = p.rope_sin[(long)m * p.head_dim + dd];
-                            v = v * c + ((dd & 1) ? partner : -partner) * sn;
-                        }
-                        dst[(long)m * p.head_dim] = from_f32<TO>(v);
-                    }
-                }
+                const int row = wm * WM + i * 32 + lr;
+                a[i] = *reinterpret_cast<const typename MF::Frag*>(As + row * KC + (((ks * 2 + lk) ^ (row & 7)) << 3));
             }
-        }
-        return;
-    }
-    TO* outp = (TO*)p.out + (long)b * p.out_bstride;
-    const TO* resp = p.res ? (const TO*)p.res + (long)b * p.out_bstride : nullptr;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * WN + j * 32 + lr;
-        if (n >= p.N) continue;
-        int col, ph = 0;
-        float bv;
-        if (p.epi == EPI_CONVT) {
-            ph = n / p.Cout;
-            col = n - ph * p.Cout;
-            bv = p.bias ? p.bias[col] : 0.f;
-        } else {
-            col = g * p.N + n;
-            bv = p.bias ? p.bias[col] : 0.f;
-        }
-        const float gv = p.gate ? p.gate[(long)b * p.gate_bstride + col] : 1.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                long row;
-                if (p.epi == EPI_CONVT) {
-                    row = (long)m * p.u + ph - p.padT;
-                    if (m >= p.M || row < 0 || row >= p.T_out) continue;
-                } else {
-                    row = m;
-                    if (m >= p.M) continue;
-                }
-                const long idx = row * p.out_rstride + col;
-                float v = act_apply(acc[i][j][r] + bv, p.act) * gv;
-                if (resp) v += to_f32(resp[idx]);
-                v *= p.alpha;
-                if (p.accumulate) v += to_f32(outp[idx]);
-                outp[idx] = from_f32<TO>(v);
+            for (int j = 0; j < TN; ++j) {
+                const int row = wn * WN + j * 32 + lr;
+                bb[j] = *reinterpret_cast<const typename MF::Frag*>(Bs + row * KC + (((ks * 2 + lk) ^ (row & 7)) << 3));
             }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma(a[i], bb[j], acc[i][j]);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        tap = ntap; c0 = nc0;
     }
+    gemm_epilogue<TO, TM, TN, WM, WN>(acc, p, m0, n0, b, g, wm, wn, lr, lk);
 }
+
+// ---------------------------------------------------------------------------------------------------
+// 16-bit main loop v3: 256x128 tile, 8 waves (two per SIMD, so one wave's LDS/barrier stalls sit under the
+// other's MFMAs), three-stage LDS ring filled by LDS-DMA two chunks ahead.  A lone workgroup of the 2-stage
+// kernel measured ~1700 cycles per K chunk against 512 cycles of MFMA (DMA issue -> landed -> barrier ->
+// ds_read is a serial chain); here the DMA for chunk c+2 is issued before the MFMAs of chunk c, the wait is a
+// COUNTED s_waitcnt vmcnt(6) (= this wave's six DMA instructions of chunk c+2 may stay in flight) and the
+// barrier is the raw s_barrier, so nothing drains the queue (a __syncthreads() would wait vmcnt(0)).
+// Swizzle: slot = kv ^ ((row >> 1) & 7): rows of equal parity inside every ds_read_b128 lane group get eight
+// distinct slots => conflict-free fragment reads.
+// ---------------------------------------------------------------------------------------------------
+template <typename T, typename TO>
+__global__ __launch_bounds__(512) void conv_gemm_dma3_kernel(const ConvGemmDev p) {
+    using MF = Mfma<T>;
+    constexpr int BM = 256, BN = 128, KC = 64, WM = 64, WN = 64, TM = 2, TN = 2, NST = 3;
+    constexpr int TILE = (BM + BN) * KC;
+    __shared__ __attribute__((aligned(1024))) T smem[NST * TILE];      // 144 KiB
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lk = lane >> 5;
+    const int L = blockIdx.x;
+    const int nt = L / p.RT, rowt = L - nt * p.RT;        // row tiles fastest: neighbours share the weight panel
+    const int b = rowt / p.Tm, mt = rowt - b * p.Tm;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int g = blockIdx.y;
+    const T* xb = (const T*)p.x + (long)b * p.x_bstride + (long)g * p.x_goff;
+    const T* wg = (const T*)p.w + (long)g * p.N * p.K;
+    const T* zero = (const T*)p.zero;
+
+    const int lrow = lane >> 3;
+    const int kv0 = (lane & 7) ^ ((lane >> 4) & 7);               // even 8-row groups
+    const int kv1 = (lane & 7) ^ ((4 + (lane >> 4)) & 7);         // odd 8-row groups
+    const int nchunks = (p.K / p.Cin) * ((p.Cin + KC - 1) / KC);
+
+    auto issue = [&](int st, int tap, int c0) {
+        T* base = smem + st * TILE;
+        const int toff = tap * p.dil - p.pad;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                             // A: 32 groups of 8 rows, 4 per wave
+            const int R0 = (wave * 4 + j) * 8;
+            const int ci = c0 + ((j & 1) ? kv1 : kv0) * 8;
+            const int t = m0 + R0 + lrow + toff;
+            const T* src = (ci < p.Cin && t >= 0 && t < p.T_in) ? xb + (long)t * p.x_rstride + ci : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (lds_void*)(base + R0 * KC), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {                             // B: 16 groups, 2 per wave
+            const int R0 = (wave * 2 + j) * 8;
+            const int ci = c0 + ((j & 1) ? kv1 : kv0) * 8;
+            const int n = n0 + R0 + lrow;
+            const T* src = (ci < p.Cin && n < p.N) ? wg + (long)n * p.K + (long)tap * p.Cin + ci : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (lds_void*)(base + (BM + R0) * KC), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // chunk cursor of the NEXT chunk to issue
+    int itap = 0, ic0 = 0;
+    auto advance = [&]() { ic0 += KC; if (ic0 >= p.Cin) { ic0 = 0; ++itap; } };
+    issue(0, itap, ic0); advance();
+    if (nchunks > 1) { issue(1, itap, ic0); advance(); asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    int st = 0;
+    for (int c = 0; c < nchunks; ++c) {
+        if (c + 2 < nchunks) {
+            int st2 = st + 2; if (st2 >= NST) st2 -= NST;
+            if (p.dbg != 1) issue(st2, itap, ic0);
+            advance();
+        }
+        const T* As = smem + st * TILE;
+        const T* Bs = As + BM * KC;
+        if (p.dbg != 2)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            typename MF::Frag a[TM], bb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = wm * WM + i * 32 + lr;
+                a[i] = *reinterpret_cast<const typename MF::Frag*>(As + row * KC + (((ks * 2 + lk) ^ ((row >> 1) & 7)) << 3));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row = wn * WN + j * 32 + lr;
+                bb[j] = *reinterpret_cast<const typename MF::Frag*>(Bs + row * KC + (((ks * 2 + lk) ^ ((row >> 1) & 7)) << 3));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma(a[i], bb[j], acc[i][j]);
+        }
+        // chunk c+1 must have landed (for every wave) before anyone reads it; chunk c+2 may stay in flight
+        if (c + 2 < nchunks && p.dbg != 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (++st == NST) st = 0;
+    }
+    gemm_epilogue<TO, TM, TN, WM, WN>(acc, p, m0, n0, b, g, wm, wn, lr, lk);
+}
+
+static bool g_use_dma = true, g_xcd_order = false, g_use_dma3 = true;
+static DevBuf g_zero_page[16];
 
 template <typename T, typename TO>
 static void dispatch_tiles(const ConvGemmDev& d, int B, hipStream_t s) {
@@ -259,6 +526,25 @@ static void dispatch_tiles(const ConvGemmDev& d, int B, hipStream_t s) {
         hipLaunchKernelGGL((conv_gemm_kernel<T, TO, 128, 64, 2, 2, KC>), grid, blk, 0, s, d);
     } else {
         dim3 grid((d.M + 127) / 128, (d.N + 127) / 128, B * d.G);
+        if constexpr (sizeof(T) == 2) {
+            if (g_use_dma3 && d.Cin % 8 == 0 && d.K % d.Cin == 0 && d.M > 128) {
+                ConvGemmDev e = d;
+                e.Tm = (d.M + 255) / 256; e.Tn = (d.N + 127) / 128; e.RT = B * e.Tm; e.RC = 0;
+                dim3 g1(e.RT * e.Tn, d.G);
+                hipLaunchKernelGGL((conv_gemm_dma3_kernel<T, TO>), g1, dim3(512), 0, s, e);
+                MI_HIP(hipGetLastError());
+                return;
+            }
+            if (g_use_dma && d.Cin % 8 == 0 && d.K % d.Cin == 0) {
+                ConvGemmDev e = d;
+                e.Tm = (d.M + 127) / 128; e.Tn = (d.N + 127) / 128; e.RT = B * e.Tm;
+                e.RC = g_xcd_order ? (e.RT + 7) / 8 : 0;
+                dim3 g1(e.RC > 0 ? 8 * e.RC * e.Tn : e.RT * e.Tn, d.G);
+                hipLaunchKernelGGL((conv_gemm_dma_kernel<T, TO>), g1, blk, 0, s, e);
+                MI_HIP(hipGetLastError());
+                return;
+            }
+        }
         hipLaunchKernelGGL((conv_gemm_kernel<T, TO, 128, 128, 2, 2, KC>), grid, blk, 0, s, d);
     }
     MI_HIP(hipGetLastError());
@@ -282,6 +568,19 @@ void launch_conv_gemm(const ConvGemm& p, hipStream_t s) {
     d.u = p.u; d.Cout = p.Cout; d.padT = p.padT; d.T_out = p.T_out;
     d.rope_cos = p.rope_cos; d.rope_sin = p.rope_sin; d.heads = p.heads; d.head_dim = p.head_dim;
     d.out2 = p.out2; d.out3 = p.out3;
+    {
+        static bool env_read = false;
+        if (!env_read) { const char* e = std::getenv("MI355TTS_NO_DMA_GEMM"); g_use_dma = !(e && e[0] == '1');
+            const char* x = std::getenv("MI355TTS_XCD_ORDER"); g_xcd_order = x && x[0] == '1';
+            const char* y = std::getenv("MI355TTS_NO_DMA3_GEMM"); g_use_dma3 = !(y && y[0] == '1'); env_read = true; }
+        int dev = 0;
+        MI_HIP(hipGetDevice(&dev));
+        DevBuf& z = g_zero_page[dev & 15];
+        if (!z.p) { z.ensure(4096); MI_HIP(hipMemset(z.p, 0, 4096)); }
+        d.zero = z.p;
+        const char* dm = std::getenv("MI355TTS_GEMM_DBG");
+        d.dbg = dm ? std::atoi(dm) : 0;
+    }
     if (p.epi == EPI_CONVT) MI_REQUIRE(p.Cout > 0 && p.N == p.u * p.Cout, "conv_gemm: convT shape");
     if (p.epi == EPI_QKV_ROPE)
         MI_REQUIRE(p.G == 1 && p.heads > 0 && p.head_dim % 2 == 0 && p.N == 3 * p.heads * p.head_dim && p.N % 32 == 0 &&

@@ -78,6 +78,8 @@ def load() -> C.CDLL:
     L.mi_f5_synthesize.argtypes = [vp, C.c_int, vp, C.c_int64, vp, C.c_int64, C.c_int64, vp, C.c_uint64, vp, i64p,
                                    C.c_int]
     L.mi_f5_synthesize.restype = C.c_int
+    L.mi_bench_conv_gemm.argtypes = [C.c_int] * 9 + [C.POINTER(C.c_double)]
+    L.mi_bench_conv_gemm.restype = C.c_int
     L.mi_prof_enable.argtypes = [C.c_int]; L.mi_prof_enable.restype = C.c_int
     L.mi_prof_reset.argtypes = []; L.mi_prof_reset.restype = C.c_int
     L.mi_prof_get.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
@@ -131,3 +133,12 @@ def prof_get(family: str) -> dict:
     ms, n, by, fl = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
     check(load().mi_prof_get(family.encode(), C.byref(ms), C.byref(n), C.byref(by), C.byref(fl)), "mi_prof_get")
     return {"ms": ms.value, "launches": n.value, "bytes": by.value, "flops": fl.value}
+
+
+def bench_conv_gemm(dtype: str, B: int, T: int, Cin: int, N: int, taps: int = 1, dil: int = 1, with_res: bool = False,
+                    iters: int = 20) -> float:
+    """Average ms per launch of the implicit-GEMM kernel on random device data (tuning hook)."""
+    ms = C.c_double()
+    check(load().mi_bench_conv_gemm(DTYPES[dtype], B, T, Cin, N, taps, dil, int(with_res), iters, C.byref(ms)),
+          "mi_bench_conv_gemm")
+    return ms.value
