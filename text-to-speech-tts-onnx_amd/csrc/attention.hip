@@ -43,7 +43,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const T* __restrict__ q, cons
     const int q0 = blockIdx.x * 128 + wave * 32;
     const T* qb = q + (long)bh * N * D;
     const T* kb = k + (long)bh * N * D;
-    const T* vb = v + (long)bh * N * D;
+    const long vld = sizeof(T) == 4 ? 0 : (long)((N + 7) / 8 * 8);
+    const T* vb = v + (sizeof(T) == 4 ? (long)bh * N * D : (long)bh * D * vld);
 
     // ---- Q fragments (B operand of S^T): Q[q = q0+lr][d = ks*2KP + hi*KP ..] ------------------
     typename MF::Frag qf[KS];
@@ -52,11 +53,15 @@ __global__ __launch_bounds__(256) void attn_kernel(const T* __restrict__ q, cons
         const bool ok = qr < N;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
+            // Q is pre-multiplied by log2(e): the softmax then needs v_exp_f32 (2^x) only, no expf expansion
             if constexpr (KP == 1) {
-                qf[ks] = ok ? qb[(long)qr * D + 2 * ks + hi] : 0.f;
+                qf[ks] = ok ? qb[(long)qr * D + 2 * ks + hi] * 1.4426950408889634f : 0.f;
             } else {
                 uint4 raw = make_uint4(0, 0, 0, 0);
                 if (ok) raw = *reinterpret_cast<const uint4*>(qb + (long)qr * D + ks * 16 + hi * 8);
+                T* e = reinterpret_cast<T*>(&raw);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) e[j] = from_f32<T>(to_f32(e[j]) * 1.4426950408889634f);
                 qf[ks] = *reinterpret_cast<const typename MF::Frag*>(&raw);
             }
         }
@@ -69,9 +74,13 @@ __global__ __launch_bounds__(256) void attn_kernel(const T* __restrict__ q, cons
             const int vi = tid + i * 256;
             const int key = vi / (D / VEC), dv = vi - key * (D / VEC);
             uint4 a = make_uint4(0, 0, 0, 0), b = make_uint4(0, 0, 0, 0);
-            if (key0 + key < N) {
-                a = *reinterpret_cast<const uint4*>(kb + (long)(key0 + key) * D + dv * VEC);
-                b = *reinterpret_cast<const uint4*>(vb + (long)(key0 + key) * D + dv * VEC);
+            if (key0 + key < N) a = *reinterpret_cast<const uint4*>(kb + (long)(key0 + key) * D + dv * VEC);
+            if constexpr (sizeof(T) == 4) {
+                if (key0 + key < N) b = *reinterpret_cast<const uint4*>(vb + (long)(key0 + key) * D + dv * VEC);
+            } else {
+                // V arrives transposed from the QKV epilogue: row d = vi / 8, eight consecutive keys per vector
+                const int d = vi >> 3, kv = vi & 7;
+                if (key0 + kv * 8 < N) b = *reinterpret_cast<const uint4*>(vb + (long)d * vld + key0 + kv * 8);
             }
             kreg[i] = a; vreg[i] = b;
         }
@@ -88,9 +97,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const T* __restrict__ q, cons
                 *reinterpret_cast<uint4*>(Vs + key * LDV + dv * VEC) = vreg[i];
             } else {
                 *reinterpret_cast<uint4*>(Ks + key * LDK + dv * VEC) = kreg[i];
-                const T* e = reinterpret_cast<const T*>(&vreg[i]);
-#pragma unroll
-                for (int j = 0; j < VEC; ++j) Vs[(dv * VEC + j) * LDV + key] = e[j];      // transpose: Vt[d][key]
+                const int d = vi >> 3, kv = vi & 7;                                           // Vt[d][key], 8-byte aligned rows
+                *reinterpret_cast<uint2*>(Vs + d * LDV + kv * 8) = make_uint2(vreg[i].x, vreg[i].y);
+                *reinterpret_cast<uint2*>(Vs + d * LDV + kv * 8 + 4) = make_uint2(vreg[i].z, vreg[i].w);
             }
         }
     };
@@ -129,16 +138,21 @@ __global__ __launch_bounds__(256) void attn_kernel(const T* __restrict__ q, cons
                     mloc = fmaxf(mloc, sacc[r]);
                 }
                 mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-                const float m_new = fmaxf(m_run, mloc);
-                const float alpha = expf(m_run - m_new);
+                // lazy rescale: keep the old reference max while it is within 2^8 of the new one (P <= 256, exact in
+                // fp32 accumulation); rescale O and l only when some query of the wave needs it (wave-uniform branch)
+                float alpha = 1.f;
+                if (!__all(mloc - m_run <= 8.0f)) {
+                    const float m_new = fmaxf(m_run, mloc);
+                    alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                    m_run = m_new;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
+                }
                 float p[16], lsum = 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { p[r] = expf(sacc[r] - m_new); lsum += p[r]; }
+                for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_exp2f(sacc[r] - m_run); lsum += p[r]; }
                 lsum += __shfl_xor(lsum, 32);
                 l_run = l_run * alpha + lsum;
-                m_run = m_new;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
                 // ---- O^T += V^T P^T ------------------------------------------------------------------
                 if constexpr (KP == 1) {
 #pragma unroll

@@ -303,7 +303,12 @@ void F5::ensure_workspace(int U, int N) {
     cat.ensure(rows * c.cat_dim() * es);
     h32.ensure(rows * c.dim * 4); hT.ensure(rows * c.dim * es); c1.ensure(rows * c.dim * es);
     X.ensure(rows * c.dim * 4); Ub.ensure(rows * c.dim * es);
-    qb.ensure(rows * c.dim * es); kb.ensure(rows * c.dim * es); vb.ensure(rows * c.dim * es); Ob.ensure(rows * c.dim * es);
+    qb.ensure(rows * c.dim * es); kb.ensure(rows * c.dim * es); Ob.ensure(rows * c.dim * es);
+    {   // V may be stored transposed with the key axis padded to a multiple of 8; the pad columns are read (and
+        // multiplied by exactly-zero probabilities), so they must hold finite values: zero the buffer once
+        const size_t vbytes = (size_t)2 * Um * (size_t)(Nm + 8) * c.dim * es;
+        if (vbytes > vb.bytes) { vb.ensure(vbytes); MI_HIP(hipMemset(vb.p, 0, vbytes)); }
+    }
     Hff.ensure(rows * c.ff() * es);
     pred.ensure(rows * c.mel * 4);
     // preprocess temporaries (one utterance at a time)
@@ -481,6 +486,7 @@ void F5::dit_eval(int U, int N, int k) {
             g.out = qb.p; g.out2 = kb.p; g.out3 = vb.p;
             g.B = B; g.T_in = N; g.M = N; g.N = 3 * d; g.Cin = d; g.x_bstride = (long)N * d; g.x_rstride = d;
             g.epi = EPI_QKV_ROPE; g.rope_cos = rope_cos.as<float>(); g.rope_sin = rope_sin.as<float>(); g.heads = H; g.head_dim = D;
+            g.v_ld = attention_v_ld(N, dtype);
             launch_conv_gemm(g, s);
         }
         launch_attention(qb.p, kb.p, vb.p, Ob.p, B * H, H, N, dtype, s);

@@ -23,7 +23,9 @@ void launch_cat_noise(const float* noise, void* cat, int U, int N, int M, int ld
 void launch_cfg_update(float* noise, const float* pred, int U, int N, int M, float cfg, const float* dt, int k, hipStream_t s);
 
 // attention.hip: softmax_fp32(q k^T) v, no mask, no scale (q/k are pre-scaled): modules.py:467
-//   q,k,v [BH][N][64] (dtype) -> o [B][N][H*64] (dtype), B = BH / H
+//   q,k [BH][N][64], v [BH][N][64] (fp32) or transposed [BH][64][v_ld] (16-bit, v_ld = attention_v_ld(N))
+//   -> o [B][N][H*64] (dtype), B = BH / H
 void launch_attention(const void* q, const void* k, const void* v, void* o, int BH, int H, int N, int dtype, hipStream_t s);
+inline long attention_v_ld(int N, int dtype) { return dtype == MI_F32 ? 0 : (long)((N + 7) / 8 * 8); }
 
 }  // namespace mi

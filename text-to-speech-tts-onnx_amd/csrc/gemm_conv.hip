@@ -49,6 +49,7 @@ struct ConvGemmDev {
     int act; float alpha; int accumulate; int epi;
     int u, Cout, padT, T_out;
     const float* rope_cos; const float* rope_sin; int heads, head_dim; void* out2; void* out3;
+    long v_ld;
     const void* zero;      // >= 16 bytes of zeros: source for out-of-range / K-tail vectors of the LDS-DMA path
     int dbg;               // tuning only: 1 = no DMA in the main loop, 2 = no ds_read/MFMA in the main loop
     int Tm, Tn, RT, RC;    // XCD-aware tile order (DMA kernel): M-tiles per batch item, N-tiles, row tiles (B*Tm), rows per XCD
@@ -86,7 +87,10 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], const ConvG
             const int hh = rem / p.head_dim, dd = rem - hh * p.head_dim;
             const float bv = p.bias ? p.bias[n] : 0.f;
             const float sgn = (dd & 1) ? 1.f : -1.f;
-            TO* dst = (TO*)(which == 0 ? p.out : which == 1 ? p.out2 : p.out3) + ((long)b * p.heads + hh) * p.M * p.head_dim + dd;
+            const bool vt = which == 2 && p.v_ld > 0;         // V transposed: [bh][d][key]
+            TO* dst = vt ? (TO*)p.out3 + (((long)b * p.heads + hh) * p.head_dim + dd) * p.v_ld
+                         : (TO*)(which == 0 ? p.out : which == 1 ? p.out2 : p.out3) + ((long)b * p.heads + hh) * p.M * p.head_dim + dd;
+            const long mstride = vt ? 1 : p.head_dim;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int mb = m0 + wm * WM + i * 32 + 4 * lk;
@@ -99,7 +103,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], const ConvG
                     const float c = which < 2 ? p.rope_cos[(long)mc * p.head_dim + dd] : 1.f;
                     const float sn = which < 2 ? p.rope_sin[(long)mc * p.head_dim + dd] : 0.f;
                     v = v * c + sgn * partner * sn;
-                    if (m < p.M) dst[(long)m * p.head_dim] = from_f32<TO>(v);
+                    if (m < p.M) dst[(long)m * mstride] = from_f32<TO>(v);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -482,24 +486,33 @@ __global__ __launch_bounds__(512) void conv_gemm_dma3_kernel(const ConvGemmDev p
         }
         const T* As = smem + st * TILE;
         const T* Bs = As + BM * KC;
-        if (p.dbg != 2)
+        if (p.dbg != 2) {
+            // fragment loads run one k-step ahead of the MFMAs (two register sets): the ~300-cycle ds_read_b128
+            // latency is then covered by 128 cycles of this wave's MFMAs plus the partner wave's on the same SIMD
+            typename MF::Frag fa[2][TM], fb[2][TN];
+            auto ldfrag = [&](int ks, int set) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            typename MF::Frag a[TM], bb[TN];
+                for (int i = 0; i < TM; ++i) {
+                    const int row = wm * WM + i * 32 + lr;
+                    fa[set][i] = *reinterpret_cast<const typename MF::Frag*>(As + row * KC + (((ks * 2 + lk) ^ ((row >> 1) & 7)) << 3));
+                }
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int row = wm * WM + i * 32 + lr;
-                a[i] = *reinterpret_cast<const typename MF::Frag*>(As + row * KC + (((ks * 2 + lk) ^ ((row >> 1) & 7)) << 3));
+                for (int j = 0; j < TN; ++j) {
+                    const int row = wn * WN + j * 32 + lr;
+                    fb[set][j] = *reinterpret_cast<const typename MF::Frag*>(Bs + row * KC + (((ks * 2 + lk) ^ ((row >> 1) & 7)) << 3));
+                }
+            };
+            ldfrag(0, 0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks + 1 < 4) ldfrag(ks + 1, (ks + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);            // keep the next k-step's reads AHEAD of these MFMAs
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma(fa[ks & 1][i], fb[ks & 1][j], acc[i][j]);
+                __builtin_amdgcn_sched_barrier(0);
             }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int row = wn * WN + j * 32 + lr;
-                bb[j] = *reinterpret_cast<const typename MF::Frag*>(Bs + row * KC + (((ks * 2 + lk) ^ ((row >> 1) & 7)) << 3));
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma(a[i], bb[j], acc[i][j]);
         }
         // chunk c+1 must have landed (for every wave) before anyone reads it; chunk c+2 may stay in flight
         if (c + 2 < nchunks && p.dbg != 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -567,7 +580,7 @@ void launch_conv_gemm(const ConvGemm& p, hipStream_t s) {
     d.act = p.act; d.alpha = p.alpha; d.accumulate = p.accumulate; d.epi = p.epi;
     d.u = p.u; d.Cout = p.Cout; d.padT = p.padT; d.T_out = p.T_out;
     d.rope_cos = p.rope_cos; d.rope_sin = p.rope_sin; d.heads = p.heads; d.head_dim = p.head_dim;
-    d.out2 = p.out2; d.out3 = p.out3;
+    d.out2 = p.out2; d.out3 = p.out3; d.v_ld = p.v_ld;
     {
         static bool env_read = false;
         if (!env_read) { const char* e = std::getenv("MI355TTS_NO_DMA_GEMM"); g_use_dma = !(e && e[0] == '1');
