@@ -18,6 +18,7 @@
 // then slides an R-long run down the time axis in registers (18 inputs -> 8 outputs), and the
 // result goes back through LDS so the HBM store is again 16-byte coalesced.
 #include "common.h"
+#include "aa_math.h"
 
 namespace mi {
 
@@ -102,43 +103,22 @@ __global__ __launch_bounds__(256) void aa_act_kernel(const T* __restrict__ x, T*
     }
     __syncthreads();
 
-    // ---- sliding-window compute ---------------------------------------------------------------
+    // ---- sliding-window compute (aa_math.h) ------------------------------------------------------
+    constexpr bool FAST = sizeof(T) == 2;           // 16-bit storage: v_sin_f32; fp32 parity path: libm sinf
+    const AATaps tp = aa_make_taps(c_h);
+    const int lo = -ext, hi = 2 * Tlen + ext;
+    const bool edge = (2 * (mp0 - 3) - 1 < lo) || (2 * (mp0 + TT + 3) >= hi);      // block-uniform
     const int nitems = CT * (TT / R);
     for (int it = tid; it < nitems; it += 256) {
         const int run = it / CT, c = it - run * CT;
         const int ml = run * R;               // local output row
-        const float al = alpha[c0 + c], ib = inv_beta[c0 + c];
-        float xv[R + 10];
+        const float al = FAST ? alpha[c0 + c] * 0.15915494309189535f : alpha[c0 + c];
+        const float ib = inv_beta[c0 + c];
+        float xv[R + 10], acc[R];
 #pragma unroll
         for (int j = 0; j < R + 10; ++j) xv[j] = xs[(ml + j) * CT + c];
-        float acc[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = 0.f;
-        const int mp = mp0 + ml;              // centred m' of acc[0]
-#pragma unroll
-        for (int e = 0; e < R + 5; ++e) {
-            float ue = 0.f, uo = 0.f;
-#pragma unroll
-            for (int ee = 0; ee < 6; ++ee) {
-                ue = fmaf(c_h[2 * ee + 1], xv[e + 5 - ee], ue);
-                uo = fmaf(c_h[2 * ee], xv[e + 5 - ee], uo);
-            }
-            ue *= 2.f; uo *= 2.f;
-            const int ie = 2 * (mp + e - 2);          // i' of the even sample
-            const int io = 2 * (mp + e - 3) + 1;      // i' of the odd sample
-            float se, so;
-            if constexpr (sizeof(T) == 4) { se = sinf(al * ue); so = sinf(al * uo); }      // fp32 parity path: libm-accurate
-            else { se = __sinf(al * ue); so = __sinf(al * uo); }                            // 16-bit storage: v_sin_f32
-            se = ue + ib * (se * se);
-            so = uo + ib * (so * so);
-            if (ie < -ext || ie >= 2 * Tlen + ext) se = 0.f;
-            if (io < -ext || io >= 2 * Tlen + ext) so = 0.f;
-#pragma unroll
-            for (int tt = 0; tt < 6; ++tt) {
-                const int r = e - tt;
-                if (r >= 0 && r < R) acc[r] = fmaf(c_h[2 * tt], so, fmaf(c_h[2 * tt + 1], se, acc[r]));
-            }
-        }
+        if (edge) aa_run<R, FAST, true>(xv, acc, tp, al, ib, mp0 + ml, lo, hi);
+        else aa_run<R, FAST, false>(xv, acc, tp, al, ib, mp0 + ml, lo, hi);
 #pragma unroll
         for (int r = 0; r < R; ++r) ys[(ml + r) * CT + c] = from_f32<T>(acc[r]);
     }
@@ -157,7 +137,7 @@ __global__ __launch_bounds__(256) void aa_act_kernel(const T* __restrict__ x, T*
 
 template <typename T>
 static void launch_t(const AAAct& p, hipStream_t s) {
-    constexpr int R = 8;
+    constexpr int R = 16;
     constexpr int VEC = 16 / (int)sizeof(T);
     MI_REQUIRE(p.C % VEC == 0, "aa_act: C must be a multiple of the 16-byte vector");
     int CT = p.C;

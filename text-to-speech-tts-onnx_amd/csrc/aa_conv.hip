@@ -14,6 +14,7 @@
 //   4. accumulators -> LDS (fp32) -> coalesced epilogue (bias, residual, alpha, accumulate) -> HBM
 #include "common.h"
 #include "mfma.h"
+#include "aa_math.h"
 
 namespace mi {
 
@@ -31,7 +32,7 @@ __global__ __launch_bounds__(256) void aa_conv_kernel(const AAConvDev p) {
     using MF = Mfma<T>;
     constexpr int KP = MF::KP;
     constexpr int VEC = 16 / (int)sizeof(T);
-    constexpr int R = 8;
+    constexpr int R = 16;
     constexpr int WM = BM / 4, TM = WM / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* XS = reinterpret_cast<T*>(smem_raw);                        // rows_x   x C   raw input
@@ -57,45 +58,26 @@ __global__ __launch_bounds__(256) void aa_conv_kernel(const AAConvDev p) {
         }
     }
     __syncthreads();
-    // ---- 2. AA: sliding window of R outputs per (channel, run) -------------------------------------------
+    // ---- 2. AA (aa_math.h): runs of R outputs per (channel, run), packed-fp32 FIRs ------------------------
     {
+        constexpr bool FAST = sizeof(T) == 2;
+        const AATaps tp = aa_make_taps(c_h_fused);
         const int runs = (p.rows_act + R - 1) / R;
         const int nitems = C * runs;
         const int t_act0 = m0 - p.halo;                              // global time of activated row 0
+        const int hi2 = 2 * p.T;
+        const bool edge = (2 * (t_act0 - 3) - 1 < 0) || (2 * (t_act0 + runs * R + 3) >= hi2);
         for (int it = tid; it < nitems; it += 256) {
             const int run = it / C, c = it - run * C;
             const int ml = run * R;
-            const float al = p.alpha_s[c], ib = p.inv_beta[c];
-            float xv[R + 10];
+            const float al = FAST ? p.alpha_s[c] * 0.15915494309189535f : p.alpha_s[c];
+            const float ib = p.inv_beta[c];
+            float xv[R + 10], acc[R];
 #pragma unroll
             for (int j = 0; j < R + 10; ++j) xv[j] = to_f32(XS[(ml + j) * C + c]);
-            float acc[R];
-#pragma unroll
-            for (int r = 0; r < R; ++r) acc[r] = 0.f;
             const int mp = t_act0 + ml;
-#pragma unroll
-            for (int e = 0; e < R + 5; ++e) {
-                float ue = 0.f, uo = 0.f;
-#pragma unroll
-                for (int ee = 0; ee < 6; ++ee) {
-                    ue = fmaf(c_h_fused[2 * ee + 1], xv[e + 5 - ee], ue);
-                    uo = fmaf(c_h_fused[2 * ee], xv[e + 5 - ee], uo);
-                }
-                ue *= 2.f; uo *= 2.f;
-                const int ie = 2 * (mp + e - 2), io = 2 * (mp + e - 3) + 1;
-                float se, so;
-                if constexpr (sizeof(T) == 4) { se = sinf(al * ue); so = sinf(al * uo); }
-                else { se = __sinf(al * ue); so = __sinf(al * uo); }
-                se = ue + ib * (se * se);
-                so = uo + ib * (so * so);
-                if (ie < 0 || ie >= 2 * p.T) se = 0.f;
-                if (io < 0 || io >= 2 * p.T) so = 0.f;
-#pragma unroll
-                for (int tt = 0; tt < 6; ++tt) {
-                    const int r = e - tt;
-                    if (r >= 0 && r < R) acc[r] = fmaf(c_h_fused[2 * tt], so, fmaf(c_h_fused[2 * tt + 1], se, acc[r]));
-                }
-            }
+            if (edge) aa_run<R, FAST, true>(xv, acc, tp, al, ib, mp, 0, hi2);
+            else aa_run<R, FAST, false>(xv, acc, tp, al, ib, mp, 0, hi2);
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int row = ml + r;
@@ -209,7 +191,7 @@ static void launch_t(const AAConv& q, hipStream_t s) {
     d.alpha = q.alpha; d.accumulate = q.accumulate;
     const int BM = q.C <= 48 ? 256 : 128;
     d.rows_act = BM + 2 * d.halo;
-    d.rows_x = (d.rows_act + 7) / 8 * 8 + 10;
+    d.rows_x = (d.rows_act + 15) / 16 * 16 + 10;
     const int TN = (q.C + 31) / 32;
     size_t lds = (size_t)d.rows_x * q.C * sizeof(T) + (size_t)d.rows_act * d.S * sizeof(T);
     lds = std::max(lds, (size_t)BM * q.C * 4);
