@@ -156,7 +156,9 @@ def run_f5(args, world, rank, local, dev, dist, torch):
     t_audio, t_ids, t_noise = torch.from_numpy(audio).to(dev), torch.from_numpy(ids).to(dev), torch.from_numpy(noise).to(dev)
     out = torch.empty((U, 1, (N - R - 1) * cfg.hop_length), dtype=torch.int16, device=dev)
     audio_s = U * out.shape[-1] / cfg.sample_rate
-    for _ in range(args.warmup):
+    # the engine runs a shape eagerly once, captures the 31-step loop into a hipGraph on its second use and replays
+    # it afterwards: at least two untimed calls so the timed region is steady state
+    for _ in range(max(args.warmup, 2)):
         eng.synthesize_torch(t_audio, t_ids, N, noise=t_noise, out=out)
 
     def barrier():
@@ -164,16 +166,21 @@ def run_f5(args, world, rank, local, dev, dist, torch):
             dist.barrier()
         torch.cuda.synchronize()
 
-    _lib.prof_reset()
-    _lib.prof_enable(["conv_gemm", "attn"])
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         eng.synthesize_torch(t_audio, t_ids, N, noise=t_noise, out=out)
     barrier()
     dt = time.perf_counter() - t0
+    # roofline leg: one more pass with HIP events around every GEMM / attention launch (the events force the eager,
+    # un-graphed launch path, so this pass is timed separately and is NOT part of `value`)
+    _lib.prof_reset()
+    _lib.prof_enable(["conv_gemm", "attn"])
+    eng.synthesize_torch(t_audio, t_ids, N, noise=t_noise, out=out)
+    torch.cuda.synchronize()
     _lib.prof_enable(())
     pg, pa = _lib.prof_get("conv_gemm"), _lib.prof_get("attn")
+    prof_steps = 1
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -197,9 +204,10 @@ def run_f5(args, world, rank, local, dev, dist, torch):
                    "end_to_end_TFLOP_per_s": alg_flops / (dt / args.steps) / 1e12},
         "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel (DiT linear layers, implicit-GEMM MFMA)", "achieved": achieved,
                      "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
-                     "launches_per_step": pg["launches"] / args.steps, "avg_launch_ms": pg["ms"] / max(pg["launches"], 1),
-                     "family_ms_per_step": pg["ms"] / args.steps,
-                     "attn_ms_per_step": pa["ms"] / args.steps,
+                     "launches_per_step": pg["launches"] / prof_steps, "avg_launch_ms": pg["ms"] / max(pg["launches"], 1),
+                     "family_ms_per_step": pg["ms"] / prof_steps,
+                     "attn_ms_per_step": pa["ms"] / prof_steps,
+                     "note": "event-timed in a separate eager pass; the timed region replays a hipGraph",
                      "attn_tflops": pa["flops"] / (pa["ms"] * 1e-3) / 1e12 if pa["ms"] > 0 else 0.0},
     }
     if world == 1 and not args.no_cpu_baseline:

@@ -69,9 +69,9 @@ __global__ __launch_bounds__(256) void aa_act_kernel(const T* __restrict__ x, T*
                                                      const float* __restrict__ inv_beta, int Tlen, int C, int CT,
                                                      int TT, int shift, int ext) {
     constexpr int VEC = 16 / (int)sizeof(T);
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* xs = lds;                          // (TT+10) x CT fp32
-    T* ys = reinterpret_cast<T*>(lds + (TT + 10) * CT);   // TT x CT
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    T* xs = reinterpret_cast<T*>(lds_raw);                // (TT+10) x CT  raw input (16-byte copies, no bank conflicts)
+    T* ys = xs + (TT + 10) * CT;                          // TT x CT
 
     const int tid = threadIdx.x;
     const int o0 = blockIdx.x * TT;           // first output row of the tile
@@ -88,18 +88,9 @@ __global__ __launch_bounds__(256) void aa_act_kernel(const T* __restrict__ x, T*
     for (int v = tid; v < nvec; v += 256) {
         const int row = v / cvn, cv = v - row * cvn;
         const int t = mp0 - 5 + row;
-        float f[VEC];
-        if (t >= 0 && t < Tlen) {
-            const uint4 raw = *reinterpret_cast<const uint4*>(xb + (long)t * C + c0 + cv * VEC);
-            const T* e = reinterpret_cast<const T*>(&raw);
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) f[k] = to_f32(e[k]);
-        } else {
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) f[k] = 0.f;
-        }
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) xs[row * CT + cv * VEC + k] = f[k];
+        uint4 raw = make_uint4(0, 0, 0, 0);
+        if (t >= 0 && t < Tlen) raw = *reinterpret_cast<const uint4*>(xb + (long)t * C + c0 + cv * VEC);
+        *reinterpret_cast<uint4*>(xs + row * CT + cv * VEC) = raw;
     }
     __syncthreads();
 
@@ -116,7 +107,7 @@ __global__ __launch_bounds__(256) void aa_act_kernel(const T* __restrict__ x, T*
         const float ib = inv_beta[c0 + c];
         float xv[R + 10], acc[R];
 #pragma unroll
-        for (int j = 0; j < R + 10; ++j) xv[j] = xs[(ml + j) * CT + c];
+        for (int j = 0; j < R + 10; ++j) xv[j] = to_f32(xs[(ml + j) * CT + c]);
         if (edge) aa_run<R, FAST, true>(xv, acc, tp, al, ib, mp0 + ml, lo, hi);
         else aa_run<R, FAST, false>(xv, acc, tp, al, ib, mp0 + ml, lo, hi);
 #pragma unroll
@@ -147,13 +138,13 @@ static void launch_t(const AAAct& p, hipStream_t s) {
             if (p.C % cand == 0 && cand % VEC == 0) { CT = cand; break; }
         MI_REQUIRE(CT > 0, "aa_act: unsupported channel count");
     }
-    int TT = (4096 / CT) / R * R;
+    int TT = (8192 / CT) / R * R;
     if (TT < R) TT = R;
     if (TT > 512) TT = 512;
     const int shift = p.post ? 15 : 0, ext = p.post ? 20 : 0;
     const int Tout = p.T + 2 * shift;
     dim3 grid((Tout + TT - 1) / TT, p.C / CT, p.B);
-    const size_t lds = (size_t)(TT + 10) * CT * 4 + (size_t)TT * CT * sizeof(T);
+    const size_t lds = ((size_t)(TT + 10) * CT + (size_t)TT * CT) * sizeof(T);
     const double bytes = (double)p.B * p.C * ((double)p.T + Tout) * sizeof(T);
     const double flops = (double)p.B * p.C * Tout * 60.0;
     ProfScope ps(FAM_AA, s, bytes, flops);

@@ -15,6 +15,7 @@
 #include "common.h"
 #include "mfma.h"
 #include "aa_math.h"
+#include <cstdlib>
 
 namespace mi {
 
@@ -25,6 +26,7 @@ struct AAConvDev {
     const void* x; const void* w; const float* bias; const float* alpha_s; const float* inv_beta; void* out; const void* res;
     int T, C, S, k, dil, K, Kpad, halo, rows_act, rows_x;
     float alpha; int accumulate;
+    int dbg;      // tuning: bit0 skip AA math, bit1 skip MFMA loop, bit2 skip epilogue global traffic
 };
 
 template <typename T, int BM, int TN>
@@ -76,7 +78,10 @@ __global__ __launch_bounds__(256) void aa_conv_kernel(const AAConvDev p) {
 #pragma unroll
             for (int j = 0; j < R + 10; ++j) xv[j] = to_f32(XS[(ml + j) * C + c]);
             const int mp = t_act0 + ml;
-            if (edge) aa_run<R, FAST, true>(xv, acc, tp, al, ib, mp, 0, hi2);
+            if (p.dbg & 1) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[r] = xv[r + 5];
+            } else if (edge) aa_run<R, FAST, true>(xv, acc, tp, al, ib, mp, 0, hi2);
             else aa_run<R, FAST, false>(xv, acc, tp, al, ib, mp, 0, hi2);
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -102,7 +107,7 @@ __global__ __launch_bounds__(256) void aa_conv_kernel(const AAConvDev p) {
         const T* wp = (const T*)p.w;
         int kk = hi * KP;                     // this lane's K offset inside the current MFMA k-step
         int tap = kk / C, ci = kk - tap * C;
-        const int nsteps = p.Kpad / (2 * KP);
+        const int nsteps = (p.dbg & 2) ? 0 : p.Kpad / (2 * KP);
         for (int ks = 0; ks < nsteps; ++ks) {
             const int tapc = tap < p.k ? tap : p.k - 1;            // padded K tail: weights are zero there
             typename MF::Frag a[TM], bf[TN];
@@ -149,7 +154,7 @@ __global__ __launch_bounds__(256) void aa_conv_kernel(const AAConvDev p) {
         for (int v = tid; v < nvec; v += 256) {
             const int row = v / cvn, cv = v - row * cvn;
             const int t = m0 + row;
-            if (t >= p.T) continue;
+            if (t >= p.T || (p.dbg & 4)) continue;
             const long gi = (long)t * C + cv * VEC;
             float o[VEC];
 #pragma unroll
@@ -189,6 +194,7 @@ static void launch_t(const AAConv& q, hipStream_t s) {
     d.S = ((q.C / 8) & 1) ? q.C : q.C + 8;             // S/8 odd => conflict-free ds_read_b128 fragment rows
     if (sizeof(T) == 4) d.S = (q.C % 2 == 0) ? q.C + 1 : q.C;   // fp32 fragments are ds_read_b32: odd dword stride
     d.alpha = q.alpha; d.accumulate = q.accumulate;
+    { const char* e = std::getenv("MI355TTS_AACONV_DBG"); d.dbg = e ? std::atoi(e) : 0; }
     const int BM = q.C <= 48 ? 256 : 128;
     d.rows_act = BM + 2 * d.halo;
     d.rows_x = (d.rows_act + 15) / 16 * 16 + 10;

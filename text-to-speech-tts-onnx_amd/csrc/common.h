@@ -92,6 +92,7 @@ struct ProfScope {
 };
 enum { FAM_CONV_GEMM = 0, FAM_AA = 1, FAM_CONV_POST = 2, FAM_ATTN = 3, FAM_NORM = 4, FAM_OTHER = 5, FAM_COUNT = 6 };
 void prof_collect();   // resolve pending events (synchronises)
+unsigned prof_mask();   // current family mask (0 = profiling off)
 
 // ---------------------------------------------------------------------------------------------
 // implicit-GEMM convolution / linear launcher (gemm_conv.hip)

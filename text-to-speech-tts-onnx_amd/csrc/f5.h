@@ -45,6 +45,13 @@ struct F5 {
     struct VBlock { DevBuf dw_w, dw_b, n_w, n_b; Lin pw1, pw2; };
     std::vector<VBlock> vblocks;
 
+    // ---- HIP graphs of the sampling loop, keyed by (U, N, k0, nsteps) ----
+    struct GraphEntry { hipGraphExec_t exec = nullptr; int uses = 0; };
+    std::map<std::vector<int>, GraphEntry> graphs;
+    bool use_graph = true;          // MI355TTS_NO_GRAPH=1 disables
+    void drop_graphs();
+    void steps_eager(int U, int N, int k0, int nsteps);
+
     // ---- workspace ----
     int ws_U = 0, ws_N = 0;
     DevBuf d_noise, d_cmt, d_cmtd, cat, h32, hT, c1, X, Ub, qb, kb, vb, Ob, Hff, pred;

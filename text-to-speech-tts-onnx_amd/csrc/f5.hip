@@ -12,6 +12,7 @@
 // modulation for all (step, block) pairs, RoPE tables, STFT / mel / ISTFT bases.
 // Batching: U utterances of equal length N are laid out as batch 2U (2u = cond, 2u+1 = uncond).
 #include "f5.h"
+#include <cstdlib>
 
 namespace mi {
 
@@ -72,6 +73,7 @@ F5::F5(const F5Cfg& c, const float* w, int64_t nw, int dt, int dev) : cfg(c), dt
     MI_REQUIRE(nw == f5_param_count(c), "f5: weight blob size does not match the config");
     MI_HIP(hipSetDevice(dev));
     MI_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    if (const char* e = std::getenv("MI355TTS_NO_GRAPH")) use_graph = !(e[0] == '1');
     hipStream_t s = stream;
     const int d = c.dim, td = c.text_dim, ff = c.ff(), ti = td * c.conv_mult, cin = c.cat_dim();
     const float* p = w;
@@ -288,11 +290,13 @@ F5::F5(const F5Cfg& c, const float* w, int64_t nw, int dt, int dev) : cfg(c), dt
 }
 
 F5::~F5() {
+    drop_graphs();
     if (stream) (void)hipStreamDestroy(stream);
 }
 
 void F5::ensure_workspace(int U, int N) {
     if (U <= ws_U && N <= ws_N) return;
+    drop_graphs();                         // captured graphs hold raw workspace pointers
     const int Um = std::max(U, ws_U), Nm = std::max(N, ws_N);
     const F5Cfg& c = cfg;
     const size_t es = dtype_size(dtype);
@@ -501,12 +505,42 @@ void F5::dit_eval(int U, int N, int k) {
     gemm(dtype, Ub.p, (long)N * d, d, d, proj_out, pred.p, MI_F32, (long)N * c.mel, c.mel, B, N);
 }
 
-void F5::steps(int U, int N, int k0, int nsteps) {
-    MI_REQUIRE(k0 >= 0 && nsteps >= 0 && k0 + nsteps <= cfg.nfe - 1, "f5: step range exceeds the NFE grid");
+void F5::steps_eager(int U, int N, int k0, int nsteps) {
     for (int k = k0; k < k0 + nsteps; ++k) {
         dit_eval(U, N, k);
         launch_cfg_update(d_noise.as<float>(), pred.as<float>(), U, N, cfg.mel, cfg.cfg_strength, delta_t.as<float>(), k, stream);
     }
+}
+
+void F5::drop_graphs() {
+    for (auto& kv : graphs)
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+    graphs.clear();
+}
+
+// The reference drives 31 host round trips (F5-TTS-ONNX-Inference.py:291-304).  Here the whole loop is ~5000 kernel
+// launches on one stream with every operand resident in HBM; from the second use of a shape on it is captured once
+// into a hipGraph and replayed, which removes the per-launch host cost (launch-bound at batch 1).
+void F5::steps(int U, int N, int k0, int nsteps) {
+    MI_REQUIRE(k0 >= 0 && nsteps >= 0 && k0 + nsteps <= cfg.nfe - 1, "f5: step range exceeds the NFE grid");
+    if (!use_graph || prof_mask() != 0 || nsteps < 2) { steps_eager(U, N, k0, nsteps); return; }
+    GraphEntry& e = graphs[{U, N, k0, nsteps}];
+    if (e.exec) { MI_HIP(hipGraphLaunch(e.exec, stream)); return; }
+    if (e.uses++ == 0) { steps_eager(U, N, k0, nsteps); return; }      // first use: eager (also warms one-time allocations)
+    hipGraph_t graph = nullptr;
+    MI_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+    try {
+        steps_eager(U, N, k0, nsteps);
+    } catch (...) {
+        (void)hipStreamEndCapture(stream, &graph);
+        if (graph) (void)hipGraphDestroy(graph);
+        throw;
+    }
+    MI_HIP(hipStreamEndCapture(stream, &graph));
+    hipError_t err = hipGraphInstantiate(&e.exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (err != hipSuccess) { e.exec = nullptr; use_graph = false; steps_eager(U, N, k0, nsteps); return; }
+    MI_HIP(hipGraphLaunch(e.exec, stream));
 }
 
 long F5::decode(const float* den, int U, int N, int R, float* out_f, int16_t* out_i) {

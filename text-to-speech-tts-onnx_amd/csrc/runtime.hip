@@ -74,6 +74,7 @@ void prof_collect() {
     g_pending.clear();
 }
 void prof_enable(unsigned mask) { g_prof_mask = mask; }
+unsigned prof_mask() { return g_prof_mask; }
 void prof_reset() {
     prof_collect();
     std::lock_guard<std::mutex> lk(g_pm);
