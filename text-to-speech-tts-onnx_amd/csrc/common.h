@@ -127,6 +127,7 @@ struct ConvGemm {
     // EPI_QKV_ROPE (f5): see f5.hip
     const float* rope_cos = nullptr; const float* rope_sin = nullptr; int heads = 0, head_dim = 0;
     void* out2 = nullptr; void* out3 = nullptr;
+    int rows_per_item = 0;        // EPI_QKV_ROPE with the batch flattened into M: tokens per batch item (0: M)
     long v_ld = 0;                // > 0: V is written transposed, [b*H + h][head_dim][v_ld] (keys contiguous)
 };
 void launch_conv_gemm(const ConvGemm& p, hipStream_t s);

@@ -335,6 +335,9 @@ void F5::gemm(int dt, const void* x, long xb, long xr, int K, const Lin& L, void
     g.res = res; g.gate = gate; g.gate_bstride = 0;
     g.B = B; g.T_in = M; g.M = M; g.N = L.n; g.Cin = K; g.taps = 1;
     g.x_bstride = xb; g.x_rstride = xr; g.out_bstride = ob; g.out_rstride = orr; g.act = act;
+    if (B > 1 && xb == (long)M * xr && ob == (long)M * orr) {      // rows of all batch items are contiguous: one M axis
+        g.B = 1; g.T_in = B * M; g.M = B * M;                      // (no per-item tile padding: 2252 rows -> 9 tiles, not 10)
+    }
     launch_conv_gemm(g, stream);
 }
 
@@ -488,7 +491,8 @@ void F5::dit_eval(int U, int N, int k) {
             ConvGemm g;
             g.dtype = dtype; g.x = Ub.p; g.w = bk.qkv.w.p; g.bias = bk.qkv.b.as<float>();
             g.out = qb.p; g.out2 = kb.p; g.out3 = vb.p;
-            g.B = B; g.T_in = N; g.M = N; g.N = 3 * d; g.Cin = d; g.x_bstride = (long)N * d; g.x_rstride = d;
+            g.B = 1; g.T_in = B * N; g.M = B * N; g.rows_per_item = N;       // batch flattened into M
+            g.N = 3 * d; g.Cin = d; g.x_bstride = (long)B * N * d; g.x_rstride = d;
             g.epi = EPI_QKV_ROPE; g.rope_cos = rope_cos.as<float>(); g.rope_sin = rope_sin.as<float>(); g.heads = H; g.head_dim = D;
             g.v_ld = attention_v_ld(N, dtype);
             launch_conv_gemm(g, s);

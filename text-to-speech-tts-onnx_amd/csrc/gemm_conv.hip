@@ -49,7 +49,7 @@ struct ConvGemmDev {
     int act; float alpha; int accumulate; int epi;
     int u, Cout, padT, T_out;
     const float* rope_cos; const float* rope_sin; int heads, head_dim; void* out2; void* out3;
-    long v_ld;
+    long v_ld; int Mb;
     const void* zero;      // >= 16 bytes of zeros: source for out-of-range / K-tail vectors of the LDS-DMA path
     int dbg;               // tuning only: 1 = no DMA in the main loop, 2 = no ds_read/MFMA in the main loop
     int Tm, Tn, RT, RC;    // XCD-aware tile order (DMA kernel): M-tiles per batch item, N-tiles, row tiles (B*Tm), rows per XCD
@@ -88,22 +88,31 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], const ConvG
             const float bv = p.bias ? p.bias[n] : 0.f;
             const float sgn = (dd & 1) ? 1.f : -1.f;
             const bool vt = which == 2 && p.v_ld > 0;         // V transposed: [bh][d][key]
-            TO* dst = vt ? (TO*)p.out3 + (((long)b * p.heads + hh) * p.head_dim + dd) * p.v_ld
-                         : (TO*)(which == 0 ? p.out : which == 1 ? p.out2 : p.out3) + ((long)b * p.heads + hh) * p.M * p.head_dim + dd;
+            TO* base = (TO*)(which == 0 ? p.out : which == 1 ? p.out2 : p.out3);
             const long mstride = vt ? 1 : p.head_dim;
+            const int Mb = p.Mb > 0 ? p.Mb : p.M;             // tokens per batch item (batch may be flattened into M)
+            const long item_stride = vt ? (long)p.heads * p.head_dim * p.v_ld : (long)p.heads * Mb * p.head_dim;
+            const long head_off = vt ? ((long)hh * p.head_dim + dd) * p.v_ld : (long)hh * Mb * p.head_dim + dd;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int mb = m0 + wm * WM + i * 32 + 4 * lk;
+                const int bi0 = p.Mb > 0 ? mb / Mb : 0;                    // one division per 32-row tile (Mb >= 32)
+                const int mloc0 = mb - bi0 * Mb;
+                TO* dst0 = base + ((long)b + bi0) * item_stride + head_off;        // this tile touches at most two items
+                TO* dst1 = dst0 + item_stride;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int m = mb + (r & 3) + 8 * (r >> 2);
+                    const int off = (r & 3) + 8 * (r >> 2);
+                    const int mg = mb + off;                               // row in the (possibly flattened) M axis
                     float v = acc[i][j][r] + bv;
                     const float partner = __shfl_xor(v, 1);
-                    const int mc = m < p.M ? m : p.M - 1;
-                    const float c = which < 2 ? p.rope_cos[(long)mc * p.head_dim + dd] : 1.f;
-                    const float sn = which < 2 ? p.rope_sin[(long)mc * p.head_dim + dd] : 0.f;
+                    int m = mloc0 + off, bi = bi0;                         // token position inside its batch item
+                    if (m >= Mb) { m -= Mb; ++bi; }
+                    if (mg >= p.M) { m = 0; bi = 0; }
+                    const float c = which < 2 ? p.rope_cos[(long)m * p.head_dim + dd] : 1.f;
+                    const float sn = which < 2 ? p.rope_sin[(long)m * p.head_dim + dd] : 0.f;
                     v = v * c + sgn * partner * sn;
-                    if (m < p.M) dst[(long)m * mstride] = from_f32<TO>(v);
+                    if (mg < p.M) (bi == bi0 ? dst0 : dst1)[(long)m * mstride] = from_f32<TO>(v);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -414,16 +423,21 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvGemmDev
 // Swizzle: slot = kv ^ ((row >> 1) & 7): rows of equal parity inside every ds_read_b128 lane group get eight
 // distinct slots => conflict-free fragment reads.
 // ---------------------------------------------------------------------------------------------------
-template <typename T, typename TO>
+template <typename T, typename TO, int BM, int BN, int WM, int WN, int NST>
 __global__ __launch_bounds__(512) void conv_gemm_dma3_kernel(const ConvGemmDev p) {
     using MF = Mfma<T>;
-    constexpr int BM = 256, BN = 128, KC = 64, WM = 64, WN = 64, TM = 2, TN = 2, NST = 3;
+    // two configurations: 256x128 tile / 64x64 per wave / 3-stage ring (default) and 256x256 tile / 128x64 per wave /
+    // 2-stage ring (1.5x fewer DMA bytes per flop, for problems that fill every CU: the per-CU L2->LDS fill rate,
+    // ~22 B/cycle measured, is what bounds this kernel)
+    constexpr int KC = 64, TM = WM / 32, TN = WN / 32, WGN = BN / WN;
+    static_assert((BM / WM) * WGN == 8, "eight waves");
     constexpr int TILE = (BM + BN) * KC;
-    __shared__ __attribute__((aligned(1024))) T smem[NST * TILE];      // 144 KiB
+    constexpr int AJ = BM / 64, BJ = BN / 64, PERW = AJ + BJ;     // 8-row DMA groups per wave per chunk
+    __shared__ __attribute__((aligned(1024))) T smem[NST * TILE];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lk = lane >> 5;
+    const int wm = wave / WGN, wn = wave % WGN, lr = lane & 31, lk = lane >> 5;
     const int L = blockIdx.x;
     const int nt = L / p.RT, rowt = L - nt * p.RT;        // row tiles fastest: neighbours share the weight panel
     const int b = rowt / p.Tm, mt = rowt - b * p.Tm;
@@ -442,18 +456,18 @@ __global__ __launch_bounds__(512) void conv_gemm_dma3_kernel(const ConvGemmDev p
         T* base = smem + st * TILE;
         const int toff = tap * p.dil - p.pad;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {                             // A: 32 groups of 8 rows, 4 per wave
-            const int R0 = (wave * 4 + j) * 8;
-            const int ci = c0 + ((j & 1) ? kv1 : kv0) * 8;
+        for (int j = 0; j < AJ; ++j) {
+            const int R0 = (wave * AJ + j) * 8;
+            const int ci = c0 + (((wave * AJ + j) & 1) ? kv1 : kv0) * 8;
             const int t = m0 + R0 + lrow + toff;
             const T* src = (ci < p.Cin && t >= 0 && t < p.T_in) ? xb + (long)t * p.x_rstride + ci : zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (lds_void*)(base + R0 * KC), 16, 0, 0);
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {                             // B: 16 groups, 2 per wave
-            const int R0 = (wave * 2 + j) * 8;
-            const int ci = c0 + ((j & 1) ? kv1 : kv0) * 8;
+        for (int j = 0; j < BJ; ++j) {
+            const int R0 = (wave * BJ + j) * 8;
+            const int ci = c0 + (((wave * BJ + j) & 1) ? kv1 : kv0) * 8;
             const int n = n0 + R0 + lrow;
             const T* src = (ci < p.Cin && n < p.N) ? wg + (long)n * p.K + (long)tap * p.Cin + ci : zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -469,18 +483,26 @@ __global__ __launch_bounds__(512) void conv_gemm_dma3_kernel(const ConvGemmDev p
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // chunk cursor of the NEXT chunk to issue
-    int itap = 0, ic0 = 0;
+    int itap = 0, ic0 = 0;                                        // cursor of the NEXT chunk to issue
     auto advance = [&]() { ic0 += KC; if (ic0 >= p.Cin) { ic0 = 0; ++itap; } };
+    auto wait_next = [&](bool more_in_flight) {
+        // everything except (optionally) this wave's newest PERW DMA instructions has landed
+        if (more_in_flight) {
+            if constexpr (PERW == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    constexpr int AHEAD = NST - 1;                                // chunks in flight beyond the one being computed
     issue(0, itap, ic0); advance();
-    if (nchunks > 1) { issue(1, itap, ic0); advance(); asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (AHEAD == 2 && nchunks > 1) { issue(1, itap, ic0); advance(); wait_next(true); }
+    else wait_next(false);
     __builtin_amdgcn_s_barrier();
 
     int st = 0;
     for (int c = 0; c < nchunks; ++c) {
-        if (c + 2 < nchunks) {
-            int st2 = st + 2; if (st2 >= NST) st2 -= NST;
+        const bool pre = c + AHEAD < nchunks;
+        if (pre) {
+            int st2 = st + AHEAD; if (st2 >= NST) st2 -= NST;
             if (p.dbg != 1) issue(st2, itap, ic0);
             advance();
         }
@@ -488,7 +510,7 @@ __global__ __launch_bounds__(512) void conv_gemm_dma3_kernel(const ConvGemmDev p
         const T* Bs = As + BM * KC;
         if (p.dbg != 2) {
             // fragment loads run one k-step ahead of the MFMAs (two register sets): the ~300-cycle ds_read_b128
-            // latency is then covered by 128 cycles of this wave's MFMAs plus the partner wave's on the same SIMD
+            // latency is then covered by this wave's MFMAs plus the partner wave's on the same SIMD
             typename MF::Frag fa[2][TM], fb[2][TN];
             auto ldfrag = [&](int ks, int set) {
 #pragma unroll
@@ -502,21 +524,25 @@ __global__ __launch_bounds__(512) void conv_gemm_dma3_kernel(const ConvGemmDev p
                     fb[set][j] = *reinterpret_cast<const typename MF::Frag*>(Bs + row * KC + (((ks * 2 + lk) ^ ((row >> 1) & 7)) << 3));
                 }
             };
+            constexpr bool PIPE = true;                        // (unpipelined was measured 4% slower even on the 128x64 wave tile)
             ldfrag(0, 0);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                if (ks + 1 < 4) ldfrag(ks + 1, (ks + 1) & 1);
-                __builtin_amdgcn_sched_barrier(0);            // keep the next k-step's reads AHEAD of these MFMAs
+                if (PIPE && ks + 1 < 4) ldfrag(ks + 1, (ks + 1) & 1);
+                if (PIPE) __builtin_amdgcn_sched_barrier(0);  // keep the next k-step's reads AHEAD of these MFMAs
+                constexpr int dummy = 0; (void)dummy;
+                const int set = PIPE ? (ks & 1) : 0;
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma(fa[ks & 1][i], fb[ks & 1][j], acc[i][j]);
-                __builtin_amdgcn_sched_barrier(0);
+                    for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma(fa[set][i], fb[set][j], acc[i][j]);
+                if (PIPE) __builtin_amdgcn_sched_barrier(0);
+                if (!PIPE && ks + 1 < 4) ldfrag(ks + 1, 0);
             }
         }
-        // chunk c+1 must have landed (for every wave) before anyone reads it; chunk c+2 may stay in flight
-        if (c + 2 < nchunks && p.dbg != 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // the next chunk to be computed must have landed for every wave; the newest one may stay in flight (3-stage)
+        if (p.dbg == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else wait_next(AHEAD == 2 && pre);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (++st == NST) st = 0;
@@ -524,7 +550,8 @@ __global__ __launch_bounds__(512) void conv_gemm_dma3_kernel(const ConvGemmDev p
     gemm_epilogue<TO, TM, TN, WM, WN>(acc, p, m0, n0, b, g, wm, wn, lr, lk);
 }
 
-static bool g_use_dma = true, g_xcd_order = false, g_use_dma3 = true;
+static bool g_use_dma = true, g_xcd_order = false, g_use_dma3 = true, g_big_tiles = true;
+static long g_big_min = 160;
 static DevBuf g_zero_page[16];
 
 template <typename T, typename TO>
@@ -540,13 +567,29 @@ static void dispatch_tiles(const ConvGemmDev& d, int B, hipStream_t s) {
     } else {
         dim3 grid((d.M + 127) / 128, (d.N + 127) / 128, B * d.G);
         if constexpr (sizeof(T) == 2) {
-            if (g_use_dma3 && d.Cin % 8 == 0 && d.K % d.Cin == 0 && d.M > 128) {
+            // measured on gfx950 (tools/gemm_bench.py): with <= 32 K-chunks the 4-wave 128x128 kernel (two workgroups
+            // per CU, short prologue/epilogue) wins; deeper K favours the 8-wave 256-row tiles.
+            if (g_use_dma3 && d.Cin % 8 == 0 && d.K % d.Cin == 0 && d.M > 128 && d.K > 2048) {
                 ConvGemmDev e = d;
-                e.Tm = (d.M + 255) / 256; e.Tn = (d.N + 127) / 128; e.RT = B * e.Tm; e.RC = 0;
-                dim3 g1(e.RT * e.Tn, d.G);
-                hipLaunchKernelGGL((conv_gemm_dma3_kernel<T, TO>), g1, dim3(512), 0, s, e);
-                MI_HIP(hipGetLastError());
-                return;
+                e.RC = 0;
+                const long blocks_128 = (long)B * ((d.M + 127) / 128) * ((d.N + 127) / 128);
+                const long blocks_256x128 = (long)B * ((d.M + 255) / 256) * ((d.N + 127) / 128);
+                const long blocks_256x256 = (long)B * ((d.M + 255) / 256) * ((d.N + 255) / 256);
+                const int n_waste_256 = ((d.N + 255) / 256) * 256 - d.N;
+                if (g_big_tiles && blocks_256x256 >= g_big_min && n_waste_256 * 4 <= d.N) {
+                    // every CU busy for >= 2 rounds: the tile with the fewest DMA bytes per flop
+                    e.Tm = (d.M + 255) / 256; e.Tn = (d.N + 255) / 256; e.RT = B * e.Tm;
+                    hipLaunchKernelGGL((conv_gemm_dma3_kernel<T, TO, 256, 256, 128, 64, 2>), dim3(e.RT * e.Tn, d.G), dim3(512), 0, s, e);
+                    MI_HIP(hipGetLastError());
+                    return;
+                }
+                if (blocks_256x128 >= 160 || blocks_128 < blocks_256x128 + 32) {
+                    e.Tm = (d.M + 255) / 256; e.Tn = (d.N + 127) / 128; e.RT = B * e.Tm;
+                    hipLaunchKernelGGL((conv_gemm_dma3_kernel<T, TO, 256, 128, 64, 64, 3>), dim3(e.RT * e.Tn, d.G), dim3(512), 0, s, e);
+                    MI_HIP(hipGetLastError());
+                    return;
+                }
+                // few tiles: fall through to the 128x128 kernel so that more CUs pull data
             }
             if (g_use_dma && d.Cin % 8 == 0 && d.K % d.Cin == 0) {
                 ConvGemmDev e = d;
@@ -580,12 +623,15 @@ void launch_conv_gemm(const ConvGemm& p, hipStream_t s) {
     d.act = p.act; d.alpha = p.alpha; d.accumulate = p.accumulate; d.epi = p.epi;
     d.u = p.u; d.Cout = p.Cout; d.padT = p.padT; d.T_out = p.T_out;
     d.rope_cos = p.rope_cos; d.rope_sin = p.rope_sin; d.heads = p.heads; d.head_dim = p.head_dim;
-    d.out2 = p.out2; d.out3 = p.out3; d.v_ld = p.v_ld;
+    d.out2 = p.out2; d.out3 = p.out3; d.v_ld = p.v_ld; d.Mb = p.rows_per_item;
     {
         static bool env_read = false;
         if (!env_read) { const char* e = std::getenv("MI355TTS_NO_DMA_GEMM"); g_use_dma = !(e && e[0] == '1');
             const char* x = std::getenv("MI355TTS_XCD_ORDER"); g_xcd_order = x && x[0] == '1';
-            const char* y = std::getenv("MI355TTS_NO_DMA3_GEMM"); g_use_dma3 = !(y && y[0] == '1'); env_read = true; }
+            const char* y = std::getenv("MI355TTS_NO_DMA3_GEMM"); g_use_dma3 = !(y && y[0] == '1');
+            const char* z = std::getenv("MI355TTS_NO_BIG_TILES"); g_big_tiles = !(z && z[0] == '1');
+            if (const char* m = std::getenv("MI355TTS_BIG_TILE_MIN")) g_big_min = std::atol(m);
+            env_read = true; }
         int dev = 0;
         MI_HIP(hipGetDevice(&dev));
         DevBuf& z = g_zero_page[dev & 15];
@@ -596,7 +642,7 @@ void launch_conv_gemm(const ConvGemm& p, hipStream_t s) {
     }
     if (p.epi == EPI_CONVT) MI_REQUIRE(p.Cout > 0 && p.N == p.u * p.Cout, "conv_gemm: convT shape");
     if (p.epi == EPI_QKV_ROPE)
-        MI_REQUIRE(p.G == 1 && p.heads > 0 && p.head_dim % 2 == 0 && p.N == 3 * p.heads * p.head_dim && p.N % 32 == 0 &&
+        MI_REQUIRE((p.rows_per_item == 0 || p.rows_per_item >= 32) && p.G == 1 && p.heads > 0 && p.head_dim % 2 == 0 && p.N == 3 * p.heads * p.head_dim && p.N % 32 == 0 &&
                        p.rope_cos && p.rope_sin && p.out2 && p.out3, "conv_gemm: qkv-rope epilogue arguments");
 
     const double esz = (double)dtype_size(p.dtype), osz = (double)dtype_size(odt);
