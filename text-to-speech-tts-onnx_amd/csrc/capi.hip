@@ -2,6 +2,8 @@
 #include "common.h"
 #include "bigvgan.h"
 #include "f5.h"
+#include <cstdlib>
+#include <algorithm>
 
 using namespace mi;
 
@@ -274,7 +276,17 @@ int mi_bench_conv_gemm(int dtype, int B, int T, int Cin, int N, int taps, int di
         auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 65536.0f - 0.5f; };
         for (auto& v : hx) v = rnd();
         for (auto& v : hw) v = rnd() * 0.1f;
+        // MI355TTS_BENCH_WSETS=n: cycle through n copies of the weights (n * bytes > 256 MiB MALL => every launch
+        // streams cold weights from HBM, like consecutive layers of a real model)
+        int nsets = 1;
+        if (const char* e = std::getenv("MI355TTS_BENCH_WSETS")) nsets = std::max(1, std::atoi(e));
         upload_as(x, hx.data(), nx, dtype, s); upload_as(w, hw.data(), nw, dtype, s); upload_f32(bias, hb.data(), N, s);
+        DevBuf wsets;
+        if (nsets > 1) {
+            wsets.ensure((size_t)nsets * nw * es);
+            for (int i = 0; i < nsets; ++i)
+                MI_HIP(hipMemcpyAsync((char*)wsets.p + (size_t)i * nw * es, w.p, nw * es, hipMemcpyDeviceToDevice, s));
+        }
         o.ensure(no * es); r.ensure(no * es);
         MI_HIP(hipMemsetAsync(r.p, 0, no * es, s));
         ConvGemm p;
@@ -285,7 +297,10 @@ int mi_bench_conv_gemm(int dtype, int B, int T, int Cin, int N, int taps, int di
         hipEvent_t e0, e1;
         MI_HIP(hipEventCreate(&e0)); MI_HIP(hipEventCreate(&e1));
         MI_HIP(hipEventRecord(e0, s));
-        for (int i = 0; i < iters; ++i) launch_conv_gemm(p, s);
+        for (int i = 0; i < iters; ++i) {
+            if (nsets > 1) p.w = (char*)wsets.p + (size_t)(i % nsets) * nw * es;
+            launch_conv_gemm(p, s);
+        }
         MI_HIP(hipEventRecord(e1, s));
         MI_HIP(hipEventSynchronize(e1));
         float t = 0.f;

@@ -22,6 +22,6 @@ if sel and sel[0] == "custom":           # custom dtype B T Cin N taps dil [more
 for name, dt, B, T, Cin, N, taps, dil in shapes:
     if sel and name not in sel:
         continue
-    ms = _lib.bench_conv_gemm(dt, B, T, Cin, N, taps, dil, iters=20)
+    ms = _lib.bench_conv_gemm(dt, B, T, Cin, N, taps, dil, iters=int(os.environ.get("ITERS", "20")))
     fl = 2.0 * B * T * N * Cin * taps
     print(f"{name:12s} {dt:5s} B{B} T{T} Cin{Cin} N{N} k{taps} d{dil}: {ms*1e3:8.1f} us  {fl/ms/1e9:8.1f} TFLOP/s", flush=True)
