@@ -244,7 +244,10 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # MI355TTS_BENCH_BACKEND=gloo + MI355TTS_BENCH_ONE_GPU=1: exercise the multi-rank code path on a 1-GPU box
+        dist.init_process_group(os.environ.get("MI355TTS_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
+    if os.environ.get("MI355TTS_BENCH_ONE_GPU") == "1":
+        local = 0
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
