@@ -552,6 +552,7 @@ __global__ __launch_bounds__(512) void conv_gemm_dma3_kernel(const ConvGemmDev p
 
 static bool g_use_dma = true, g_xcd_order = false, g_use_dma3 = true, g_big_tiles = true;
 static long g_big_min = 160;
+static bool g_n192 = true;
 static DevBuf g_zero_page[16];
 
 template <typename T, typename TO>
@@ -569,6 +570,16 @@ static void dispatch_tiles(const ConvGemmDev& d, int B, hipStream_t s) {
         if constexpr (sizeof(T) == 2) {
             // measured on gfx950 (tools/gemm_bench.py): with <= 32 K-chunks the 4-wave 128x128 kernel (two workgroups
             // per CU, short prologue/epilogue) wins; deeper K favours the 8-wave 256-row tiles.
+            if (g_use_dma3 && g_n192 && d.Cin % 8 == 0 && d.K % d.Cin == 0 && d.M > 128 && d.N % 192 == 0 && d.N % 256 != 0 &&
+                d.K >= 576 && (long)B * ((d.M + 255) / 256) * (d.N / 192) >= 160) {
+                // N = 192 / 384 (BigVGAN stages 2 and 1): a 192-wide tile has no padded columns (128-wide tiles waste 25 %
+                // of the MFMAs and DMA bytes at N = 192) and the fewest DMA bytes per useful flop after 256x256
+                ConvGemmDev e = d;
+                e.RC = 0; e.Tm = (d.M + 255) / 256; e.Tn = d.N / 192; e.RT = B * e.Tm;
+                hipLaunchKernelGGL((conv_gemm_dma3_kernel<T, TO, 256, 192, 64, 96, 2>), dim3(e.RT * e.Tn, d.G), dim3(512), 0, s, e);
+                MI_HIP(hipGetLastError());
+                return;
+            }
             if (g_use_dma3 && d.Cin % 8 == 0 && d.K % d.Cin == 0 && d.M > 128 && d.K > 2048) {
                 ConvGemmDev e = d;
                 e.RC = 0;
@@ -631,6 +642,7 @@ void launch_conv_gemm(const ConvGemm& p, hipStream_t s) {
             const char* y = std::getenv("MI355TTS_NO_DMA3_GEMM"); g_use_dma3 = !(y && y[0] == '1');
             const char* z = std::getenv("MI355TTS_NO_BIG_TILES"); g_big_tiles = !(z && z[0] == '1');
             if (const char* m = std::getenv("MI355TTS_BIG_TILE_MIN")) g_big_min = std::atol(m);
+            if (const char* n = std::getenv("MI355TTS_NO_N192")) g_n192 = !(n[0] == '1');
             env_read = true; }
         int dev = 0;
         MI_HIP(hipGetDevice(&dev));
