@@ -26,6 +26,7 @@ struct AAConvDev {
     const void* x; const void* w; const float* bias; const float* alpha_s; const float* inv_beta; void* out; const void* res;
     int T, C, S, k, dil, K, Kpad, halo, rows_act, rows_x;
     float alpha; int accumulate;
+    int w_off;    // element offset of the weight ring inside the LDS block (0: aliases the dead raw-input region)
     int dbg;      // tuning: bit0 skip AA math, bit1 skip MFMA loop, bit2 skip epilogue global traffic
 };
 
@@ -104,33 +105,78 @@ __global__ __launch_bounds__(256) void aa_conv_kernel(const AAConvDev p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     {
+        // Weights go through LDS once per workgroup (they used to be fetched from L2 by each of the four waves, with the
+        // L2 latency exposed in front of every MFMA group): 64-deep K chunks [N_pad][64 (+pad)], double buffered in the
+        // region that held the raw input tile (dead after the AA pass), next chunk's global loads issued before the MFMAs.
+        constexpr int KCH = 64;                                   // K elements per chunk
+        constexpr int NP = TN * 32;                               // padded N
+        constexpr int LDW = KCH + (sizeof(T) == 4 ? 1 : 8);
+        constexpr int WV = NP * KCH / VEC;                        // 16-byte vectors per chunk
+        constexpr int WPT = (WV + 255) / 256;                     // per thread
+        constexpr int STEPS = KCH / (2 * KP);                     // MFMA k-steps per chunk
+        T* Wb = XS + p.w_off;                                     // 2 x NP x LDW ; w_off = 0 aliases the dead raw-input tile
         const T* wp = (const T*)p.w;
-        int kk = hi * KP;                     // this lane's K offset inside the current MFMA k-step
-        int tap = kk / C, ci = kk - tap * C;
-        const int nsteps = (p.dbg & 2) ? 0 : p.Kpad / (2 * KP);
-        for (int ks = 0; ks < nsteps; ++ks) {
-            const int tapc = tap < p.k ? tap : p.k - 1;            // padded K tail: weights are zero there
-            typename MF::Frag a[TM], bf[TN];
+        const int nch = p.Kpad / KCH;
+        uint4 wreg[WPT];
+        auto wload = [&](int c) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-                a[i] = *reinterpret_cast<const typename MF::Frag*>(AS + (wave * WM + i * 32 + lr + tapc * p.dil) * S + ci);
+            for (int q = 0; q < WPT; ++q) {
+                const int v = tid + q * 256;
+                const int n = v / (KCH / VEC), kv = v - n * (KCH / VEC);
+                const int k2 = c * KCH + kv * VEC;
+                uint4 raw = make_uint4(0, 0, 0, 0);
+                if (v < WV && n < C && k2 < p.K) raw = *reinterpret_cast<const uint4*>(wp + (long)n * p.K + k2);
+                wreg[q] = raw;
+            }
+        };
+        auto wstore = [&](int buf) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = j * 32 + lr;
-                if constexpr (KP == 1) {
-                    bf[j] = (n < C && kk < p.K) ? wp[(long)n * p.K + kk] : 0.f;
-                } else {
-                    uint4 raw = make_uint4(0, 0, 0, 0);
-                    if (n < C && kk < p.K) raw = *reinterpret_cast<const uint4*>(wp + (long)n * p.K + kk);
-                    bf[j] = *reinterpret_cast<const typename MF::Frag*>(&raw);
+            for (int q = 0; q < WPT; ++q) {
+                const int v = tid + q * 256;
+                if (v < WV) {
+                    const int n = v / (KCH / VEC), kv = v - n * (KCH / VEC);
+                    T* d = Wb + (buf * NP + n) * LDW + kv * VEC;
+                    if constexpr (sizeof(T) == 4) {
+                        float* f = reinterpret_cast<float*>(d);
+                        f[0] = __uint_as_float(wreg[q].x); f[1] = __uint_as_float(wreg[q].y);
+                        f[2] = __uint_as_float(wreg[q].z); f[3] = __uint_as_float(wreg[q].w);
+                    } else {
+                        *reinterpret_cast<uint4*>(d) = wreg[q];
+                    }
                 }
             }
+        };
+        int kk = hi * KP;                     // this lane's K offset inside the current MFMA k-step
+        int tap = kk / C, ci = kk - tap * C;
+        if (!(p.dbg & 2)) {
+            wload(0);
+            wstore(0);
+            __syncthreads();
+            for (int c = 0; c < nch; ++c) {
+                if (c + 1 < nch) wload(c + 1);
+                const T* Wc = Wb + (c & 1) * NP * LDW;
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int ks = 0; ks < STEPS; ++ks) {
+                    const int tapc = tap < p.k ? tap : p.k - 1;        // padded K tail: weights are zero there
+                    typename MF::Frag a[TM], bf[TN];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma(a[i], bf[j], acc[i][j]);
-            kk += 2 * KP; ci += 2 * KP;
-            while (ci >= C) { ci -= C; ++tap; }
+                    for (int i = 0; i < TM; ++i)
+                        a[i] = *reinterpret_cast<const typename MF::Frag*>(AS + (wave * WM + i * 32 + lr + tapc * p.dil) * S + ci);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        bf[j] = *reinterpret_cast<const typename MF::Frag*>(Wc + (j * 32 + lr) * LDW + ks * 2 * KP + hi * KP);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma(a[i], bf[j], acc[i][j]);
+                    ci += 2 * KP;
+                    while (ci >= C) { ci -= C; ++tap; }
+                }
+                if (c + 1 < nch) {
+                    wstore((c + 1) & 1);      // the other buffer: last read in iteration c-1, fenced by that barrier
+                    __syncthreads();
+                }
+            }
         }
     }
     __syncthreads();                          // every wave is done reading AS before OUT overwrites it
@@ -189,7 +235,7 @@ static void launch_t(const AAConv& q, hipStream_t s) {
     AAConvDev d;
     d.x = q.x; d.w = q.w; d.bias = q.bias; d.alpha_s = q.snake_alpha; d.inv_beta = q.snake_inv_beta; d.out = q.out; d.res = q.res;
     d.T = q.T; d.C = q.C; d.k = q.k; d.dil = q.dil; d.K = q.k * q.C;
-    d.Kpad = (d.K + 2 * KP - 1) / (2 * KP) * (2 * KP);
+    d.Kpad = (d.K + 63) / 64 * 64;                         // whole 64-deep weight chunks (zero filled past K)
     d.halo = (q.k * q.dil - q.dil) / 2;
     d.S = ((q.C / 8) & 1) ? q.C : q.C + 8;             // S/8 odd => conflict-free ds_read_b128 fragment rows
     if (sizeof(T) == 4) d.S = (q.C % 2 == 0) ? q.C + 1 : q.C;   // fp32 fragments are ds_read_b32: odd dword stride
@@ -202,6 +248,16 @@ static void launch_t(const AAConv& q, hipStream_t s) {
     size_t lds = (size_t)d.rows_x * q.C * sizeof(T) + (size_t)d.rows_act * d.S * sizeof(T);
     lds = std::max(lds, (size_t)BM * q.C * 4);
     lds = (lds + 15) / 16 * 16;
+    {
+        const size_t ldw = 64 + (sizeof(T) == 4 ? 1 : 8);
+        const size_t ring = (size_t)2 * TN * 32 * ldw;                       // elements
+        if (ring <= (size_t)d.rows_x * q.C) d.w_off = 0;
+        else {                                                               // tiny channel counts: ring gets its own region
+            const size_t off = ((size_t)d.rows_x * q.C + (size_t)d.rows_act * d.S + 7) / 8 * 8;
+            d.w_off = (int)off;
+            lds = std::max(lds, ((off + ring) * sizeof(T) + 15) / 16 * 16);
+        }
+    }
     MI_REQUIRE(lds <= 160 * 1024, "aa_conv: tile does not fit LDS");
     dim3 grid((q.T + BM - 1) / BM, q.B);
     const double E = (double)q.B * q.T * q.C * sizeof(T);

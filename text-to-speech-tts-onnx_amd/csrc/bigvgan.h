@@ -40,6 +40,7 @@ struct BigVGAN {
     void aa(const SnakeP& sp, const void* x, void* y, int B, int T, int C, int post);
     void aa_conv(const SnakeP& sp, const ConvW& cw, const void* x, void* out, int B, int T, int C, int k, int dil,
                  const void* res, float alpha, int accumulate);
+    int fused_max_c = 96;
     bool use_fused = true;     // MI355TTS_NO_FUSED_AA=1 selects the unfused AA + conv path (A/B and debugging)
     void run(const float* mel, int B, int F, float* out_f32, int16_t* out_i16, int mem);
 };

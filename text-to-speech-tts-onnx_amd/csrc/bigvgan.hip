@@ -97,6 +97,7 @@ BigVGAN::BigVGAN(const BigVGANCfg& g, const float* w, int64_t nw, int dt, int de
     MI_HIP(hipSetDevice(dev));
     MI_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     if (const char* e = std::getenv("MI355TTS_NO_FUSED_AA")) use_fused = !(e[0] == '1');
+    if (const char* e = std::getenv("MI355TTS_FUSED_MAX_C")) fused_max_c = std::atoi(e);
     const int vec = 16 / (int)dtype_size(dt);
     MI_REQUIRE((g.c0 >> g.n_up) % vec == 0, "bigvgan: last-stage channels must be a multiple of the 16-byte vector");
     mel_pad = round_up(g.num_mels, vec);
@@ -235,7 +236,7 @@ void BigVGAN::run(const float* mel, int B, int F, float* out_f32, int16_t* out_i
             for (int l = 0; l < cfg.n_dil; ++l) {
                 const bool last = l == cfg.n_dil - 1;
                 void* dst = last ? IN->p : ((l & 1) ? bQ.p : bP.p);
-                if (use_fused && C <= 96) {
+                if (use_fused && C <= fused_max_c) {
                     // HBM-bound stages: AA folded into the conv's operand staging (5 tensor passes instead of 9)
                     aa_conv(bk.acts[2 * l], bk.c1[l], cur, bT2.p, B, Tn, C, bk.k, cfg.dil[j][l], nullptr, 1.f, 0);
                     aa_conv(bk.acts[2 * l + 1], bk.c2[l], bT2.p, dst, B, Tn, C, bk.k, 1, cur, last ? inv_nk : 1.f, last && j > 0);
