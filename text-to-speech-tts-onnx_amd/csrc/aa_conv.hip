@@ -66,30 +66,47 @@ __global__ __launch_bounds__(256) void aa_conv_kernel(const AAConvDev p) {
         constexpr bool FAST = sizeof(T) == 2;
         const AATaps tp = aa_make_taps(c_h_fused);
         const int runs = (p.rows_act + R - 1) / R;
-        const int nitems = C * runs;
         const int t_act0 = m0 - p.halo;                              // global time of activated row 0
         const int hi2 = 2 * p.T;
         const bool edge = (2 * (t_act0 - 3) - 1 < 0) || (2 * (t_act0 + runs * R + 3) >= hi2);
-        for (int it = tid; it < nitems; it += 256) {
-            const int run = it / C, c = it - run * C;
+        // two adjacent channels per work item: every LDS access moves a channel PAIR (the 2-byte-per-lane version was
+        // bound by LDS instruction issue, not by the FIR math)
+        struct alignas(2 * sizeof(T)) Pair { T a, b; };
+        const int CP = C >> 1;
+        const int npairs = CP * runs;
+        for (int it = tid; it < npairs; it += 256) {
+            const int run = it / CP, cp = it - run * CP;
+            const int c = 2 * cp;
             const int ml = run * R;
-            const float al = FAST ? p.alpha_s[c] * 0.15915494309189535f : p.alpha_s[c];
-            const float ib = p.inv_beta[c];
-            float xv[R + 10], acc[R];
+            const float s0 = FAST ? 0.15915494309189535f : 1.f;
+            const float al0 = p.alpha_s[c] * s0, al1 = p.alpha_s[c + 1] * s0;
+            const float ib0 = p.inv_beta[c], ib1 = p.inv_beta[c + 1];
+            float xv0[R + 10], xv1[R + 10], o0[R], o1[R];
 #pragma unroll
-            for (int j = 0; j < R + 10; ++j) xv[j] = to_f32(XS[(ml + j) * C + c]);
+            for (int j = 0; j < R + 10; ++j) {
+                const Pair pr = *reinterpret_cast<const Pair*>(XS + (ml + j) * C + c);
+                xv0[j] = to_f32(pr.a); xv1[j] = to_f32(pr.b);
+            }
             const int mp = t_act0 + ml;
             if (p.dbg & 1) {
 #pragma unroll
-                for (int r = 0; r < R; ++r) acc[r] = xv[r + 5];
-            } else if (edge) aa_run<R, FAST, true>(xv, acc, tp, al, ib, mp, 0, hi2);
-            else aa_run<R, FAST, false>(xv, acc, tp, al, ib, mp, 0, hi2);
+                for (int r = 0; r < R; ++r) { o0[r] = xv0[r + 5]; o1[r] = xv1[r + 5]; }
+            } else if (edge) {
+                aa_run<R, FAST, true>(xv0, o0, tp, al0, ib0, mp, 0, hi2);
+                aa_run<R, FAST, true>(xv1, o1, tp, al1, ib1, mp, 0, hi2);
+            } else {
+                aa_run<R, FAST, false>(xv0, o0, tp, al0, ib0, mp, 0, hi2);
+                aa_run<R, FAST, false>(xv1, o1, tp, al1, ib1, mp, 0, hi2);
+            }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int row = ml + r;
                 if (row < p.rows_act) {
                     const int t = mp + r;
-                    AS[row * S + c] = from_f32<T>((t >= 0 && t < p.T) ? acc[r] : 0.f);
+                    const bool in = t >= 0 && t < p.T;
+                    Pair pr;
+                    pr.a = from_f32<T>(in ? o0[r] : 0.f); pr.b = from_f32<T>(in ? o1[r] : 0.f);
+                    *reinterpret_cast<Pair*>(AS + row * S + c) = pr;
                 }
             }
         }
@@ -204,7 +221,12 @@ __global__ __launch_bounds__(256) void aa_conv_kernel(const AAConvDev p) {
             const long gi = (long)t * C + cv * VEC;
             float o[VEC];
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) o[e] = OUT[row * C + cv * VEC + e] + p.bias[cv * VEC + e];
+            for (int e4 = 0; e4 < VEC; e4 += 4) {
+                const float4 ov4 = *reinterpret_cast<const float4*>(OUT + row * C + cv * VEC + e4);   // C % 8 == 0: 16-byte aligned
+                o[e4] = ov4.x; o[e4 + 1] = ov4.y; o[e4 + 2] = ov4.z; o[e4 + 3] = ov4.w;
+            }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) o[e] += p.bias[cv * VEC + e];
             if (rb) {
                 const uint4 raw = *reinterpret_cast<const uint4*>(rb + gi);
                 const T* rv = reinterpret_cast<const T*>(&raw);
