@@ -122,6 +122,10 @@ int         mi_f5_synthesize(mi_f5* h, int U, const int16_t* audio, int64_t L, c
 int         mi_bench_conv_gemm(int dtype, int B, int T, int Cin, int N, int taps, int dil, int with_res, int iters,
                                double* ms);
 
+/* test / tuning hook: tile-dispatch thresholds of the implicit-GEMM kernel ("gemm_big_tile_min", "gemm_n192_min",
+ * "gemm_mid_tile_min", "gemm_dma3_k_min", "gemm_use_dma3", "gemm_use_dma", "gemm_big_tiles", "gemm_n192").      */
+int         mi_set_option(const char* key, int64_t value);
+
 /* ---- profiling hooks (bench.py roofline leg) -------------------------------------------------
  * family_mask: bit i enables family i (0 = off, -1 = all).  Every launch of an enabled kernel
  * family is bracketed by HIP events on the handle's own stream; mi_prof_get returns accumulated

@@ -227,3 +227,44 @@ def test_bad_inputs_raise(small_voc):
     from mi355tts._lib import MiError
     with pytest.raises(MiError):
         BV.BigVGANVocoder(cfg, blob=np.zeros(10, np.float32))
+
+
+# ---------------------------------------------------------------------------------------------
+# every tile configuration of the 16-bit LDS-DMA GEMM, forced at test sizes (they normally engage
+# only when the launch fills the chip) and compared with the oracle
+# ---------------------------------------------------------------------------------------------
+_DEFAULTS = {"gemm_big_tile_min": 160, "gemm_n192_min": 160, "gemm_mid_tile_min": 160, "gemm_dma3_k_min": 2048,
+             "gemm_use_dma3": 1, "gemm_use_dma": 1, "gemm_big_tiles": 1, "gemm_n192": 1}
+
+
+@pytest.fixture
+def gemm_options():
+    from mi355tts import _lib
+    yield _lib.set_option
+    for k, v in _DEFAULTS.items():
+        _lib.set_option(k, v)
+
+
+@pytest.mark.parametrize("cfg_name,opts,Ci,Co,k,d,T,B", [
+    ("256x256/2-stage", {"gemm_big_tile_min": 1, "gemm_dma3_k_min": 0}, 768, 768, 7, 3, 700, 2),
+    ("256x256/2-stage ragged N", {"gemm_big_tile_min": 1, "gemm_dma3_k_min": 0}, 256, 1000, 3, 1, 333, 1),
+    ("256x192/2-stage", {"gemm_n192_min": 1}, 192, 192, 11, 5, 900, 2),
+    ("256x192/2-stage N=384", {"gemm_n192_min": 1}, 384, 384, 3, 1, 515, 1),
+    ("256x128/3-stage", {"gemm_big_tiles": 0, "gemm_n192": 0, "gemm_mid_tile_min": 1, "gemm_dma3_k_min": 0}, 384, 384, 7, 1, 600, 2),
+    ("128x128/2-stage dma", {"gemm_use_dma3": 0}, 768, 768, 3, 1, 300, 1),
+    ("register-staged", {"gemm_use_dma3": 0, "gemm_use_dma": 0}, 192, 192, 7, 3, 300, 1),
+])
+@pytest.mark.parametrize("dtype,tol", [("f16", 6e-3), ("bf16", 4e-2)])
+def test_gemm_tile_configs_vs_oracle(gemm_options, cfg_name, opts, Ci, Co, k, d, T, B, dtype, tol):
+    for key, v in opts.items():
+        gemm_options(key, v)
+    x = W.synth_normal(21, f"tx{Ci}{k}", (B, Ci, T))
+    w = W.synth_normal(22, f"tw{Ci}{Co}{k}", (Co, Ci, k), std=1.0 / np.sqrt(Ci * k))
+    b = W.synth_normal(23, "tb", (Co,), std=0.1)
+    pad = (k * d - d) // 2
+    ref = O.conv1d(x, w, b, dilation=d, padding=pad)
+    y = BV.conv1d(x, w, b, dilation=d, padding=pad, dtype=dtype)
+    assert y.shape == ref.shape
+    assert rms(y - ref) / rms(ref) < tol, cfg_name
+    # element-wise too (a transposed or shifted tile would pass an RMS-of-noise check only by accident)
+    assert np.abs(y - ref).max() < 40 * tol * rms(ref), cfg_name

@@ -310,6 +310,13 @@ int mi_bench_conv_gemm(int dtype, int B, int T, int Cin, int N, int taps, int di
     });
 }
 
+int mi_set_option(const char* key, int64_t value) {
+    return guard([&] {
+        MI_REQUIRE(key != nullptr, "mi_set_option: null key");
+        MI_REQUIRE(gemm_set_option(key, (long)value), "mi_set_option: unknown key");
+    });
+}
+
 int mi_prof_enable(int family_mask) { prof_enable((unsigned)family_mask); return MI_OK; }
 int mi_prof_reset(void) { return guard([&] { prof_reset(); }); }
 int mi_prof_get(const char* family, double* ms, int64_t* launches, double* bytes, double* flops) {

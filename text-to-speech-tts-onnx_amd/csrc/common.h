@@ -131,6 +131,7 @@ struct ConvGemm {
     long v_ld = 0;                // > 0: V is written transposed, [b*H + h][head_dim][v_ld] (keys contiguous)
 };
 void launch_conv_gemm(const ConvGemm& p, hipStream_t s);
+bool gemm_set_option(const char* key, long v);
 
 // anti-aliased SnakeBeta (aa_act.hip); channels-last (B,T,C) -> (B,T+2*shift,C)
 struct AAAct {

@@ -551,7 +551,7 @@ __global__ __launch_bounds__(512) void conv_gemm_dma3_kernel(const ConvGemmDev p
 }
 
 static bool g_use_dma = true, g_xcd_order = false, g_use_dma3 = true, g_big_tiles = true;
-static long g_big_min = 160;
+static long g_big_min = 160, g_n192_min = 160, g_mid_min = 160, g_k_min = 2048;
 static bool g_n192 = true;
 static DevBuf g_zero_page[16];
 
@@ -571,7 +571,7 @@ static void dispatch_tiles(const ConvGemmDev& d, int B, hipStream_t s) {
             // measured on gfx950 (tools/gemm_bench.py): with <= 32 K-chunks the 4-wave 128x128 kernel (two workgroups
             // per CU, short prologue/epilogue) wins; deeper K favours the 8-wave 256-row tiles.
             if (g_use_dma3 && g_n192 && d.Cin % 8 == 0 && d.K % d.Cin == 0 && d.M > 128 && d.N % 192 == 0 && d.N % 256 != 0 &&
-                d.K >= 576 && (long)B * ((d.M + 255) / 256) * (d.N / 192) >= 160) {
+                d.K >= 576 && (long)B * ((d.M + 255) / 256) * (d.N / 192) >= g_n192_min) {
                 // N = 192 / 384 (BigVGAN stages 2 and 1): a 192-wide tile has no padded columns (128-wide tiles waste 25 %
                 // of the MFMAs and DMA bytes at N = 192) and the fewest DMA bytes per useful flop after 256x256
                 ConvGemmDev e = d;
@@ -580,7 +580,7 @@ static void dispatch_tiles(const ConvGemmDev& d, int B, hipStream_t s) {
                 MI_HIP(hipGetLastError());
                 return;
             }
-            if (g_use_dma3 && d.Cin % 8 == 0 && d.K % d.Cin == 0 && d.M > 128 && d.K > 2048) {
+            if (g_use_dma3 && d.Cin % 8 == 0 && d.K % d.Cin == 0 && d.M > 128 && d.K > g_k_min) {
                 ConvGemmDev e = d;
                 e.RC = 0;
                 const long blocks_128 = (long)B * ((d.M + 127) / 128) * ((d.N + 127) / 128);
@@ -594,7 +594,7 @@ static void dispatch_tiles(const ConvGemmDev& d, int B, hipStream_t s) {
                     MI_HIP(hipGetLastError());
                     return;
                 }
-                if (blocks_256x128 >= 160 || blocks_128 < blocks_256x128 + 32) {
+                if (blocks_256x128 >= g_mid_min || blocks_128 < blocks_256x128 + 32) {
                     e.Tm = (d.M + 255) / 256; e.Tn = (d.N + 127) / 128; e.RT = B * e.Tm;
                     hipLaunchKernelGGL((conv_gemm_dma3_kernel<T, TO, 256, 128, 64, 64, 3>), dim3(e.RT * e.Tn, d.G), dim3(512), 0, s, e);
                     MI_HIP(hipGetLastError());
@@ -615,6 +615,21 @@ static void dispatch_tiles(const ConvGemmDev& d, int B, hipStream_t s) {
         hipLaunchKernelGGL((conv_gemm_kernel<T, TO, 128, 128, 2, 2, KC>), grid, blk, 0, s, d);
     }
     MI_HIP(hipGetLastError());
+}
+
+// test / tuning hook: force a tile configuration regardless of problem size
+bool gemm_set_option(const char* key, long v) {
+    const std::string k(key);
+    if (k == "gemm_big_tile_min") g_big_min = v;
+    else if (k == "gemm_n192_min") g_n192_min = v;
+    else if (k == "gemm_mid_tile_min") g_mid_min = v;
+    else if (k == "gemm_dma3_k_min") g_k_min = v;
+    else if (k == "gemm_use_dma3") g_use_dma3 = v != 0;
+    else if (k == "gemm_use_dma") g_use_dma = v != 0;
+    else if (k == "gemm_big_tiles") g_big_tiles = v != 0;
+    else if (k == "gemm_n192") g_n192 = v != 0;
+    else return false;
+    return true;
 }
 
 void launch_conv_gemm(const ConvGemm& p, hipStream_t s) {

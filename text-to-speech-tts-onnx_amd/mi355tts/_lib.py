@@ -80,6 +80,7 @@ def load() -> C.CDLL:
     L.mi_f5_synthesize.restype = C.c_int
     L.mi_bench_conv_gemm.argtypes = [C.c_int] * 9 + [C.POINTER(C.c_double)]
     L.mi_bench_conv_gemm.restype = C.c_int
+    L.mi_set_option.argtypes = [C.c_char_p, C.c_int64]; L.mi_set_option.restype = C.c_int
     L.mi_prof_enable.argtypes = [C.c_int]; L.mi_prof_enable.restype = C.c_int
     L.mi_prof_reset.argtypes = []; L.mi_prof_reset.restype = C.c_int
     L.mi_prof_get.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
@@ -142,3 +143,7 @@ def bench_conv_gemm(dtype: str, B: int, T: int, Cin: int, N: int, taps: int = 1,
     check(load().mi_bench_conv_gemm(DTYPES[dtype], B, T, Cin, N, taps, dil, int(with_res), iters, C.byref(ms)),
           "mi_bench_conv_gemm")
     return ms.value
+
+
+def set_option(key: str, value: int) -> None:
+    check(load().mi_set_option(key.encode(), int(value)), "mi_set_option")
