@@ -336,7 +336,12 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "launches_per_step": prof["launches"] / args.steps,
                          "avg_launch_ms": k_ms, "family_ms_per_step": prof["ms"] / args.steps,
-                         "tflops": prof["flops"] / (prof["ms"] * 1e-3) / 1e12 if prof["ms"] > 0 else 0.0},
+                         "tflops": prof["flops"] / (prof["ms"] * 1e-3) / 1e12 if prof["ms"] > 0 else 0.0,
+                         "mfma_peak_tflops": MFMA_F32_PEAK_TF if args.dtype == "f32" else MFMA_F16_PEAK_TF,
+                         "mfma_frac": (prof["flops"] / (prof["ms"] * 1e-3) / 1e12 if prof["ms"] > 0 else 0.0) /
+                                      (MFMA_F32_PEAK_TF if args.dtype == "f32" else MFMA_F16_PEAK_TF),
+                         "note": "family = every implicit-GEMM launch of the forward (stages 0-2 are MFMA / LDS-fill bound, "
+                                 "stages 3-5 + fused AA are HBM bound); bytes are the layer-granular algorithmic count"},
         }
         if world == 1 and not args.no_cpu_baseline:
             if state is None:
