@@ -220,7 +220,7 @@ def run_f5(args, world, rank, local, dev, dist, torch):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="bigvgan", choices=["bigvgan", "f5"])
+    ap.add_argument("--workload", default="bigvgan", choices=["bigvgan", "f5", "indextts_f"])
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=3)
@@ -266,7 +266,10 @@ def main():
             dist.destroy_process_group()
         return
 
-    cfg = BigVGANConfig()
+    ixf = args.workload == "indextts_f"        # BASELINE configs[4] vocoder leg: IndexTTS graph F, T_codes = 128
+    cfg = BigVGANConfig.indextts() if ixf else BigVGANConfig()
+    if ixf:
+        args.batch, args.frames = 1, 126
     spec = W.bigvgan_spec(cfg)
     # weights: rank 0 packs, everybody else receives the blob over RCCL (xGMI)
     nparam = sum(int(np.prod(s)) for _, s, _ in spec)
@@ -287,13 +290,20 @@ def main():
     del blob_t
 
     B, F = args.batch, args.frames
-    mel = torch.from_numpy(W.synth_normal(100 + rank, "mel", (B, cfg.num_mels, F), std=2.0, mean=-2.0)
-                           .clip(-11.5, 2.5)).to(dev)
     out = torch.empty((B, 1, voc.out_len(F)), dtype=torch.int16, device=dev)
     audio_s = B * voc.out_len(F) / cfg.sampling_rate
+    if ixf:
+        latent = torch.from_numpy(W.synth_normal(100 + rank, "latent", (F + 2, cfg.num_mels), std=1.5, mean=0.3)).to(dev)
+        ncond = cfg.upsample_initial_channel + sum(cfg.stage_channels(i) for i in range(cfg.num_upsamples))
+        conds = torch.from_numpy(W.synth_normal(100 + rank, "conds", (ncond,), std=0.2)).to(dev)
+        step = lambda: voc.run_latent_torch(latent, conds, out)
+    else:
+        mel = torch.from_numpy(W.synth_normal(100 + rank, "mel", (B, cfg.num_mels, F), std=2.0, mean=-2.0)
+                               .clip(-11.5, 2.5)).to(dev)
+        step = lambda: voc.run_torch(mel, out)
 
     for _ in range(args.warmup):
-        voc.run_torch(mel, out)
+        step()
 
     def barrier():
         if world > 1:
@@ -305,7 +315,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        voc.run_torch(mel, out)
+        step()
     barrier()
     dt = time.perf_counter() - t0
     _lib.prof_enable(())
@@ -325,8 +335,10 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": f"BigVGAN-v2 24khz_100band_256x {args.dtype} vocoder, mel ({B},100,{F}) per GPU "
-                                   f"(BASELINE configs[1])",
+            "config": {"workload": (f"IndexTTS graph F (speaker-conditioned BigVGAN, 1024x) {args.dtype}, T_codes = {F + 2} "
+                                    f"(BASELINE configs[4] vocoder leg)") if ixf else
+                                   (f"BigVGAN-v2 24khz_100band_256x {args.dtype} vocoder, mel ({B},100,{F}) per GPU "
+                                    f"(BASELINE configs[1])"),
                        "batch_per_gpu": B, "frames": F, "audio_seconds_per_step_per_gpu": audio_s,
                        "rtf": dt / args.steps / audio_s, "weights": "synthetic seeded (112.4 M params)",
                        "weight_bcast_ms": bcast_ms,
@@ -343,7 +355,7 @@ def main():
                          "note": "family = every implicit-GEMM launch of the forward (stages 0-2 are MFMA / LDS-fill bound, "
                                  "stages 3-5 + fused AA are HBM bound); bytes are the layer-granular algorithmic count"},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not ixf:
             if state is None:
                 state = W.synth_state(spec, 9527)
             line["cpu_baseline"] = cpu_baseline_bigvgan(cfg, state, args.cpu_frames)

@@ -54,7 +54,8 @@ const char* mi_version(void);
 /* ---- BigVGAN-v2 vocoder ---------------------------------------------------------------------
  * cfg: int32 array = BigVGANConfig.to_int_array():
  *   [num_mels, initial_channel, n_up, n_kernels, bias_at_final, tanh_at_final, snake_logscale,
- *    rates[n_up], up_kernels[n_up], res_kernels[n_kernels], n_dil, dil[n_kernels][n_dil]]      */
+ *    rates[n_up], up_kernels[n_up], res_kernels[n_kernels], n_dil, dil[n_kernels][n_dil],
+ *    pre_layernorm, speaker_cond]   (the last two are optional; 1,1 = IndexTTS graph F)          */
 int64_t     mi_bigvgan_param_count(const int32_t* cfg, int n_cfg);
 mi_bigvgan* mi_bigvgan_create(const int32_t* cfg, int n_cfg, const float* weights, int64_t n_weights,
                               int dtype, int device);
@@ -65,6 +66,13 @@ int64_t     mi_bigvgan_out_len(const mi_bigvgan* h, int frames);      /* frames*
 int         mi_bigvgan_forward(mi_bigvgan* h, const float* mel, int B, int frames, int16_t* out, int mem);
 /* same, but the float waveform before the int16 conversion (tests)                            */
 int         mi_bigvgan_forward_f32(mi_bigvgan* h, const float* mel, int B, int frames, float* out, int mem);
+/* IndexTTS graph F (speaker-conditioned vocoder): ort_session_F.run_with_ort_values, IndexTTS/Inference_IndexTTS_ONNX.py:787
+ * (graph = IndexTTS_F.forward, IndexTTS/Export_IndexTTS.py:300-314).  The handle must be created from a config with the
+ * pre_layernorm / speaker_cond flags (BigVGANConfig.indextts()).  latent: `save_hidden_state` (T_codes, gpt_dim) fp32
+ * (the last two rows are dropped, like the reference); conds: save_bigvgan_conds_0..n-1 followed by
+ * bigvgan_cond_layer_speaker_embedding, concatenated (n_conds floats).  out: int16 (1,1,(T_codes-2)*hop+30).            */
+int         mi_bigvgan_forward_latent(mi_bigvgan* h, const float* latent, int T_codes, const float* conds, int64_t n_conds,
+                                      int16_t* out, float* out_f32, int mem);
 /* unit-level entry (tests): one anti-aliased SnakeBeta Activation1d on x (B,C,T) fp32
  * channels-first host memory; post!=0 selects the pad-15 variant (out T+30).                   */
 int         mi_aa_activation1d(const float* x, int B, int C, int T, const float* alpha_log,

@@ -161,15 +161,21 @@ def amp_block1(x, st, n: int, k: int, dils, h, logscale=True):
     return x
 
 
-def generator(cfg, st, mel: np.ndarray, taps=None) -> np.ndarray:
-    """BigVGAN.forward: mel (B, num_mels, F) float32 -> (B, 1, F*hop + 30) float32 in [-1, 1]."""
+def generator(cfg, st, mel: np.ndarray, taps=None, conds=None) -> np.ndarray:
+    """BigVGAN.forward: mel (B, num_mels, F) float32 -> (B, 1, F*hop + 30) float32 in [-1, 1].
+    conds (IndexTTS graph F, Export_IndexTTS.py:300-314): list [cond_0 .. cond_{n-1}, cond_pre], each (C,) — added after
+    every upsampler / after conv_pre."""
     h = aa_filter()
     x = conv1d(mel.astype(F32), st["conv_pre.weight"], st["conv_pre.bias"], padding=3)
+    if conds is not None:
+        x = x + conds[-1].astype(F32)[None, :, None]
     if taps is not None:
         taps["conv_pre"] = x
     nk = cfg.num_kernels
     for i, (u, k) in enumerate(zip(cfg.upsample_rates, cfg.upsample_kernel_sizes)):
         x = conv_transpose1d(x, st[f"ups.{i}.0.weight"], st[f"ups.{i}.0.bias"], stride=u, padding=(k - u) // 2)
+        if conds is not None:
+            x = (x + conds[i].astype(F32)[None, :, None]).astype(F32)
         if taps is not None:
             taps[f"ups.{i}"] = x
         xs = None
@@ -196,3 +202,22 @@ def bigvgan_int16(cfg, st, mel: np.ndarray) -> np.ndarray:
     if cfg.use_tanh_at_final:
         w = np.clip(w, -32768.0, 32767.0)
     return w.astype(np.int16)      # numpy float->int16 cast truncates toward zero, like torch .to(int16)
+
+
+def indextts_f_int16(cfg, st, latent: np.ndarray, conds) -> np.ndarray:
+    """IndexTTS_F.forward (IndexTTS/Export_IndexTTS.py:300-314): latent (T_codes, gpt_dim) channels-last ->
+    LayerNorm(latent[:-2]) -> generator with speaker-conditioning biases -> tanh -> clamp(-1,1)*32767 -> int16."""
+    x = latent[:-2].astype(F32)
+    mu = x.mean(axis=-1, keepdims=True, dtype=np.float64)
+    var = ((x - mu) ** 2).mean(axis=-1, keepdims=True, dtype=np.float64)
+    x = ((x - mu) / np.sqrt(var + cfg.ln_eps)).astype(F32) * st["final_norm.weight"] + st["final_norm.bias"]
+    y = generator(cfg, st, x.T[None].astype(F32), conds=conds)
+    return (np.clip(y, -1.0, 1.0) * F32(32767.0)).astype(np.int16)
+
+
+def indextts_f_float(cfg, st, latent: np.ndarray, conds) -> np.ndarray:
+    x = latent[:-2].astype(F32)
+    mu = x.mean(axis=-1, keepdims=True, dtype=np.float64)
+    var = ((x - mu) ** 2).mean(axis=-1, keepdims=True, dtype=np.float64)
+    x = ((x - mu) / np.sqrt(var + cfg.ln_eps)).astype(F32) * st["final_norm.weight"] + st["final_norm.bias"]
+    return generator(cfg, st, x.T[None].astype(F32), conds=conds)

@@ -175,3 +175,36 @@ def load_f5_ref():
     vmodels = _load("vocos.models", d + "vocos/models.py")
     stft = _load("STFT_Process", REF + "/F5_TTS/STFT_Process.py")
     return modules, dit, vmodels, vheads, stft
+
+
+# ------------------------------------------------------------------------------------------
+# IndexTTS vocoder (graph F)
+# ------------------------------------------------------------------------------------------
+def load_indextts_bigvgan_ref():
+    """Returns the reference IndexTTS ``models`` module (IndexTTS/modeling_modified/models.py) with its alias-free
+    activation modules; un-vendored ``indextts.BigVGAN.{activations, ECAPA_TDNN, utils}`` are stubbed / restated."""
+    _pkg("indextts")
+    bvp = _pkg("indextts.BigVGAN")
+    act = types.ModuleType("indextts.BigVGAN.activations")
+    act.SnakeBeta = _SnakeBeta
+    act.Snake = _SnakeBeta
+    sys.modules["indextts.BigVGAN.activations"] = act
+    bvp.activations = act
+    ec = types.ModuleType("indextts.BigVGAN.ECAPA_TDNN")
+
+    class ECAPA_TDNN(nn.Module):          # speaker encoder: belongs to graph A, not exercised by graph F
+        def __init__(self, *a, **k):
+            super().__init__()
+    ec.ECAPA_TDNN = ECAPA_TDNN
+    sys.modules["indextts.BigVGAN.ECAPA_TDNN"] = ec
+    ut = types.ModuleType("indextts.BigVGAN.utils")
+    ut.init_weights = lambda m, mean=0.0, std=0.01: None
+    ut.get_padding = lambda k, d=1: int((k * d - d) / 2)
+    sys.modules["indextts.BigVGAN.utils"] = ut
+    d = REF + "/IndexTTS/modeling_modified/"
+    _pkg("indextts.BigVGAN.alias_free_torch")
+    _load("indextts.BigVGAN.alias_free_torch.filter", d + "filter.py")
+    _load("indextts.BigVGAN.alias_free_torch.resample", d + "resample.py")
+    aft = _load("indextts.BigVGAN.alias_free_torch.act", d + "act.py")
+    sys.modules["indextts.BigVGAN.alias_free_torch"].Activation1d = aft.Activation1d
+    return _load("indextts.BigVGAN.models", d + "models.py")

@@ -111,8 +111,61 @@ def gen_bigvgan():
     print("  int16 output rms %.1f  max %d" % (np.sqrt((i16 ** 2).mean()), np.abs(i16).max()))
 
 
+# ---------------------------------------------------------------------------------------------
+# IndexTTS graph F (speaker-conditioned vocoder)
+# ---------------------------------------------------------------------------------------------
+def gen_indextts():
+    import torch.nn as nn
+    cfg = BigVGANConfig.indextts()
+    state = W.synth_state(W.bigvgan_spec(cfg), SEED)
+    models = R.load_indextts_bigvgan_ref()
+    h = R._AttrDict(gpt_dim=cfg.num_mels, upsample_initial_channel=cfg.upsample_initial_channel,
+                    upsample_rates=list(cfg.upsample_rates), upsample_kernel_sizes=list(cfg.upsample_kernel_sizes),
+                    resblock="1", resblock_kernel_sizes=list(cfg.resblock_kernel_sizes),
+                    resblock_dilation_sizes=[list(d) for d in cfg.resblock_dilation_sizes], activation="snakebeta",
+                    snake_logscale=True, feat_upsample=False, cond_d_vector_in_each_upsampling_layer=True, num_mels=100,
+                    speaker_embedding_dim=512)
+    bv = models.BigVGAN(h, use_cuda_kernel=False)
+    bv.remove_weight_norm()
+    bv = bv.eval().float()
+    sd = {k: t(v) for k, v in state.items() if not k.startswith("final_norm.")}
+    missing, unexpected = bv.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all(("filter" in m) or m.startswith("cond") or m.startswith("speaker_encoder") for m in missing), missing
+
+    class GPT(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.final_norm = nn.LayerNorm(cfg.num_mels)
+    gpt = GPT()
+    gpt.final_norm.weight.data = t(state["final_norm.weight"])
+    gpt.final_norm.bias.data = t(state["final_norm.bias"])
+    import types
+    idx = types.SimpleNamespace(gpt=gpt, bigvgan=bv)
+    ns = {"torch": torch}
+    R.exec_lines(R.REF + "/IndexTTS/Export_IndexTTS.py", 292, 314, ns)
+    part_F = ns["IndexTTS_F"](idx)
+    out = {}
+    T_codes = 5
+    latent = W.synth_normal(SEED, "ix.latent", (T_codes, cfg.num_mels), std=1.5, mean=0.3)
+    conds = [W.synth_normal(SEED, f"ix.cond{i}", (1, cfg.stage_channels(i), 1), std=0.2) for i in range(cfg.num_upsamples)]
+    cpre = W.synth_normal(SEED, "ix.cond_pre", (1, cfg.upsample_initial_channel, 1), std=0.2)
+    wav = part_F(*[t(c) for c in conds], t(cpre), t(latent))
+    out["latent"] = latent
+    for i, c in enumerate(conds):
+        out[f"cond{i}"] = c
+    out["cond_pre"] = cpre
+    out["wav_i16"] = wav.numpy()
+    assert wav.shape == (1, 1, (T_codes - 2) * cfg.hop + 30), wav.shape
+    np.savez_compressed(os.path.join(HERE, "indextts_f.npz"), **out)
+    w = out["wav_i16"].astype(np.float64)
+    print("indextts_f.npz:", {k: v.shape for k, v in out.items()}, "rms", np.sqrt((w ** 2).mean()), "max", np.abs(w).max())
+
+
 if __name__ == "__main__":
-    what = set(sys.argv[1:]) or {"bigvgan", "f5"}
+    what = set(sys.argv[1:]) or {"bigvgan", "f5", "indextts"}
+    if "indextts" in what:
+        gen_indextts()
     if "bigvgan" in what:
         gen_bigvgan()
     if "f5" in what:

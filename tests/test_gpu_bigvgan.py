@@ -268,3 +268,39 @@ def test_gemm_tile_configs_vs_oracle(gemm_options, cfg_name, opts, Ci, Co, k, d,
     assert rms(y - ref) / rms(ref) < tol, cfg_name
     # element-wise too (a transposed or shifted tile would pass an RMS-of-noise check only by accident)
     assert np.abs(y - ref).max() < 40 * tol * rms(ref), cfg_name
+
+
+# ---------------------------------------------------------------------------------------------
+# IndexTTS graph F (config 5 vocoder): pre-LayerNorm, speaker-conditioning biases, k = u ConvTranspose, biased conv_post
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("Ci,Co,u,k,T", [(96, 48, 4, 4, 50), (48, 24, 2, 4, 33), (16, 8, 4, 8, 5)])
+def test_conv_transpose_kernel_equals_stride(Ci, Co, u, k, T):
+    x = W.synth_normal(1, f"xtk{Ci}", (1, Ci, T))
+    w = W.synth_normal(2, f"wtk{Ci}", (Ci, Co, k), std=1.0 / np.sqrt(Ci))
+    b = W.synth_normal(3, "btk", (Co,), std=0.1)
+    ref = O.conv_transpose1d(x, w, b, stride=u, padding=(k - u) // 2)
+    y = BV.conv_transpose1d(x, w, b, stride=u, padding=(k - u) // 2)
+    assert y.shape == ref.shape == (1, Co, T * u)
+    np.testing.assert_allclose(y, ref, atol=2e-5, rtol=1e-5)
+
+
+def test_indextts_graph_f_golden_and_oracle(golden_dir):
+    g = np.load(os.path.join(golden_dir, "indextts_f.npz"))
+    cfg = BigVGANConfig.indextts()
+    st = W.synth_state(W.bigvgan_spec(cfg), 9527)
+    conds = [g[f"cond{i}"] for i in range(cfg.num_upsamples)] + [g["cond_pre"]]
+    v = BV.BigVGANVocoder(cfg, st, dtype="f32")
+    w, wf = v.run_latent(g["latent"], conds, return_float=True)
+    assert w.shape == g["wav_i16"].shape and w.dtype == np.int16
+    assert np.abs(w.astype(np.int32) - g["wav_i16"].astype(np.int32)).max() <= 3        # vs the reference wrapper
+    ref = O.indextts_f_float(cfg, st, g["latent"], [c.reshape(-1) for c in conds])
+    assert rms(wf - ref) < 1e-5                                                          # vs the oracle, fp32
+    with pytest.raises(Exception):
+        v.run(np.zeros((1, cfg.num_mels, 4), np.float32))                                # wrong entry point for this handle
+    with pytest.raises(ValueError):
+        v.run_latent(g["latent"][:2], conds)                                             # fewer than 3 latent rows
+    v.close()
+    v16 = BV.BigVGANVocoder(cfg, st, dtype="f16")
+    w16 = v16.run_latent(g["latent"], conds)
+    assert rms((w16.astype(np.float64) - g["wav_i16"]) / 32767.0) < 2e-2
+    v16.close()

@@ -79,3 +79,19 @@ def test_synthesize_convenience_text_in_wave_out(tmp_path):
     assert w.shape == (1, 1, (N - (6000 // 256 + 1) - 1) * 256) and w.dtype == np.int16
     assert np.array_equal(w, onnxruntime.synthesize(eng, audio, "ABC AB", "AB CA", vocab, seed=1))   # seeded
     eng.close()
+
+
+def test_indextts_f_session_like_the_reference_call(tmp_path, golden_dir):
+    """ort_session_F.run_with_ort_values([generated_wav], input_feed_F) — Inference_IndexTTS_ONNX.py:787."""
+    g = np.load(os.path.join(golden_dir, "indextts_f.npz"))
+    cfg = BigVGANConfig.indextts()
+    wfile = tmp_path / "ixf.npy"
+    np.save(wfile, W.pack_bigvgan(cfg, W.synth_state(W.bigvgan_spec(cfg), 9527)))
+    path = onnxruntime.save_model(str(tmp_path / "IndexTTS_F.mi355.json"), "IndexTTS_F", cfg, str(wfile), "f32")
+    sess = onnxruntime.InferenceSession(path, sess_options=onnxruntime.SessionOptions(), providers=[])
+    in_names = [a.name for a in sess.get_inputs()]
+    feed = {f"save_bigvgan_conds_{i}": onnxruntime.OrtValue.ortvalue_from_numpy(g[f"cond{i}"], "cpu", 0) for i in range(6)}
+    feed["bigvgan_cond_layer_speaker_embedding"] = onnxruntime.OrtValue.ortvalue_from_numpy(g["cond_pre"], "cpu", 0)
+    feed[in_names[-1]] = onnxruntime.OrtValue.ortvalue_from_numpy(g["latent"], "cpu", 0)
+    wav = sess.run_with_ort_values([sess.get_outputs()[0].name], feed)[0].numpy()
+    assert np.abs(wav.astype(np.int32) - g["wav_i16"].astype(np.int32)).max() <= 3

@@ -117,3 +117,17 @@ def test_f5_fold_matches_spec_counts():
     k2 = "vocos.backbone.convnext.0.pwconv2.weight"
     np.testing.assert_allclose(st[k2], raw["vocos.backbone.convnext.0.gamma"][:, None] * raw[k2], rtol=1e-6)
     assert not any(k.endswith(".gamma") and k.startswith("vocos") for k in st)
+
+
+def test_indextts_graph_f_io_names_match_the_export():
+    cfg = BigVGANConfig.indextts()
+    i, o = ORT._graph_io("IndexTTS_F", cfg, "f16")
+    assert [a.name for a in i] == [f"save_bigvgan_conds_{k}" for k in range(6)] + \
+        ["bigvgan_cond_layer_speaker_embedding", "save_hidden_state"]
+    assert [a.shape[1] for a in i[:6]] == [768, 384, 192, 96, 48, 24] and i[6].shape == [1, 1536, 1]
+    assert i[7].shape == ["kv_seq_len", 1280] and o[0].name == "generated_wav"
+    assert cfg.hop == 1024 and cfg.out_len(126) == 126 * 1024 + 30
+    n_spec = sum(int(np.prod(s)) for _, s, _ in W.bigvgan_spec(cfg))
+    assert n_spec == sum(int(np.prod(s)) for _, s, _ in W.bigvgan_spec(BigVGANConfig(
+        num_mels=1280, upsample_rates=cfg.upsample_rates, upsample_kernel_sizes=cfg.upsample_kernel_sizes,
+        use_bias_at_final=True))) + 2 * 1280

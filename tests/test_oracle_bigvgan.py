@@ -82,3 +82,16 @@ def test_synth_weights_deterministic():
     assert abs(float(a.mean())) < 0.15 and 0.85 < float(a.std()) < 1.15
     # pinned values: the generator is counter-based and must never change
     np.testing.assert_allclose(W.synth_normal(1, "pin", (3,)), W.synth_normal(1, "pin", (5,))[:3])
+
+
+def test_indextts_graph_f_against_reference_wrapper(golden_dir):
+    """IndexTTS_F.forward (Export_IndexTTS.py:292-314) exec'ed from the reference + its modeling_modified/models.py:
+    full-size speaker-conditioned vocoder (k = u transposed convs, biased conv_post, pre-LayerNorm)."""
+    g = np.load(os.path.join(golden_dir, "indextts_f.npz"))
+    cfg = BigVGANConfig.indextts()
+    st = W.synth_state(W.bigvgan_spec(cfg), 9527)
+    conds = [g[f"cond{i}"].reshape(-1) for i in range(cfg.num_upsamples)] + [g["cond_pre"].reshape(-1)]
+    w = O.indextts_f_int16(cfg, st, g["latent"], conds)
+    assert w.shape == g["wav_i16"].shape == (1, 1, 3 * 1024 + 30)
+    assert np.abs(w.astype(np.int32) - g["wav_i16"].astype(np.int32)).max() <= 2
+    assert np.sqrt(np.mean(g["wav_i16"].astype(np.float64) ** 2)) > 1000

@@ -6,6 +6,7 @@ namespace mi {
 
 struct BigVGANCfg {
     int num_mels = 0, c0 = 0, n_up = 0, n_kernels = 0, bias_final = 0, tanh_final = 1, logscale = 1, n_dil = 0;
+    int pre_ln = 0, cond = 0;          // IndexTTS graph F: LayerNorm in front, speaker-conditioning biases
     int hop = 1;
     std::vector<int> rates, up_k, res_k;
     std::vector<std::vector<int>> dil;
@@ -13,10 +14,10 @@ struct BigVGANCfg {
 BigVGANCfg parse_bigvgan_cfg(const int32_t* c, int n);
 int64_t bigvgan_param_count(const BigVGANCfg& g);
 
-struct ConvW { DevBuf w, b; };
+struct ConvW { DevBuf w, b; std::vector<float> hb; DevBuf b_eff; };   // hb / b_eff: bias + per-call speaker conditioning
 struct SnakeP { DevBuf alpha, inv_beta; };
 struct AmpBlock { int k = 3; std::vector<ConvW> c1, c2; std::vector<SnakeP> acts; };
-struct Stage { int cin = 0, cout = 0, u = 1; ConvW up; std::vector<AmpBlock> blocks; };
+struct Stage { int cin = 0, cout = 0, u = 1, k = 2; ConvW up; std::vector<AmpBlock> blocks; };
 
 struct BigVGAN {
     BigVGANCfg cfg;
@@ -43,6 +44,11 @@ struct BigVGAN {
     int fused_max_c = 96;
     bool use_fused = true;     // MI355TTS_NO_FUSED_AA=1 selects the unfused AA + conv path (A/B and debugging)
     void run(const float* mel, int B, int F, float* out_f32, int16_t* out_i16, int mem);
+    // IndexTTS graph F: latent (T_codes, num_mels) channels-last fp32, conds = [cond_0 .. cond_{n_up-1}, cond_pre] concatenated
+    void run_latent(const float* latent, int T_codes, const float* conds, long n_conds, float* out_f32, int16_t* out_i16, int mem);
+    void body(const void* x0, int B, int F, const float* const* cond_ptrs, float* out_f32, int16_t* out_i16, int mem);
+    long total_cond() const;
+    DevBuf ln_w, ln_b, d_latent;
 };
 
 void unit_aa_activation1d(const float* x, int B, int C, int T, const float* alpha_log, const float* beta_log,

@@ -12,6 +12,7 @@
 // between calls with the same (B, frames).
 #include "common.h"
 #include "bigvgan.h"
+#include "f5_kernels.h"
 #include <cstdlib>
 
 namespace mi {
@@ -30,16 +31,19 @@ BigVGANCfg parse_bigvgan_cfg(const int32_t* c, int n) {
     for (int k = 0; k < g.n_up; ++k) g.up_k.push_back(c[i++]);
     for (int k = 0; k < g.n_kernels; ++k) g.res_k.push_back(c[i++]);
     g.n_dil = c[i++];
-    MI_REQUIRE(g.n_dil > 0 && g.n_dil <= 4 && n == i + g.n_kernels * g.n_dil, "bigvgan cfg: dilation table");
+    MI_REQUIRE(g.n_dil > 0 && g.n_dil <= 4 && (n == i + g.n_kernels * g.n_dil || n == i + g.n_kernels * g.n_dil + 2),
+               "bigvgan cfg: dilation table");
     for (int k = 0; k < g.n_kernels; ++k) {
         std::vector<int> d;
         for (int l = 0; l < g.n_dil; ++l) d.push_back(c[i++]);
         g.dil.push_back(d);
     }
+    if (i + 2 <= n) { g.pre_ln = c[i++]; g.cond = c[i++]; }
     g.hop = 1;
     for (int k = 0; k < g.n_up; ++k) {
-        MI_REQUIRE(g.up_k[k] == 2 * g.rates[k] && g.rates[k] % 2 == 0,
-                   "bigvgan: ConvTranspose1d needs kernel == 2*stride and an even stride");
+        MI_REQUIRE(g.rates[k] > 0 && g.up_k[k] % g.rates[k] == 0 && g.up_k[k] / g.rates[k] <= 2 &&
+                       (g.up_k[k] - g.rates[k]) % 2 == 0,
+                   "bigvgan: ConvTranspose1d needs kernel == stride or 2*stride, and (kernel - stride) even");
         g.hop *= g.rates[k];
     }
     MI_REQUIRE(g.c0 % (1 << g.n_up) == 0, "bigvgan: initial channel not divisible");
@@ -47,7 +51,7 @@ BigVGANCfg parse_bigvgan_cfg(const int32_t* c, int n) {
 }
 
 int64_t bigvgan_param_count(const BigVGANCfg& g) {
-    int64_t n = (int64_t)g.c0 * g.num_mels * 7 + g.c0;
+    int64_t n = (int64_t)g.c0 * g.num_mels * 7 + g.c0 + (g.pre_ln ? 2 * g.num_mels : 0);
     for (int i = 0; i < g.n_up; ++i) {
         const int64_t cin = g.c0 >> i, cout = g.c0 >> (i + 1);
         n += cin * cout * g.up_k[i] + cout;
@@ -66,17 +70,19 @@ static void relayout_conv(const float* w, int Co, int Ci, int k, int Cip, std::v
         for (int ci = 0; ci < Ci; ++ci)
             for (int j = 0; j < k; ++j) out[((size_t)co * k + j) * Cip + ci] = w[((size_t)co * Ci + ci) * k + j];
 }
-// ConvTranspose1d weight (Ci,Co,k=2u) -> [n = r*Co + co][tap][ci]; tap0 <-> x[q-1] uses j = r+u, tap1 <-> x[q] uses j = r
-static void relayout_convt(const float* w, int Ci, int Co, int u, std::vector<float>& out) {
-    const int k = 2 * u;
-    out.assign((size_t)u * Co * 2 * Ci, 0.f);
+// ConvTranspose1d weight (Ci,Co,k), k = taps*u  ->  [n = r*Co + co][tap][ci].
+// out[tau] = sum_{s,j: tau + p = s*u + j} x[s] W[:,:,j]; with q = (tau+p)/u, r = (tau+p)%u the contributing taps are
+// j = r + m*u (m = 0..taps-1) at s = q - m; as a conv over rows q - (taps-1) + t, tap t uses j = r + (taps-1-t)*u.
+static void relayout_convt(const float* w, int Ci, int Co, int u, int k, std::vector<float>& out) {
+    const int taps = k / u;
+    out.assign((size_t)u * Co * taps * Ci, 0.f);
     for (int r = 0; r < u; ++r)
         for (int co = 0; co < Co; ++co)
-            for (int ci = 0; ci < Ci; ++ci) {
-                const size_t n = (size_t)r * Co + co;
-                out[(n * 2 + 0) * Ci + ci] = w[((size_t)ci * Co + co) * k + r + u];
-                out[(n * 2 + 1) * Ci + ci] = w[((size_t)ci * Co + co) * k + r];
-            }
+            for (int t = 0; t < taps; ++t)
+                for (int ci = 0; ci < Ci; ++ci) {
+                    const size_t n = (size_t)r * Co + co;
+                    out[(n * taps + t) * Ci + ci] = w[((size_t)ci * Co + co) * k + r + (taps - 1 - t) * u];
+                }
 }
 
 static void make_snake(const float* a, const float* b, int C, bool logscale, DevBuf& d_alpha, DevBuf& d_ib, hipStream_t s) {
@@ -103,19 +109,27 @@ BigVGAN::BigVGAN(const BigVGANCfg& g, const float* w, int64_t nw, int dt, int de
     mel_pad = round_up(g.num_mels, vec);
     std::vector<float> tmp;
     const float* p = w;
+    if (g.pre_ln) {
+        MI_REQUIRE(g.num_mels % 4 == 0 && g.num_mels <= 2048 && g.num_mels % vec == 0, "bigvgan: LayerNorm width");
+        upload_f32(ln_w, p, g.num_mels, stream); p += g.num_mels;
+        upload_f32(ln_b, p, g.num_mels, stream); p += g.num_mels;
+    }
     relayout_conv(p, g.c0, g.num_mels, 7, mel_pad, tmp);
     upload_as(pre.w, tmp.data(), tmp.size(), dt, stream);
     p += (size_t)g.c0 * g.num_mels * 7;
     upload_f32(pre.b, p, g.c0, stream);
+    pre.hb.assign(p, p + g.c0);
     p += g.c0;
     stages.resize(g.n_up);
     for (int i = 0; i < g.n_up; ++i) {
         Stage& st = stages[i];
         st.cin = g.c0 >> i; st.cout = g.c0 >> (i + 1); st.u = g.rates[i];
-        relayout_convt(p, st.cin, st.cout, st.u, tmp);
+        st.k = g.up_k[i];
+        relayout_convt(p, st.cin, st.cout, st.u, st.k, tmp);
         upload_as(st.up.w, tmp.data(), tmp.size(), dt, stream);
         p += (size_t)st.cin * st.cout * g.up_k[i];
         upload_f32(st.up.b, p, st.cout, stream);
+        st.up.hb.assign(p, p + st.cout);
         p += st.cout;
         st.blocks.resize(g.n_kernels);
         for (int j = 0; j < g.n_kernels; ++j) {
@@ -198,14 +212,19 @@ void BigVGAN::aa(const SnakeP& sp, const void* x, void* y, int B, int T, int C, 
     launch_aa_act(a, stream);
 }
 
-// returns the buffer holding the stage result
+long BigVGAN::total_cond() const {
+    long n = cfg.c0;
+    for (int i = 0; i < cfg.n_up; ++i) n += cfg.c0 >> (i + 1);
+    return n;
+}
+
 void BigVGAN::run(const float* mel, int B, int F, float* out_f32, int16_t* out_i16, int mem) {
     MI_REQUIRE(mel && B > 0 && F > 0, "bigvgan_forward: bad arguments");
     MI_REQUIRE(out_f32 || out_i16, "bigvgan_forward: no output buffer");
+    MI_REQUIRE(!cfg.pre_ln && !cfg.cond, "bigvgan_forward: this handle is an IndexTTS graph-F vocoder, use mi_bigvgan_forward_latent");
     MI_REQUIRE((long)F * cfg.hop < (1L << 30), "bigvgan_forward: too many frames");
     MI_HIP(hipSetDevice(device));
     ensure_workspace(B, F);
-    const long Tout = (long)F * cfg.hop + 30;
     const float* dmel = mel;
     if (mem == MI_HOST) {
         MI_HIP(hipMemcpyAsync(d_mel.p, mel, (size_t)B * cfg.num_mels * F * 4, hipMemcpyHostToDevice, stream));
@@ -213,20 +232,72 @@ void BigVGAN::run(const float* mel, int B, int F, float* out_f32, int16_t* out_i
     }
     // mel (B,100,F) -> channels-last padded (B,F,mel_pad)
     launch_ncl_to_nlc(dmel, bT1.p, B, cfg.num_mels, F, mel_pad, dtype, stream);
+    body(bT1.p, B, F, nullptr, out_f32, out_i16, mem);
+}
+
+// IndexTTS graph F (IndexTTS/Export_IndexTTS.py:300-314): gpt.final_norm(latent[:-2]) -> conv_pre + cond_pre -> stages with
+// + cond_i after each upsampler -> post activation -> conv_post(+bias) -> tanh -> int16.
+void BigVGAN::run_latent(const float* latent, int T_codes, const float* conds, long n_conds, float* out_f32,
+                         int16_t* out_i16, int mem) {
+    MI_REQUIRE(cfg.pre_ln && cfg.cond, "bigvgan_forward_latent: handle was not created with the IndexTTS graph-F flags");
+    MI_REQUIRE(latent && conds && T_codes >= 3 && (out_f32 || out_i16), "bigvgan_forward_latent: bad arguments (needs >= 3 latent rows)");
+    MI_REQUIRE(n_conds == total_cond(), "bigvgan_forward_latent: conditioning vector length");
+    MI_HIP(hipSetDevice(device));
+    const int F = T_codes - 2;                          // the reference drops the last two latent rows
+    ensure_workspace(1, F);
+    std::vector<float> hc((size_t)n_conds);
+    if (mem == MI_HOST) std::memcpy(hc.data(), conds, (size_t)n_conds * 4);
+    else MI_HIP(hipMemcpy(hc.data(), conds, (size_t)n_conds * 4, hipMemcpyDeviceToHost));
+    std::vector<const float*> ptrs(cfg.n_up + 1);
+    long off = 0;
+    for (int i = 0; i < cfg.n_up; ++i) { ptrs[i] = hc.data() + off; off += cfg.c0 >> (i + 1); }
+    ptrs[cfg.n_up] = hc.data() + off;                   // cond_pre (c0 values) is last, like the graph's input order
+    const float* dl = latent;
+    if (mem == MI_HOST) {
+        d_latent.ensure((size_t)T_codes * cfg.num_mels * 4);
+        MI_HIP(hipMemcpyAsync(d_latent.p, latent, (size_t)F * cfg.num_mels * 4, hipMemcpyHostToDevice, stream));
+        dl = d_latent.as<float>();
+    }
+    launch_rownorm(NORM_LN_AFFINE, dl, bT1.p, dtype, ln_w.as<float>(), ln_b.as<float>(), F, cfg.num_mels, 1e-5f, stream);
+    body(bT1.p, 1, F, ptrs.data(), out_f32, out_i16, mem);
+}
+
+static void eff_bias(ConvW& cw, const float* cond, hipStream_t s) {
+    std::vector<float> e(cw.hb);
+    for (size_t i = 0; i < e.size(); ++i) e[i] += cond[i];
+    cw.b_eff.ensure(e.size() * 4);
+    MI_HIP(hipMemcpyAsync(cw.b_eff.p, e.data(), e.size() * 4, hipMemcpyHostToDevice, s));
+    MI_HIP(hipStreamSynchronize(s));                    // `e` is a stack temporary
+}
+
+// x0: channels-last (B, F, mel_pad) in the engine dtype, held in bT1
+void BigVGAN::body(const void* x0, int B, int F, const float* const* cond, float* out_f32, int16_t* out_i16, int mem) {
+    const long Tout = (long)F * cfg.hop + 30;
     DevBuf* IN = &bIN;     // holds the running stage input/output
     DevBuf* X = &bX;
-    conv(pre, bT1.p, IN->p, B, F, mel_pad, cfg.c0, 7, 1, nullptr, 1.f, 0);
+    {
+        const float* bias = pre.b.as<float>();
+        if (cond) { eff_bias(pre, cond[cfg.n_up], stream); bias = pre.b_eff.as<float>(); }
+        ConvGemm p;
+        p.dtype = dtype; p.x = x0; p.w = pre.w.p; p.bias = bias; p.out = IN->p;
+        p.B = B; p.T_in = F; p.M = F; p.N = cfg.c0; p.Cin = mel_pad; p.taps = 7; p.dil = 1; p.pad = 3;
+        p.x_bstride = (long)F * mel_pad; p.x_rstride = mel_pad; p.out_bstride = (long)F * cfg.c0; p.out_rstride = cfg.c0;
+        launch_conv_gemm(p, stream);
+    }
     int T = F;
     const float inv_nk = 1.0f / (float)cfg.n_kernels;
     for (int i = 0; i < cfg.n_up; ++i) {
         Stage& st = stages[i];
         const int Tn = T * st.u, C = st.cout;
-        {   // ConvTranspose1d as a 2-tap conv producing u*Cout phase-major channels
+        {   // ConvTranspose1d as a `taps`-tap conv producing u*Cout phase-major channels (taps = k/u)
+            const int taps = st.k / st.u;
+            const float* bias = st.up.b.as<float>();
+            if (cond) { eff_bias(st.up, cond[i], stream); bias = st.up.b_eff.as<float>(); }
             ConvGemm p;
-            p.dtype = dtype; p.x = IN->p; p.w = st.up.w.p; p.bias = st.up.b.as<float>(); p.out = X->p;
-            p.B = B; p.T_in = T; p.M = T + 1; p.N = st.u * C; p.Cin = st.cin; p.taps = 2; p.dil = 1; p.pad = 1;
+            p.dtype = dtype; p.x = IN->p; p.w = st.up.w.p; p.bias = bias; p.out = X->p;
+            p.B = B; p.T_in = T; p.M = T + taps - 1; p.N = st.u * C; p.Cin = st.cin; p.taps = taps; p.dil = 1; p.pad = taps - 1;
             p.x_bstride = (long)T * st.cin; p.x_rstride = st.cin; p.out_bstride = (long)Tn * C; p.out_rstride = C;
-            p.epi = EPI_CONVT; p.u = st.u; p.Cout = C; p.padT = st.u / 2; p.T_out = Tn;
+            p.epi = EPI_CONVT; p.u = st.u; p.Cout = C; p.padT = (st.k - st.u) / 2; p.T_out = Tn;
             launch_conv_gemm(p, stream);
         }
         // AMP blocks: XS(=IN) = 1/3 * sum_j block_j(X)
@@ -324,8 +395,8 @@ void unit_conv1d(const float* x, int B, int Cin, int T, const float* w, const fl
 
 void unit_conv_transpose1d(const float* x, int B, int Cin, int T, const float* w, const float* bias, int Cout, int k,
                            int stride, int padding, int dtype, float* y) {
-    MI_REQUIRE(k == 2 * stride && stride % 2 == 0 && padding == (k - stride) / 2,
-               "conv_transpose1d: only k == 2*stride, padding == stride/2 (the BigVGAN upsamplers)");
+    MI_REQUIRE(k % stride == 0 && k / stride <= 2 && (k - stride) % 2 == 0 && padding == (k - stride) / 2,
+               "conv_transpose1d: kernel == stride or 2*stride with padding == (kernel - stride)/2 (the BigVGAN upsamplers)");
     const int vec = 16 / (int)dtype_size(dtype);
     MI_REQUIRE(Cin % vec == 0, "conv_transpose1d: Cin % vec");
     TmpStream ts;
@@ -336,15 +407,16 @@ void unit_conv_transpose1d(const float* x, int B, int Cin, int T, const float* w
     dxl.ensure((size_t)B * T * Cin * es);
     launch_ncl_to_nlc(dx.as<float>(), dxl.p, B, Cin, T, Cin, dtype, ts.s);
     std::vector<float> wl;
-    relayout_convt(w, Cin, Cout, stride, wl);
+    relayout_convt(w, Cin, Cout, stride, k, wl);
     upload_as(dw, wl.data(), wl.size(), dtype, ts.s);
     if (bias) upload_f32(db, bias, Cout, ts.s);
     dyl.ensure((size_t)B * To * Cout * es); dy.ensure((size_t)B * To * Cout * 4);
     ConvGemm p;
     p.dtype = dtype; p.x = dxl.p; p.w = dw.p; p.bias = bias ? db.as<float>() : nullptr; p.out = dyl.p;
-    p.B = B; p.T_in = T; p.M = T + 1; p.N = stride * Cout; p.Cin = Cin; p.taps = 2; p.dil = 1; p.pad = 1;
+    const int taps = k / stride;
+    p.B = B; p.T_in = T; p.M = T + taps - 1; p.N = stride * Cout; p.Cin = Cin; p.taps = taps; p.dil = 1; p.pad = taps - 1;
     p.x_bstride = (long)T * Cin; p.x_rstride = Cin; p.out_bstride = (long)To * Cout; p.out_rstride = Cout;
-    p.epi = EPI_CONVT; p.u = stride; p.Cout = Cout; p.padT = stride / 2; p.T_out = To;
+    p.epi = EPI_CONVT; p.u = stride; p.Cout = Cout; p.padT = padding; p.T_out = To;
     launch_conv_gemm(p, ts.s);
     launch_nlc_to_ncl(dyl.p, dy.as<float>(), B, Cout, To, dtype, ts.s);
     MI_HIP(hipMemcpyAsync(y, dy.p, (size_t)B * Cout * To * 4, hipMemcpyDeviceToHost, ts.s));

@@ -94,6 +94,15 @@ int mi_bigvgan_forward_f32(mi_bigvgan* h, const float* mel, int B, int frames, f
     });
 }
 
+int mi_bigvgan_forward_latent(mi_bigvgan* h, const float* latent, int T_codes, const float* conds, int64_t n_conds,
+                              int16_t* out, float* out_f32, int mem) {
+    return guard([&] {
+        MI_REQUIRE(h && h->impl, "mi_bigvgan_forward_latent: null handle");
+        MI_REQUIRE(mem == MI_HOST || mem == MI_DEVICE, "mi_bigvgan_forward_latent: bad mem kind");
+        h->impl->run_latent(latent, T_codes, conds, (long)n_conds, out_f32, out, mem);
+    });
+}
+
 int mi_aa_activation1d(const float* x, int B, int C, int T, const float* alpha_log, const float* beta_log,
                        int logscale, int post, int dtype, float* y) {
     return guard([&] {

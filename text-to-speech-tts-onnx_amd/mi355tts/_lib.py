@@ -50,6 +50,8 @@ def load() -> C.CDLL:
     L.mi_bigvgan_forward.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int]; L.mi_bigvgan_forward.restype = C.c_int
     L.mi_bigvgan_forward_f32.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int]
     L.mi_bigvgan_forward_f32.restype = C.c_int
+    L.mi_bigvgan_forward_latent.argtypes = [vp, vp, C.c_int, vp, C.c_int64, vp, vp, C.c_int]
+    L.mi_bigvgan_forward_latent.restype = C.c_int
     L.mi_aa_activation1d.argtypes = [f32p, C.c_int, C.c_int, C.c_int, f32p, f32p, C.c_int, C.c_int, C.c_int, f32p]
     L.mi_aa_activation1d.restype = C.c_int
     L.mi_conv1d.argtypes = [f32p, C.c_int, C.c_int, C.c_int, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

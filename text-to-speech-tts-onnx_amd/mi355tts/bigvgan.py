@@ -85,6 +85,51 @@ class BigVGANVocoder:
                    "mi_bigvgan_forward")
         return out
 
+    # ---- IndexTTS graph F: latent + speaker conditioning in, waveform out ------------------------------------
+    def run_latent(self, latent: np.ndarray, conds, return_float: bool = False):
+        """latent (T_codes, gpt_dim) float32 ('save_hidden_state'); conds = [save_bigvgan_conds_0..n-1,
+        bigvgan_cond_layer_speaker_embedding], each (1, C, 1) / (C,).  Returns int16 (1, 1, (T_codes-2)*hop + 30)."""
+        cfg = self.cfg
+        if not (cfg.pre_layernorm and cfg.speaker_cond):
+            raise ValueError("this vocoder was not created from an IndexTTS graph-F config")
+        latent = np.ascontiguousarray(latent, dtype=np.float32)
+        if latent.ndim != 2 or latent.shape[1] != cfg.num_mels or latent.shape[0] < 3:
+            raise ValueError(f"save_hidden_state must be (T_codes >= 3, {cfg.num_mels}), got {latent.shape}")
+        want = [cfg.stage_channels(i) for i in range(cfg.num_upsamples)] + [cfg.upsample_initial_channel]
+        if len(conds) != len(want):
+            raise ValueError(f"expected {len(want)} conditioning vectors")
+        flat = []
+        for c, n in zip(conds, want):
+            c = np.asarray(c, dtype=np.float32).reshape(-1)
+            if c.size != n:
+                raise ValueError(f"conditioning vector has {c.size} values, expected {n}")
+            flat.append(c)
+        flat = np.ascontiguousarray(np.concatenate(flat))
+        T = latent.shape[0]
+        n = (T - 2) * cfg.hop + 30
+        out = np.empty((1, 1, n), np.int16)
+        outf = np.empty((1, 1, n), np.float32) if return_float else None
+        _lib.check(_lib.load().mi_bigvgan_forward_latent(self._h, latent.ctypes.data, T, flat.ctypes.data, flat.size,
+                                                         out.ctypes.data, None if outf is None else outf.ctypes.data,
+                                                         _lib.MI_HOST), "mi_bigvgan_forward_latent")
+        return (out, outf) if return_float else out
+
+    def run_latent_torch(self, latent, conds_flat, out=None):
+        """Device-resident variant: latent (T_codes, gpt_dim) float32 CUDA tensor, conds_flat = the concatenated
+        conditioning vectors (float32 CUDA tensor, total_cond values)."""
+        import torch
+        cfg = self.cfg
+        assert latent.is_cuda and latent.dtype == torch.float32 and latent.is_contiguous()
+        assert conds_flat.is_cuda and conds_flat.dtype == torch.float32 and conds_flat.is_contiguous()
+        T = latent.shape[0]
+        if out is None:
+            out = torch.empty((1, 1, (T - 2) * cfg.hop + 30), dtype=torch.int16, device=latent.device)
+        torch.cuda.current_stream(latent.device).synchronize()
+        _lib.check(_lib.load().mi_bigvgan_forward_latent(self._h, latent.data_ptr(), T, conds_flat.data_ptr(),
+                                                         conds_flat.numel(), out.data_ptr(), None, _lib.MI_DEVICE),
+                   "mi_bigvgan_forward_latent")
+        return out
+
     def _check_mel(self, mel):
         mel = np.asarray(mel)
         if mel.ndim != 3 or mel.shape[1] != self.cfg.num_mels or mel.shape[2] < 1 or mel.shape[0] < 1:

@@ -30,6 +30,12 @@ class BigVGANConfig:
     use_tanh_at_final: bool = True       # forced on by Export_BigVGAN.py:21,41
     snake_logscale: bool = True
     sampling_rate: int = 24000
+    # IndexTTS graph F variant (IndexTTS/Export_IndexTTS.py:292-314): the input is the GPT latent sequence, channels-last
+    # (T, num_mels=gpt_dim), passed through gpt.final_norm (LayerNorm, affine) first; speaker-conditioning vectors are
+    # added after conv_pre and after every upsampler; int16 = trunc(clamp(tanh(.), -1, 1) * 32767).
+    pre_layernorm: bool = False
+    speaker_cond: bool = False
+    ln_eps: float = 1e-5
 
     @property
     def num_upsamples(self) -> int:
@@ -66,7 +72,16 @@ class BigVGANConfig:
         for d in self.resblock_dilation_sizes:
             assert len(d) == nd
             out += list(d)
+        out += [int(self.pre_layernorm), int(self.speaker_cond)]
         return out
+
+    @staticmethod
+    def indextts() -> "BigVGANConfig":
+        """IndexTTS-1.5 vocoder (graph F).  The hyper-parameters live in the un-vendored IndexTTS config.yaml; the
+        channel ladder [768..24] is corroborated by IndexTTS/modeling_modified/filter.py:85."""
+        return BigVGANConfig(num_mels=1280, upsample_initial_channel=1536, upsample_rates=(4, 4, 4, 4, 2, 2),
+                             upsample_kernel_sizes=(8, 8, 4, 4, 4, 4), use_bias_at_final=True, pre_layernorm=True,
+                             speaker_cond=True)
 
     @staticmethod
     def small() -> "BigVGANConfig":

@@ -156,6 +156,12 @@ def _graph_io(graph: str, cfg, dtype: str):
     if graph == "BigVGAN":
         return ([NodeArg("mel_features", "tensor(float)", [1, cfg.num_mels, "mel_features_len"])],
                 [NodeArg("generated_wav", "tensor(int16)", [1, 1, "generated_len"])])
+    if graph == "IndexTTS_F":          # IndexTTS/Export_IndexTTS.py:497-520
+        ins = [NodeArg(f"save_bigvgan_conds_{i}", "tensor(float)", [1, cfg.stage_channels(i), 1])
+               for i in range(cfg.num_upsamples)]
+        ins.append(NodeArg("bigvgan_cond_layer_speaker_embedding", "tensor(float)", [1, cfg.upsample_initial_channel, 1]))
+        ins.append(NodeArg("save_hidden_state", "tensor(float)", ["kv_seq_len", cfg.num_mels]))
+        return ins, [NodeArg("generated_wav", "tensor(int16)", [1, 1, "generated_len"])]
     H, D, M, cd = cfg.heads, cfg.dim_head, cfg.mel_dim, cfg.mel_dim + cfg.text_dim
     ft = "tensor(float)"          # the engine keeps graph I/O in fp32 whatever the DiT operand dtype
     cond = [NodeArg("noise", ft, [1, "max_duration", M]), NodeArg("rope_cos_q", ft, [2, H, "max_duration", D]),
@@ -174,7 +180,7 @@ def _graph_io(graph: str, cfg, dtype: str):
     raise InvalidArgument(graph)
 
 
-_GRAPHS = ("BigVGAN", "F5_Preprocess", "F5_Transformer", "F5_Decode")
+_GRAPHS = ("BigVGAN", "IndexTTS_F", "F5_Preprocess", "F5_Transformer", "F5_Decode")
 
 
 class InferenceSession:
@@ -193,7 +199,7 @@ class InferenceSession:
             if isinstance(po, dict) and "device_id" in po:
                 device = int(po["device_id"])
         c = dict(man["config"])
-        if self._graph == "BigVGAN":
+        if self._graph in ("BigVGAN", "IndexTTS_F"):
             for k in ("upsample_rates", "upsample_kernel_sizes", "resblock_kernel_sizes"):
                 c[k] = tuple(c[k])
             c["resblock_dilation_sizes"] = tuple(tuple(d) for d in c["resblock_dilation_sizes"])
@@ -201,7 +207,7 @@ class InferenceSession:
         else:
             self._cfg = F5Config(**c)
         wfile = os.path.join(os.path.dirname(os.path.abspath(path_or_bytes)), man["weights"])
-        self._eng = _engine("bigvgan" if self._graph == "BigVGAN" else "f5", self._cfg, wfile, self._dtype, device)
+        self._eng = _engine("bigvgan" if self._graph in ("BigVGAN", "IndexTTS_F") else "f5", self._cfg, wfile, self._dtype, device)
         self._inputs, self._outputs = _graph_io(self._graph, self._cfg, self._dtype)
         self._inputs_meta, self._outputs_meta = self._inputs, self._outputs
 
@@ -268,6 +274,10 @@ class InferenceSession:
             if mel.dtype not in (np.float32, np.float16) or mel.ndim != 3:
                 raise InvalidArgument("mel_features must be a rank-3 float tensor")
             return {"generated_wav": e.run(mel.astype(np.float32))}
+        if g == "IndexTTS_F":
+            conds = [self._chk(feed, a.name, np.float32, 3) for a in self._inputs[:-1]]
+            lat = self._chk(feed, "save_hidden_state", np.float32, 2)
+            return {"generated_wav": e.run_latent(lat, conds)}
         if g == "F5_Preprocess":
             audio = self._chk(feed, "audio", np.int16, 3)
             ids = self._chk(feed, "text_ids", np.int32, 2)

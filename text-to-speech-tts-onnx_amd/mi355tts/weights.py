@@ -61,6 +61,9 @@ def bigvgan_spec(cfg: BigVGANConfig) -> Spec:
     """
     s: Spec = []
     c0 = cfg.upsample_initial_channel
+    if cfg.pre_layernorm:        # IndexTTS graph F: gpt.final_norm in front of the vocoder
+        s.append(("final_norm.weight", (cfg.num_mels,), "norm_w"))
+        s.append(("final_norm.bias", (cfg.num_mels,), "bias"))
     s.append(("conv_pre.weight", (c0, cfg.num_mels, 7), "conv_pre"))
     s.append(("conv_pre.bias", (c0,), "bias"))
     for i, (u, k) in enumerate(zip(cfg.upsample_rates, cfg.upsample_kernel_sizes)):
@@ -93,7 +96,7 @@ _GAIN = {"conv": 1.0, "convt": 1.0, "linear": 1.0, "conv_pre": 0.35, "conv_res":
 def _fan_in(shape, kind: str) -> int:
     if kind in ("conv", "conv_pre", "conv_res", "conv_post"):
         return shape[1] * shape[2]
-    if kind == "convt":      # each output sample sees Cin * k/stride taps; k = 2*stride here
+    if kind == "convt":      # each output sample sees Cin * k/stride taps (k = 2*stride, or k = stride in IndexTTS)
         return shape[0] * 2
     if kind in ("linear",):
         return shape[1]
