@@ -153,5 +153,44 @@ class F5Config:
                         vocos_layers=2, nfe_step=6)
 
 
+@dataclass
+class IndexGPTConfig:
+    """IndexTTS-1.5 acoustic GPT-2 (graphs B..E, IndexTTS/Export_IndexTTS.py:203-289).
+
+    The numbers live in the un-vendored IndexTTS ``config.yaml``; the export reads them from the loaded model
+    (Export_IndexTTS.py:326-331) and the driver hard-wires the special ids (Inference_IndexTTS_ONNX.py:36-39,
+    680: start mel token 8192, stop 8193)."""
+    hidden: int = 1280
+    layers: int = 24
+    heads: int = 20
+    inner: int = 5120                   # GPT2Config.n_inner default = 4 * hidden
+    mel_codes: int = 8194               # gpt.number_mel_codes (8192 codes + start + stop)
+    text_tokens: int = 12001            # text_embedding rows
+    max_mel_pos: int = 803              # mel_pos_embedding rows
+    max_text_pos: int = 603             # text_pos_embedding rows
+    max_seq: int = 1024                 # KV-cache capacity of this engine (>= MAX_GENERATE_LENGTH = 800)
+    ln_eps: float = 1e-5
+    start_mel_token: int = 8192
+    stop_mel_token: int = 8193
+    max_generate_length: int = 800      # Inference_IndexTTS_ONNX.py:37
+    repeat_penalty: float = 0.7         # :38
+    penalty_range: int = 10             # :39
+
+    @property
+    def head_dim(self) -> int:
+        return self.hidden // self.heads
+
+    def to_int_array(self) -> List[int]:
+        return [self.hidden, self.layers, self.heads, self.inner, self.mel_codes, self.text_tokens, self.max_mel_pos,
+                self.max_text_pos, self.max_seq]
+
+    @staticmethod
+    def small() -> "IndexGPTConfig":
+        """Reduced model for the golden fixture (head_dim stays 64)."""
+        return IndexGPTConfig(hidden=128, layers=2, heads=2, inner=512, mel_codes=50, text_tokens=40, max_mel_pos=40,
+                              max_text_pos=24, max_seq=64, start_mel_token=48, stop_mel_token=49,
+                              max_generate_length=40)
+
+
 def as_dict(cfg) -> dict:
     return asdict(cfg)

@@ -21,7 +21,7 @@ from typing import Dict, List, Tuple
 
 import numpy as np
 
-from .config import BigVGANConfig, F5Config
+from .config import BigVGANConfig, F5Config, IndexGPTConfig
 
 Spec = List[Tuple[str, Tuple[int, ...], str]]   # (name, shape, kind)
 
@@ -114,6 +114,12 @@ def synth_tensor(seed: int, name: str, shape, kind: str) -> np.ndarray:
         return synth_normal(seed, name, shape, std=0.3)
     if kind == "embed":
         return synth_normal(seed, name, shape, std=1.0)
+    if kind == "embed_s":    # GPT token / position tables (upstream init std 0.02; larger so the tables matter)
+        return synth_normal(seed, name, shape, std=0.5)
+    if kind == "linear_t":   # HF Conv1D: (in, out)
+        return synth_normal(seed, name, shape, std=1.0 / math.sqrt(shape[0]))
+    if kind == "linear_t_res":
+        return synth_normal(seed, name, shape, std=0.5 / math.sqrt(shape[0]))
     if kind == "norm_w":
         return synth_normal(seed, name, shape, std=0.1, mean=1.0)
     if kind == "mod":        # AdaLN modulation linears (upstream zero-inits these: dit.py:156-166)
@@ -255,6 +261,57 @@ def fold_f5(cfg: F5Config, state: Dict[str, np.ndarray]) -> "OrderedDict[str, np
 def pack_f5(cfg: F5Config, state: Dict[str, np.ndarray]) -> np.ndarray:
     """Unfolded upstream-style state dict -> folded canonical fp32 blob."""
     return pack_state(f5_packed_spec(cfg), fold_f5(cfg, state))
+
+
+# --------------------------------------------------------------------------------------
+# IndexTTS acoustic GPT-2 (graphs B..E)
+# --------------------------------------------------------------------------------------
+def gpt_spec(cfg: IndexGPTConfig) -> Spec:
+    """Upstream-named state of ``indexTTS.gpt`` as the export wrappers read it (IndexTTS/Export_IndexTTS.py:203-289).
+    ``c_attn / c_proj / c_fc`` are HF ``Conv1D`` modules: weight is (in, out)."""
+    h, n = cfg.hidden, cfg.inner
+    s: Spec = [("text_embedding.weight", (cfg.text_tokens, h), "embed_s"),
+               ("text_pos_embedding.emb.weight", (cfg.max_text_pos, h), "embed_s"),
+               ("inference_model.embeddings.weight", (cfg.mel_codes, h), "embed_s"),
+               ("inference_model.text_pos_embedding.emb.weight", (cfg.max_mel_pos, h), "embed_s")]
+    for i in range(cfg.layers):
+        p = f"inference_model.transformer.h.{i}."
+        s += [(p + "ln_1.weight", (h,), "norm_w"), (p + "ln_1.bias", (h,), "bias"),
+              (p + "attn.c_attn.weight", (h, 3 * h), "linear_t"), (p + "attn.c_attn.bias", (3 * h,), "bias"),
+              (p + "attn.c_proj.weight", (h, h), "linear_t_res"), (p + "attn.c_proj.bias", (h,), "bias"),
+              (p + "ln_2.weight", (h,), "norm_w"), (p + "ln_2.bias", (h,), "bias"),
+              (p + "mlp.c_fc.weight", (h, n), "linear_t"), (p + "mlp.c_fc.bias", (n,), "bias"),
+              (p + "mlp.c_proj.weight", (n, h), "linear_t_res"), (p + "mlp.c_proj.bias", (h,), "bias")]
+    s += [("inference_model.transformer.ln_f.weight", (h,), "norm_w"),
+          ("inference_model.transformer.ln_f.bias", (h,), "bias"),
+          ("inference_model.lm_head.0.weight", (h,), "norm_w"), ("inference_model.lm_head.0.bias", (h,), "bias"),
+          ("inference_model.lm_head.1.weight", (cfg.mel_codes, h), "linear"),
+          ("inference_model.lm_head.1.bias", (cfg.mel_codes,), "bias")]
+    return s
+
+
+def fold_gpt(cfg: IndexGPTConfig, state: Dict[str, np.ndarray]) -> "OrderedDict[str, np.ndarray]":
+    """Export-time folds of IndexTTS_E.__init__ (Export_IndexTTS.py:252-268): Conv1D weights transposed to
+    (out, in) rows, q and k rows (weight and bias) scaled by head_dim**-0.25.  Keys/order stay those of gpt_spec;
+    the transposed tensors keep their names."""
+    st = OrderedDict((k, np.array(v, dtype=np.float32, copy=True)) for k, v in state.items())
+    sc = np.float32(float(cfg.head_dim) ** -0.25)
+    h = cfg.hidden
+    for i in range(cfg.layers):
+        p = f"inference_model.transformer.h.{i}."
+        w = np.ascontiguousarray(st[p + "attn.c_attn.weight"].T)
+        b = st[p + "attn.c_attn.bias"]
+        w[: 2 * h] *= sc
+        b[: 2 * h] *= sc
+        st[p + "attn.c_attn.weight"] = w
+        for nm in ("attn.c_proj.weight", "mlp.c_fc.weight", "mlp.c_proj.weight"):
+            st[p + nm] = np.ascontiguousarray(st[p + nm].T)
+    return st
+
+
+def pack_gpt(cfg: IndexGPTConfig, state: Dict[str, np.ndarray]) -> np.ndarray:
+    st = fold_gpt(cfg, state)
+    return np.ascontiguousarray(np.concatenate([st[name].reshape(-1) for name, _, _ in gpt_spec(cfg)]))
 
 
 def synth_vocab(n: int = 2545) -> Dict[str, int]:
