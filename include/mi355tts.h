@@ -125,6 +125,42 @@ int         mi_f5_synthesize(mi_f5* h, int U, const int16_t* audio, int64_t L, c
                              int64_t max_duration, const float* noise_in, uint64_t seed, int16_t* out,
                              int64_t* out_len, int mem);
 
+/* ---- IndexTTS acoustic GPT-2 (graphs B, C, E + the greedy decode loop) ------------------------------------------
+ * Replaces ort_session_B / _C / _E of IndexTTS/Inference_IndexTTS_ONNX.py:619-675 and the loop at :745-783
+ * (graph definitions: IndexTTS/Export_IndexTTS.py:203-289).  The KV cache lives in the handle (the reference
+ * passes 2*layers growing tensors in and out of every call); mi_gpt_kv_read / _write expose it in the reference's
+ * tensor layouts.  cfg = {hidden, layers, heads, inner, mel_codes, text_tokens, max_mel_pos, max_text_pos, max_seq}.
+ * weights: canonical fp32 blob of mi355tts.weights.pack_gpt (Conv1D weights transposed to (out, in); q and k rows
+ * pre-scaled by head_dim^-0.25 like Export_IndexTTS.py:257-258).                                                  */
+typedef struct mi_gpt mi_gpt;
+int64_t     mi_gpt_param_count(const int32_t* cfg, int n_cfg);
+mi_gpt*     mi_gpt_create(const int32_t* cfg, int n_cfg, const float* weights, int64_t n_weights, int dtype, int device);
+void        mi_gpt_destroy(mi_gpt* h);
+/* graph B: text_ids (n) -> text_hidden_state (n + 2, hidden): start id 0 / end id 1 added, + position rows. */
+int         mi_gpt_text_embed(mi_gpt* h, const int32_t* text_ids, int n, float* out, int mem);
+/* graph C: mel embedding of gpt_id + mel position row gen_len -> (hidden). (the caller keeps gen_len + 1) */
+int         mi_gpt_mel_embed(mi_gpt* h, int32_t gpt_id, int64_t gen_len, float* out, int mem);
+/* history_len := 0 (the reference re-feeds the empty init_past_keys_E / init_past_values_E, :796-800) */
+int         mi_gpt_reset(mi_gpt* h);
+int64_t     mi_gpt_history_len(mi_gpt* h);
+/* graph E: hidden_state (ids_len, hidden) appended after the handle's history; repeat_penality (mel_codes) or NULL
+ * (= ones); attention_mask 1 for the prompt pass, 0 for single-token steps.  Outputs: last_hidden_state (hidden),
+ * max_logit_id (1), optionally the logits before the penalty multiply (mel_codes).  history_len += ids_len.     */
+int         mi_gpt_step(mi_gpt* h, const float* hidden_state, int ids_len, const float* repeat_penality,
+                        int attention_mask, float* last_hidden_state, int32_t* max_logit_id, float* logits, int mem);
+/* in_key_i / in_value_i / out_key_i / out_value_i of graph E: keys (heads, 64, history), values (heads, history, 64).
+ * mi_gpt_kv_write sets history_len := hist (write every layer with the same hist). */
+int         mi_gpt_kv_read(mi_gpt* h, int layer, float* keys, float* values, int mem);
+int         mi_gpt_kv_write(mi_gpt* h, int layer, const float* keys, const float* values, int hist, int mem);
+/* The per-sentence loop (:745-783) on the device: prompt (P, hidden) = graph D's concat; at most max_new tokens
+ * (the reference's generate_limit = MAX_GENERATE_LENGTH - P); stops after a token in stop_ids; repeat_value /
+ * penalty_range = REPEAT_PENALITY / PENALITY_RANGE.  repeat_penality (mel_codes) is read and written back (the
+ * reference carries it across sentences, :685) — NULL starts from ones.  Outputs: tokens (max_new), hidden
+ * (max_new, hidden) = the stacked last_hidden_state rows graph F consumes, *n_out (host) = tokens produced.     */
+int         mi_gpt_generate(mi_gpt* h, const float* prompt, int P, int max_new, const int32_t* stop_ids, int n_stop,
+                            float repeat_value, int penalty_range, float* repeat_penality, int32_t* tokens,
+                            float* hidden, int32_t* n_out, int mem);
+
 /* tuning hook: time `iters` launches of the implicit-GEMM conv kernel on random device data (no host copies);
  * returns average milliseconds per launch in *ms.  x (B,T,Cin), w (N, taps*Cin), out (B,T,N), "same" padding. */
 int         mi_bench_conv_gemm(int dtype, int B, int T, int Cin, int N, int taps, int dil, int with_res, int iters,

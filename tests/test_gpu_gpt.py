@@ -1,0 +1,256 @@
+"""GPU parity: the HIP IndexTTS GPT path (graphs B, C, E and the on-device decode loop, through the C-ABI) against the
+golden vectors produced by the reference wrapper classes over Hugging Face GPT2Block modules, and against the numpy
+oracle on larger seeded cases.
+
+Tolerances
+  fp32: exact-fp32 arithmetic (fp32 MFMA for the prompt pass, fp32 FMAs in the GEMV / attention kernels); only the
+        summation order differs: <= 2e-4 abs on O(1) hidden states, greedy tokens identical.
+  fp16 / bf16: weights, KV cache and GEMV inputs are rounded to 16 bits (like the reference's whole-graph fp16 cast,
+        IndexTTS/Export_IndexTTS.py fp16 branch); teacher-forced hidden states within 4e-2 / 2e-1 abs.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from mi355tts import weights as W
+from mi355tts import _lib
+from mi355tts.config import IndexGPTConfig
+from mi355tts.indextts import IndexGPT
+from oracle import gpt_np as O
+
+pytestmark = pytest.mark.gpu
+SEED = 9527
+
+
+@pytest.fixture(scope="module")
+def g(golden_dir):
+    return np.load(os.path.join(golden_dir, "indextts_gpt.npz"))
+
+
+@pytest.fixture(scope="module")
+def small():
+    cfg = IndexGPTConfig.small()
+    st = W.synth_state(W.gpt_spec(cfg), SEED)
+    return cfg, st
+
+
+@pytest.fixture(scope="module")
+def eng(small):
+    cfg, st = small
+    e = IndexGPT(cfg, st, dtype="f32")
+    yield e
+    e.close()
+
+
+def test_graph_b_c_d_golden(eng, g):
+    tb = eng.text_embed(g["text_ids"])
+    np.testing.assert_allclose(tb, g["B_text_hidden"], rtol=0, atol=1e-6)
+    hc, gl = eng.mel_embed([[eng.cfg.start_mel_token]], [0])
+    np.testing.assert_allclose(hc, g["C_hidden_0"], rtol=0, atol=1e-6)
+    assert int(gl[0]) == 1
+    d, n = eng.concat(g["conds_latent"], tb, hc)
+    np.testing.assert_allclose(d, g["D_hidden"], rtol=0, atol=1e-6)
+    assert int(n[0]) == int(g["D_len"][0])
+
+
+def test_graph_e_prompt_pass_golden(eng, g):
+    eng.reset()
+    kv, last, tok = eng.step(g["D_hidden"], np.ones((1, eng.cfg.mel_codes), np.float32), attention_mask=1)
+    assert int(kv[0]) == 13 and eng.history_len == 13
+    np.testing.assert_allclose(last, g["E0_last_hidden"], rtol=0, atol=2e-4)
+    assert int(tok[0, 0]) == int(g["gen_tokens"][0])
+    k0, _ = eng.kv_read(0)
+    _, v1 = eng.kv_read(1)
+    np.testing.assert_allclose(k0, g["E0_key0"], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(v1, g["E0_value1"], rtol=0, atol=2e-4)
+
+
+def test_graph_e_single_step_with_given_cache_golden(eng, g):
+    eng.kv_write(list(g["S_keys_in"]), list(g["S_values_in"]))
+    hist = g["S_keys_in"].shape[3]
+    assert eng.history_len == hist
+    kv, last, tok = eng.step(g["S_hidden_in"], g["S_pen"], attention_mask=0)
+    assert int(kv[0]) == hist + 1
+    np.testing.assert_allclose(last, g["S_last_hidden"], rtol=0, atol=2e-4)
+    assert int(tok[0, 0]) == int(g["S_token"][0, 0])
+
+
+def test_driver_loop_step_by_step_golden(eng, g):
+    """Inference_IndexTTS_ONNX.py:752-783 driven from the host, one mi_gpt_step per token (the drop-in shape)."""
+    cfg = eng.cfg
+    rep, prange = float(g["gen_params"][0]), int(g["gen_params"][1])
+    eng.reset()
+    pen = np.ones((1, cfg.mel_codes), np.float32)
+    hs, gen_len = g["D_hidden"], np.array([1])
+    flag, toks, reset = 1, [], 0
+    for n in range(len(g["gen_tokens"])):
+        kv, last, tok = eng.step(hs, pen, attention_mask=flag)
+        t = int(tok[0, 0])
+        toks.append(t)
+        np.testing.assert_allclose(last[0], g["gen_hidden"][n], rtol=0, atol=3e-4)
+        flag = 0
+        pen[:, t] = rep
+        if n + 1 > prange and toks[reset] != t:
+            pen[:, toks[reset]] = 1.0
+            reset += 1
+        hs, gen_len = eng.mel_embed(tok, gen_len)
+    assert toks == [int(x) for x in g["gen_tokens"]]
+    np.testing.assert_array_equal(pen, g["gen_penalty"])
+    k0, _ = eng.kv_read(0)
+    np.testing.assert_allclose(k0, g["gen_key0"], rtol=0, atol=3e-4)
+
+
+def test_generate_on_device_golden(eng, g):
+    rep, prange = float(g["gen_params"][0]), int(g["gen_params"][1])
+    n = len(g["gen_tokens"])
+    toks, hid, pen = eng.generate(g["conds_latent"], g["text_ids"], max_generate_length=13 + n, stop_tokens=[],
+                                  repeat_value=rep, penalty_range=prange,
+                                  repeat_penality=np.ones((1, eng.cfg.mel_codes), np.float32))
+    assert toks.tolist() == [int(x) for x in g["gen_tokens"]]
+    np.testing.assert_allclose(hid, g["gen_hidden"], rtol=0, atol=3e-4)
+    np.testing.assert_array_equal(pen, g["gen_penalty"])
+    # second run replays the captured decode step: same answer
+    toks2, hid2, _ = eng.generate(g["conds_latent"], g["text_ids"], max_generate_length=13 + n, stop_tokens=[],
+                                  repeat_value=rep, penalty_range=prange,
+                                  repeat_penality=np.ones((1, eng.cfg.mel_codes), np.float32))
+    assert toks2.tolist() == toks.tolist()
+    np.testing.assert_array_equal(hid2, hid)
+
+
+def test_generate_stops_at_stop_token(eng, small, g):
+    rep, prange = float(g["gen_params"][0]), int(g["gen_params"][1])
+    stop = int(g["gen_tokens"][4])
+    first = [int(x) for x in g["gen_tokens"]].index(stop)
+    toks, hid, pen = eng.generate(g["conds_latent"], g["text_ids"], max_generate_length=13 + 12, stop_tokens=[stop, 1000],
+                                  repeat_value=rep, penalty_range=prange,
+                                  repeat_penality=np.ones((1, eng.cfg.mel_codes), np.float32))
+    assert toks.tolist() == [int(x) for x in g["gen_tokens"][: first + 1]]
+    assert hid.shape == (first + 1, eng.cfg.hidden)
+    # the stop token itself is not penalised (the reference breaks before the update, :761-762): same as the oracle
+    cfg, st = small
+    o_toks, _, o_pen = O.generate(cfg, st, g["conds_latent"], g["text_ids"], max_generate_length=13 + 12,
+                                  repeat_value=rep, penalty_range=prange, stop_tokens=[stop, 1000])
+    assert toks.tolist() == o_toks
+    np.testing.assert_array_equal(pen, o_pen)
+
+
+def test_generate_limit_and_empty(eng, g):
+    toks, hid, _ = eng.generate(g["conds_latent"], g["text_ids"], max_generate_length=13 + 3, stop_tokens=[])
+    assert len(toks) == 3 and hid.shape[0] == 3
+    toks, hid, _ = eng.generate(g["conds_latent"], g["text_ids"], max_generate_length=13, stop_tokens=[])
+    assert len(toks) == 0 and hid.shape[0] == 0
+
+
+def test_penalty_carries_across_sentences(small, g):
+    cfg, st = small
+    e = IndexGPT(cfg, st, dtype="f32")
+    t1, _, p1 = e.generate(g["conds_latent"], g["text_ids"], max_generate_length=13 + 6, stop_tokens=[])
+    assert np.array_equal(e.repeat_penality, p1) and (p1 != 1).any()
+    o1, _, op1 = O.generate(cfg, st, g["conds_latent"], g["text_ids"], max_generate_length=13 + 6, stop_tokens=[])
+    assert t1.tolist() == o1
+    t2, _, p2 = e.generate(g["conds_latent"], g["text_ids"][:, :4], max_generate_length=11 + 6, stop_tokens=[])
+    o2, _, op2 = O.generate(cfg, st, g["conds_latent"], g["text_ids"][:, :4], repeat_penality=op1,
+                            max_generate_length=11 + 6, stop_tokens=[])
+    assert t2.tolist() == o2
+    np.testing.assert_array_equal(p2, op2)
+    e.close()
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 3e-4), ("f16", 4e-2), ("bf16", 2.5e-1)])
+def test_medium_model_vs_oracle(dtype, tol):
+    """hidden 256 / 4 heads / 3 layers, 75-row prompt (MFMA GEMM path with a ragged tile), then teacher-forced single
+    steps (GEMV path) against the oracle."""
+    cfg = IndexGPTConfig(hidden=256, layers=3, heads=4, inner=1024, mel_codes=301, text_tokens=64, max_mel_pos=80,
+                         max_text_pos=80, max_seq=160, start_mel_token=299, stop_mel_token=300, max_generate_length=120)
+    st = W.synth_state(W.gpt_spec(cfg), 77)
+    e = IndexGPT(cfg, st, dtype=dtype)
+    conds = W.synth_normal(5, "conds", (1, 32, cfg.hidden), std=0.5)
+    text = (np.arange(40, dtype=np.int32) * 7 % 60 + 2)[None]
+    tb = e.text_embed(text)
+    mh, gl = e.mel_embed(cfg.start_mel_token, 0)
+    prompt, n = e.concat(conds, tb, mh)
+    assert int(n[0]) == 75
+    np.testing.assert_allclose(prompt, O.graph_d(conds, O.graph_b(cfg, st, text), O.graph_c(cfg, st, [[299]], [0])[0])[0],
+                               rtol=0, atol=1e-6)
+    pen = W.synth_normal(6, "pen", (1, cfg.mel_codes), std=0.1, mean=1.0)
+    keys = [np.zeros((cfg.heads, 64, 0), np.float32)] * cfg.layers
+    vals = [np.zeros((cfg.heads, 0, 64), np.float32)] * cfg.layers
+    e.reset()
+    kv, last, tok, logits = e.step(prompt, pen, attention_mask=1, return_logits=True)
+    keys, vals, okv, olast, otok, ologits = O.graph_e(cfg, st, keys, vals, 0, pen, 75, prompt, 1)
+    assert int(kv[0]) == int(okv[0]) == 75
+    np.testing.assert_allclose(last, olast, rtol=0, atol=tol)
+    np.testing.assert_allclose(logits * pen, ologits, rtol=0, atol=tol * 4)
+    if dtype == "f32":
+        assert int(tok[0, 0]) == int(otok[0, 0])
+    hist = 75
+    for s in range(6):                                    # teacher-forced with the oracle's tokens
+        hs, gl = e.mel_embed(otok, gl)
+        kv, last, tok, logits = e.step(hs, pen, attention_mask=0, return_logits=True)
+        keys, vals, okv, olast, otok2, ologits = O.graph_e(cfg, st, keys, vals, hist, pen, 1, hs, 0)
+        hist += 1
+        np.testing.assert_allclose(last, olast, rtol=0, atol=tol)
+        np.testing.assert_allclose(logits * pen, ologits, rtol=0, atol=tol * 4)
+        if dtype == "f32":
+            assert int(tok[0, 0]) == int(otok2[0, 0])
+        # argmax consistency with the engine's own logits (first index on ties)
+        assert int(tok[0, 0]) == int(np.argmax(logits * pen))
+        otok = otok2
+    k1, v1 = e.kv_read(1)
+    np.testing.assert_allclose(k1, keys[1], rtol=0, atol=tol)
+    np.testing.assert_allclose(v1, vals[1], rtol=0, atol=tol)
+    e.close()
+
+
+def test_long_history_attention(small):
+    """kv length > 512 (more than one pass of the 512-thread score loop) on the small model."""
+    cfg0, _ = small
+    cfg = IndexGPTConfig(**{**cfg0.__dict__, "max_seq": 640, "max_mel_pos": 640})
+    st = W.synth_state(W.gpt_spec(cfg), 3)
+    e = IndexGPT(cfg, st, dtype="f32")
+    hist = 600
+    keys = [W.synth_normal(9, f"k{i}", (cfg.heads, 64, hist), std=0.6) for i in range(cfg.layers)]
+    vals = [W.synth_normal(9, f"v{i}", (cfg.heads, hist, 64), std=0.6) for i in range(cfg.layers)]
+    e.kv_write(keys, vals)
+    hs = W.synth_normal(9, "hs", (1, 1, cfg.hidden), std=0.7)
+    kv, last, tok = e.step(hs, None, attention_mask=0)
+    _, _, _, olast, otok, _ = O.graph_e(cfg, st, keys, vals, hist, np.ones((1, cfg.mel_codes), np.float32), 1, hs, 0)
+    np.testing.assert_allclose(last, olast, rtol=0, atol=3e-4)
+    assert int(tok[0, 0]) == int(otok[0, 0]) and int(kv[0]) == hist + 1
+    e.close()
+
+
+def test_graph_replay_equals_eager(small, g, monkeypatch):
+    cfg, st = small
+    a = IndexGPT(cfg, st, dtype="f16")
+    monkeypatch.setenv("MI355TTS_NO_GRAPH", "1")
+    b = IndexGPT(cfg, st, dtype="f16")
+    monkeypatch.delenv("MI355TTS_NO_GRAPH")
+    for _ in range(2):
+        ta, ha, _ = a.generate(g["conds_latent"], g["text_ids"], max_generate_length=13 + 20, stop_tokens=[],
+                               repeat_penality=np.ones((1, cfg.mel_codes), np.float32))
+        tb, hb, _ = b.generate(g["conds_latent"], g["text_ids"], max_generate_length=13 + 20, stop_tokens=[],
+                               repeat_penality=np.ones((1, cfg.mel_codes), np.float32))
+        assert ta.tolist() == tb.tolist() and len(ta) == 20
+        np.testing.assert_array_equal(ha, hb)
+    a.close()
+    b.close()
+
+
+def test_errors(eng, g):
+    with pytest.raises(_lib.MiError):
+        eng.text_embed(np.array([[eng.cfg.text_tokens]], np.int32))          # id out of range
+    with pytest.raises(_lib.MiError):
+        eng.text_embed(np.zeros((1, eng.cfg.max_text_pos), np.int32))         # longer than the position table
+    with pytest.raises(_lib.MiError):
+        eng.mel_embed(eng.cfg.mel_codes, 0)
+    eng.reset()
+    with pytest.raises(_lib.MiError):
+        eng.step(np.zeros((1, eng.cfg.max_seq + 1, eng.cfg.hidden), np.float32), None, 1)
+    with pytest.raises(_lib.MiError):
+        eng.generate_from_prompt(np.zeros((1, 10, eng.cfg.hidden), np.float32), eng.cfg.max_seq)
+    with pytest.raises(ValueError):
+        eng.step(np.zeros((1, 2, 7), np.float32))
+    with pytest.raises(ValueError):
+        eng.kv_write([np.zeros((2, 64, 3))], [np.zeros((2, 3, 64))])

@@ -2,6 +2,7 @@
 #include "common.h"
 #include "bigvgan.h"
 #include "f5.h"
+#include "gpt.h"
 #include <cstdlib>
 #include <algorithm>
 
@@ -9,6 +10,7 @@ using namespace mi;
 
 struct mi_bigvgan { BigVGAN* impl; };
 struct mi_f5 { F5* impl; };
+struct mi_gpt { Gpt* impl; };
 
 template <typename F> static int guard(F&& f) {
     try {
@@ -269,6 +271,196 @@ int mi_f5_synthesize(mi_f5* h, int U, const int16_t* audio, int64_t L, const int
         copy_out(out, e.v_outi.p, (size_t)U * len * 2, mem, e.stream);
         MI_HIP(hipStreamSynchronize(e.stream));
         if (out_len) *out_len = len;
+    });
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// IndexTTS GPT
+// ---------------------------------------------------------------------------------------------------------------
+int64_t mi_gpt_param_count(const int32_t* cfg, int n_cfg) {
+    int64_t n = -1;
+    int rc = guard([&] { n = gpt_param_count(parse_gpt_cfg(cfg, n_cfg)); });
+    return rc == MI_OK ? n : (int64_t)rc;
+}
+
+mi_gpt* mi_gpt_create(const int32_t* cfg, int n_cfg, const float* weights, int64_t n_weights, int dtype, int device) {
+    mi_gpt* h = nullptr;
+    int rc = guard([&] {
+        MI_REQUIRE(weights != nullptr, "mi_gpt_create: null weights");
+        GptCfg c = parse_gpt_cfg(cfg, n_cfg);
+        h = new mi_gpt{new Gpt(c, weights, n_weights, dtype, device)};
+    });
+    return rc == MI_OK ? h : nullptr;
+}
+
+void mi_gpt_destroy(mi_gpt* h) {
+    if (!h) return;
+    delete h->impl;
+    delete h;
+}
+
+#define GPT_CHECK(h, mem, name)                                                    \
+    MI_REQUIRE((h) && (h)->impl, name ": null handle");                            \
+    MI_REQUIRE((mem) == MI_HOST || (mem) == MI_DEVICE, name ": bad mem kind");     \
+    MI_HIP(hipSetDevice((h)->impl->device))
+
+// input staged to the device when it lives on the host
+static const void* stage_in(DevBuf& buf, const void* src, size_t bytes, int mem, hipStream_t s) {
+    if (mem == MI_DEVICE) return src;
+    buf.ensure(bytes);
+    MI_HIP(hipMemcpyAsync(buf.p, src, bytes, hipMemcpyHostToDevice, s));
+    return buf.p;
+}
+
+int mi_gpt_text_embed(mi_gpt* h, const int32_t* text_ids, int n, float* out, int mem) {
+    return guard([&] {
+        GPT_CHECK(h, mem, "mi_gpt_text_embed");
+        Gpt& e = *h->impl;
+        MI_REQUIRE(out && n >= 0 && (n == 0 || text_ids), "mi_gpt_text_embed: null argument");
+        MI_REQUIRE(n + 2 <= e.cfg.max_text_pos, "mi_gpt_text_embed: text is longer than the text position table");
+        if (mem == MI_HOST)
+            for (int i = 0; i < n; ++i)
+                MI_REQUIRE(text_ids[i] >= 0 && text_ids[i] < e.cfg.text_tokens, "mi_gpt_text_embed: text id out of range");
+        const size_t ob = (size_t)(n + 2) * e.cfg.hidden * 4;
+        const int32_t* ids = n ? (const int32_t*)stage_in(e.io_a, text_ids, (size_t)n * 4, mem, e.stream) : nullptr;
+        float* o = out;
+        if (mem == MI_HOST) { e.io_b.ensure(ob); o = e.io_b.as<float>(); }
+        e.text_embed(ids, n, o);
+        if (mem == MI_HOST) copy_out(out, o, ob, mem, e.stream);
+        MI_HIP(hipStreamSynchronize(e.stream));
+    });
+}
+
+int mi_gpt_mel_embed(mi_gpt* h, int32_t gpt_id, int64_t gen_len, float* out, int mem) {
+    return guard([&] {
+        GPT_CHECK(h, mem, "mi_gpt_mel_embed");
+        Gpt& e = *h->impl;
+        MI_REQUIRE(out != nullptr, "mi_gpt_mel_embed: null output");
+        const size_t ob = (size_t)e.cfg.hidden * 4;
+        float* o = out;
+        if (mem == MI_HOST) { e.io_b.ensure(ob); o = e.io_b.as<float>(); }
+        e.mel_embed(gpt_id, gen_len, o);
+        if (mem == MI_HOST) copy_out(out, o, ob, mem, e.stream);
+        MI_HIP(hipStreamSynchronize(e.stream));
+    });
+}
+
+int mi_gpt_reset(mi_gpt* h) {
+    return guard([&] {
+        MI_REQUIRE(h && h->impl, "mi_gpt_reset: null handle");
+        MI_HIP(hipSetDevice(h->impl->device));
+        h->impl->reset();
+    });
+}
+
+int64_t mi_gpt_history_len(mi_gpt* h) {
+    if (!h || !h->impl) return MI_EINVAL;
+    return h->impl->history;
+}
+
+int mi_gpt_step(mi_gpt* h, const float* hidden_state, int ids_len, const float* repeat_penality, int attention_mask,
+                float* last_hidden_state, int32_t* max_logit_id, float* logits, int mem) {
+    return guard([&] {
+        GPT_CHECK(h, mem, "mi_gpt_step");
+        Gpt& e = *h->impl;
+        const GptCfg& c = e.cfg;
+        MI_REQUIRE(hidden_state && ids_len >= 1, "mi_gpt_step: hidden_state must hold at least one row");
+        MI_REQUIRE(e.history + ids_len <= c.max_seq, "mi_gpt_step: history_len + ids_len exceeds the KV cache (max_seq)");
+        hipStream_t s = e.stream;
+        const hipMemcpyKind in = mem == MI_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+        MI_HIP(hipMemcpyAsync(e.X.p, hidden_state, (size_t)ids_len * c.hidden * 4, in, s));
+        if (repeat_penality) MI_HIP(hipMemcpyAsync(e.pen.p, repeat_penality, (size_t)c.mel_codes * 4, in, s));
+        else {
+            std::vector<float> ones(c.mel_codes, 1.f);
+            MI_HIP(hipMemcpyAsync(e.pen.p, ones.data(), ones.size() * 4, hipMemcpyHostToDevice, s));
+            MI_HIP(hipStreamSynchronize(s));
+        }
+        std::vector<int32_t> w(GS_WORDS, 0);
+        w[GS_HIST] = e.history;
+        e.set_state(w);
+        e.forward_rows(ids_len, attention_mask ? 1 : 0);
+        copy_out(last_hidden_state, e.last.p, (size_t)c.hidden * 4, mem, s);
+        copy_out(logits, e.logits.p, (size_t)c.mel_codes * 4, mem, s);      // un-penalised; see below
+        copy_out(max_logit_id, e.state.as<int32_t>() + GS_TOKEN, 4, mem, s);
+        w = e.get_state();                                                  // synchronises; history := hist + ids_len
+    });
+}
+
+int mi_gpt_kv_read(mi_gpt* h, int layer, float* keys, float* values, int mem) {
+    return guard([&] {
+        GPT_CHECK(h, mem, "mi_gpt_kv_read");
+        Gpt& e = *h->impl;
+        const size_t n = (size_t)e.cfg.hidden * e.history * 4;
+        if (n == 0) return;
+        float *k = keys, *v = values;
+        if (mem == MI_HOST) {
+            e.io_a.ensure(n); e.io_b.ensure(n);
+            k = keys ? e.io_a.as<float>() : nullptr; v = values ? e.io_b.as<float>() : nullptr;
+        }
+        e.kv_read(layer, k, v);
+        if (mem == MI_HOST) { copy_out(keys, k, n, mem, e.stream); copy_out(values, v, n, mem, e.stream); }
+        MI_HIP(hipStreamSynchronize(e.stream));
+    });
+}
+
+int mi_gpt_kv_write(mi_gpt* h, int layer, const float* keys, const float* values, int hist, int mem) {
+    return guard([&] {
+        GPT_CHECK(h, mem, "mi_gpt_kv_write");
+        Gpt& e = *h->impl;
+        MI_REQUIRE(hist >= 0 && hist < e.cfg.max_seq, "mi_gpt_kv_write: history does not fit the KV cache (max_seq)");
+        MI_REQUIRE(hist == 0 || (keys && values), "mi_gpt_kv_write: null keys/values");
+        const size_t n = (size_t)e.cfg.hidden * hist * 4;
+        const float* k = hist ? (const float*)stage_in(e.io_a, keys, n, mem, e.stream) : nullptr;
+        const float* v = hist ? (const float*)stage_in(e.io_b, values, n, mem, e.stream) : nullptr;
+        e.kv_write(layer, k, v, hist);
+    });
+}
+
+int mi_gpt_generate(mi_gpt* h, const float* prompt, int P, int max_new, const int32_t* stop_ids, int n_stop,
+                    float repeat_value, int penalty_range, float* repeat_penality, int32_t* tokens, float* hidden,
+                    int32_t* n_out, int mem) {
+    return guard([&] {
+        GPT_CHECK(h, mem, "mi_gpt_generate");
+        Gpt& e = *h->impl;
+        const GptCfg& c = e.cfg;
+        MI_REQUIRE(prompt && P >= 1 && n_out, "mi_gpt_generate: null argument");
+        MI_REQUIRE(n_stop >= 0 && n_stop <= GS_WORDS - GS_STOP0 && (n_stop == 0 || stop_ids), "mi_gpt_generate: at most 7 stop ids");
+        *n_out = 0;
+        if (max_new <= 0) return;                                        // `while num_decode < generate_limit` never runs
+        MI_REQUIRE(P + max_new - 1 <= c.max_seq, "mi_gpt_generate: prompt + max_new exceeds the KV cache (max_seq)");
+        MI_REQUIRE(max_new <= c.max_mel_pos, "mi_gpt_generate: max_new exceeds the mel position table");
+        hipStream_t s = e.stream;
+        const hipMemcpyKind in = mem == MI_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+        MI_HIP(hipMemcpyAsync(e.X.p, prompt, (size_t)P * c.hidden * 4, in, s));
+        if (repeat_penality) MI_HIP(hipMemcpyAsync(e.pen.p, repeat_penality, (size_t)c.mel_codes * 4, in, s));
+        else {
+            std::vector<float> ones(c.mel_codes, 1.f);
+            MI_HIP(hipMemcpyAsync(e.pen.p, ones.data(), ones.size() * 4, hipMemcpyHostToDevice, s));
+            MI_HIP(hipStreamSynchronize(s));
+        }
+        e.rep_value = repeat_value;
+        std::vector<int32_t> w(GS_WORDS, 0);
+        w[GS_GEN_LEN] = 0; w[GS_NSTOP] = n_stop; w[GS_RANGE] = penalty_range; w[GS_UPDATE_PEN] = 1;
+        if (mem == MI_HOST) for (int i = 0; i < n_stop; ++i) w[GS_STOP0 + i] = stop_ids[i];
+        else MI_HIP(hipMemcpy(&w[GS_STOP0], stop_ids, (size_t)n_stop * 4, hipMemcpyDeviceToHost));
+        e.set_state(w);
+        e.forward_rows(P, 1);                                            // prompt pass: first token
+        int left = max_new - 1;
+        // the stop test needs the host: look at the state every `chunk` tokens (steps after a stop are no-ops)
+        const int chunk = 16;
+        for (;;) {
+            w = e.get_state();
+            if (w[GS_DONE] || left <= 0) break;
+            const int n = left < chunk ? left : chunk;
+            e.decode_steps(n);
+            left -= n;
+        }
+        const int n = w[GS_NDEC];
+        *n_out = n;
+        copy_out(tokens, e.toks.p, (size_t)n * 4, mem, s);
+        copy_out(hidden, e.hid.p, (size_t)n * c.hidden * 4, mem, s);
+        copy_out(repeat_penality, e.pen.p, (size_t)c.mel_codes * 4, mem, s);
+        MI_HIP(hipStreamSynchronize(s));
     });
 }
 

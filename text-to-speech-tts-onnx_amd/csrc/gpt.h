@@ -1,0 +1,59 @@
+// gpt.h — IndexTTS acoustic GPT-2 decoder (graphs B, C, E of IndexTTS/Export_IndexTTS.py:203-289) with the KV cache,
+// the repeat-penalty vector and the greedy decode loop (Inference_IndexTTS_ONNX.py:745-783) resident on the device.
+#pragma once
+#include "common.h"
+#include "f5_kernels.h"
+
+namespace mi {
+
+struct GptCfg {
+    int hidden, layers, heads, inner, mel_codes, text_tokens, max_mel_pos, max_text_pos, max_seq;
+    int head_dim() const { return hidden / heads; }
+};
+GptCfg parse_gpt_cfg(const int32_t* ci, int ni);
+int64_t gpt_param_count(const GptCfg& c);
+
+// device-side decode state (one int32 array; kernels read it so that a decode step has no host-dependent argument
+// and can be captured once into a hipGraph)
+enum { GS_HIST = 0, GS_TOKEN = 1, GS_GEN_LEN = 2, GS_NDEC = 3, GS_RESET = 4, GS_DONE = 5, GS_NSTOP = 6, GS_RANGE = 7,
+       GS_UPDATE_PEN = 8, GS_STOP0 = 9, GS_WORDS = 16 };
+
+struct Gpt {
+    GptCfg cfg;
+    int dtype, device;
+    hipStream_t stream = nullptr;
+
+    struct GLin { DevBuf w, b; int n = 0, k = 0; };
+    struct Layer { DevBuf ln1_w, ln1_b, ln2_w, ln2_b; GLin qkv, proj, fc, fc2; };
+    std::vector<Layer> L;
+    DevBuf text_emb, text_pos, mel_emb, mel_pos;       // fp32 tables
+    DevBuf lnf_w, lnf_b, fn_w, fn_b;
+    GLin head;
+
+    DevBuf kc, vc;            // [layer][head][max_seq][D] in the engine dtype
+    DevBuf X, xn, qkv, att, ff, logits, last, z, pen, toks, hid, state;
+    DevBuf io_a, io_b;        // host<->device staging
+    float rep_value = 0.7f;
+    int history = 0;          // host mirror of state[GS_HIST] (valid outside generate())
+
+    hipGraphExec_t step_graph = nullptr;
+    bool use_graph = true;
+
+    Gpt(const GptCfg& c, const float* w, int64_t nw, int dt, int dev);
+    ~Gpt();
+
+    void text_embed(const int32_t* ids_dev, int n, float* out_dev);                 // graph B (n + 2 rows)
+    void mel_embed(int32_t id, long gen_len, float* out_dev);                        // graph C
+    void reset();
+    // graph E on rows new positions whose hidden states are already in X[0..rows): fills last / logits / state token
+    void forward_rows(int rows, int flag);
+    void set_state(const std::vector<int32_t>& words);
+    std::vector<int32_t> get_state();
+    void decode_step_eager();                                                        // C (from state) + E + bookkeeping
+    void decode_steps(int n);                                                        // n graph replays
+    void kv_read(int layer, float* keys_dev, float* values_dev);
+    void kv_write(int layer, const float* keys_dev, const float* values_dev, int hist);
+    void linear(const GLin& l, const void* x, int rows, void* out, int odt, int act, const float* res);
+};
+
+}  // namespace mi

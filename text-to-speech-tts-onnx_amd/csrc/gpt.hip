@@ -1,0 +1,510 @@
+// gpt.hip — IndexTTS acoustic GPT-2 on gfx950: the autoregressive mel-code decoder behind graphs B, C and E.
+//
+//   text_embed   = IndexTTS_B.forward   IndexTTS/Export_IndexTTS.py:210-214
+//   mel_embed    = IndexTTS_C.forward   :222-225
+//   forward_rows = IndexTTS_E.forward   :270-289  (LayerNorm -> per-head q/k/v -> cache append -> softmax(qk + mask) v ->
+//                                                   c_proj -> MLP(gelu_new) ; ln_f(last row) ; lm_head * penalty ; argmax)
+//   decode_steps = the while-loop of IndexTTS/Inference_IndexTTS_ONNX.py:752-783, one hipGraph replay per token
+//
+// What is different from the reference graph, and why: the reference passes the whole KV cache in and out of every
+// ORT call (2 * layers tensors that grow by one column per token, re-concatenated each step, :277-278).  Here the cache
+// is a fixed [layer][head][max_seq][64] allocation in HBM that a step appends one row to; the history length, the last
+// token, the penalty vector and the per-token outputs are device state, so a decode step has no host-dependent
+// argument: it is captured once and replayed.  A decode step is a chain of weight-streaming GEMVs (HBM-bound:
+// every weight byte is read once per token), so the GEMV kernel is a plain coalesced 16-byte-per-lane dot product,
+// not an MFMA tile; the prompt pass (ids_len rows at once) goes through the MFMA implicit-GEMM kernel instead.
+#include "gpt.h"
+#include <cstdlib>
+
+namespace mi {
+
+GptCfg parse_gpt_cfg(const int32_t* ci, int ni) {
+    MI_REQUIRE(ci && ni == 9, "gpt cfg: expected 9 ints");
+    GptCfg c;
+    int i = 0;
+    c.hidden = ci[i++]; c.layers = ci[i++]; c.heads = ci[i++]; c.inner = ci[i++]; c.mel_codes = ci[i++];
+    c.text_tokens = ci[i++]; c.max_mel_pos = ci[i++]; c.max_text_pos = ci[i++]; c.max_seq = ci[i++];
+    MI_REQUIRE(c.heads > 0 && c.hidden == c.heads * 64, "gpt: the attention kernel is built for head_dim 64");
+    MI_REQUIRE(c.hidden % 8 == 0 && c.hidden <= 2048 && c.inner % 8 == 0 && c.inner > 0, "gpt cfg: widths");
+    MI_REQUIRE(c.layers > 0 && c.mel_codes > 1 && c.text_tokens > 1 && c.max_mel_pos > 1 && c.max_text_pos > 2, "gpt cfg: sizes");
+    MI_REQUIRE(c.max_seq >= 8 && c.max_seq <= 8192, "gpt cfg: max_seq must be in [8, 8192]");
+    return c;
+}
+
+int64_t gpt_param_count(const GptCfg& c) {
+    const int64_t h = c.hidden, n = c.inner;
+    int64_t t = (int64_t)(c.text_tokens + c.max_text_pos + c.mel_codes + c.max_mel_pos) * h;
+    t += (int64_t)c.layers * (2 * h + 3 * h * h + 3 * h + h * h + h + 2 * h + h * n + n + n * h + h);
+    t += 4 * h + (int64_t)c.mel_codes * h + c.mel_codes;
+    return t;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T> struct Pack16 {
+    static constexpr int N = 16 / sizeof(T);
+    T v[N];
+};
+template <typename T> __device__ inline Pack16<T> ld16(const T* p) {
+    Pack16<T> r;
+    *reinterpret_cast<uint4*>(&r) = *reinterpret_cast<const uint4*>(p);
+    return r;
+}
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ inline float gelu_new(float x) {
+    return 0.5f * x * (1.f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));
+}
+
+// out[n] = act(dot(w[n, :], x) + bias[n]) (+ res[n]) ; one wave per two output rows, 16 bytes per lane per load.
+template <typename T>
+__global__ __launch_bounds__(256) void gemv_kernel(const T* __restrict__ w, const T* __restrict__ x,
+                                                   const float* __restrict__ bias, const float* res, void* out,
+                                                   int out_f32, int act, int N, int K) {
+    constexpr int V = Pack16<T>::N;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n0 = (blockIdx.x * 4 + wave) * 2;
+    if (n0 >= N) return;
+    const bool two = n0 + 1 < N;
+    const T* w0 = w + (size_t)n0 * K;
+    const T* w1 = w0 + (two ? K : 0);
+    float a0 = 0.f, a1 = 0.f;
+    for (int k = lane * V; k < K; k += 64 * V) {
+        const Pack16<T> xv = ld16(x + k), p0 = ld16(w0 + k), p1 = ld16(w1 + k);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const float xe = (float)xv.v[e];
+            a0 = fmaf((float)p0.v[e], xe, a0);
+            a1 = fmaf((float)p1.v[e], xe, a1);
+        }
+    }
+    a0 = wave_sum(a0);
+    a1 = wave_sum(a1);
+    if (lane < (two ? 2 : 1)) {
+        const int n = n0 + lane;
+        float v = (lane ? a1 : a0) + (bias ? bias[n] : 0.f);
+        if (act == ACT_GELU_TANH) v = gelu_new(v);
+        if (res) v += res[n];
+        if (out_f32) ((float*)out)[n] = v; else ((T*)out)[n] = (T)v;
+    }
+}
+
+// rows of (q | k | v) -> K / V cache rows hist .. hist+rows-1 of one layer
+template <typename T>
+__global__ __launch_bounds__(256) void kv_append_kernel(const T* __restrict__ qkv, T* __restrict__ kc, T* __restrict__ vc,
+                                                        const int* __restrict__ st, int rows, int hidden, int max_seq) {
+    const int per = 2 * hidden / 8;                       // 16-byte groups for T = 2 bytes, 8 elements in general
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)rows * per) return;
+    const int r = (int)(i / per), c = (int)(i % per) * 8;
+    const int which = c / hidden, cc = c % hidden, head = cc >> 6, d = cc & 63;
+    const int pos = st[GS_HIST] + r;
+    if (pos >= max_seq) return;
+    const T* src = qkv + (size_t)r * 3 * hidden + hidden + c;
+    T* dst = (which ? vc : kc) + ((size_t)head * max_seq + pos) * 64 + d;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dst[e] = src[e];
+}
+
+// one block per (head, new row): softmax(q K^T + mask) V over the cache.  lane-per-key dot products (each lane streams
+// one 64-wide key row with 16-byte loads), then 8 lanes per value row.
+template <typename T>
+__global__ __launch_bounds__(512) void gpt_attn_kernel(const T* __restrict__ qkv, const T* __restrict__ kc,
+                                                       const T* __restrict__ vc, T* __restrict__ out,
+                                                       const int* __restrict__ st, int rows, int flag, int hidden,
+                                                       int max_seq) {
+    constexpr int V = Pack16<T>::N;            // elements per 16 bytes
+    constexpr int CH = 64 / V;                 // 16-byte chunks per key row
+    extern __shared__ float sm[];
+    float* sc = sm;                            // [max_seq]
+    float* qs = sm + max_seq;                  // [64]
+    float* red = qs + 64;                      // [8 * 64]
+    __shared__ float bc[2];
+    const int head = blockIdx.x, i = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hist = st[GS_HIST];
+    const int kv = min(hist + rows, max_seq);
+    if (tid < 64) qs[tid] = (float)qkv[(size_t)i * 3 * hidden + head * 64 + tid];
+    __syncthreads();
+    const T* kb = kc + (size_t)head * max_seq * 64;
+    const T* vb = vc + (size_t)head * max_seq * 64;
+    float mx = -3.0e38f;
+    for (int j = tid; j < kv; j += 512) {
+        const T* kr = kb + (size_t)j * 64;
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const Pack16<T> p = ld16(kr + c * V);
+#pragma unroll
+            for (int e = 0; e < V; ++e) s = fmaf(qs[c * V + e], (float)p.v[e], s);
+        }
+        if (flag && j > i) s += -128.f;
+        sc[j] = s;
+        mx = fmaxf(mx, s);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    if (tid == 0) { float m = red[0]; for (int w = 1; w < 8; ++w) m = fmaxf(m, red[w]); bc[0] = m; }
+    __syncthreads();
+    mx = bc[0];
+    float sum = 0.f;
+    for (int j = tid; j < kv; j += 512) { const float e = __expf(sc[j] - mx); sc[j] = e; sum += e; }
+    sum = wave_sum(sum);
+    __syncthreads();
+    if (lane == 0) red[wave] = sum;
+    __syncthreads();
+    if (tid == 0) { float t = 0.f; for (int w = 0; w < 8; ++w) t += red[w]; bc[1] = t; }
+    __syncthreads();
+    const float inv = 1.f / bc[1];
+    // values: lane = (key-in-group g, chunk c) ; a wave covers 64/CH keys per pass
+    constexpr int KPW = 64 / CH;               // keys per wave pass
+    const int g = lane / CH, c = lane % CH;
+    float acc[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[e] = 0.f;
+    for (int j = wave * KPW + g; j < kv; j += 8 * KPW) {
+        const float p = sc[j];
+        const Pack16<T> v = ld16(vb + (size_t)j * 64 + c * V);
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] = fmaf(p, (float)v.v[e], acc[e]);
+    }
+    // reduce over g (lanes that share c): xor over the g bits
+#pragma unroll
+    for (int o = CH; o < 64; o <<= 1)
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
+    __syncthreads();
+    if (g == 0)
+#pragma unroll
+        for (int e = 0; e < V; ++e) red[wave * 64 + c * V + e] = acc[e];
+    __syncthreads();
+    if (tid < 64) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) t += red[w * 64 + tid];
+        out[(size_t)i * hidden + head * 64 + tid] = (T)(t * inv);
+    }
+}
+
+__global__ __launch_bounds__(256) void gpt_text_embed_kernel(const int* __restrict__ ids, const float* __restrict__ emb,
+                                                             const float* __restrict__ pos, float* __restrict__ out,
+                                                             int n, int hidden, int vocab) {
+    const int r = blockIdx.x;                  // 0 .. n+1
+    int id = r == 0 ? 0 : (r == n + 1 ? 1 : ids[r - 1]);
+    id = min(max(id, 0), vocab - 1);
+    for (int c = threadIdx.x; c < hidden; c += 256)
+        out[(size_t)r * hidden + c] = emb[(size_t)id * hidden + c] + pos[(size_t)r * hidden + c];
+}
+
+// hidden state of the next decode step from the device state (graph C fed by the previous step's max_logit_id)
+__global__ __launch_bounds__(256) void gpt_embed_state_kernel(const int* __restrict__ st, const float* __restrict__ emb,
+                                                              const float* __restrict__ pos, float* __restrict__ x,
+                                                              int hidden, int codes, int max_pos, int id_arg, int gen_arg) {
+    const int id = min(max(id_arg >= 0 ? id_arg : st[GS_TOKEN], 0), codes - 1);
+    const int g = min(max(gen_arg >= 0 ? gen_arg : st[GS_GEN_LEN], 0), max_pos - 1);
+    for (int c = threadIdx.x; c < hidden; c += 256) x[c] = emb[(size_t)id * hidden + c] + pos[(size_t)g * hidden + c];
+}
+
+// logits * penalty -> argmax (first index on ties, like torch.argmax) -> the driver loop's bookkeeping
+__global__ __launch_bounds__(1024) void gpt_pick_kernel(const float* __restrict__ logits, float* __restrict__ pen,
+                                                        const float* __restrict__ last, int* __restrict__ st,
+                                                        int* __restrict__ toks, float* __restrict__ hid, int codes,
+                                                        int hidden, int rows, float rep, int max_tok) {
+    __shared__ float bv[16];
+    __shared__ int bi[16];
+    __shared__ int slot;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float best = -INFINITY;
+    int idx = 0x7fffffff;
+    for (int c = tid; c < codes; c += 1024) {
+        const float v = logits[c] * pen[c];
+        if (v > best || (v == best && c < idx)) { best = v; idx = c; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(idx, o, 64);
+        if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+    }
+    if (lane == 0) { bv[wave] = best; bi[wave] = idx; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 16; ++w)
+            if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+        if (idx == 0x7fffffff) idx = 0;
+        slot = -1;
+        if (!st[GS_DONE]) {
+            const int t = idx, n = st[GS_NDEC];
+            st[GS_TOKEN] = t;
+            if (n < max_tok) { toks[n] = t; slot = n; }
+            st[GS_NDEC] = n + 1;
+            bool stop = false;
+            for (int s = 0; s < st[GS_NSTOP]; ++s) stop |= (st[GS_STOP0 + s] == t);
+            if (stop) st[GS_DONE] = 1;
+            else if (st[GS_UPDATE_PEN]) {                     // Inference_IndexTTS_ONNX.py:768-772
+                pen[t] = rep;
+                const int r = st[GS_RESET];
+                if (n + 1 > st[GS_RANGE] && r < max_tok && toks[r] != t) { pen[toks[r]] = 1.f; st[GS_RESET] = r + 1; }
+            }
+            st[GS_HIST] += rows;
+            st[GS_GEN_LEN] += 1;
+        }
+    }
+    __syncthreads();
+    if (slot >= 0)
+        for (int c = tid; c < hidden; c += 1024) hid[(size_t)slot * hidden + c] = last[c];
+}
+
+// cache <-> the reference's tensor layouts: keys (H, D, hist), values (H, hist, D), fp32
+template <typename T>
+__global__ __launch_bounds__(256) void kv_export_kernel(const T* __restrict__ kc, const T* __restrict__ vc,
+                                                        float* __restrict__ keys, float* __restrict__ values, int H,
+                                                        int hist, int max_seq) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)H * hist * 64) return;
+    const int d = (int)(i & 63), j = (int)((i >> 6) % hist), h = (int)((i >> 6) / hist);
+    const size_t src = ((size_t)h * max_seq + j) * 64 + d;
+    if (keys) keys[((size_t)h * 64 + d) * hist + j] = (float)kc[src];
+    if (values) values[((size_t)h * hist + j) * 64 + d] = (float)vc[src];
+}
+template <typename T>
+__global__ __launch_bounds__(256) void kv_import_kernel(T* __restrict__ kc, T* __restrict__ vc, const float* __restrict__ keys,
+                                                        const float* __restrict__ values, int H, int hist, int max_seq) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)H * hist * 64) return;
+    const int d = (int)(i & 63), j = (int)((i >> 6) % hist), h = (int)((i >> 6) / hist);
+    const size_t dst = ((size_t)h * max_seq + j) * 64 + d;
+    kc[dst] = (T)keys[((size_t)h * 64 + d) * hist + j];
+    vc[dst] = (T)values[((size_t)h * hist + j) * 64 + d];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// engine
+// ---------------------------------------------------------------------------------------------------------------
+static void up_glin(Gpt::GLin& l, const float*& p, int n, int k, int dt, hipStream_t s) {
+    l.n = n; l.k = k;
+    upload_as(l.w, p, (size_t)n * k, dt, s); p += (size_t)n * k;
+    upload_f32(l.b, p, n, s); p += n;
+}
+static void up_vec(DevBuf& b, const float*& p, size_t n, hipStream_t s) { upload_f32(b, p, n, s); p += n; }
+
+Gpt::Gpt(const GptCfg& c, const float* w, int64_t nw, int dt, int dev) : cfg(c), dtype(dt), device(dev) {
+    MI_REQUIRE(dt == MI_F32 || dt == MI_F16 || dt == MI_BF16, "gpt: dtype");
+    MI_REQUIRE(nw == gpt_param_count(c), "gpt: weight blob size does not match the config");
+    MI_HIP(hipSetDevice(dev));
+    MI_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    hipStream_t s = stream;
+    const int h = c.hidden, n = c.inner;
+    const float* p = w;
+    up_vec(text_emb, p, (size_t)c.text_tokens * h, s);
+    up_vec(text_pos, p, (size_t)c.max_text_pos * h, s);
+    up_vec(mel_emb, p, (size_t)c.mel_codes * h, s);
+    up_vec(mel_pos, p, (size_t)c.max_mel_pos * h, s);
+    L.resize(c.layers);
+    for (auto& l : L) {
+        up_vec(l.ln1_w, p, h, s); up_vec(l.ln1_b, p, h, s);
+        up_glin(l.qkv, p, 3 * h, h, dt, s);
+        up_glin(l.proj, p, h, h, dt, s);
+        up_vec(l.ln2_w, p, h, s); up_vec(l.ln2_b, p, h, s);
+        up_glin(l.fc, p, n, h, dt, s);
+        up_glin(l.fc2, p, h, n, dt, s);
+    }
+    up_vec(lnf_w, p, h, s); up_vec(lnf_b, p, h, s);
+    up_vec(fn_w, p, h, s); up_vec(fn_b, p, h, s);
+    up_glin(head, p, c.mel_codes, h, dt, s);
+    MI_REQUIRE(p - w == nw, "gpt: blob walk mismatch");
+
+    const size_t es = dtype_size(dt), S = c.max_seq;
+    kc.ensure((size_t)c.layers * h * S * es); vc.ensure((size_t)c.layers * h * S * es);
+    X.ensure(S * h * 4); xn.ensure(S * h * es); qkv.ensure(S * 3 * h * es); att.ensure(S * h * es);
+    ff.ensure(S * n * es); logits.ensure((size_t)c.mel_codes * 4); last.ensure((size_t)h * 4); z.ensure((size_t)h * es);
+    pen.ensure((size_t)c.mel_codes * 4); toks.ensure(S * 4); hid.ensure(S * h * 4); state.ensure(GS_WORDS * 4);
+    MI_HIP(hipMemsetAsync(kc.p, 0, kc.bytes, s));
+    MI_HIP(hipMemsetAsync(vc.p, 0, vc.bytes, s));
+    MI_HIP(hipMemsetAsync(state.p, 0, state.bytes, s));
+    std::vector<float> ones(c.mel_codes, 1.f);
+    MI_HIP(hipMemcpyAsync(pen.p, ones.data(), ones.size() * 4, hipMemcpyHostToDevice, s));
+    MI_HIP(hipStreamSynchronize(s));
+    const char* ng = std::getenv("MI355TTS_NO_GRAPH");
+    use_graph = !(ng && ng[0] == '1');
+    // the attention kernel's score buffer is dynamic LDS: max_seq + 64 + 512 floats
+    const int lds = (c.max_seq + 64 + 512) * 4;
+    MI_HIP(hipFuncSetAttribute((const void*)gpt_attn_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    MI_HIP(hipFuncSetAttribute((const void*)gpt_attn_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    MI_HIP(hipFuncSetAttribute((const void*)gpt_attn_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+}
+
+Gpt::~Gpt() {
+    if (step_graph) (void)hipGraphExecDestroy(step_graph);
+    if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
+}
+
+void Gpt::set_state(const std::vector<int32_t>& words) {
+    MI_REQUIRE(words.size() == GS_WORDS, "gpt: state size");
+    MI_HIP(hipMemcpyAsync(state.p, words.data(), GS_WORDS * 4, hipMemcpyHostToDevice, stream));
+    MI_HIP(hipStreamSynchronize(stream));      // `words` may be a temporary
+    history = words[GS_HIST];
+}
+std::vector<int32_t> Gpt::get_state() {
+    std::vector<int32_t> w(GS_WORDS);
+    MI_HIP(hipMemcpyAsync(w.data(), state.p, GS_WORDS * 4, hipMemcpyDeviceToHost, stream));
+    MI_HIP(hipStreamSynchronize(stream));
+    history = w[GS_HIST];
+    return w;
+}
+void Gpt::reset() {
+    std::vector<int32_t> w(GS_WORDS, 0);
+    set_state(w);
+}
+
+void Gpt::linear(const GLin& l, const void* x, int rows, void* out, int odt, int act, const float* res) {
+    if (rows == 1) {
+        MI_REQUIRE(l.k % 8 == 0, "gemv: K must be a multiple of 8");
+        const dim3 grid((unsigned)((l.n + 7) / 8));
+        ProfScope ps(FAM_CONV_GEMM, stream, (double)l.n * l.k * dtype_size(dtype), 2.0 * l.n * l.k);
+        const int of = odt == MI_F32;
+        MI_REQUIRE(of || odt == dtype, "gemv: output dtype");
+        if (dtype == MI_F32)
+            hipLaunchKernelGGL(gemv_kernel<float>, grid, dim3(256), 0, stream, l.w.as<float>(), (const float*)x, l.b.as<float>(), res, out, of, act, l.n, l.k);
+        else if (dtype == MI_F16)
+            hipLaunchKernelGGL(gemv_kernel<f16>, grid, dim3(256), 0, stream, l.w.as<f16>(), (const f16*)x, l.b.as<float>(), res, out, of, act, l.n, l.k);
+        else
+            hipLaunchKernelGGL(gemv_kernel<bf16>, grid, dim3(256), 0, stream, l.w.as<bf16>(), (const bf16*)x, l.b.as<float>(), res, out, of, act, l.n, l.k);
+        MI_HIP(hipGetLastError());
+        return;
+    }
+    ConvGemm g;
+    g.dtype = dtype; g.out_dtype = odt; g.x = x; g.w = l.w.p; g.bias = l.b.as<float>(); g.out = out; g.res = res;
+    g.B = 1; g.T_in = rows; g.M = rows; g.N = l.n; g.Cin = l.k; g.taps = 1;
+    g.x_bstride = (long)rows * l.k; g.x_rstride = l.k; g.out_bstride = (long)rows * l.n; g.out_rstride = l.n; g.act = act;
+    launch_conv_gemm(g, stream);
+}
+
+#define GPT_DISPATCH(KERNEL, ...)                                                     \
+    do {                                                                              \
+        if (dtype == MI_F32) { KERNEL(float, __VA_ARGS__); }                          \
+        else if (dtype == MI_F16) { KERNEL(f16, __VA_ARGS__); }                       \
+        else { KERNEL(bf16, __VA_ARGS__); }                                           \
+        MI_HIP(hipGetLastError());                                                    \
+    } while (0)
+
+void Gpt::forward_rows(int rows, int flag) {
+    const GptCfg& c = cfg;
+    const int h = c.hidden, S = c.max_seq;
+    hipStream_t s = stream;
+    const size_t es = dtype_size(dtype);
+    const int* st = state.as<int>();
+    float* x = X.as<float>();
+    const int lds = (S + 64 + 512) * 4;
+    for (int li = 0; li < c.layers; ++li) {
+        Layer& l = L[li];
+        char* kcl = (char*)kc.p + (size_t)li * h * S * es;
+        char* vcl = (char*)vc.p + (size_t)li * h * S * es;
+        launch_rownorm(NORM_LN_AFFINE, x, xn.p, dtype, l.ln1_w.as<float>(), l.ln1_b.as<float>(), rows, h, 1e-5f, s);
+        linear(l.qkv, xn.p, rows, qkv.p, dtype, ACT_NONE, nullptr);
+        {
+            const long items = (long)rows * (2 * h / 8);
+            const dim3 grid((unsigned)((items + 255) / 256));
+#define KVA(T, ...) hipLaunchKernelGGL(kv_append_kernel<T>, grid, dim3(256), 0, s, (const T*)qkv.p, (T*)kcl, (T*)vcl, st, rows, h, S)
+            GPT_DISPATCH(KVA, 0);
+#undef KVA
+        }
+        {
+            ProfScope ps(FAM_ATTN, s, 2.0 * (double)h * (history + rows) * es, 4.0 * (double)h * rows * (history + rows));
+#define ATT(T, ...) hipLaunchKernelGGL(gpt_attn_kernel<T>, dim3(c.heads, rows), dim3(512), lds, s, (const T*)qkv.p, (const T*)kcl, (const T*)vcl, (T*)att.p, st, rows, flag, h, S)
+            GPT_DISPATCH(ATT, 0);
+#undef ATT
+        }
+        linear(l.proj, att.p, rows, x, MI_F32, ACT_NONE, x);
+        launch_rownorm(NORM_LN_AFFINE, x, xn.p, dtype, l.ln2_w.as<float>(), l.ln2_b.as<float>(), rows, h, 1e-5f, s);
+        linear(l.fc, xn.p, rows, ff.p, dtype, ACT_GELU_TANH, nullptr);
+        linear(l.fc2, ff.p, rows, x, MI_F32, ACT_NONE, x);
+    }
+    const float* xl = x + (size_t)(rows - 1) * h;
+    launch_rownorm(NORM_LN_AFFINE, xl, last.p, MI_F32, lnf_w.as<float>(), lnf_b.as<float>(), 1, h, 1e-5f, s);
+    launch_rownorm(NORM_LN_AFFINE, last.as<float>(), z.p, dtype, fn_w.as<float>(), fn_b.as<float>(), 1, h, 1e-5f, s);
+    linear(head, z.p, 1, logits.p, MI_F32, ACT_NONE, nullptr);
+    hipLaunchKernelGGL(gpt_pick_kernel, dim3(1), dim3(1024), 0, s, logits.as<float>(), pen.as<float>(), last.as<float>(),
+                       state.as<int>(), toks.as<int>(), hid.as<float>(), c.mel_codes, h, rows, rep_value, S);
+    MI_HIP(hipGetLastError());
+}
+
+void Gpt::decode_step_eager() {
+    hipLaunchKernelGGL(gpt_embed_state_kernel, dim3(1), dim3(256), 0, stream, state.as<int>(), mel_emb.as<float>(),
+                       mel_pos.as<float>(), X.as<float>(), cfg.hidden, cfg.mel_codes, cfg.max_mel_pos, -1, -1);
+    MI_HIP(hipGetLastError());
+    forward_rows(1, 0);
+}
+
+void Gpt::decode_steps(int n) {
+    if (n <= 0) return;
+    if (!use_graph || prof_mask() != 0) { for (int i = 0; i < n; ++i) decode_step_eager(); return; }
+    if (!step_graph) {
+        decode_step_eager();                   // first step eager (one-time lazy initialisation stays out of the capture)
+        --n;
+        hipGraph_t graph = nullptr;
+        MI_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+        try {
+            decode_step_eager();
+        } catch (...) {
+            (void)hipStreamEndCapture(stream, &graph);
+            if (graph) (void)hipGraphDestroy(graph);
+            throw;
+        }
+        MI_HIP(hipStreamEndCapture(stream, &graph));
+        hipError_t err = hipGraphInstantiate(&step_graph, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (err != hipSuccess) { step_graph = nullptr; use_graph = false; for (int i = 0; i < n; ++i) decode_step_eager(); return; }
+    }
+    for (int i = 0; i < n; ++i) MI_HIP(hipGraphLaunch(step_graph, stream));
+}
+
+void Gpt::text_embed(const int32_t* ids_dev, int n, float* out_dev) {
+    MI_REQUIRE(n >= 0 && n + 2 <= cfg.max_text_pos, "gpt: text is longer than the text position table");
+    hipLaunchKernelGGL(gpt_text_embed_kernel, dim3(n + 2), dim3(256), 0, stream, ids_dev, text_emb.as<float>(),
+                       text_pos.as<float>(), out_dev, n, cfg.hidden, cfg.text_tokens);
+    MI_HIP(hipGetLastError());
+}
+
+void Gpt::mel_embed(int32_t id, long gen_len, float* out_dev) {
+    MI_REQUIRE(id >= 0 && id < cfg.mel_codes, "gpt: mel code out of range");
+    MI_REQUIRE(gen_len >= 0 && gen_len < cfg.max_mel_pos, "gpt: gen_len exceeds the mel position table");
+    hipLaunchKernelGGL(gpt_embed_state_kernel, dim3(1), dim3(256), 0, stream, state.as<int>(), mel_emb.as<float>(),
+                       mel_pos.as<float>(), out_dev, cfg.hidden, cfg.mel_codes, cfg.max_mel_pos, (int)id, (int)gen_len);
+    MI_HIP(hipGetLastError());
+}
+
+void Gpt::kv_read(int layer, float* keys_dev, float* values_dev) {
+    MI_REQUIRE(layer >= 0 && layer < cfg.layers, "gpt: layer index");
+    const int hist = history;
+    if (hist == 0) return;
+    const size_t es = dtype_size(dtype), off = (size_t)layer * cfg.hidden * cfg.max_seq * es;
+    const long items = (long)cfg.heads * hist * 64;
+    const dim3 grid((unsigned)((items + 255) / 256));
+#define KVE(T, ...) hipLaunchKernelGGL(kv_export_kernel<T>, grid, dim3(256), 0, stream, (const T*)((char*)kc.p + off), (const T*)((char*)vc.p + off), keys_dev, values_dev, cfg.heads, hist, cfg.max_seq)
+    GPT_DISPATCH(KVE, 0);
+#undef KVE
+}
+
+void Gpt::kv_write(int layer, const float* keys_dev, const float* values_dev, int hist) {
+    MI_REQUIRE(layer >= 0 && layer < cfg.layers, "gpt: layer index");
+    MI_REQUIRE(hist >= 0 && hist < cfg.max_seq, "gpt: history does not fit the KV cache (max_seq)");
+    if (hist > 0) {
+        const size_t es = dtype_size(dtype), off = (size_t)layer * cfg.hidden * cfg.max_seq * es;
+        const long items = (long)cfg.heads * hist * 64;
+        const dim3 grid((unsigned)((items + 255) / 256));
+#define KVI(T, ...) hipLaunchKernelGGL(kv_import_kernel<T>, grid, dim3(256), 0, stream, (T*)((char*)kc.p + off), (T*)((char*)vc.p + off), keys_dev, values_dev, cfg.heads, hist, cfg.max_seq)
+        GPT_DISPATCH(KVI, 0);
+#undef KVI
+    }
+    std::vector<int32_t> w = get_state();
+    w[GS_HIST] = hist;
+    set_state(w);
+}
+
+}  // namespace mi

@@ -80,6 +80,20 @@ def load() -> C.CDLL:
     L.mi_f5_synthesize.argtypes = [vp, C.c_int, vp, C.c_int64, vp, C.c_int64, C.c_int64, vp, C.c_uint64, vp, i64p,
                                    C.c_int]
     L.mi_f5_synthesize.restype = C.c_int
+    L.mi_gpt_param_count.argtypes = [C.POINTER(C.c_int32), C.c_int]; L.mi_gpt_param_count.restype = C.c_int64
+    L.mi_gpt_create.argtypes = [C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_float), C.c_int64, C.c_int, C.c_int]
+    L.mi_gpt_create.restype = C.c_void_p
+    L.mi_gpt_destroy.argtypes = [vp]; L.mi_gpt_destroy.restype = None
+    L.mi_gpt_text_embed.argtypes = [vp, vp, C.c_int, vp, C.c_int]; L.mi_gpt_text_embed.restype = C.c_int
+    L.mi_gpt_mel_embed.argtypes = [vp, C.c_int32, C.c_int64, vp, C.c_int]; L.mi_gpt_mel_embed.restype = C.c_int
+    L.mi_gpt_reset.argtypes = [vp]; L.mi_gpt_reset.restype = C.c_int
+    L.mi_gpt_history_len.argtypes = [vp]; L.mi_gpt_history_len.restype = C.c_int64
+    L.mi_gpt_step.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, vp, C.c_int]; L.mi_gpt_step.restype = C.c_int
+    L.mi_gpt_kv_read.argtypes = [vp, C.c_int, vp, vp, C.c_int]; L.mi_gpt_kv_read.restype = C.c_int
+    L.mi_gpt_kv_write.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int]; L.mi_gpt_kv_write.restype = C.c_int
+    L.mi_gpt_generate.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_float, C.c_int, vp, vp, vp,
+                                  C.POINTER(C.c_int32), C.c_int]
+    L.mi_gpt_generate.restype = C.c_int
     L.mi_bench_conv_gemm.argtypes = [C.c_int] * 9 + [C.POINTER(C.c_double)]
     L.mi_bench_conv_gemm.restype = C.c_int
     L.mi_set_option.argtypes = [C.c_char_p, C.c_int64]; L.mi_set_option.restype = C.c_int

@@ -1,0 +1,168 @@
+"""IndexTTS acoustic GPT-2: host-side mirror of the reference's graphs B, C, D, E and of the per-sentence decode loop.
+
+``IndexGPT`` is what ``ort_session_B/_C/_D/_E`` are in /root/reference IndexTTS/Inference_IndexTTS_ONNX.py:619-675
+(graph definitions: IndexTTS/Export_IndexTTS.py:203-289), executed by hand-written gfx950 kernels through the C-ABI:
+
+    text_embed(text_ids)                      graph B   (:723-727)
+    mel_embed(gpt_id, gen_len)                graph C   (:729-734, :775-780)
+    concat(conds_latent, text_h, mel_h)       graph D   (:736-742)  — a host concatenate, nothing to accelerate
+    step(hidden_state, ...)                   graph E   (:754)      — KV cache resident in the handle
+    generate(conds_latent, text_ids)          the loop  (:716-783)  — all tokens without leaving the device
+
+There is no CPU fallback: without libmi355tts.so and an MI355X every call raises.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from .config import IndexGPTConfig
+from .weights import pack_gpt
+
+
+class IndexGPT:
+    def __init__(self, cfg: IndexGPTConfig, state: Optional[dict] = None, *, blob: Optional[np.ndarray] = None,
+                 dtype: str = "f32", device: int = 0):
+        self.cfg = cfg
+        self.dtype = dtype
+        self.device = device
+        self._h = None
+        L = _lib.load()
+        _lib.init(device)
+        if blob is None:
+            if state is None:
+                raise ValueError("IndexGPT needs a state dict or a packed blob")
+            blob = pack_gpt(cfg, state)
+        blob = np.ascontiguousarray(blob, dtype=np.float32)
+        ci = np.asarray(cfg.to_int_array(), dtype=np.int32)
+        expect = L.mi_gpt_param_count(_lib.i32p(ci), len(ci))
+        if expect != blob.size:
+            raise _lib.MiError(f"weight blob has {blob.size} floats, config needs {expect}")
+        self._h = L.mi_gpt_create(_lib.i32p(ci), len(ci), _lib.f32p(blob), blob.size, _lib.DTYPES[dtype], device)
+        if not self._h:
+            raise _lib.MiError("mi_gpt_create: " + L.mi_last_error().decode())
+        # the reference initialises repeat_penality once and carries it across sentences (:685)
+        self.repeat_penality = np.ones((1, cfg.mel_codes), np.float32)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.load().mi_gpt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- graph B ------------------------------------------------------------------------------------------------
+    def text_embed(self, text_ids) -> np.ndarray:
+        ids = np.ascontiguousarray(np.asarray(text_ids).reshape(-1), dtype=np.int32)
+        out = np.empty((1, ids.size + 2, self.cfg.hidden), np.float32)
+        _lib.check(_lib.load().mi_gpt_text_embed(self._h, ids.ctypes.data, ids.size, out.ctypes.data, _lib.MI_HOST),
+                   "mi_gpt_text_embed")
+        return out
+
+    # ---- graph C ------------------------------------------------------------------------------------------------
+    def mel_embed(self, gpt_id, gen_len):
+        g = int(np.asarray(gen_len).reshape(-1)[0])
+        out = np.empty((1, 1, self.cfg.hidden), np.float32)
+        _lib.check(_lib.load().mi_gpt_mel_embed(self._h, int(np.asarray(gpt_id).reshape(-1)[0]), g, out.ctypes.data,
+                                                _lib.MI_HOST), "mi_gpt_mel_embed")
+        return out, np.array([g + 1], np.int64)
+
+    # ---- graph D ------------------------------------------------------------------------------------------------
+    @staticmethod
+    def concat(embed_x, embed_y, embed_z):
+        c = np.ascontiguousarray(np.concatenate([embed_x, embed_y, embed_z], axis=1), dtype=np.float32)
+        return c, np.array([c.shape[1]], np.int64)
+
+    # ---- graph E ------------------------------------------------------------------------------------------------
+    @property
+    def history_len(self) -> int:
+        return int(_lib.load().mi_gpt_history_len(self._h))
+
+    def reset(self):
+        _lib.check(_lib.load().mi_gpt_reset(self._h), "mi_gpt_reset")
+
+    def step(self, hidden_state, repeat_penality=None, attention_mask: int = 0, return_logits: bool = False):
+        """hidden_state (1, ids_len, hidden) appended after the handle's history.  Returns (kv_seq_len,
+        last_hidden_state (1, hidden), max_logit_id (1, 1) int32[, logits (1, mel_codes)])."""
+        hs = np.ascontiguousarray(hidden_state, dtype=np.float32)
+        if hs.ndim != 3 or hs.shape[0] != 1 or hs.shape[2] != self.cfg.hidden or hs.shape[1] < 1:
+            raise ValueError(f"hidden_state must be (1, ids_len >= 1, {self.cfg.hidden}), got {hs.shape}")
+        pen = None
+        if repeat_penality is not None:
+            pen = np.ascontiguousarray(repeat_penality, dtype=np.float32).reshape(-1)
+            if pen.size != self.cfg.mel_codes:
+                raise ValueError(f"repeat_penality must hold {self.cfg.mel_codes} values")
+        last = np.empty((1, self.cfg.hidden), np.float32)
+        tok = np.empty((1, 1), np.int32)
+        logits = np.empty((1, self.cfg.mel_codes), np.float32) if return_logits else None
+        _lib.check(_lib.load().mi_gpt_step(self._h, hs.ctypes.data, hs.shape[1], None if pen is None else pen.ctypes.data,
+                                           int(attention_mask), last.ctypes.data, tok.ctypes.data,
+                                           None if logits is None else logits.ctypes.data, _lib.MI_HOST), "mi_gpt_step")
+        kv = np.array([self.history_len], np.int64)
+        return (kv, last, tok, logits) if return_logits else (kv, last, tok)
+
+    def kv_read(self, layer: int):
+        """(keys (H, 64, history), values (H, history, 64)) of one layer, in the reference's out_key_i / out_value_i
+        layouts."""
+        c, hist = self.cfg, self.history_len
+        k = np.zeros((c.heads, c.head_dim, hist), np.float32)
+        v = np.zeros((c.heads, hist, c.head_dim), np.float32)
+        if hist:
+            _lib.check(_lib.load().mi_gpt_kv_read(self._h, layer, k.ctypes.data, v.ctypes.data, _lib.MI_HOST),
+                       "mi_gpt_kv_read")
+        return k, v
+
+    def kv_write(self, keys: Sequence[np.ndarray], values: Sequence[np.ndarray]):
+        """Load a cache given as the reference's in_key_i / in_value_i lists; history_len := keys[0].shape[2]."""
+        c = self.cfg
+        if len(keys) != c.layers or len(values) != c.layers:
+            raise ValueError(f"expected {c.layers} key and value tensors")
+        hist = int(np.asarray(keys[0]).shape[2])
+        for i in range(c.layers):
+            k = np.ascontiguousarray(keys[i], dtype=np.float32)
+            v = np.ascontiguousarray(values[i], dtype=np.float32)
+            if k.shape != (c.heads, c.head_dim, hist) or v.shape != (c.heads, hist, c.head_dim):
+                raise ValueError(f"layer {i}: keys {k.shape} / values {v.shape} do not match history {hist}")
+            _lib.check(_lib.load().mi_gpt_kv_write(self._h, i, k.ctypes.data, v.ctypes.data, hist, _lib.MI_HOST),
+                       "mi_gpt_kv_write")
+
+    # ---- the per-sentence loop ------------------------------------------------------------------------------------
+    def generate_from_prompt(self, prompt, max_new: int, *, stop_tokens=None, repeat_value=None, penalty_range=None,
+                             repeat_penality=None):
+        """prompt (1, P, hidden) = graph D's output.  Returns (tokens (n,), hidden (n, hidden), repeat_penality)."""
+        c = self.cfg
+        p = np.ascontiguousarray(prompt, dtype=np.float32)
+        if p.ndim != 3 or p.shape[0] != 1 or p.shape[2] != c.hidden or p.shape[1] < 1:
+            raise ValueError(f"prompt must be (1, P >= 1, {c.hidden}), got {p.shape}")
+        stops = np.ascontiguousarray([c.stop_mel_token] if stop_tokens is None else list(stop_tokens), dtype=np.int32)
+        pen = np.ascontiguousarray(self.repeat_penality if repeat_penality is None else repeat_penality,
+                                   dtype=np.float32).reshape(1, -1).copy()
+        max_new = int(max_new)
+        toks = np.zeros((max(max_new, 1),), np.int32)
+        hid = np.zeros((max(max_new, 1), c.hidden), np.float32)
+        import ctypes as C
+        n = C.c_int32(0)
+        _lib.check(_lib.load().mi_gpt_generate(
+            self._h, p.ctypes.data, p.shape[1], max_new, stops.ctypes.data if stops.size else None, stops.size,
+            float(c.repeat_penalty if repeat_value is None else repeat_value),
+            int(c.penalty_range if penalty_range is None else penalty_range), pen.ctypes.data, toks.ctypes.data,
+            hid.ctypes.data, C.byref(n), _lib.MI_HOST), "mi_gpt_generate")
+        if repeat_penality is None:
+            self.repeat_penality = pen
+        return toks[: n.value].copy(), hid[: n.value].copy(), pen
+
+    def generate(self, conds_latent, text_ids, *, max_generate_length=None, **kw):
+        """Inference_IndexTTS_ONNX.py:723-783 for one sentence: B, C, D then E until a stop token or
+        MAX_GENERATE_LENGTH - concat_len tokens.  Returns (tokens, save_last_hidden_state (n, hidden), penalty)."""
+        c = self.cfg
+        text_h = self.text_embed(text_ids)
+        mel_h, _ = self.mel_embed(c.start_mel_token, 0)
+        prompt, concat_len = self.concat(np.asarray(conds_latent, np.float32), text_h, mel_h)
+        limit = (c.max_generate_length if max_generate_length is None else int(max_generate_length)) - int(concat_len[0])
+        return self.generate_from_prompt(prompt, limit, **kw)
