@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py — headline benchmark of the MI355X-native TTS hot path.
 
-    python bench.py --gpus N --steps K --warmup W [--workload bigvgan|f5]
+    python bench.py --gpus N --steps K --warmup W [--workload bigvgan|f5|indextts_f|indextts]
 
 Workload (BASELINE.json configs[1]): BigVGAN-v2 24khz_100band_256x, fp16 HIP vocoder, mel (8,100,512)
 per GPU, synthetic seeded weights and mel already resident in HBM.  One step = one vocoder pass over
@@ -218,9 +218,139 @@ def run_f5(args, world, rank, local, dev, dist, torch):
     eng.close()
 
 
+def run_indextts(args, world, rank, local, dev, dist, torch):
+    """BASELINE configs[4] minus graph A: one sentence = GPT-2 prompt pass + greedy mel-code decode (graphs B/C/D/E and
+    the loop, Inference_IndexTTS_ONNX.py:723-783) + the speaker-conditioned BigVGAN (graph F, :787).  conds_latent and
+    the vocoder conditioning vectors (graph A's outputs) are synthetic."""
+    from mi355tts.config import IndexGPTConfig, BigVGANConfig
+    from mi355tts import weights as W
+    from mi355tts import _lib
+    from mi355tts.indextts import IndexGPT
+    from mi355tts.bigvgan import BigVGANVocoder
+    gcfg, vcfg = IndexGPTConfig(), BigVGANConfig.indextts()
+    gspec, vspec = W.gpt_spec(gcfg), W.bigvgan_spec(vcfg)
+    ng = sum(int(np.prod(sh)) for _, sh, _ in gspec)
+    nv = sum(int(np.prod(sh)) for _, sh, _ in vspec)
+    graw = None
+    if rank == 0:
+        graw = W.synth_state(gspec, 9527, fast=True)
+        blob_t = torch.from_numpy(np.concatenate([W.pack_gpt(gcfg, graw),
+                                                  W.pack_bigvgan(vcfg, W.synth_state(vspec, 9527, fast=True))])).to(dev)
+    else:
+        blob_t = torch.empty(ng + nv, dtype=torch.float32, device=dev)
+    bcast_ms = 0.0
+    if world > 1:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dist.broadcast(blob_t, src=0)
+        torch.cuda.synchronize()
+        bcast_ms = (time.perf_counter() - t0) * 1e3
+    blob = blob_t.cpu().numpy()
+    del blob_t
+    gpt = IndexGPT(gcfg, blob=blob[:ng], dtype=args.dtype, device=local)
+    voc = BigVGANVocoder(vcfg, blob=blob[ng:], dtype=args.dtype, device=local)
+    del blob
+    n_text, n_cond, n_tok = 30, 32, args.tokens
+    text = (np.arange(n_text, dtype=np.int32) * 37 + 11 * rank) % (gcfg.text_tokens - 2) + 2
+    conds = W.synth_normal_fast(100 + rank, "conds_latent", (1, n_cond, gcfg.hidden), std=0.5)
+    mel_h, _ = gpt.mel_embed(gcfg.start_mel_token, 0)
+    prompt_np, concat_len = gpt.concat(conds, gpt.text_embed(text), mel_h)
+    P = int(concat_len[0])
+    prompt = torch.from_numpy(prompt_np[0]).to(dev)
+    toks = torch.zeros((n_tok,), dtype=torch.int32, device=dev)
+    hid = torch.zeros((n_tok, gcfg.hidden), dtype=torch.float32, device=dev)
+    ncond = vcfg.upsample_initial_channel + sum(vcfg.stage_channels(i) for i in range(vcfg.num_upsamples))
+    vconds = torch.from_numpy(W.synth_normal_fast(100 + rank, "conds", (ncond,), std=0.2)).to(dev)
+    wav = torch.empty((1, 1, (n_tok - 2) * vcfg.hop + 30), dtype=torch.int16, device=dev)
+    audio_s = wav.shape[-1] / vcfg.sampling_rate
+
+    def step():
+        # stop_tokens=[]: a fixed amount of work per sentence (random weights never emit the stop code on cue)
+        n = gpt.generate_torch(prompt, n_tok, toks, hid, stop_tokens=[])
+        assert n == n_tok
+        voc.run_latent_torch(hid, vconds, wav)
+
+    for _ in range(max(args.warmup, 2)):
+        step()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    # GPT leg alone (same state), then the roofline leg: one eager pass with HIP events around every GEMV / GEMM launch
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    gpt.generate_torch(prompt, n_tok, toks, hid, stop_tokens=[])
+    torch.cuda.synchronize()
+    gpt_s = time.perf_counter() - t1
+    _lib.prof_reset()
+    _lib.prof_enable(["conv_gemm", "attn"])
+    gpt.generate_torch(prompt, n_tok, toks, hid, stop_tokens=[])
+    torch.cuda.synchronize()
+    _lib.prof_enable(())
+    pg, pa = _lib.prof_get("conv_gemm"), _lib.prof_get("attn")
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank != 0:
+        gpt.close(); voc.close()
+        return
+    esz = 4 if args.dtype == "f32" else 2
+    achieved = pg["bytes"] / (pg["ms"] * 1e-3) / 1e9 if pg["ms"] > 0 else 0.0
+    wbytes = (gcfg.layers * 12 * gcfg.hidden * gcfg.hidden + gcfg.mel_codes * gcfg.hidden) * esz
+    line = {
+        "metric": "audio_seconds_per_second", "value": world * audio_s * args.steps / dt, "unit": "audio-s/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"IndexTTS-1.5 {args.dtype}: GPT-2 (24 x 1280, 20 heads) prompt pass of {P} rows + greedy decode of "
+                               f"{n_tok} mel codes + BigVGAN graph F, one sentence per GPU per step (BASELINE configs[4] "
+                               f"without graph A: conds_latent / speaker conditioning synthetic)",
+                   "tokens": n_tok, "prompt_rows": P, "audio_seconds_per_step_per_gpu": audio_s,
+                   "rtf": dt / args.steps / audio_s, "gpt_leg_ms": gpt_s * 1e3, "decode_tokens_per_s": n_tok / gpt_s,
+                   "weight_bytes_streamed_per_token_GB": wbytes / 1e9,
+                   "decode_weight_stream_GBps": wbytes * n_tok / gpt_s / 1e9,
+                   "weights": "synthetic seeded (510 M GPT + vocoder)", "weight_bcast_ms": bcast_ms},
+        "roofline": {"bound": "hbm", "kernel": "gemv_kernel (decode-step linear layers: weights streamed once per token)",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "launches_per_step": pg["launches"], "avg_launch_ms": pg["ms"] / max(pg["launches"], 1),
+                     "family_ms_per_step": pg["ms"], "attn_ms_per_step": pa["ms"],
+                     "note": "event-timed in a separate eager pass (the timed region replays a hipGraph per token); the "
+                             "family also holds the prompt pass's 4 x 24 MFMA GEMM launches"},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import gpt_np as O
+        n_cpu = 6
+        folds = [O.fold_layer(gcfg, graw, i) for i in range(gcfg.layers)]
+        keys = [np.zeros((gcfg.heads, 64, 0), np.float32)] * gcfg.layers
+        vals = [np.zeros((gcfg.heads, 0, 64), np.float32)] * gcfg.layers
+        pen = np.ones((1, gcfg.mel_codes), np.float32)
+        t2 = time.perf_counter()
+        keys, vals, kvl, last, tok, _ = O.graph_e(gcfg, graw, keys, vals, 0, pen, P, prompt_np, 1, folds)
+        gl = np.array([1])
+        for _ in range(n_cpu - 1):
+            hs, gl = O.graph_c(gcfg, graw, tok, gl)
+            keys, vals, kvl, last, tok, _ = O.graph_e(gcfg, graw, keys, vals, int(kvl[0]), pen, 1, hs, 0, folds)
+        cpu_s = time.perf_counter() - t2
+        line["cpu_baseline"] = {"value": n_cpu * vcfg.hop / vcfg.sampling_rate / cpu_s, "unit": "audio-s/s",
+                                "cores": os.cpu_count(), "kind": "port",
+                                "sample": f"numpy oracle, fp32: prompt pass of {P} rows + {n_cpu - 1} decode steps of the "
+                                          f"same GPT (graph E only, no vocoder leg), {cpu_s:.1f} s; audio = tokens x 1024 / 24 kHz"}
+    print(json.dumps(line), flush=True)
+    gpt.close(); voc.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="bigvgan", choices=["bigvgan", "f5", "indextts_f"])
+    ap.add_argument("--tokens", type=int, default=256, help="indextts: mel codes decoded per sentence")
+    ap.add_argument("--workload", default="bigvgan", choices=["bigvgan", "f5", "indextts_f", "indextts"])
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=3)
@@ -260,6 +390,13 @@ def main():
         args.batch = 8 if args.workload == "bigvgan" else 1
     if args.dtype is None:
         args.dtype = "f16" if args.workload == "bigvgan" else "bf16"
+    if args.workload == "indextts":
+        if args.dtype == "bf16" and "--dtype" not in " ".join(sys.argv):
+            args.dtype = "f16"
+        run_indextts(args, world, rank, local, dev, dist, torch)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     if args.workload == "f5":
         run_f5(args, world, rank, local, dev, dist, torch)
         if world > 1:

@@ -81,7 +81,7 @@ def graph_d(embed_x, embed_y, embed_z):
     return c, np.array([c.shape[1]], np.int64)
 
 
-def graph_e(cfg, st, keys, values, history_len, repeat_penality, ids_len, hidden_state, attention_mask):
+def graph_e(cfg, st, keys, values, history_len, repeat_penality, ids_len, hidden_state, attention_mask, folds=None):
     """IndexTTS_E.forward (:270-289).
 
     keys[i] (H, D, hist), values[i] (H, hist, D); hidden_state (1, ids_len, hidden); repeat_penality (1, codes);
@@ -97,7 +97,7 @@ def graph_e(cfg, st, keys, values, history_len, repeat_penality, ids_len, hidden
     out_k, out_v = [], []
     for i in range(cfg.layers):
         p = f"inference_model.transformer.h.{i}."
-        f = fold_layer(cfg, st, i)
+        f = folds[i] if folds is not None else fold_layer(cfg, st, i)     # (the export does this once, at build time)
         xn = layer_norm(hs, st[p + "ln_1.weight"], st[p + "ln_1.bias"], cfg.ln_eps)          # (1, ids, h)
         q = np.matmul(xn, f["wq"]) + f["bq"]                                                    # (H, ids, D)
         k = (np.matmul(xn, f["wk"]) + f["bk"]).transpose(0, 2, 1)                               # (H, D, ids)
@@ -142,8 +142,9 @@ def generate(cfg, st, conds_latent, text_ids, repeat_penality=None, max_generate
     toks, hid = [], []
     reset = 0
     n = 0
+    folds = [fold_layer(cfg, st, i) for i in range(cfg.layers)]
     while n < limit:
-        keys, values, kvl, last, tok, _ = graph_e(cfg, st, keys, values, hist, pen, ids_len, hs, flag)
+        keys, values, kvl, last, tok, _ = graph_e(cfg, st, keys, values, hist, pen, ids_len, hs, flag, folds)
         t = int(tok[0, 0])
         toks.append(t)
         hid.append(last)

@@ -95,3 +95,125 @@ def test_indextts_f_session_like_the_reference_call(tmp_path, golden_dir):
     feed[in_names[-1]] = onnxruntime.OrtValue.ortvalue_from_numpy(g["latent"], "cpu", 0)
     wav = sess.run_with_ort_values([sess.get_outputs()[0].name], feed)[0].numpy()
     assert np.abs(wav.astype(np.int32) - g["wav_i16"].astype(np.int32)).max() <= 3
+
+
+def test_indextts_gpt_driver_loop_through_facade(tmp_path, golden_dir):
+    """Inference_IndexTTS_ONNX.py:619-800 for one sentence with sessions B, C, D, E: same variable names and feed
+    bookkeeping as the reference driver; out_key/out_value OrtValues are fed straight back as in_key/in_value."""
+    from mi355tts.config import IndexGPTConfig
+    g = np.load(os.path.join(golden_dir, "indextts_gpt.npz"))
+    cfg = IndexGPTConfig.small()
+    wfile = tmp_path / "gpt_weights.npy"
+    np.save(wfile, W.pack_gpt(cfg, W.synth_state(W.gpt_spec(cfg), 9527)))
+    paths = {k: onnxruntime.save_model(str(tmp_path / f"{k}.mi355.json"), k, cfg, str(wfile), "f32")
+             for k in ("IndexTTS_B", "IndexTTS_C", "IndexTTS_D", "IndexTTS_E")}
+    device_type, DEVICE_ID = "cpu", 0
+    REPEAT_PENALITY, PENALITY_RANGE = float(g["gen_params"][0]), int(g["gen_params"][1])
+    STOP_TOKEN = [cfg.stop_mel_token]
+    ort_session_B = onnxruntime.InferenceSession(paths["IndexTTS_B"])
+    ort_session_C = onnxruntime.InferenceSession(paths["IndexTTS_C"])
+    ort_session_D = onnxruntime.InferenceSession(paths["IndexTTS_D"])
+    ort_session_E = onnxruntime.InferenceSession(paths["IndexTTS_E"])
+    in_name_B0, out_name_B0 = ort_session_B.get_inputs()[0].name, ort_session_B.get_outputs()[0].name
+    in_name_C = [a.name for a in ort_session_C.get_inputs()]
+    out_name_C = [a.name for a in ort_session_C.get_outputs()]
+    in_name_D = [a.name for a in ort_session_D.get_inputs()]
+    out_name_D = [a.name for a in ort_session_D.get_outputs()]
+    model_E_dtype = np.float16 if "float16" in ort_session_E._inputs_meta[0].type else np.float32
+    in_names_E = [a.name for a in ort_session_E.get_inputs()]
+    out_name_E = [a.name for a in ort_session_E.get_outputs()]
+    amount_of_outputs_E = len(out_name_E)
+    num_layers = (amount_of_outputs_E - 3) // 2
+    assert num_layers == cfg.layers and len(in_names_E) == 2 * num_layers + 5
+    num_layers_2 = num_layers * 2
+    last_input_indices_E, last_output_indices_E = len(in_names_E) - 1, amount_of_outputs_E - 1
+    second_last_output_indices_E = amount_of_outputs_E - 2
+    OV = onnxruntime.OrtValue.ortvalue_from_numpy
+    init_gpt_ids = OV(np.array([[cfg.start_mel_token]], dtype=np.int32), device_type, DEVICE_ID)
+    init_gen_len = OV(np.array([0], dtype=np.int64), device_type, DEVICE_ID)
+    init_ids_len_1 = OV(np.array([1], dtype=np.int64), device_type, DEVICE_ID)
+    init_history_len = OV(np.array([0], dtype=np.int64), device_type, DEVICE_ID)
+    init_attention_mask_0 = OV(np.array([0], dtype=np.int8), device_type, DEVICE_ID)
+    init_attention_mask_1 = OV(np.array([1], dtype=np.int8), device_type, DEVICE_ID)
+    m = ort_session_E._inputs_meta
+    init_past_keys_E = OV(np.zeros((m[0].shape[0], m[0].shape[1], 0), dtype=model_E_dtype), device_type, DEVICE_ID)
+    init_past_values_E = OV(np.zeros((m[num_layers].shape[0], 0, m[num_layers].shape[2]), dtype=model_E_dtype), device_type, DEVICE_ID)
+    repeat_penality = OV(np.ones((1, m[num_layers_2 + 1].shape[1]), dtype=model_E_dtype), device_type, DEVICE_ID)
+    input_feed_E = {in_names_E[last_input_indices_E]: init_attention_mask_1, in_names_E[num_layers_2]: init_history_len,
+                    in_names_E[num_layers_2 + 1]: repeat_penality}
+    for i in range(num_layers):
+        input_feed_E[in_names_E[i]] = init_past_keys_E
+    for i in range(num_layers, num_layers_2):
+        input_feed_E[in_names_E[i]] = init_past_values_E
+
+    conds_latent = OV(g["conds_latent"], device_type, DEVICE_ID)
+    text_ids = OV(g["text_ids"], device_type, DEVICE_ID)
+    text_hidden_state = ort_session_B.run_with_ort_values([out_name_B0], {in_name_B0: text_ids})[0]
+    gpt_hidden_state, gen_len = ort_session_C.run_with_ort_values(out_name_C, {in_name_C[0]: init_gpt_ids, in_name_C[1]: init_gen_len})
+    gpt_hidden_state, concat_len = ort_session_D.run_with_ort_values(
+        out_name_D, {in_name_D[0]: conds_latent, in_name_D[1]: text_hidden_state, in_name_D[2]: gpt_hidden_state})
+    np.testing.assert_allclose(gpt_hidden_state.numpy(), g["D_hidden"], atol=1e-6, rtol=0)
+    generate_limit = 13 + len(g["gen_tokens"]) - onnxruntime.OrtValue.numpy(concat_len)
+    input_feed_E[in_names_E[num_layers_2 + 2]] = concat_len
+    save_last_hidden_state, save_max_logits_ids = [], []
+    reset_penality = num_decode = 0
+    while num_decode < generate_limit:
+        input_feed_E[in_names_E[num_layers_2 + 3]] = gpt_hidden_state
+        all_outputs_E = ort_session_E.run_with_ort_values(out_name_E, input_feed_E)
+        max_logit_ids = onnxruntime.OrtValue.numpy(all_outputs_E[last_output_indices_E])
+        save_max_logits_ids.append(max_logit_ids)
+        save_last_hidden_state.append(all_outputs_E[second_last_output_indices_E])
+        num_decode += 1
+        if max_logit_ids in STOP_TOKEN:
+            break
+        if num_decode < 2:
+            input_feed_E[in_names_E[last_input_indices_E]] = init_attention_mask_0
+            input_feed_E[in_names_E[num_layers_2 + 2]] = init_ids_len_1
+        for i in range(second_last_output_indices_E):
+            input_feed_E[in_names_E[i]] = all_outputs_E[i]
+        repeat_penality = onnxruntime.OrtValue.numpy(repeat_penality)
+        repeat_penality[:, max_logit_ids] = REPEAT_PENALITY
+        if (num_decode > PENALITY_RANGE) and (save_max_logits_ids[reset_penality] != max_logit_ids):
+            repeat_penality[:, save_max_logits_ids[reset_penality]] = 1.0
+            reset_penality += 1
+        repeat_penality = OV(repeat_penality, device_type, DEVICE_ID)
+        input_feed_E[in_names_E[num_layers_2 + 1]] = repeat_penality
+        gpt_hidden_state, gen_len = ort_session_C.run_with_ort_values(
+            out_name_C, {in_name_C[0]: all_outputs_E[last_output_indices_E], in_name_C[1]: gen_len})
+    toks = [int(t.reshape(-1)[0]) for t in save_max_logits_ids]
+    assert toks == [int(x) for x in g["gen_tokens"]]
+    hid = np.concatenate([onnxruntime.OrtValue.numpy(h) for h in save_last_hidden_state], axis=0)
+    np.testing.assert_allclose(hid, g["gen_hidden"], atol=3e-4, rtol=0)
+    # the final cache can still be materialised in the reference's layouts
+    np.testing.assert_allclose(all_outputs_E[0].numpy(), g["gen_key0"], atol=3e-4, rtol=0)
+    np.testing.assert_allclose(all_outputs_E[num_layers + 1].numpy(), g["gen_value1"], atol=3e-4, rtol=0)
+    # next sentence: the empty caches are fed again (:796-800) -> history restarts
+    input_feed_E[in_names_E[last_input_indices_E]] = init_attention_mask_1
+    input_feed_E[in_names_E[num_layers_2]] = init_history_len
+    for i in range(num_layers):
+        input_feed_E[in_names_E[i]] = init_past_keys_E
+    for i in range(num_layers, num_layers_2):
+        input_feed_E[in_names_E[i]] = init_past_values_E
+    input_feed_E[in_names_E[num_layers_2 + 2]] = concat_len
+    input_feed_E[in_names_E[num_layers_2 + 3]] = OV(g["D_hidden"], device_type, DEVICE_ID)
+    input_feed_E[in_names_E[num_layers_2 + 1]] = OV(np.ones((1, cfg.mel_codes), np.float32), device_type, DEVICE_ID)
+    again = ort_session_E.run_with_ort_values(out_name_E, input_feed_E)
+    assert int(again[last_output_indices_E].numpy().reshape(-1)[0]) == int(g["gen_tokens"][0])
+    assert int(again[num_layers_2].numpy()[0]) == 13
+    # stale references are refused, numpy round trips work (plain .run materialises the cache)
+    with pytest.raises(onnxruntime.Fail):
+        all_outputs_E[0].numpy()
+    feed_np = {k: (v.numpy() if hasattr(v, "numpy") else v) for k, v in input_feed_E.items()}
+    outs = ort_session_E.run(None, feed_np)
+    assert outs[0].shape == (cfg.heads, cfg.head_dim, 13) and int(outs[-1].reshape(-1)[0]) == int(g["gen_tokens"][0])
+    # a history given as arrays (not references) is loaded into the cache: one more step from the golden mid-state
+    feed_np = {f"in_key_{i}": g["S_keys_in"][i] for i in range(num_layers)}
+    feed_np.update({f"in_value_{i}": g["S_values_in"][i] for i in range(num_layers)})
+    feed_np.update({"history_len": np.array([g["S_keys_in"].shape[3]], np.int64), "repeat_penality": g["S_pen"],
+                    "ids_len": np.array([1], np.int64), "hidden_state": g["S_hidden_in"],
+                    "attention_mask": np.array([0], np.int8)})
+    kv, last, tok = ort_session_E.run(["kv_seq_len", "last_hidden_state", "max_logit_id"], feed_np)
+    assert int(kv[0]) == g["S_keys_in"].shape[3] + 1 and int(tok[0, 0]) == int(g["S_token"][0, 0])
+    np.testing.assert_allclose(last, g["S_last_hidden"], atol=3e-4, rtol=0)
+    with pytest.raises(onnxruntime.InvalidArgument):
+        ort_session_E.run(None, {**feed_np, "ids_len": np.array([2], np.int64)})

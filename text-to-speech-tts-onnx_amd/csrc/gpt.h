@@ -54,6 +54,8 @@ struct Gpt {
     void kv_read(int layer, float* keys_dev, float* values_dev);
     void kv_write(int layer, const float* keys_dev, const float* values_dev, int hist);
     void linear(const GLin& l, const void* x, int rows, void* out, int odt, int act, const float* res);
+    void gemv(const GLin& l, const void* x, const float* ln_w, const float* ln_b, void* out, int odt, int act,
+              const float* res, void* kcl, void* vcl);
 };
 
 }  // namespace mi

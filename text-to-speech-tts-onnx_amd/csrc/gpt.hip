@@ -60,37 +60,130 @@ __device__ inline float gelu_new(float x) {
     return 0.5f * x * (1.f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));
 }
 
-// out[n] = act(dot(w[n, :], x) + bias[n]) (+ res[n]) ; one wave per two output rows, 16 bytes per lane per load.
-template <typename T>
+// shared epilogue of the GEMV kernels: lane r < R holds output row n0 + r
+template <typename T, int R, bool QKV>
+__device__ inline void gemv_store(float (&acc)[R], int lane, int n0, int N, const float* bias, const float* res, void* out,
+                                  int out_f32, int act, T* kc, T* vc, const int* st, int max_seq) {
+    if (lane < R && n0 + lane < N) {
+        const int n = n0 + lane;
+        float v = acc[0];
+#pragma unroll
+        for (int r = 1; r < R; ++r) v = lane == r ? acc[r] : v;
+        v += bias ? bias[n] : 0.f;
+        if (act == ACT_GELU_TANH) v = gelu_new(v);
+        if (res) v += res[n];
+        if (QKV) {
+            const int hidden = N / 3;
+            if (n >= hidden) {
+                const int c = n - hidden, which = c / hidden, cc = c % hidden;
+                const int pos = st[GS_HIST];
+                if (pos < max_seq) (which ? vc : kc)[((size_t)(cc >> 6) * max_seq + pos) * 64 + (cc & 63)] = (T)v;
+                return;
+            }
+        }
+        if (out_f32) ((float*)out)[n] = v; else ((T*)out)[n] = (T)v;
+    }
+}
+
+// out[n] = act(dot(w[n, :], x) + bias[n]) (+ res[n]) ; one wave per R output rows, 16 bytes per lane per load.
+template <typename T, int R>
 __global__ __launch_bounds__(256) void gemv_kernel(const T* __restrict__ w, const T* __restrict__ x,
                                                    const float* __restrict__ bias, const float* res, void* out,
                                                    int out_f32, int act, int N, int K) {
     constexpr int V = Pack16<T>::N;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int n0 = (blockIdx.x * 4 + wave) * 2;
+    const int n0 = (blockIdx.x * 4 + wave) * R;
     if (n0 >= N) return;
-    const bool two = n0 + 1 < N;
-    const T* w0 = w + (size_t)n0 * K;
-    const T* w1 = w0 + (two ? K : 0);
-    float a0 = 0.f, a1 = 0.f;
-    for (int k = lane * V; k < K; k += 64 * V) {
-        const Pack16<T> xv = ld16(x + k), p0 = ld16(w0 + k), p1 = ld16(w1 + k);
+    const T* wr[R];
 #pragma unroll
-        for (int e = 0; e < V; ++e) {
-            const float xe = (float)xv.v[e];
-            a0 = fmaf((float)p0.v[e], xe, a0);
-            a1 = fmaf((float)p1.v[e], xe, a1);
+    for (int r = 0; r < R; ++r) wr[r] = w + (size_t)min(n0 + r, N - 1) * K;
+    float acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.f;
+#pragma unroll 4
+    for (int k = lane * V; k < K; k += 64 * V) {
+        Pack16<T> p[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) p[r] = ld16(wr[r] + k);
+        const Pack16<T> xv = ld16(x + k);
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int e = 0; e < V; ++e) acc[r] = fmaf((float)p[r].v[e], (float)xv.v[e], acc[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
+    gemv_store<T, R, false>(acc, lane, n0, N, bias, res, out, out_f32, act, nullptr, nullptr, nullptr, 0);
+}
+
+// LayerNorm fused in front: x is the fp32 residual row (K = hidden <= 2048) and x' = LayerNorm(x) * ln_w + ln_b is formed
+// on the fly.  Every wave derives the row statistics itself (two-pass, from registers) — no extra launch, no block
+// barrier — and all of its weight / x / gamma / beta loads (KI compile-time iterations) are issued BEFORE the
+// statistics are reduced, so the HBM latency of the weight rows overlaps the reduction.
+//   QKV: rows [hidden, 3*hidden) go straight into the K / V cache row st[GS_HIST] of this layer.
+template <typename T, int R, int KI, bool QKV>
+__global__ __launch_bounds__(256) void gemv_ln_kernel(const T* __restrict__ w, const float* __restrict__ xf,
+                                                      const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                                      const float* __restrict__ bias, void* out, int out_f32, int act,
+                                                      int N, int K, T* __restrict__ kc, T* __restrict__ vc,
+                                                      const int* __restrict__ st, int max_seq) {
+    constexpr int V = Pack16<T>::N;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n0 = (blockIdx.x * 4 + wave) * R;
+    if (n0 >= N) return;
+    const T* wr[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) wr[r] = w + (size_t)min(n0 + r, N - 1) * K;
+    Pack16<T> p[KI][R];
+    float xe[KI][V], ge[KI][V], be[KI][V];
+#pragma unroll
+    for (int it = 0; it < KI; ++it) {
+        const int k = lane * V + it * 64 * V;
+        const bool ok = k < K;
+        const int kk = ok ? k : 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) p[it][r] = ld16(wr[r] + kk);
+#pragma unroll
+        for (int e = 0; e < V; e += 4) {
+            const float4 v = *(const float4*)(xf + kk + e), g = *(const float4*)(ln_w + kk + e), bb = *(const float4*)(ln_b + kk + e);
+            xe[it][e] = v.x; xe[it][e + 1] = v.y; xe[it][e + 2] = v.z; xe[it][e + 3] = v.w;
+            ge[it][e] = ok ? g.x : 0.f; ge[it][e + 1] = ok ? g.y : 0.f; ge[it][e + 2] = ok ? g.z : 0.f; ge[it][e + 3] = ok ? g.w : 0.f;
+            be[it][e] = ok ? bb.x : 0.f; be[it][e + 1] = ok ? bb.y : 0.f; be[it][e + 2] = ok ? bb.z : 0.f; be[it][e + 3] = ok ? bb.w : 0.f;
+        }
+        if (!ok) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) xe[it][e] = 0.f;
         }
     }
-    a0 = wave_sum(a0);
-    a1 = wave_sum(a1);
-    if (lane < (two ? 2 : 1)) {
-        const int n = n0 + lane;
-        float v = (lane ? a1 : a0) + (bias ? bias[n] : 0.f);
-        if (act == ACT_GELU_TANH) v = gelu_new(v);
-        if (res) v += res[n];
-        if (out_f32) ((float*)out)[n] = v; else ((T*)out)[n] = (T)v;
+    // statistics over exactly the elements this wave holds (each x element is held once across the wave)
+    float sum = 0.f;
+#pragma unroll
+    for (int it = 0; it < KI; ++it)
+#pragma unroll
+        for (int e = 0; e < V; ++e) sum += xe[it][e];
+    const float mean = wave_sum(sum) / (float)K;
+    float sq = 0.f;
+#pragma unroll
+    for (int it = 0; it < KI; ++it) {
+        const bool ok = lane * V + it * 64 * V < K;
+#pragma unroll
+        for (int e = 0; e < V; ++e) { const float d = ok ? xe[it][e] - mean : 0.f; sq = fmaf(d, d, sq); }
     }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)K + 1e-5f);
+    float acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int it = 0; it < KI; ++it)
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const float xn = (xe[it][e] - mean) * rstd * ge[it][e] + be[it][e];     // padded lanes: g = b = 0 -> 0
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] = fmaf((float)p[it][r].v[e], xn, acc[r]);
+        }
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
+    gemv_store<T, R, QKV>(acc, lane, n0, N, bias, nullptr, out, out_f32, act, kc, vc, st, max_seq);
 }
 
 // rows of (q | k | v) -> K / V cache rows hist .. hist+rows-1 of one layer
@@ -363,26 +456,56 @@ void Gpt::reset() {
 }
 
 void Gpt::linear(const GLin& l, const void* x, int rows, void* out, int odt, int act, const float* res) {
-    if (rows == 1) {
-        MI_REQUIRE(l.k % 8 == 0, "gemv: K must be a multiple of 8");
-        const dim3 grid((unsigned)((l.n + 7) / 8));
-        ProfScope ps(FAM_CONV_GEMM, stream, (double)l.n * l.k * dtype_size(dtype), 2.0 * l.n * l.k);
-        const int of = odt == MI_F32;
-        MI_REQUIRE(of || odt == dtype, "gemv: output dtype");
-        if (dtype == MI_F32)
-            hipLaunchKernelGGL(gemv_kernel<float>, grid, dim3(256), 0, stream, l.w.as<float>(), (const float*)x, l.b.as<float>(), res, out, of, act, l.n, l.k);
-        else if (dtype == MI_F16)
-            hipLaunchKernelGGL(gemv_kernel<f16>, grid, dim3(256), 0, stream, l.w.as<f16>(), (const f16*)x, l.b.as<float>(), res, out, of, act, l.n, l.k);
-        else
-            hipLaunchKernelGGL(gemv_kernel<bf16>, grid, dim3(256), 0, stream, l.w.as<bf16>(), (const bf16*)x, l.b.as<float>(), res, out, of, act, l.n, l.k);
-        MI_HIP(hipGetLastError());
-        return;
-    }
+    MI_REQUIRE(rows > 1, "gpt: linear() is the multi-row path");
     ConvGemm g;
     g.dtype = dtype; g.out_dtype = odt; g.x = x; g.w = l.w.p; g.bias = l.b.as<float>(); g.out = out; g.res = res;
     g.B = 1; g.T_in = rows; g.M = rows; g.N = l.n; g.Cin = l.k; g.taps = 1;
     g.x_bstride = (long)rows * l.k; g.x_rstride = l.k; g.out_bstride = (long)rows * l.n; g.out_rstride = l.n; g.act = act;
     launch_conv_gemm(g, stream);
+}
+
+// single-row linear layer: weight-streaming GEMV.  ln_w != nullptr: x is the fp32 residual row, LayerNorm fused in.
+// kcl != nullptr: QKV epilogue (k and v rows go to the cache).
+void Gpt::gemv(const GLin& l, const void* x, const float* ln_w, const float* ln_b, void* out, int odt, int act,
+               const float* res, void* kcl, void* vcl) {
+    MI_REQUIRE(l.k % 8 == 0, "gemv: K must be a multiple of 8");
+    const int of = odt == MI_F32;
+    MI_REQUIRE(of || odt == dtype, "gemv: output dtype");
+    MI_REQUIRE(!kcl || ln_w, "gemv: the QKV epilogue comes with the fused LayerNorm");
+    MI_REQUIRE(!ln_w || !res, "gemv: the fused-LayerNorm variant has no residual input");
+    // rows per wave: 2 when there are enough rows to fill the chip twice over, else 1 (more waves in flight)
+    const int R = l.n >= 4096 ? 2 : 1;
+    const dim3 grid((unsigned)((l.n + 4 * R - 1) / (4 * R)));
+    ProfScope ps(FAM_CONV_GEMM, stream, (double)l.n * l.k * dtype_size(dtype), 2.0 * l.n * l.k);
+    const int* st = state.as<int>();
+    const int V = 16 / (int)dtype_size(dtype);
+    const int KI = (l.k + 64 * V - 1) / (64 * V);
+    if (ln_w) {
+        MI_REQUIRE(KI <= 8, "gemv: fused LayerNorm supports K <= 2048");
+#define GL(T, RR, KK, QK) hipLaunchKernelGGL((gemv_ln_kernel<T, RR, KK, QK>), grid, dim3(256), 0, stream, (const T*)l.w.p, (const float*)x, ln_w, ln_b, l.b.as<float>(), out, of, act, l.n, l.k, (T*)kcl, (T*)vcl, st, cfg.max_seq)
+#define GL_K(T, RR, QK)                                                                   \
+    do {                                                                                  \
+        if (KI <= 1) GL(T, RR, 1, QK); else if (KI == 2) GL(T, RR, 2, QK);                 \
+        else if (KI == 3) GL(T, RR, 3, QK); else if (KI == 4) GL(T, RR, 4, QK);            \
+        else if (KI <= 6) GL(T, RR, 6, QK); else GL(T, RR, 8, QK);                          \
+    } while (0)
+#define GL_T(T)                                                                           \
+    do {                                                                                  \
+        if (kcl) { if (R == 2) GL_K(T, 2, true); else GL_K(T, 1, true); }                  \
+        else { if (R == 2) GL_K(T, 2, false); else GL_K(T, 1, false); }                    \
+    } while (0)
+        if (dtype == MI_F32) GL_T(float); else if (dtype == MI_F16) GL_T(f16); else GL_T(bf16);
+#undef GL_T
+#undef GL_K
+#undef GL
+    } else {
+#define GV(T, RR) hipLaunchKernelGGL((gemv_kernel<T, RR>), grid, dim3(256), 0, stream, (const T*)l.w.p, (const T*)x, l.b.as<float>(), res, out, of, act, l.n, l.k)
+#define GV_T(T) do { if (R == 2) GV(T, 2); else GV(T, 1); } while (0)
+        if (dtype == MI_F32) GV_T(float); else if (dtype == MI_F16) GV_T(f16); else GV_T(bf16);
+#undef GV_T
+#undef GV
+    }
+    MI_HIP(hipGetLastError());
 }
 
 #define GPT_DISPATCH(KERNEL, ...)                                                     \
@@ -405,9 +528,11 @@ void Gpt::forward_rows(int rows, int flag) {
         Layer& l = L[li];
         char* kcl = (char*)kc.p + (size_t)li * h * S * es;
         char* vcl = (char*)vc.p + (size_t)li * h * S * es;
-        launch_rownorm(NORM_LN_AFFINE, x, xn.p, dtype, l.ln1_w.as<float>(), l.ln1_b.as<float>(), rows, h, 1e-5f, s);
-        linear(l.qkv, xn.p, rows, qkv.p, dtype, ACT_NONE, nullptr);
-        {
+        if (rows == 1) {
+            gemv(l.qkv, x, l.ln1_w.as<float>(), l.ln1_b.as<float>(), qkv.p, dtype, ACT_NONE, nullptr, kcl, vcl);
+        } else {
+            launch_rownorm(NORM_LN_AFFINE, x, xn.p, dtype, l.ln1_w.as<float>(), l.ln1_b.as<float>(), rows, h, 1e-5f, s);
+            linear(l.qkv, xn.p, rows, qkv.p, dtype, ACT_NONE, nullptr);
             const long items = (long)rows * (2 * h / 8);
             const dim3 grid((unsigned)((items + 255) / 256));
 #define KVA(T, ...) hipLaunchKernelGGL(kv_append_kernel<T>, grid, dim3(256), 0, s, (const T*)qkv.p, (T*)kcl, (T*)vcl, st, rows, h, S)
@@ -420,15 +545,20 @@ void Gpt::forward_rows(int rows, int flag) {
             GPT_DISPATCH(ATT, 0);
 #undef ATT
         }
-        linear(l.proj, att.p, rows, x, MI_F32, ACT_NONE, x);
-        launch_rownorm(NORM_LN_AFFINE, x, xn.p, dtype, l.ln2_w.as<float>(), l.ln2_b.as<float>(), rows, h, 1e-5f, s);
-        linear(l.fc, xn.p, rows, ff.p, dtype, ACT_GELU_TANH, nullptr);
-        linear(l.fc2, ff.p, rows, x, MI_F32, ACT_NONE, x);
+        if (rows == 1) {
+            gemv(l.proj, att.p, nullptr, nullptr, x, MI_F32, ACT_NONE, x, nullptr, nullptr);
+            gemv(l.fc, x, l.ln2_w.as<float>(), l.ln2_b.as<float>(), ff.p, dtype, ACT_GELU_TANH, nullptr, nullptr, nullptr);
+            gemv(l.fc2, ff.p, nullptr, nullptr, x, MI_F32, ACT_NONE, x, nullptr, nullptr);
+        } else {
+            linear(l.proj, att.p, rows, x, MI_F32, ACT_NONE, x);
+            launch_rownorm(NORM_LN_AFFINE, x, xn.p, dtype, l.ln2_w.as<float>(), l.ln2_b.as<float>(), rows, h, 1e-5f, s);
+            linear(l.fc, xn.p, rows, ff.p, dtype, ACT_GELU_TANH, nullptr);
+            linear(l.fc2, ff.p, rows, x, MI_F32, ACT_NONE, x);
+        }
     }
     const float* xl = x + (size_t)(rows - 1) * h;
     launch_rownorm(NORM_LN_AFFINE, xl, last.p, MI_F32, lnf_w.as<float>(), lnf_b.as<float>(), 1, h, 1e-5f, s);
-    launch_rownorm(NORM_LN_AFFINE, last.as<float>(), z.p, dtype, fn_w.as<float>(), fn_b.as<float>(), 1, h, 1e-5f, s);
-    linear(head, z.p, 1, logits.p, MI_F32, ACT_NONE, nullptr);
+    gemv(head, last.p, fn_w.as<float>(), fn_b.as<float>(), logits.p, MI_F32, ACT_NONE, nullptr, nullptr, nullptr);
     hipLaunchKernelGGL(gpt_pick_kernel, dim3(1), dim3(1024), 0, s, logits.as<float>(), pen.as<float>(), last.as<float>(),
                        state.as<int>(), toks.as<int>(), hid.as<float>(), c.mel_codes, h, rows, rep_value, S);
     MI_HIP(hipGetLastError());

@@ -157,6 +157,29 @@ class IndexGPT:
             self.repeat_penality = pen
         return toks[: n.value].copy(), hid[: n.value].copy(), pen
 
+    def generate_torch(self, prompt, max_new: int, tokens, hidden, *, stop_tokens=None, repeat_value=None,
+                       penalty_range=None, repeat_penality=None) -> int:
+        """Device-resident variant: prompt (P, hidden) float32 CUDA tensor; tokens (>= max_new) int32 and hidden
+        (>= max_new, hidden) float32 CUDA tensors are filled; repeat_penality (mel_codes) float32 CUDA tensor or None
+        (= ones, not written back).  Returns the number of tokens produced."""
+        import ctypes as C
+        import torch
+        c = self.cfg
+        assert prompt.is_cuda and prompt.dtype == torch.float32 and prompt.is_contiguous() and prompt.shape[-1] == c.hidden
+        assert tokens.is_cuda and tokens.dtype == torch.int32 and tokens.numel() >= max_new
+        assert hidden.is_cuda and hidden.dtype == torch.float32 and hidden.is_contiguous() and hidden.shape[0] >= max_new
+        stops = [c.stop_mel_token] if stop_tokens is None else list(stop_tokens)
+        st = torch.tensor(stops, dtype=torch.int32, device=prompt.device) if stops else None
+        torch.cuda.current_stream(prompt.device).synchronize()
+        n = C.c_int32(0)
+        _lib.check(_lib.load().mi_gpt_generate(
+            self._h, prompt.data_ptr(), prompt.shape[-2], int(max_new), st.data_ptr() if st is not None else None,
+            len(stops), float(c.repeat_penalty if repeat_value is None else repeat_value),
+            int(c.penalty_range if penalty_range is None else penalty_range),
+            repeat_penality.data_ptr() if repeat_penality is not None else None, tokens.data_ptr(), hidden.data_ptr(),
+            C.byref(n), _lib.MI_DEVICE), "mi_gpt_generate")
+        return int(n.value)
+
     def generate(self, conds_latent, text_ids, *, max_generate_length=None, **kw):
         """Inference_IndexTTS_ONNX.py:723-783 for one sentence: B, C, D then E until a stop token or
         MAX_GENERATE_LENGTH - concat_len tokens.  Returns (tokens, save_last_hidden_state (n, hidden), penalty)."""

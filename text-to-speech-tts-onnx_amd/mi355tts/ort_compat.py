@@ -141,6 +141,9 @@ def _engine(kind: str, cfg, wfile: str, dtype: str, device: int):
         if kind == "f5":
             from .f5 import F5Engine
             _ENGINES[key] = F5Engine(cfg, blob=np.asarray(blob), dtype=dtype, device=device)
+        elif kind == "gpt":
+            from .indextts import IndexGPT
+            _ENGINES[key] = IndexGPT(cfg, blob=np.asarray(blob), dtype=dtype, device=device)
         else:
             from .bigvgan import BigVGANVocoder
             _ENGINES[key] = BigVGANVocoder(cfg, blob=np.asarray(blob), dtype=dtype, device=device)
@@ -162,6 +165,29 @@ def _graph_io(graph: str, cfg, dtype: str):
         ins.append(NodeArg("bigvgan_cond_layer_speaker_embedding", "tensor(float)", [1, cfg.upsample_initial_channel, 1]))
         ins.append(NodeArg("save_hidden_state", "tensor(float)", ["kv_seq_len", cfg.num_mels]))
         return ins, [NodeArg("generated_wav", "tensor(int16)", [1, 1, "generated_len"])]
+    if graph in _GPT_GRAPHS:           # IndexTTS/Export_IndexTTS.py:352-482
+        ft, h = "tensor(float)", cfg.hidden
+        if graph == "IndexTTS_B":
+            return ([NodeArg("text_ids", "tensor(int32)", [1, "text_ids_len"])],
+                    [NodeArg("text_hidden_state", ft, [1, "text_ids_len_plus_2", h])])
+        if graph == "IndexTTS_C":
+            return ([NodeArg("gpt_ids", "tensor(int32)", [1, 1]), NodeArg("kv_seq_len", "tensor(int64)", [1])],
+                    [NodeArg("gpt_hidden_state", ft, [1, 1, h]), NodeArg("next_kv_seq_len", "tensor(int64)", [1])])
+        if graph == "IndexTTS_D":
+            return ([NodeArg("embed_x", ft, [1, "embed_x_len", h]), NodeArg("embed_y", ft, [1, "embed_y_len", h]),
+                     NodeArg("embed_z", ft, [1, "embed_z_len", h])],
+                    [NodeArg("concat_hidden_state", ft, [1, "concat_len", h]), NodeArg("concat_len", "tensor(int64)", [1])])
+        L, H, D = cfg.layers, cfg.heads, cfg.head_dim
+        ins = [NodeArg(f"in_key_{i}", ft, [H, D, "history_len"]) for i in range(L)]
+        ins += [NodeArg(f"in_value_{i}", ft, [H, "history_len", D]) for i in range(L)]
+        ins += [NodeArg("history_len", "tensor(int64)", [1]), NodeArg("repeat_penality", ft, [1, cfg.mel_codes]),
+                NodeArg("ids_len", "tensor(int64)", [1]), NodeArg("hidden_state", ft, [1, "ids_len", h]),
+                NodeArg("attention_mask", "tensor(int8)", [1])]
+        outs = [NodeArg(f"out_key_{i}", ft, [H, D, "history_len_plus_ids_len"]) for i in range(L)]
+        outs += [NodeArg(f"out_value_{i}", ft, [H, "history_len_plus_ids_len", D]) for i in range(L)]
+        outs += [NodeArg("kv_seq_len", "tensor(int64)", [1]), NodeArg("last_hidden_state", ft, [1, h]),
+                 NodeArg("max_logit_id", "tensor(int32)", [1, 1])]
+        return ins, outs
     H, D, M, cd = cfg.heads, cfg.dim_head, cfg.mel_dim, cfg.mel_dim + cfg.text_dim
     ft = "tensor(float)"          # the engine keeps graph I/O in fp32 whatever the DiT operand dtype
     cond = [NodeArg("noise", ft, [1, "max_duration", M]), NodeArg("rope_cos_q", ft, [2, H, "max_duration", D]),
@@ -180,7 +206,35 @@ def _graph_io(graph: str, cfg, dtype: str):
     raise InvalidArgument(graph)
 
 
-_GRAPHS = ("BigVGAN", "IndexTTS_F", "F5_Preprocess", "F5_Transformer", "F5_Decode")
+_GPT_GRAPHS = ("IndexTTS_B", "IndexTTS_C", "IndexTTS_D", "IndexTTS_E")
+_GRAPHS = ("BigVGAN", "IndexTTS_F", "F5_Preprocess", "F5_Transformer", "F5_Decode") + _GPT_GRAPHS
+
+
+class _KVRef(OrtValue):
+    """out_key_i / out_value_i of graph E: a reference to the cache held by the engine instead of a copy (the
+    reference round-trips 2 * layers growing tensors through every call, Inference_IndexTTS_ONNX.py:765-766).  Fed back
+    as in_key_i / in_value_i it costs nothing; ``.numpy()`` materialises it while it is still current."""
+
+    def __init__(self, sess, layer: int, is_value: bool, length: int, epoch: int):
+        self._s, self._layer, self._is_value, self._len, self._epoch = sess, layer, is_value, length, epoch
+        self._device, self._device_id = "cpu", 0
+
+    def current(self) -> bool:
+        return self._epoch == self._s._kv_epoch and self._len == self._s._eng.history_len
+
+    def numpy(self) -> np.ndarray:
+        if not self.current():
+            raise Fail("this out_key/out_value refers to a KV-cache state the session has moved past")
+        k, v = self._s._eng.kv_read(self._layer)
+        return v if self._is_value else k
+
+    @property
+    def _arr(self):
+        return self.numpy()
+
+    def shape(self):
+        c = self._s._cfg
+        return [c.heads, self._len, c.head_dim] if self._is_value else [c.heads, c.head_dim, self._len]
 
 
 class InferenceSession:
@@ -204,10 +258,15 @@ class InferenceSession:
                 c[k] = tuple(c[k])
             c["resblock_dilation_sizes"] = tuple(tuple(d) for d in c["resblock_dilation_sizes"])
             self._cfg = BigVGANConfig(**c)
+        elif self._graph in _GPT_GRAPHS:
+            from .config import IndexGPTConfig
+            self._cfg = IndexGPTConfig(**c)
         else:
             self._cfg = F5Config(**c)
         wfile = os.path.join(os.path.dirname(os.path.abspath(path_or_bytes)), man["weights"])
-        self._eng = _engine("bigvgan" if self._graph in ("BigVGAN", "IndexTTS_F") else "f5", self._cfg, wfile, self._dtype, device)
+        kind = "bigvgan" if self._graph in ("BigVGAN", "IndexTTS_F") else "gpt" if self._graph in _GPT_GRAPHS else "f5"
+        self._eng = None if self._graph == "IndexTTS_D" else _engine(kind, self._cfg, wfile, self._dtype, device)
+        self._kv_epoch = 0
         self._inputs, self._outputs = _graph_io(self._graph, self._cfg, self._dtype)
         self._inputs_meta, self._outputs_meta = self._inputs, self._outputs
 
@@ -225,7 +284,7 @@ class InferenceSession:
         return IOBinding(self)
 
     # ---- execution ----------------------------------------------------------------------------------
-    def run(self, output_names, input_feed: Dict[str, np.ndarray], run_options=None):
+    def run(self, output_names, input_feed: Dict[str, np.ndarray], run_options=None, _keep_refs: bool = False):
         names = [o.name for o in self._outputs]
         want = list(output_names) if output_names else names
         for n in want:
@@ -238,10 +297,16 @@ class InferenceSession:
         extra = [n for n in input_feed if n not in need]
         if extra:
             raise InvalidArgument(f"Invalid input name: {extra[0]}")
+        if self._graph == "IndexTTS_E":
+            res = self._run_gpt_e(input_feed)
+            return [res[n] if _keep_refs or not isinstance(res[n], OrtValue) else res[n].numpy() for n in want]
         res = self._run(input_feed)
         return [res[n] for n in want]
 
     def run_with_ort_values(self, output_names, input_feed: Dict[str, OrtValue], run_options=None):
+        if self._graph == "IndexTTS_E":            # KV tensors stay references
+            outs = self.run(output_names, dict(input_feed), _keep_refs=True)
+            return [o if isinstance(o, OrtValue) else OrtValue(o) for o in outs]
         outs = self.run(output_names, {k: v.numpy() for k, v in input_feed.items()})
         return [OrtValue(o) for o in outs]
 
@@ -267,8 +332,56 @@ class InferenceSession:
             raise InvalidArgument(f"Invalid rank for input: {name} Got: {a.ndim} Expected: {ndim}")
         return a
 
+    def _run_gpt_e(self, feed):
+        """graph E (IndexTTS/Export_IndexTTS.py:270-289).  Feed values are numpy arrays, OrtValues or the _KVRef
+        objects a previous call returned."""
+        e, c = self._eng, self._cfg
+        val = lambda x: x.numpy() if isinstance(x, OrtValue) and not isinstance(x, _KVRef) else x
+        hs = np.asarray(val(feed["hidden_state"]))
+        if hs.dtype != np.float32 or hs.ndim != 3:
+            raise InvalidArgument("hidden_state must be a rank-3 float tensor")
+        ids_len = int(np.asarray(val(feed["ids_len"])).reshape(-1)[0])
+        hist = int(np.asarray(val(feed["history_len"])).reshape(-1)[0])
+        if ids_len != hs.shape[1]:
+            raise InvalidArgument(f"ids_len ({ids_len}) does not match hidden_state rows ({hs.shape[1]})")
+        flag = int(np.asarray(val(feed["attention_mask"])).reshape(-1)[0])
+        pen = np.asarray(val(feed["repeat_penality"]), dtype=np.float32)
+        k0 = feed["in_key_0"]
+        if isinstance(k0, _KVRef):
+            refs = [feed[f"in_key_{i}"] for i in range(c.layers)] + [feed[f"in_value_{i}"] for i in range(c.layers)]
+            if not all(isinstance(r, _KVRef) and r._s is self and r.current() for r in refs):
+                raise Fail("in_key/in_value references are stale (not the outputs of this session's latest call)")
+            if hist != e.history_len:
+                raise InvalidArgument(f"history_len ({hist}) does not match the cache ({e.history_len})")
+        else:
+            keys = [np.asarray(val(feed[f"in_key_{i}"])) for i in range(c.layers)]
+            vals = [np.asarray(val(feed[f"in_value_{i}"])) for i in range(c.layers)]
+            if keys[0].ndim != 3 or keys[0].shape[2] != hist:
+                raise InvalidArgument(f"history_len ({hist}) does not match in_key_0 {keys[0].shape}")
+            if hist == 0:
+                e.reset()
+            else:
+                e.kv_write(keys, vals)
+        kv, last, tok = e.step(hs, pen, attention_mask=flag)
+        self._kv_epoch += 1
+        out = {"kv_seq_len": kv, "last_hidden_state": last, "max_logit_id": tok}
+        n = int(kv[0])
+        for i in range(c.layers):
+            out[f"out_key_{i}"] = _KVRef(self, i, False, n, self._kv_epoch)
+            out[f"out_value_{i}"] = _KVRef(self, i, True, n, self._kv_epoch)
+        return out
+
     def _run(self, feed) -> Dict[str, np.ndarray]:
         g, e = self._graph, self._eng
+        if g == "IndexTTS_B":
+            return {"text_hidden_state": e.text_embed(self._chk(feed, "text_ids", np.int32, 2))}
+        if g == "IndexTTS_C":
+            hs, nxt = e.mel_embed(self._chk(feed, "gpt_ids", np.int32, 2), self._chk(feed, "kv_seq_len", np.int64, 1))
+            return {"gpt_hidden_state": hs, "next_kv_seq_len": nxt}
+        if g == "IndexTTS_D":
+            from .indextts import IndexGPT
+            cat, n = IndexGPT.concat(*[self._chk(feed, k, np.float32, 3) for k in ("embed_x", "embed_y", "embed_z")])
+            return {"concat_hidden_state": cat, "concat_len": n}
         if g == "BigVGAN":
             mel = np.asarray(feed["mel_features"])
             if mel.dtype not in (np.float32, np.float16) or mel.ndim != 3:

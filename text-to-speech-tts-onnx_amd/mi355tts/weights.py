@@ -51,6 +51,19 @@ def synth_normal(seed: int, name: str, shape, std: float = 1.0, mean: float = 0.
     return (mean + std * z).astype(np.float32).reshape(shape)
 
 
+def synth_normal_fast(seed: int, name: str, shape, std: float = 1.0, mean: float = 0.0) -> np.ndarray:
+    """Same contract as synth_normal but drawn from numpy's PCG64 stream (~100x faster): for the full-size
+    benchmark models only — golden fixtures and parity tests use the counter-based generator above."""
+    h = int.from_bytes(hashlib.sha256(f"{seed}:{name}".encode()).digest()[:8], "little")
+    rng = np.random.default_rng([seed, h])
+    n = int(np.prod(shape)) if len(shape) else 1
+    z = rng.standard_normal(n, dtype=np.float32)
+    z *= np.float32(std)
+    if mean:
+        z += np.float32(mean)
+    return z.reshape(shape)
+
+
 # --------------------------------------------------------------------------------------
 # BigVGAN
 # --------------------------------------------------------------------------------------
@@ -103,9 +116,10 @@ def _fan_in(shape, kind: str) -> int:
     return 1
 
 
-def synth_tensor(seed: int, name: str, shape, kind: str) -> np.ndarray:
+def synth_tensor(seed: int, name: str, shape, kind: str, fast: bool = False) -> np.ndarray:
     """Fan-in scaled init so activations stay O(1) through the stack (so the int16
     output is neither silent nor saturated; see DESIGN.md 'synthetic weights')."""
+    synth_normal = globals()["synth_normal_fast" if fast else "synth_normal"]
     if kind in _GAIN:
         return synth_normal(seed, name, shape, std=_GAIN[kind] / math.sqrt(_fan_in(shape, kind)))
     if kind == "bias":
@@ -129,8 +143,8 @@ def synth_tensor(seed: int, name: str, shape, kind: str) -> np.ndarray:
     raise ValueError(kind)
 
 
-def synth_state(spec: Spec, seed: int = 9527) -> "OrderedDict[str, np.ndarray]":
-    return OrderedDict((name, synth_tensor(seed, name, shape, kind)) for name, shape, kind in spec)
+def synth_state(spec: Spec, seed: int = 9527, fast: bool = False) -> "OrderedDict[str, np.ndarray]":
+    return OrderedDict((name, synth_tensor(seed, name, shape, kind, fast)) for name, shape, kind in spec)
 
 
 def pack_state(spec: Spec, state: Dict[str, np.ndarray]) -> np.ndarray:
