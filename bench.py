@@ -247,6 +247,8 @@ def run_indextts(args, world, rank, local, dev, dist, torch):
         bcast_ms = (time.perf_counter() - t0) * 1e3
     blob = blob_t.cpu().numpy()
     del blob_t
+    NB = max(1, args.batch)
+    gcfg.max_batch = NB
     gpt = IndexGPT(gcfg, blob=blob[:ng], dtype=args.dtype, device=local)
     voc = BigVGANVocoder(vcfg, blob=blob[ng:], dtype=args.dtype, device=local)
     del blob
@@ -262,13 +264,29 @@ def run_indextts(args, world, rank, local, dev, dist, torch):
     ncond = vcfg.upsample_initial_channel + sum(vcfg.stage_channels(i) for i in range(vcfg.num_upsamples))
     vconds = torch.from_numpy(W.synth_normal_fast(100 + rank, "conds", (ncond,), std=0.2)).to(dev)
     wav = torch.empty((1, 1, (n_tok - 2) * vcfg.hop + 30), dtype=torch.int16, device=dev)
-    audio_s = wav.shape[-1] / vcfg.sampling_rate
+    audio_s = NB * wav.shape[-1] / vcfg.sampling_rate
+    if NB > 1:      # NB sentences per step: different texts, one shared weight stream per decode step
+        ps = []
+        for b in range(NB):
+            tb = (np.arange(n_text, dtype=np.int32) * 37 + 11 * rank + 101 * b) % (gcfg.text_tokens - 2) + 2
+            ps.append(gpt.concat(conds, gpt.text_embed(tb), mel_h)[0][0])
+        prompts_cat = torch.from_numpy(np.concatenate(ps, axis=0)).to(dev)
+        toks_b = torch.zeros((NB, n_tok), dtype=torch.int32, device=dev)
+        hid_b = torch.zeros((NB, n_tok, gcfg.hidden), dtype=torch.float32, device=dev)
+
+    def gpt_leg():
+        if NB == 1:
+            n = gpt.generate_torch(prompt, n_tok, toks, hid, stop_tokens=[])
+            assert n == n_tok
+        else:
+            n = gpt.generate_batch_torch(prompts_cat, [P] * NB, [n_tok] * NB, toks_b, hid_b, stop_tokens=[])
+            assert (n == n_tok).all()
 
     def step():
         # stop_tokens=[]: a fixed amount of work per sentence (random weights never emit the stop code on cue)
-        n = gpt.generate_torch(prompt, n_tok, toks, hid, stop_tokens=[])
-        assert n == n_tok
-        voc.run_latent_torch(hid, vconds, wav)
+        gpt_leg()
+        for b in range(NB):
+            voc.run_latent_torch(hid if NB == 1 else hid_b[b], vconds, wav)
 
     for _ in range(max(args.warmup, 2)):
         step()
@@ -287,12 +305,12 @@ def run_indextts(args, world, rank, local, dev, dist, torch):
     # GPT leg alone (same state), then the roofline leg: one eager pass with HIP events around every GEMV / GEMM launch
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    gpt.generate_torch(prompt, n_tok, toks, hid, stop_tokens=[])
+    gpt_leg()
     torch.cuda.synchronize()
     gpt_s = time.perf_counter() - t1
     _lib.prof_reset()
     _lib.prof_enable(["conv_gemm", "attn"])
-    gpt.generate_torch(prompt, n_tok, toks, hid, stop_tokens=[])
+    gpt_leg()
     torch.cuda.synchronize()
     _lib.prof_enable(())
     pg, pa = _lib.prof_get("conv_gemm"), _lib.prof_get("attn")
@@ -311,10 +329,11 @@ def run_indextts(args, world, rank, local, dev, dist, torch):
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"IndexTTS-1.5 {args.dtype}: GPT-2 (24 x 1280, 20 heads) prompt pass of {P} rows + greedy decode of "
-                               f"{n_tok} mel codes + BigVGAN graph F, one sentence per GPU per step (BASELINE configs[4] "
+                               f"{n_tok} mel codes + BigVGAN graph F, {NB} sentence(s) per GPU per step (BASELINE configs[4] "
                                f"without graph A: conds_latent / speaker conditioning synthetic)",
                    "tokens": n_tok, "prompt_rows": P, "audio_seconds_per_step_per_gpu": audio_s,
-                   "rtf": dt / args.steps / audio_s, "gpt_leg_ms": gpt_s * 1e3, "decode_tokens_per_s": n_tok / gpt_s,
+                   "sentences_per_gpu": NB,
+                   "rtf": dt / args.steps / audio_s, "gpt_leg_ms": gpt_s * 1e3, "decode_tokens_per_s": NB * n_tok / gpt_s,
                    "weight_bytes_streamed_per_token_GB": wbytes / 1e9,
                    "decode_weight_stream_GBps": wbytes * n_tok / gpt_s / 1e9,
                    "weights": "synthetic seeded (510 M GPT + vocoder)", "weight_bcast_ms": bcast_ms},

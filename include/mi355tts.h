@@ -129,7 +129,8 @@ int         mi_f5_synthesize(mi_f5* h, int U, const int16_t* audio, int64_t L, c
  * Replaces ort_session_B / _C / _E of IndexTTS/Inference_IndexTTS_ONNX.py:619-675 and the loop at :745-783
  * (graph definitions: IndexTTS/Export_IndexTTS.py:203-289).  The KV cache lives in the handle (the reference
  * passes 2*layers growing tensors in and out of every call); mi_gpt_kv_read / _write expose it in the reference's
- * tensor layouts.  cfg = {hidden, layers, heads, inner, mel_codes, text_tokens, max_mel_pos, max_text_pos, max_seq}.
+ * tensor layouts.  cfg = {hidden, layers, heads, inner, mel_codes, text_tokens, max_mel_pos, max_text_pos, max_seq
+ * [, max_batch = 1]}.
  * weights: canonical fp32 blob of mi355tts.weights.pack_gpt (Conv1D weights transposed to (out, in); q and k rows
  * pre-scaled by head_dim^-0.25 like Export_IndexTTS.py:257-258).                                                  */
 typedef struct mi_gpt mi_gpt;
@@ -160,6 +161,17 @@ int         mi_gpt_kv_write(mi_gpt* h, int layer, const float* keys, const float
 int         mi_gpt_generate(mi_gpt* h, const float* prompt, int P, int max_new, const int32_t* stop_ids, int n_stop,
                             float repeat_value, int penalty_range, float* repeat_penality, int32_t* tokens,
                             float* hidden, int32_t* n_out, int mem);
+
+/* The same loop for nb sentences at once (nb <= the handle's max_batch = optional 10th cfg int): prompt passes run one
+ * after the other, then every decode step serves all unfinished sentences with ONE pass over the weights (batched
+ * GEMV), each sentence with its own cache, history, penalty vector, stop test and limit.  prompts = the nb prompts
+ * concatenated row-wise (sum(prompt_rows), hidden); prompt_rows / max_new / n_out are host arrays of nb ints;
+ * repeat_penality (nb, mel_codes) in/out or NULL; tokens (nb, cap), hidden (nb, cap, hidden).  Results per sentence
+ * are identical to mi_gpt_generate on that sentence alone (fp32: bit-for-bit the same kernels' arithmetic order). */
+int         mi_gpt_generate_batch(mi_gpt* h, int nb, const float* prompts, const int32_t* prompt_rows,
+                                  const int32_t* max_new, const int32_t* stop_ids, int n_stop, float repeat_value,
+                                  int penalty_range, float* repeat_penality, int32_t* tokens, float* hidden, int cap,
+                                  int32_t* n_out, int mem);
 
 /* tuning hook: time `iters` launches of the implicit-GEMM conv kernel on random device data (no host copies);
  * returns average milliseconds per launch in *ms.  x (B,T,Cin), w (N, taps*Cin), out (B,T,N), "same" padding. */

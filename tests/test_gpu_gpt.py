@@ -254,3 +254,79 @@ def test_errors(eng, g):
         eng.step(np.zeros((1, 2, 7), np.float32))
     with pytest.raises(ValueError):
         eng.kv_write([np.zeros((2, 64, 3))], [np.zeros((2, 3, 64))])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# batched decode (engine extension): every sentence must come out exactly as if it had been decoded alone
+# ---------------------------------------------------------------------------------------------------------------
+def _prompt(e, cfg, seed, n_text, n_cond=4):
+    conds = W.synth_normal(seed, "conds", (1, n_cond, cfg.hidden), std=0.5)
+    text = (np.arange(n_text, dtype=np.int32) * 5 + seed) % (cfg.text_tokens - 2) + 2
+    mh, _ = e.mel_embed(cfg.start_mel_token, 0)
+    p, _ = e.concat(conds, e.text_embed(text), mh)
+    return conds, text, p
+
+
+def test_generate_batch_equals_reference_loop_per_sentence(small):
+    cfg0, st = small
+    cfg = IndexGPTConfig(**{**cfg0.__dict__, "max_batch": 4})
+    e = IndexGPT(cfg, st, dtype="f32")
+    items = [_prompt(e, cfg, 1, 6), _prompt(e, cfg, 2, 3), _prompt(e, cfg, 3, 9)]
+    limits = [14, 9, 11]
+    # sentence 1 stops early on a token the oracle is known to emit
+    o_free, _, _ = O.generate(cfg, st, items[1][0], items[1][1], max_generate_length=items[1][2].shape[1] + 9, stop_tokens=[])
+    stop = o_free[4]
+    res, pen = e.generate_batch([it[2] for it in items], limits, stop_tokens=[stop])
+    for b, (conds, text, p) in enumerate(items):
+        ot, oh, op = O.generate(cfg, st, conds, text, max_generate_length=p.shape[1] + limits[b], stop_tokens=[stop])
+        assert res[b][0].tolist() == ot, b
+        np.testing.assert_allclose(res[b][1], oh, rtol=0, atol=3e-4)
+        np.testing.assert_array_equal(pen[b:b + 1], op)
+    assert len(res[1][0]) <= 5 or stop in res[1][0].tolist()
+    # and again through the captured graph, with one idle slot (max_new = 0)
+    res2, _ = e.generate_batch([it[2] for it in items], [limits[0], 0, limits[2]], stop_tokens=[stop])
+    assert res2[0][0].tolist() == res[0][0].tolist() and len(res2[1][0]) == 0 and res2[2][0].tolist() == res[2][0].tolist()
+    # the single-sentence API still works on the same handle afterwards
+    t, _, _ = e.generate_from_prompt(items[0][2], limits[0], stop_tokens=[stop], repeat_penality=np.ones((1, cfg.mel_codes), np.float32))
+    assert t.tolist() == res[0][0].tolist()
+    with pytest.raises(ValueError):
+        e.generate_batch([it[2] for it in items] * 2, limits * 2)
+    e.close()
+
+
+@pytest.mark.parametrize("nb", [2, 5, 9, 16])
+def test_generate_batch_template_widths(nb):
+    cfg = IndexGPTConfig(hidden=256, layers=2, heads=4, inner=1024, mel_codes=301, text_tokens=64, max_mel_pos=80,
+                         max_text_pos=80, max_seq=96, max_batch=16, start_mel_token=299, stop_mel_token=300)
+    st = W.synth_state(W.gpt_spec(cfg), 11)
+    e = IndexGPT(cfg, st, dtype="f32")
+    items = [_prompt(e, cfg, 10 + b, 3 + (b * 7) % 11, n_cond=8) for b in range(nb)]
+    limits = [6 + (b * 5) % 9 for b in range(nb)]
+    res, pen = e.generate_batch([it[2] for it in items], limits, stop_tokens=[])
+    for b in range(nb):
+        t, h, p = e.generate_from_prompt(items[b][2], limits[b], stop_tokens=[],
+                                         repeat_penality=np.ones((1, cfg.mel_codes), np.float32))
+        assert res[b][0].tolist() == t.tolist(), b
+        np.testing.assert_allclose(res[b][1], h, rtol=0, atol=2e-4)
+        np.testing.assert_array_equal(pen[b:b + 1], p)
+    e.close()
+
+
+def test_generate_batch_f16_tracks_single(small):
+    cfg0, st = small
+    cfg = IndexGPTConfig(**{**cfg0.__dict__, "max_batch": 4})
+    e = IndexGPT(cfg, st, dtype="f16")
+    items = [_prompt(e, cfg, 1, 6), _prompt(e, cfg, 2, 3), _prompt(e, cfg, 3, 9), _prompt(e, cfg, 4, 5)]
+    res, _ = e.generate_batch([it[2] for it in items], [10] * 4, stop_tokens=[])
+    agree = 0
+    for b in range(4):
+        t, h, _ = e.generate_from_prompt(items[b][2], 10, stop_tokens=[], repeat_penality=np.ones((1, cfg.mel_codes), np.float32))
+        assert res[b][0][0] == t[0]                                 # the prompt pass is the same code path
+        np.testing.assert_array_equal(res[b][1][0], h[0])
+        k = 0
+        while k < 10 and res[b][0][k] == t[k]:
+            np.testing.assert_allclose(res[b][1][k], h[k], rtol=0, atol=5e-2)
+            k += 1
+        agree += k
+    assert agree >= 30          # 16-bit rounding differs between the fused-LN GEMV and the batched GEMV; ties are rare
+    e.close()

@@ -424,7 +424,7 @@ int mi_gpt_generate(mi_gpt* h, const float* prompt, int P, int max_new, const in
         Gpt& e = *h->impl;
         const GptCfg& c = e.cfg;
         MI_REQUIRE(prompt && P >= 1 && n_out, "mi_gpt_generate: null argument");
-        MI_REQUIRE(n_stop >= 0 && n_stop <= GS_WORDS - GS_STOP0 && (n_stop == 0 || stop_ids), "mi_gpt_generate: at most 7 stop ids");
+        MI_REQUIRE(n_stop >= 0 && n_stop <= GS_WORDS - GS_STOP0 && (n_stop == 0 || stop_ids), "mi_gpt_generate: at most 6 stop ids");
         *n_out = 0;
         if (max_new <= 0) return;                                        // `while num_decode < generate_limit` never runs
         MI_REQUIRE(P + max_new - 1 <= c.max_seq, "mi_gpt_generate: prompt + max_new exceeds the KV cache (max_seq)");
@@ -460,6 +460,78 @@ int mi_gpt_generate(mi_gpt* h, const float* prompt, int P, int max_new, const in
         copy_out(tokens, e.toks.p, (size_t)n * 4, mem, s);
         copy_out(hidden, e.hid.p, (size_t)n * c.hidden * 4, mem, s);
         copy_out(repeat_penality, e.pen.p, (size_t)c.mel_codes * 4, mem, s);
+        MI_HIP(hipStreamSynchronize(s));
+    });
+}
+
+int mi_gpt_generate_batch(mi_gpt* h, int nb, const float* prompts, const int32_t* prompt_rows, const int32_t* max_new,
+                          const int32_t* stop_ids, int n_stop, float repeat_value, int penalty_range,
+                          float* repeat_penality, int32_t* tokens, float* hidden, int cap, int32_t* n_out, int mem) {
+    return guard([&] {
+        GPT_CHECK(h, mem, "mi_gpt_generate_batch");
+        Gpt& e = *h->impl;
+        const GptCfg& c = e.cfg;
+        MI_REQUIRE(prompts && prompt_rows && max_new && n_out && cap >= 1, "mi_gpt_generate_batch: null argument");
+        MI_REQUIRE(nb >= 1 && nb <= c.max_batch, "mi_gpt_generate_batch: batch exceeds the handle's max_batch");
+        MI_REQUIRE(n_stop >= 0 && n_stop <= GS_WORDS - GS_STOP0 && (n_stop == 0 || stop_ids), "mi_gpt_generate_batch: at most 6 stop ids");
+        hipStream_t s = e.stream;
+        const hipMemcpyKind in = mem == MI_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+        std::vector<int32_t> stops(n_stop);
+        if (n_stop) {
+            if (mem == MI_HOST) std::copy(stop_ids, stop_ids + n_stop, stops.begin());
+            else MI_HIP(hipMemcpy(stops.data(), stop_ids, (size_t)n_stop * 4, hipMemcpyDeviceToHost));
+        }
+        size_t row0 = 0;
+        for (int b = 0; b < nb; ++b) {
+            MI_REQUIRE(prompt_rows[b] >= 1 && max_new[b] >= 0 && max_new[b] <= cap, "mi_gpt_generate_batch: prompt_rows / max_new");
+            MI_REQUIRE(max_new[b] == 0 || prompt_rows[b] + max_new[b] - 1 <= c.max_seq, "mi_gpt_generate_batch: prompt + max_new exceeds the KV cache (max_seq)");
+            MI_REQUIRE(max_new[b] <= c.max_mel_pos, "mi_gpt_generate_batch: max_new exceeds the mel position table");
+        }
+        if (repeat_penality) MI_HIP(hipMemcpyAsync(e.pen.p, repeat_penality, (size_t)nb * c.mel_codes * 4, in, s));
+        else {
+            std::vector<float> ones((size_t)nb * c.mel_codes, 1.f);
+            MI_HIP(hipMemcpyAsync(e.pen.p, ones.data(), ones.size() * 4, hipMemcpyHostToDevice, s));
+            MI_HIP(hipStreamSynchronize(s));
+        }
+        e.rep_value = repeat_value;
+        bool any = false;
+        for (int b = 0; b < nb; ++b) {                               // prompt passes, one sentence at a time
+            std::vector<int32_t> w(GS_WORDS, 0);
+            w[GS_NSTOP] = n_stop; w[GS_RANGE] = penalty_range; w[GS_UPDATE_PEN] = 1; w[GS_LIMIT] = max_new[b];
+            for (int i = 0; i < n_stop; ++i) w[GS_STOP0 + i] = stops[i];
+            if (max_new[b] == 0) w[GS_DONE] = 1;
+            e.set_state(w, b);
+            if (max_new[b] > 0) {
+                MI_HIP(hipMemcpyAsync(e.X.p, prompts + row0 * c.hidden, (size_t)prompt_rows[b] * c.hidden * 4, in, s));
+                e.forward_rows(prompt_rows[b], 1, b);
+                any = true;
+            }
+            row0 += prompt_rows[b];
+        }
+        std::vector<int32_t> all((size_t)nb * GS_WORDS);
+        auto read_states = [&] {
+            MI_HIP(hipMemcpyAsync(all.data(), e.state.p, all.size() * 4, hipMemcpyDeviceToHost, s));
+            MI_HIP(hipStreamSynchronize(s));
+            bool done = true;
+            for (int b = 0; b < nb; ++b) done &= all[(size_t)b * GS_WORDS + GS_DONE] != 0;
+            return done;
+        };
+        int guard_steps = 0;
+        while (any && !read_states()) {
+            e.decode_batch_steps(nb, 16);
+            guard_steps += 16;
+            MI_REQUIRE(guard_steps <= c.max_seq + 32, "mi_gpt_generate_batch: decode loop did not terminate");
+        }
+        if (!any) read_states();
+        e.history = all[GS_HIST];
+        for (int b = 0; b < nb; ++b) {
+            const int n = all[(size_t)b * GS_WORDS + GS_NDEC];
+            n_out[b] = n;
+            copy_out(tokens ? tokens + (size_t)b * cap : nullptr, e.toks.as<int32_t>() + (size_t)b * c.max_seq, (size_t)n * 4, mem, s);
+            copy_out(hidden ? hidden + (size_t)b * cap * c.hidden : nullptr, e.hid.as<float>() + (size_t)b * c.max_seq * c.hidden,
+                     (size_t)n * c.hidden * 4, mem, s);
+        }
+        copy_out(repeat_penality, e.pen.p, (size_t)nb * c.mel_codes * 4, mem, s);
         MI_HIP(hipStreamSynchronize(s));
     });
 }

@@ -19,7 +19,7 @@
 namespace mi {
 
 GptCfg parse_gpt_cfg(const int32_t* ci, int ni) {
-    MI_REQUIRE(ci && ni == 9, "gpt cfg: expected 9 ints");
+    MI_REQUIRE(ci && (ni == 9 || ni == 10), "gpt cfg: expected 9 or 10 ints");
     GptCfg c;
     int i = 0;
     c.hidden = ci[i++]; c.layers = ci[i++]; c.heads = ci[i++]; c.inner = ci[i++]; c.mel_codes = ci[i++];
@@ -28,6 +28,8 @@ GptCfg parse_gpt_cfg(const int32_t* ci, int ni) {
     MI_REQUIRE(c.hidden % 8 == 0 && c.hidden <= 2048 && c.inner % 8 == 0 && c.inner > 0, "gpt cfg: widths");
     MI_REQUIRE(c.layers > 0 && c.mel_codes > 1 && c.text_tokens > 1 && c.max_mel_pos > 1 && c.max_text_pos > 2, "gpt cfg: sizes");
     MI_REQUIRE(c.max_seq >= 8 && c.max_seq <= 8192, "gpt cfg: max_seq must be in [8, 8192]");
+    c.max_batch = ni == 10 ? ci[9] : 1;
+    MI_REQUIRE(c.max_batch >= 1 && c.max_batch <= 16, "gpt cfg: max_batch must be in [1, 16]");
     return c;
 }
 
@@ -56,6 +58,30 @@ __device__ inline float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// acc += dot(a[0..V), b[0..V)) with fp32 accumulation; 16-bit types use the packed dot instructions (v_dot2_f32_f16 /
+// v_dot2_f32_bf16: two multiply-adds per lane per issue, no conversions)
+__device__ inline float dot_pack(const Pack16<float>& a, const Pack16<float>& b, float acc) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = fmaf(a.v[e], b.v[e], acc);
+    return acc;
+}
+__device__ inline float dot_pack(const Pack16<f16>& a, const Pack16<f16>& b, float acc) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2* pa = reinterpret_cast<const h2*>(&a);
+    const h2* pb = reinterpret_cast<const h2*>(&b);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_fdot2(pa[e], pb[e], acc, false);
+    return acc;
+}
+__device__ inline float dot_pack(const Pack16<bf16>& a, const Pack16<bf16>& b, float acc) {
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    const b2* pa = reinterpret_cast<const b2*>(&a);
+    const b2* pb = reinterpret_cast<const b2*>(&b);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_fdot2_f32_bf16(pa[e], pb[e], acc, false);
+    return acc;
+}
+
 __device__ inline float gelu_new(float x) {
     return 0.5f * x * (1.f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));
 }
@@ -186,6 +212,118 @@ __global__ __launch_bounds__(256) void gemv_ln_kernel(const T* __restrict__ w, c
     gemv_store<T, R, QKV>(acc, lane, n0, N, bias, nullptr, out, out_f32, act, kc, vc, st, max_seq);
 }
 
+// NV per-lane partial sums -> full sums: after the call, lane l holds the total of value index
+//   idx = sum_s ((l >> (5 - s)) & 1) << (log2(NV) - 1 - s)   (and every lane sharing those bits holds the same total).
+// log2(NV) halving exchange steps (NV - 1 shuffles) + the remaining butterfly, instead of 6 * NV shuffles.
+template <int NV> __device__ inline float reduce_multi(float (&v)[NV], int lane) {
+    int off = 32;
+#pragma unroll
+    for (int n = NV; n > 1; n >>= 1) {
+        const bool hi = (lane & off) != 0;
+#pragma unroll
+        for (int i = 0; i < n / 2; ++i) {
+            const float send = hi ? v[i] : v[i + n / 2];
+            const float keep = hi ? v[i + n / 2] : v[i];
+            v[i] = keep + __shfl_xor(send, off, 64);
+        }
+        off >>= 1;
+    }
+    for (; off > 0; off >>= 1) v[0] += __shfl_xor(v[0], off, 64);
+    return v[0];
+}
+
+// batched decode step: out[b][n] = act(dot(w[n, :], x[b, :]) + bias[n]) (+ res[b][n]) for BB slots at once — every
+// weight row is streamed once for all sentences.  QKV: k / v rows of slot b go to that slot's cache row st[b].hist.
+// 8 waves per block share the x rows through LDS in 1024-element K chunks (read straight from L2 by every wave they
+// cost BB x the weight traffic); a chunk's weight loads are issued before the barrier that publishes the x chunk.
+constexpr int GB_KC = 1024;
+template <typename T, int R, int BB, bool QKV>
+__global__ __launch_bounds__(512) void gemv_b_kernel(const T* __restrict__ w, const T* __restrict__ x,
+                                                     const float* __restrict__ bias, const float* res, void* out,
+                                                     int out_f32, int act, int N, int K, int nb, T* __restrict__ kc,
+                                                     T* __restrict__ vc, const int* __restrict__ st, int max_seq,
+                                                     size_t slot_stride) {
+    constexpr int V = Pack16<T>::N;
+    constexpr int ITS = GB_KC / (64 * V);          // k iterations of a wave inside one chunk
+    __shared__ __attribute__((aligned(16))) T xs[BB * GB_KC];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n0 = (blockIdx.x * 8 + wave) * R;
+    const T* wr[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) wr[r] = w + (size_t)min(n0 + r, N - 1) * K;
+    float acc[R][BB];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int b = 0; b < BB; ++b) acc[r][b] = 0.f;
+    for (int k0 = 0; k0 < K; k0 += GB_KC) {
+        const int kn = min(GB_KC, K - k0);
+        Pack16<T> p[ITS][R];
+#pragma unroll
+        for (int it = 0; it < ITS; ++it) {
+            const int kl = lane * V + it * 64 * V;
+#pragma unroll
+            for (int r = 0; r < R; ++r) p[it][r] = ld16(wr[r] + k0 + (kl < kn ? kl : 0));
+        }
+        __syncthreads();                            // the previous chunk has been consumed
+        for (int i = threadIdx.x * V; i < BB * kn; i += 512 * V) {
+            const int b = i / kn, kk = i % kn;      // kn is a multiple of V
+            *reinterpret_cast<uint4*>(&xs[b * GB_KC + kk]) = *reinterpret_cast<const uint4*>(x + (size_t)b * K + k0 + kk);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < ITS; ++it) {
+            const int kl = lane * V + it * 64 * V;
+            if (kl < kn) {
+#pragma unroll
+                for (int b = 0; b < BB; ++b) {
+                    const Pack16<T> xv = ld16(&xs[b * GB_KC + kl]);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) acc[r][b] = dot_pack(p[it][r], xv, acc[r][b]);
+                }
+            }
+        }
+    }
+    if (n0 >= N) return;
+    // lane -> slot index it ends up holding (see reduce_multi)
+    constexpr int LOG = BB == 16 ? 4 : BB == 8 ? 3 : BB == 4 ? 2 : BB == 2 ? 1 : 0;
+    int b = 0;
+#pragma unroll
+    for (int s = 0; s < LOG; ++s) b |= ((lane >> (5 - s)) & 1) << (LOG - 1 - s);
+    const bool writer = (lane & ((64 >> LOG) - 1)) == 0 && b < nb;
+    float tot[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float tmp[BB];
+#pragma unroll
+        for (int q = 0; q < BB; ++q) tmp[q] = acc[r][q];
+        tot[r] = reduce_multi<BB>(tmp, lane);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int n = n0 + r;
+        if (writer && n < N) {
+            float v = tot[r] + (bias ? bias[n] : 0.f);
+            if (act == ACT_GELU_TANH) v = gelu_new(v);
+            if (res) v += res[(size_t)b * N + n];
+            bool to_cache = false;
+            if (QKV) {
+                const int hidden = N / 3;
+                if (n >= hidden) {
+                    const int c = n - hidden, which = c / hidden, cc = c % hidden;
+                    const int pos = st[b * GS_WORDS + GS_HIST];
+                    if (pos < max_seq)
+                        (which ? vc : kc)[(size_t)b * slot_stride + ((size_t)(cc >> 6) * max_seq + pos) * 64 + (cc & 63)] = (T)v;
+                    to_cache = true;
+                }
+            }
+            if (!to_cache) {
+                if (out_f32) ((float*)out)[(size_t)b * N + n] = v; else ((T*)out)[(size_t)b * N + n] = (T)v;
+            }
+        }
+    }
+}
+
 // rows of (q | k | v) -> K / V cache rows hist .. hist+rows-1 of one layer
 template <typename T>
 __global__ __launch_bounds__(256) void kv_append_kernel(const T* __restrict__ qkv, T* __restrict__ kc, T* __restrict__ vc,
@@ -209,7 +347,7 @@ template <typename T>
 __global__ __launch_bounds__(512) void gpt_attn_kernel(const T* __restrict__ qkv, const T* __restrict__ kc,
                                                        const T* __restrict__ vc, T* __restrict__ out,
                                                        const int* __restrict__ st, int rows, int flag, int hidden,
-                                                       int max_seq) {
+                                                       int max_seq, int batched, size_t slot_stride) {
     constexpr int V = Pack16<T>::N;            // elements per 16 bytes
     constexpr int CH = 64 / V;                 // 16-byte chunks per key row
     extern __shared__ float sm[];
@@ -217,10 +355,13 @@ __global__ __launch_bounds__(512) void gpt_attn_kernel(const T* __restrict__ qkv
     float* qs = sm + max_seq;                  // [64]
     float* red = qs + 64;                      // [8 * 64]
     __shared__ float bc[2];
-    const int head = blockIdx.x, i = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // batched decode: blockIdx.y is the slot (one new row each, row index 0 inside its block); otherwise the new row
+    const int head = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row = blockIdx.y, i = batched ? 0 : row;
+    if (batched) { st += row * GS_WORDS; kc += (size_t)row * slot_stride; vc += (size_t)row * slot_stride; }
     const int hist = st[GS_HIST];
     const int kv = min(hist + rows, max_seq);
-    if (tid < 64) qs[tid] = (float)qkv[(size_t)i * 3 * hidden + head * 64 + tid];
+    if (tid < 64) qs[tid] = (float)qkv[(size_t)row * 3 * hidden + head * 64 + tid];
     __syncthreads();
     const T* kb = kc + (size_t)head * max_seq * 64;
     const T* vb = vc + (size_t)head * max_seq * 64;
@@ -280,7 +421,7 @@ __global__ __launch_bounds__(512) void gpt_attn_kernel(const T* __restrict__ qkv
         float t = 0.f;
 #pragma unroll
         for (int w = 0; w < 8; ++w) t += red[w * 64 + tid];
-        out[(size_t)i * hidden + head * 64 + tid] = (T)(t * inv);
+        out[(size_t)row * hidden + head * 64 + tid] = (T)(t * inv);
     }
 }
 
@@ -298,6 +439,8 @@ __global__ __launch_bounds__(256) void gpt_text_embed_kernel(const int* __restri
 __global__ __launch_bounds__(256) void gpt_embed_state_kernel(const int* __restrict__ st, const float* __restrict__ emb,
                                                               const float* __restrict__ pos, float* __restrict__ x,
                                                               int hidden, int codes, int max_pos, int id_arg, int gen_arg) {
+    st += blockIdx.x * GS_WORDS;               // one block per slot
+    x += (size_t)blockIdx.x * hidden;
     const int id = min(max(id_arg >= 0 ? id_arg : st[GS_TOKEN], 0), codes - 1);
     const int g = min(max(gen_arg >= 0 ? gen_arg : st[GS_GEN_LEN], 0), max_pos - 1);
     for (int c = threadIdx.x; c < hidden; c += 256) x[c] = emb[(size_t)id * hidden + c] + pos[(size_t)g * hidden + c];
@@ -311,6 +454,11 @@ __global__ __launch_bounds__(1024) void gpt_pick_kernel(const float* __restrict_
     __shared__ float bv[16];
     __shared__ int bi[16];
     __shared__ int slot;
+    {   // one block per sentence slot
+        const size_t sl = blockIdx.x;
+        logits += sl * codes; pen += sl * codes; last += sl * hidden; st += sl * GS_WORDS; toks += sl * max_tok;
+        hid += sl * (size_t)max_tok * hidden;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float best = -INFINITY;
     int idx = 0x7fffffff;
@@ -346,6 +494,7 @@ __global__ __launch_bounds__(1024) void gpt_pick_kernel(const float* __restrict_
             }
             st[GS_HIST] += rows;
             st[GS_GEN_LEN] += 1;
+            if (st[GS_LIMIT] > 0 && n + 1 >= st[GS_LIMIT]) st[GS_DONE] = 1;   // `while num_decode < generate_limit`
         }
     }
     __syncthreads();
@@ -412,15 +561,18 @@ Gpt::Gpt(const GptCfg& c, const float* w, int64_t nw, int dt, int dev) : cfg(c),
     up_glin(head, p, c.mel_codes, h, dt, s);
     MI_REQUIRE(p - w == nw, "gpt: blob walk mismatch");
 
-    const size_t es = dtype_size(dt), S = c.max_seq;
-    kc.ensure((size_t)c.layers * h * S * es); vc.ensure((size_t)c.layers * h * S * es);
-    X.ensure(S * h * 4); xn.ensure(S * h * es); qkv.ensure(S * 3 * h * es); att.ensure(S * h * es);
-    ff.ensure(S * n * es); logits.ensure((size_t)c.mel_codes * 4); last.ensure((size_t)h * 4); z.ensure((size_t)h * es);
-    pen.ensure((size_t)c.mel_codes * 4); toks.ensure(S * 4); hid.ensure(S * h * 4); state.ensure(GS_WORDS * 4);
-    MI_HIP(hipMemsetAsync(kc.p, 0, kc.bytes, s));
-    MI_HIP(hipMemsetAsync(vc.p, 0, vc.bytes, s));
-    MI_HIP(hipMemsetAsync(state.p, 0, state.bytes, s));
-    std::vector<float> ones(c.mel_codes, 1.f);
+    const size_t es = dtype_size(dt), S = c.max_seq, MB = c.max_batch;
+    MBp = c.max_batch <= 1 ? 1 : c.max_batch <= 2 ? 2 : c.max_batch <= 4 ? 4 : c.max_batch <= 8 ? 8 : 16;
+    kc.ensure(MB * slot_cache_elems() * es); vc.ensure(MB * slot_cache_elems() * es);
+    X.ensure(S * h * 4); xn.ensure(S * h * es); qkv.ensure(S * 3 * h * es); att.ensure(S * h * es); ff.ensure(S * n * es);
+    const size_t P = MBp;                       // padded slot rows of the batched decode scratch
+    logits.ensure(P * c.mel_codes * 4); last.ensure(P * h * 4); pen.ensure(P * c.mel_codes * 4);
+    toks.ensure(MB * S * 4); hid.ensure(MB * S * h * 4); state.ensure(P * GS_WORDS * 4);
+    Xd.ensure(P * h * 4); xnd.ensure(P * h * es); qkvd.ensure(P * 3 * h * es); attd.ensure(P * h * es);
+    ffd.ensure(P * n * es); zd.ensure(P * h * es);
+    for (DevBuf* bfr : {&kc, &vc, &state, &Xd, &xnd, &qkvd, &attd, &ffd, &zd, &last, &logits})
+        MI_HIP(hipMemsetAsync(bfr->p, 0, bfr->bytes, s));
+    std::vector<float> ones(P * c.mel_codes, 1.f);
     MI_HIP(hipMemcpyAsync(pen.p, ones.data(), ones.size() * 4, hipMemcpyHostToDevice, s));
     MI_HIP(hipStreamSynchronize(s));
     const char* ng = std::getenv("MI355TTS_NO_GRAPH");
@@ -434,25 +586,27 @@ Gpt::Gpt(const GptCfg& c, const float* w, int64_t nw, int dt, int dev) : cfg(c),
 
 Gpt::~Gpt() {
     if (step_graph) (void)hipGraphExecDestroy(step_graph);
+    for (auto& kv : batch_graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);
     if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
 }
 
-void Gpt::set_state(const std::vector<int32_t>& words) {
-    MI_REQUIRE(words.size() == GS_WORDS, "gpt: state size");
-    MI_HIP(hipMemcpyAsync(state.p, words.data(), GS_WORDS * 4, hipMemcpyHostToDevice, stream));
+void Gpt::set_state(const std::vector<int32_t>& words, int slot) {
+    MI_REQUIRE(words.size() == GS_WORDS && slot >= 0 && slot < cfg.max_batch, "gpt: state slot");
+    MI_HIP(hipMemcpyAsync(state.as<int32_t>() + (size_t)slot * GS_WORDS, words.data(), GS_WORDS * 4, hipMemcpyHostToDevice, stream));
     MI_HIP(hipStreamSynchronize(stream));      // `words` may be a temporary
-    history = words[GS_HIST];
+    if (slot == 0) history = words[GS_HIST];
 }
-std::vector<int32_t> Gpt::get_state() {
+std::vector<int32_t> Gpt::get_state(int slot) {
+    MI_REQUIRE(slot >= 0 && slot < cfg.max_batch, "gpt: state slot");
     std::vector<int32_t> w(GS_WORDS);
-    MI_HIP(hipMemcpyAsync(w.data(), state.p, GS_WORDS * 4, hipMemcpyDeviceToHost, stream));
+    MI_HIP(hipMemcpyAsync(w.data(), state.as<int32_t>() + (size_t)slot * GS_WORDS, GS_WORDS * 4, hipMemcpyDeviceToHost, stream));
     MI_HIP(hipStreamSynchronize(stream));
-    history = w[GS_HIST];
+    if (slot == 0) history = w[GS_HIST];
     return w;
 }
 void Gpt::reset() {
     std::vector<int32_t> w(GS_WORDS, 0);
-    set_state(w);
+    set_state(w, 0);
 }
 
 void Gpt::linear(const GLin& l, const void* x, int rows, void* out, int odt, int act, const float* res) {
@@ -467,7 +621,7 @@ void Gpt::linear(const GLin& l, const void* x, int rows, void* out, int odt, int
 // single-row linear layer: weight-streaming GEMV.  ln_w != nullptr: x is the fp32 residual row, LayerNorm fused in.
 // kcl != nullptr: QKV epilogue (k and v rows go to the cache).
 void Gpt::gemv(const GLin& l, const void* x, const float* ln_w, const float* ln_b, void* out, int odt, int act,
-               const float* res, void* kcl, void* vcl) {
+               const float* res, void* kcl, void* vcl, int slot) {
     MI_REQUIRE(l.k % 8 == 0, "gemv: K must be a multiple of 8");
     const int of = odt == MI_F32;
     MI_REQUIRE(of || odt == dtype, "gemv: output dtype");
@@ -477,7 +631,7 @@ void Gpt::gemv(const GLin& l, const void* x, const float* ln_w, const float* ln_
     const int R = l.n >= 4096 ? 2 : 1;
     const dim3 grid((unsigned)((l.n + 4 * R - 1) / (4 * R)));
     ProfScope ps(FAM_CONV_GEMM, stream, (double)l.n * l.k * dtype_size(dtype), 2.0 * l.n * l.k);
-    const int* st = state.as<int>();
+    const int* st = state.as<int>() + (size_t)slot * GS_WORDS;
     const int V = 16 / (int)dtype_size(dtype);
     const int KI = (l.k + 64 * V - 1) / (64 * V);
     if (ln_w) {
@@ -516,20 +670,23 @@ void Gpt::gemv(const GLin& l, const void* x, const float* ln_w, const float* ln_
         MI_HIP(hipGetLastError());                                                    \
     } while (0)
 
-void Gpt::forward_rows(int rows, int flag) {
+void Gpt::forward_rows(int rows, int flag, int slot) {
     const GptCfg& c = cfg;
     const int h = c.hidden, S = c.max_seq;
     hipStream_t s = stream;
     const size_t es = dtype_size(dtype);
-    const int* st = state.as<int>();
+    MI_REQUIRE(slot >= 0 && slot < c.max_batch, "gpt: slot");
+    const int* st = state.as<int>() + (size_t)slot * GS_WORDS;
     float* x = X.as<float>();
     const int lds = (S + 64 + 512) * 4;
+    float* last_s = last.as<float>() + (size_t)slot * h;
+    float* logits_s = logits.as<float>() + (size_t)slot * c.mel_codes;
     for (int li = 0; li < c.layers; ++li) {
         Layer& l = L[li];
-        char* kcl = (char*)kc.p + (size_t)li * h * S * es;
-        char* vcl = (char*)vc.p + (size_t)li * h * S * es;
+        char* kcl = (char*)kc.p + ((size_t)slot * slot_cache_elems() + (size_t)li * h * S) * es;
+        char* vcl = (char*)vc.p + ((size_t)slot * slot_cache_elems() + (size_t)li * h * S) * es;
         if (rows == 1) {
-            gemv(l.qkv, x, l.ln1_w.as<float>(), l.ln1_b.as<float>(), qkv.p, dtype, ACT_NONE, nullptr, kcl, vcl);
+            gemv(l.qkv, x, l.ln1_w.as<float>(), l.ln1_b.as<float>(), qkv.p, dtype, ACT_NONE, nullptr, kcl, vcl, slot);
         } else {
             launch_rownorm(NORM_LN_AFFINE, x, xn.p, dtype, l.ln1_w.as<float>(), l.ln1_b.as<float>(), rows, h, 1e-5f, s);
             linear(l.qkv, xn.p, rows, qkv.p, dtype, ACT_NONE, nullptr);
@@ -541,7 +698,7 @@ void Gpt::forward_rows(int rows, int flag) {
         }
         {
             ProfScope ps(FAM_ATTN, s, 2.0 * (double)h * (history + rows) * es, 4.0 * (double)h * rows * (history + rows));
-#define ATT(T, ...) hipLaunchKernelGGL(gpt_attn_kernel<T>, dim3(c.heads, rows), dim3(512), lds, s, (const T*)qkv.p, (const T*)kcl, (const T*)vcl, (T*)att.p, st, rows, flag, h, S)
+#define ATT(T, ...) hipLaunchKernelGGL(gpt_attn_kernel<T>, dim3(c.heads, rows), dim3(512), lds, s, (const T*)qkv.p, (const T*)kcl, (const T*)vcl, (T*)att.p, st, rows, flag, h, S, 0, (size_t)0)
             GPT_DISPATCH(ATT, 0);
 #undef ATT
         }
@@ -557,10 +714,11 @@ void Gpt::forward_rows(int rows, int flag) {
         }
     }
     const float* xl = x + (size_t)(rows - 1) * h;
-    launch_rownorm(NORM_LN_AFFINE, xl, last.p, MI_F32, lnf_w.as<float>(), lnf_b.as<float>(), 1, h, 1e-5f, s);
-    gemv(head, last.p, fn_w.as<float>(), fn_b.as<float>(), logits.p, MI_F32, ACT_NONE, nullptr, nullptr, nullptr);
-    hipLaunchKernelGGL(gpt_pick_kernel, dim3(1), dim3(1024), 0, s, logits.as<float>(), pen.as<float>(), last.as<float>(),
-                       state.as<int>(), toks.as<int>(), hid.as<float>(), c.mel_codes, h, rows, rep_value, S);
+    launch_rownorm(NORM_LN_AFFINE, xl, last_s, MI_F32, lnf_w.as<float>(), lnf_b.as<float>(), 1, h, 1e-5f, s);
+    gemv(head, last_s, fn_w.as<float>(), fn_b.as<float>(), logits_s, MI_F32, ACT_NONE, nullptr, nullptr, nullptr);
+    hipLaunchKernelGGL(gpt_pick_kernel, dim3(1), dim3(1024), 0, s, logits_s, pen.as<float>() + (size_t)slot * c.mel_codes,
+                       last_s, state.as<int>() + (size_t)slot * GS_WORDS, toks.as<int>() + (size_t)slot * S,
+                       hid.as<float>() + (size_t)slot * S * h, c.mel_codes, h, rows, rep_value, S);
     MI_HIP(hipGetLastError());
 }
 
@@ -592,6 +750,92 @@ void Gpt::decode_steps(int n) {
         if (err != hipSuccess) { step_graph = nullptr; use_graph = false; for (int i = 0; i < n; ++i) decode_step_eager(); return; }
     }
     for (int i = 0; i < n; ++i) MI_HIP(hipGraphLaunch(step_graph, stream));
+}
+
+// batched GEMV dispatch: x (nb rows of K, engine dtype) -> out (nb rows of N)
+void Gpt::gemv_b(const GLin& l, const void* x, int nb, void* out, int odt, int act, const float* res, void* kcl, void* vcl) {
+    MI_REQUIRE(l.k % 8 == 0 && nb >= 1 && nb <= MBp, "gemv_b: shape");
+    const int of = odt == MI_F32;
+    MI_REQUIRE(of || odt == dtype, "gemv_b: output dtype");
+    const int BB = nb <= 2 ? 2 : nb <= 4 ? 4 : nb <= 8 ? 8 : 16;
+    const int R = l.n >= 4096 ? 2 : 1;
+    const dim3 grid((unsigned)((l.n + 8 * R - 1) / (8 * R)));
+    ProfScope ps(FAM_CONV_GEMM, stream, (double)l.n * l.k * dtype_size(dtype), 2.0 * l.n * l.k * nb);
+    const size_t sstride = slot_cache_elems();
+#define GB(T, RR, B_, QK) hipLaunchKernelGGL((gemv_b_kernel<T, RR, B_, QK>), grid, dim3(512), 0, stream, (const T*)l.w.p, (const T*)x, l.b.as<float>(), res, out, of, act, l.n, l.k, nb, (T*)kcl, (T*)vcl, state.as<int>(), cfg.max_seq, sstride)
+#define GB_B(T, RR, QK) do { if (BB == 2) GB(T, RR, 2, QK); else if (BB == 4) GB(T, RR, 4, QK); else if (BB == 8) GB(T, RR, 8, QK); else GB(T, RR, 16, QK); } while (0)
+#define GB_T(T)                                                                 \
+    do {                                                                        \
+        if (kcl) { if (R == 2) GB_B(T, 2, true); else GB_B(T, 1, true); }        \
+        else { if (R == 2) GB_B(T, 2, false); else GB_B(T, 1, false); }          \
+    } while (0)
+    if (dtype == MI_F32) GB_T(float); else if (dtype == MI_F16) GB_T(f16); else GB_T(bf16);
+#undef GB_T
+#undef GB_B
+#undef GB
+    MI_HIP(hipGetLastError());
+}
+
+// one decode step for slots 0..nb-1 together: graph C from each slot's state, graph E with every weight row streamed
+// once for all slots, per-slot argmax / penalty / stop bookkeeping.  Finished slots keep running as no-ops.
+void Gpt::decode_batch_eager(int nb) {
+    const GptCfg& c = cfg;
+    MI_REQUIRE(nb >= 1 && nb <= c.max_batch, "gpt: batch exceeds max_batch");
+    const int h = c.hidden, S = c.max_seq;
+    hipStream_t s = stream;
+    const size_t es = dtype_size(dtype);
+    const int lds = (S + 64 + 512) * 4;
+    float* x = Xd.as<float>();
+    hipLaunchKernelGGL(gpt_embed_state_kernel, dim3(nb), dim3(256), 0, s, state.as<int>(), mel_emb.as<float>(),
+                       mel_pos.as<float>(), x, h, c.mel_codes, c.max_mel_pos, -1, -1);
+    MI_HIP(hipGetLastError());
+    for (int li = 0; li < c.layers; ++li) {
+        Layer& l = L[li];
+        char* kcl = (char*)kc.p + (size_t)li * h * S * es;          // slot 0's layer; slots are slot_cache_elems apart
+        char* vcl = (char*)vc.p + (size_t)li * h * S * es;
+        launch_rownorm(NORM_LN_AFFINE, x, xnd.p, dtype, l.ln1_w.as<float>(), l.ln1_b.as<float>(), nb, h, 1e-5f, s);
+        gemv_b(l.qkv, xnd.p, nb, qkvd.p, dtype, ACT_NONE, nullptr, kcl, vcl);
+        {
+            ProfScope ps(FAM_ATTN, s, 0.0, 0.0);
+#define ATT(T, ...) hipLaunchKernelGGL(gpt_attn_kernel<T>, dim3(c.heads, nb), dim3(512), lds, s, (const T*)qkvd.p, (const T*)kcl, (const T*)vcl, (T*)attd.p, state.as<int>(), 1, 0, h, S, 1, slot_cache_elems())
+            GPT_DISPATCH(ATT, 0);
+#undef ATT
+        }
+        gemv_b(l.proj, attd.p, nb, x, MI_F32, ACT_NONE, x, nullptr, nullptr);
+        launch_rownorm(NORM_LN_AFFINE, x, xnd.p, dtype, l.ln2_w.as<float>(), l.ln2_b.as<float>(), nb, h, 1e-5f, s);
+        gemv_b(l.fc, xnd.p, nb, ffd.p, dtype, ACT_GELU_TANH, nullptr, nullptr, nullptr);
+        gemv_b(l.fc2, ffd.p, nb, x, MI_F32, ACT_NONE, x, nullptr, nullptr);
+    }
+    launch_rownorm(NORM_LN_AFFINE, x, last.p, MI_F32, lnf_w.as<float>(), lnf_b.as<float>(), nb, h, 1e-5f, s);
+    launch_rownorm(NORM_LN_AFFINE, last.as<float>(), zd.p, dtype, fn_w.as<float>(), fn_b.as<float>(), nb, h, 1e-5f, s);
+    gemv_b(head, zd.p, nb, logits.p, MI_F32, ACT_NONE, nullptr, nullptr, nullptr);
+    hipLaunchKernelGGL(gpt_pick_kernel, dim3(nb), dim3(1024), 0, s, logits.as<float>(), pen.as<float>(), last.as<float>(),
+                       state.as<int>(), toks.as<int>(), hid.as<float>(), c.mel_codes, h, 1, rep_value, S);
+    MI_HIP(hipGetLastError());
+}
+
+void Gpt::decode_batch_steps(int nb, int n) {
+    if (n <= 0) return;
+    if (!use_graph || prof_mask() != 0) { for (int i = 0; i < n; ++i) decode_batch_eager(nb); return; }
+    hipGraphExec_t& exec = batch_graphs[nb];
+    if (!exec) {
+        decode_batch_eager(nb);
+        --n;
+        hipGraph_t graph = nullptr;
+        MI_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+        try {
+            decode_batch_eager(nb);
+        } catch (...) {
+            (void)hipStreamEndCapture(stream, &graph);
+            if (graph) (void)hipGraphDestroy(graph);
+            throw;
+        }
+        MI_HIP(hipStreamEndCapture(stream, &graph));
+        hipError_t err = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (err != hipSuccess) { exec = nullptr; use_graph = false; for (int i = 0; i < n; ++i) decode_batch_eager(nb); return; }
+    }
+    for (int i = 0; i < n; ++i) MI_HIP(hipGraphLaunch(exec, stream));
 }
 
 void Gpt::text_embed(const int32_t* ids_dev, int n, float* out_dev) {

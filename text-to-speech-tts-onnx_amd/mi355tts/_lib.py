@@ -94,6 +94,9 @@ def load() -> C.CDLL:
     L.mi_gpt_generate.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_float, C.c_int, vp, vp, vp,
                                   C.POINTER(C.c_int32), C.c_int]
     L.mi_gpt_generate.restype = C.c_int
+    L.mi_gpt_generate_batch.argtypes = [vp, C.c_int, vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), vp, C.c_int,
+                                        C.c_float, C.c_int, vp, vp, vp, C.c_int, C.POINTER(C.c_int32), C.c_int]
+    L.mi_gpt_generate_batch.restype = C.c_int
     L.mi_bench_conv_gemm.argtypes = [C.c_int] * 9 + [C.POINTER(C.c_double)]
     L.mi_bench_conv_gemm.restype = C.c_int
     L.mi_set_option.argtypes = [C.c_char_p, C.c_int64]; L.mi_set_option.restype = C.c_int

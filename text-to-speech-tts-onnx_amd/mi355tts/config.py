@@ -169,6 +169,7 @@ class IndexGPTConfig:
     max_mel_pos: int = 803              # mel_pos_embedding rows
     max_text_pos: int = 603             # text_pos_embedding rows
     max_seq: int = 1024                 # KV-cache capacity of this engine (>= MAX_GENERATE_LENGTH = 800)
+    max_batch: int = 1                  # sentences decoded together by generate_batch (engine extension; <= 16)
     ln_eps: float = 1e-5
     start_mel_token: int = 8192
     stop_mel_token: int = 8193
@@ -182,7 +183,7 @@ class IndexGPTConfig:
 
     def to_int_array(self) -> List[int]:
         return [self.hidden, self.layers, self.heads, self.inner, self.mel_codes, self.text_tokens, self.max_mel_pos,
-                self.max_text_pos, self.max_seq]
+                self.max_text_pos, self.max_seq, self.max_batch]
 
     @staticmethod
     def small() -> "IndexGPTConfig":

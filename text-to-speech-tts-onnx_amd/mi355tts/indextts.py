@@ -180,6 +180,56 @@ class IndexGPT:
             C.byref(n), _lib.MI_DEVICE), "mi_gpt_generate")
         return int(n.value)
 
+    def generate_batch(self, prompts, max_new, *, stop_tokens=None, repeat_value=None, penalty_range=None,
+                       repeat_penality=None):
+        """Several sentences at once (engine extension: the reference decodes one sentence at a time).  prompts = list
+        of (1, P_b, hidden) graph-D outputs, max_new = list of per-sentence limits.  Every decode step streams the
+        weights once for all sentences.  Returns a list of (tokens, hidden) and the (nb, mel_codes) penalty matrix."""
+        c = self.cfg
+        nb = len(prompts)
+        if nb < 1 or nb > c.max_batch or len(max_new) != nb:
+            raise ValueError(f"batch of {nb} sentences; this engine was created with max_batch = {c.max_batch}")
+        ps = [np.ascontiguousarray(p, dtype=np.float32).reshape(-1, c.hidden) for p in prompts]
+        rows = np.ascontiguousarray([p.shape[0] for p in ps], dtype=np.int32)
+        cat = np.ascontiguousarray(np.concatenate(ps, axis=0))
+        mx = np.ascontiguousarray([int(m) for m in max_new], dtype=np.int32)
+        cap = max(int(mx.max()), 1)
+        stops = np.ascontiguousarray([c.stop_mel_token] if stop_tokens is None else list(stop_tokens), dtype=np.int32)
+        pen = (np.ones((nb, c.mel_codes), np.float32) if repeat_penality is None
+               else np.ascontiguousarray(repeat_penality, dtype=np.float32).reshape(nb, c.mel_codes).copy())
+        toks = np.zeros((nb, cap), np.int32)
+        hid = np.zeros((nb, cap, c.hidden), np.float32)
+        n = np.zeros((nb,), np.int32)
+        _lib.check(_lib.load().mi_gpt_generate_batch(
+            self._h, nb, cat.ctypes.data, _lib.i32p(rows), _lib.i32p(mx), stops.ctypes.data if stops.size else None,
+            stops.size, float(c.repeat_penalty if repeat_value is None else repeat_value),
+            int(c.penalty_range if penalty_range is None else penalty_range), pen.ctypes.data, toks.ctypes.data,
+            hid.ctypes.data, cap, _lib.i32p(n), _lib.MI_HOST), "mi_gpt_generate_batch")
+        return [(toks[b, : n[b]].copy(), hid[b, : n[b]].copy()) for b in range(nb)], pen
+
+    def generate_batch_torch(self, prompts_cat, prompt_rows, max_new, tokens, hidden, *, stop_tokens=None,
+                             repeat_value=None, penalty_range=None):
+        """Device-resident variant: prompts_cat (sum P_b, hidden) float32 CUDA tensor; tokens (nb, cap) int32 and hidden
+        (nb, cap, hidden) float32 CUDA tensors are filled.  Returns the per-sentence token counts."""
+        import torch
+        c = self.cfg
+        nb = len(prompt_rows)
+        assert prompts_cat.is_cuda and prompts_cat.dtype == torch.float32 and prompts_cat.is_contiguous()
+        assert tokens.is_cuda and tokens.dtype == torch.int32 and tokens.is_contiguous() and tokens.shape[0] == nb
+        assert hidden.is_cuda and hidden.dtype == torch.float32 and hidden.is_contiguous() and hidden.shape[:2] == tokens.shape
+        rows = np.ascontiguousarray(prompt_rows, dtype=np.int32)
+        mx = np.ascontiguousarray(max_new, dtype=np.int32)
+        stops = [c.stop_mel_token] if stop_tokens is None else list(stop_tokens)
+        st = torch.tensor(stops, dtype=torch.int32, device=prompts_cat.device) if stops else None
+        torch.cuda.current_stream(prompts_cat.device).synchronize()
+        n = np.zeros((nb,), np.int32)
+        _lib.check(_lib.load().mi_gpt_generate_batch(
+            self._h, nb, prompts_cat.data_ptr(), _lib.i32p(rows), _lib.i32p(mx), st.data_ptr() if st is not None else None,
+            len(stops), float(c.repeat_penalty if repeat_value is None else repeat_value),
+            int(c.penalty_range if penalty_range is None else penalty_range), None, tokens.data_ptr(), hidden.data_ptr(),
+            int(tokens.shape[1]), _lib.i32p(n), _lib.MI_DEVICE), "mi_gpt_generate_batch")
+        return n
+
     def generate(self, conds_latent, text_ids, *, max_generate_length=None, **kw):
         """Inference_IndexTTS_ONNX.py:723-783 for one sentence: B, C, D then E until a stop token or
         MAX_GENERATE_LENGTH - concat_len tokens.  Returns (tokens, save_last_hidden_state (n, hidden), penalty)."""
