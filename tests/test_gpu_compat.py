@@ -217,3 +217,46 @@ def test_indextts_gpt_driver_loop_through_facade(tmp_path, golden_dir):
     np.testing.assert_allclose(last, g["S_last_hidden"], atol=3e-4, rtol=0)
     with pytest.raises(onnxruntime.InvalidArgument):
         ort_session_E.run(None, {**feed_np, "ids_len": np.array([2], np.int64)})
+
+
+def test_handles_are_thread_safe(golden_dir):
+    """SURVEY.md §8b threading: calls on one handle are serialised, different handles run concurrently; ctypes drops
+    the GIL for the duration of a call."""
+    import threading
+    from mi355tts.bigvgan import BigVGANVocoder
+    cfg = BigVGANConfig.small()
+    st = W.synth_state(W.bigvgan_spec(cfg), 9527)
+    a, b = BigVGANVocoder(cfg, st, dtype="f32"), BigVGANVocoder(cfg, st, dtype="f32")
+    mels = [W.synth_normal(50 + i, "mel", (1, cfg.num_mels, 40 + 8 * i), std=1.0) for i in range(6)]
+    want = [a.run(m) for m in mels]
+    got, errs = {}, []
+
+    def work(tid, eng):
+        try:
+            for rep in range(4):
+                for i, m in enumerate(mels):
+                    got[(tid, rep, i)] = eng.run(m)
+        except Exception as e:                      # pragma: no cover
+            errs.append(e)
+    th = [threading.Thread(target=work, args=(t, a if t < 3 else b)) for t in range(5)]     # 3 threads share handle a
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    for (tid, rep, i), y in got.items():
+        np.testing.assert_array_equal(y, want[i])
+    a.close(); b.close()
+
+
+def test_example_script_runs(tmp_path):
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from mi355tts import audio_io
+    prompt = str(tmp_path / "prompt.wav")
+    t = np.arange(44100)
+    audio_io.write_wavex(prompt, (8000 * np.sin(2 * np.pi * 330 * t / 44100)).astype(np.int16), 44100)
+    out = str(tmp_path / "gen.wav")
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "f5_tts_infer.py"), "--small", "--dtype", "f32",
+                        "--prompt", prompt, "--out", out], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    wav, rate = audio_io.read_wav(out)
+    assert rate == 24000 and wav.shape[1] == 1 and wav.shape[0] > 1000 and "RTF" in r.stdout

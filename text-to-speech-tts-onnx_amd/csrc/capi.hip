@@ -5,12 +5,14 @@
 #include "gpt.h"
 #include <cstdlib>
 #include <algorithm>
+#include <mutex>
 
 using namespace mi;
 
-struct mi_bigvgan { BigVGAN* impl; };
-struct mi_f5 { F5* impl; };
-struct mi_gpt { Gpt* impl; };
+// calls on one handle are serialised (one HIP stream + one workspace per handle); different handles run concurrently
+struct mi_bigvgan { BigVGAN* impl; std::mutex mu; };
+struct mi_f5 { F5* impl; std::mutex mu; };
+struct mi_gpt { Gpt* impl; std::mutex mu; };
 
 template <typename F> static int guard(F&& f) {
     try {
@@ -64,7 +66,8 @@ mi_bigvgan* mi_bigvgan_create(const int32_t* cfg, int n_cfg, const float* weight
     int rc = guard([&] {
         MI_REQUIRE(weights != nullptr, "mi_bigvgan_create: null weights");
         BigVGANCfg g = parse_bigvgan_cfg(cfg, n_cfg);
-        h = new mi_bigvgan{new BigVGAN(g, weights, n_weights, dtype, device)};
+        BigVGAN* impl = new BigVGAN(g, weights, n_weights, dtype, device);
+        h = new mi_bigvgan; h->impl = impl;
     });
     return rc == MI_OK ? h : nullptr;
 }
@@ -83,6 +86,7 @@ int64_t mi_bigvgan_out_len(const mi_bigvgan* h, int frames) {
 int mi_bigvgan_forward(mi_bigvgan* h, const float* mel, int B, int frames, int16_t* out, int mem) {
     return guard([&] {
         MI_REQUIRE(h && h->impl, "mi_bigvgan_forward: null handle");
+        std::lock_guard<std::mutex> lk_(h->mu);
         MI_REQUIRE(mem == MI_HOST || mem == MI_DEVICE, "mi_bigvgan_forward: bad mem kind");
         h->impl->run(mel, B, frames, nullptr, out, mem);
     });
@@ -91,6 +95,7 @@ int mi_bigvgan_forward(mi_bigvgan* h, const float* mel, int B, int frames, int16
 int mi_bigvgan_forward_f32(mi_bigvgan* h, const float* mel, int B, int frames, float* out, int mem) {
     return guard([&] {
         MI_REQUIRE(h && h->impl, "mi_bigvgan_forward_f32: null handle");
+        std::lock_guard<std::mutex> lk_(h->mu);
         MI_REQUIRE(mem == MI_HOST || mem == MI_DEVICE, "mi_bigvgan_forward_f32: bad mem kind");
         h->impl->run(mel, B, frames, out, nullptr, mem);
     });
@@ -100,6 +105,7 @@ int mi_bigvgan_forward_latent(mi_bigvgan* h, const float* latent, int T_codes, c
                               int16_t* out, float* out_f32, int mem) {
     return guard([&] {
         MI_REQUIRE(h && h->impl, "mi_bigvgan_forward_latent: null handle");
+        std::lock_guard<std::mutex> lk_(h->mu);
         MI_REQUIRE(mem == MI_HOST || mem == MI_DEVICE, "mi_bigvgan_forward_latent: bad mem kind");
         h->impl->run_latent(latent, T_codes, conds, (long)n_conds, out_f32, out, mem);
     });
@@ -145,7 +151,8 @@ mi_f5* mi_f5_create(const int32_t* cfg_i, int n_i, const float* cfg_f, int n_f, 
     int rc = guard([&] {
         MI_REQUIRE(weights != nullptr, "mi_f5_create: null weights");
         F5Cfg c = parse_f5_cfg(cfg_i, n_i, cfg_f, n_f);
-        h = new mi_f5{new F5(c, weights, n_weights, dtype, device)};
+        F5* impl = new F5(c, weights, n_weights, dtype, device);
+        h = new mi_f5; h->impl = impl;
     });
     return rc == MI_OK ? h : nullptr;
 }
@@ -158,6 +165,7 @@ void mi_f5_destroy(mi_f5* h) {
 
 #define F5_CHECK(h, mem, name)                                                     \
     MI_REQUIRE((h) && (h)->impl, name ": null handle");                            \
+    std::lock_guard<std::mutex> lk_((h)->mu);                                      \
     MI_REQUIRE((mem) == MI_HOST || (mem) == MI_DEVICE, name ": bad mem kind")
 
 static void copy_out(void* dst, const void* src, size_t bytes, int mem, hipStream_t s) {
@@ -168,6 +176,7 @@ static void copy_out(void* dst, const void* src, size_t bytes, int mem, hipStrea
 int mi_f5_tables(mi_f5* h, float* time_expand, float* delta_t) {
     return guard([&] {
         MI_REQUIRE(h && h->impl, "mi_f5_tables: null handle");
+        std::lock_guard<std::mutex> lk_(h->mu);
         F5& e = *h->impl;
         if (time_expand) std::memcpy(time_expand, e.h_time_expand.data(), e.h_time_expand.size() * 4);
         if (delta_t) std::memcpy(delta_t, e.h_delta.data(), e.h_delta.size() * 4);
@@ -288,7 +297,8 @@ mi_gpt* mi_gpt_create(const int32_t* cfg, int n_cfg, const float* weights, int64
     int rc = guard([&] {
         MI_REQUIRE(weights != nullptr, "mi_gpt_create: null weights");
         GptCfg c = parse_gpt_cfg(cfg, n_cfg);
-        h = new mi_gpt{new Gpt(c, weights, n_weights, dtype, device)};
+        Gpt* impl = new Gpt(c, weights, n_weights, dtype, device);
+        h = new mi_gpt; h->impl = impl;
     });
     return rc == MI_OK ? h : nullptr;
 }
@@ -301,6 +311,7 @@ void mi_gpt_destroy(mi_gpt* h) {
 
 #define GPT_CHECK(h, mem, name)                                                    \
     MI_REQUIRE((h) && (h)->impl, name ": null handle");                            \
+    std::lock_guard<std::mutex> lk_((h)->mu);                                      \
     MI_REQUIRE((mem) == MI_HOST || (mem) == MI_DEVICE, name ": bad mem kind");     \
     MI_HIP(hipSetDevice((h)->impl->device))
 
@@ -348,6 +359,7 @@ int mi_gpt_mel_embed(mi_gpt* h, int32_t gpt_id, int64_t gen_len, float* out, int
 int mi_gpt_reset(mi_gpt* h) {
     return guard([&] {
         MI_REQUIRE(h && h->impl, "mi_gpt_reset: null handle");
+        std::lock_guard<std::mutex> lk_(h->mu);
         MI_HIP(hipSetDevice(h->impl->device));
         h->impl->reset();
     });
