@@ -52,6 +52,7 @@ struct ConvGemmDev {
     long v_ld; int Mb;
     const void* zero;      // >= 16 bytes of zeros: source for out-of-range / K-tail vectors of the LDS-DMA path
     int dbg;               // tuning only: 1 = no DMA in the main loop, 2 = no ds_read/MFMA in the main loop
+    int lds_epi;           // 1: outputs leave through the LDS-staged, 16-byte-store epilogue (alignment checked on the host)
     int Tm, Tn, RT, RC;    // XCD-aware tile order (DMA kernel): M-tiles per batch item, N-tiles, row tiles (B*Tm), rows per XCD
 };
 
@@ -168,6 +169,91 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], const ConvG
             for (int r = 0; r < 16; ++r) { bool o; const long ix = row_of(r, o); if (o) outp[ix] = from_f32<TO>(v[r]); }
             __builtin_amdgcn_sched_barrier(0);                // keep one tile's addresses live at a time
         }
+    }
+}
+
+// LDS-staged epilogue for the DMA kernels (EPI_PLAIN / EPI_CONVT): the accumulator layout gives every lane ONE output
+// column, so the direct epilogue above leaves the chip as 2- or 4-byte stores (a 256x256 bf16 tile = 128 store
+// instructions of 128 bytes per wave; measured: 25-35 us of fixed cost per block wave, more than the K loop of a
+// K = 1024 GEMM).  Here each wave parks 32*RT rows x WN columns of fp32 results (bias / activation / gate applied) in
+// its own slice of the now idle operand ring, then reads them back row-wise and leaves with 16-byte stores (residual
+// and accumulate operands are fetched with 16-byte loads in the same layout).  Wave-local: no block barrier.
+template <typename TO, int TM, int TN, int WM, int WN>
+__device__ __forceinline__ void gemm_epilogue_lds(f32x16 (&acc)[TM][TN], const ConvGemmDev& p, int m0, int n0, int b, int g,
+                                                  int wm, int wn, int lr, int lk, float* stage) {
+    constexpr int CH = sizeof(TO) == 2 ? 8 : 4;            // columns per lane: one 16-byte store
+    constexpr int LPR = WN / CH;                            // lanes per output row
+    constexpr int RPI = 64 / LPR;                           // rows per wave instruction
+    constexpr int RT = (WN <= 64 && TM % 2 == 0) ? 2 : 1;   // 32-row tiles per pass (<= 16 KB of fp32 per wave)
+    const int lane = lk * 32 + lr;
+    TO* outp = (TO*)p.out + (long)b * p.out_bstride;
+    const TO* resp = p.res ? (const TO*)p.res + (long)b * p.out_bstride : nullptr;
+    const int cl = (lane % LPR) * CH, rl0 = lane / LPR;
+    const int nchunk = n0 + wn * WN + cl;                   // first of this lane's CH columns
+    int ccol = g * p.N + nchunk, cph = 0;
+    if (p.epi == EPI_CONVT) { cph = nchunk / p.Cout; ccol = nchunk - cph * p.Cout; }
+    const bool cok = nchunk < p.N && lane < RPI * LPR;
+#pragma unroll
+    for (int i0 = 0; i0 < TM; i0 += RT) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * WN + j * 32 + lr;
+            const int nc = n < p.N ? n : 0;
+            const int col = p.epi == EPI_CONVT ? nc % p.Cout : g * p.N + nc;
+            const float bv = p.bias ? p.bias[col] : 0.f;
+            const float gv = p.gate ? p.gate[(long)b * p.gate_bstride + col] : 1.f;
+#pragma unroll
+            for (int ii = 0; ii < RT; ++ii) {
+                float v[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = acc[i0 + ii][j][r] + bv;
+                switch (p.act) {
+                    case ACT_GELU_TANH: act16<ACT_GELU_TANH>(v); break;
+                    case ACT_GELU_ERF: act16<ACT_GELU_ERF>(v); break;
+                    case ACT_MISH: act16<ACT_MISH>(v); break;
+                    case ACT_SILU: act16<ACT_SILU>(v); break;
+                    default: break;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    stage[(ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * WN + j * 32 + lr] = v[r] * gv;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int rr = rl0; rr < RT * 32; rr += RPI) {
+            const int m = m0 + wm * WM + i0 * 32 + rr;
+            long row = m;
+            bool ok = cok && m < p.M;
+            if (p.epi == EPI_CONVT) { row = (long)m * p.u + cph - p.padT; ok = ok && row >= 0 && row < p.T_out; }
+            if (!ok) continue;
+            float x[CH];
+#pragma unroll
+            for (int q = 0; q < CH; q += 4) {
+                const float4 t = *reinterpret_cast<const float4*>(&stage[rr * WN + cl + q]);
+                x[q] = t.x; x[q + 1] = t.y; x[q + 2] = t.z; x[q + 3] = t.w;
+            }
+            const long ix = row * p.out_rstride + ccol;
+            struct alignas(16) Pk { TO v[CH]; };
+            if (resp) {
+                const Pk rv = *reinterpret_cast<const Pk*>(resp + ix);
+#pragma unroll
+                for (int q = 0; q < CH; ++q) x[q] += to_f32(rv.v[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < CH; ++q) x[q] *= p.alpha;
+            if (p.accumulate) {
+                const Pk ov = *reinterpret_cast<const Pk*>(outp + ix);
+#pragma unroll
+                for (int q = 0; q < CH; ++q) x[q] += to_f32(ov.v[q]);
+            }
+            Pk o;
+#pragma unroll
+            for (int q = 0; q < CH; ++q) o.v[q] = from_f32<TO>(x[q]);
+            *reinterpret_cast<Pk*>(outp + ix) = o;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -311,7 +397,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmDev p) 
 // ---------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void lds_void;
 
-template <typename T, typename TO>
+template <typename T, typename TO, bool LEPI>
 __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvGemmDev p) {
     using MF = Mfma<T>;
     constexpr int BM = 128, BN = 128, KC = 64, WM = 64, WN = 64, TM = 2, TN = 2;
@@ -410,7 +496,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvGemmDev
         __syncthreads();
         tap = ntap; c0 = nc0;
     }
-    gemm_epilogue<TO, TM, TN, WM, WN>(acc, p, m0, n0, b, g, wm, wn, lr, lk);
+    if constexpr (LEPI) {
+        constexpr int ERT = (WN <= 64 && TM % 2 == 0) ? 2 : 1;
+        gemm_epilogue_lds<TO, TM, TN, WM, WN>(acc, p, m0, n0, b, g, wm, wn, lr, lk,
+                                              reinterpret_cast<float*>(smem) + wave * (ERT * 32 * WN));
+    } else {
+        gemm_epilogue<TO, TM, TN, WM, WN>(acc, p, m0, n0, b, g, wm, wn, lr, lk);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -607,7 +699,8 @@ static void dispatch_tiles(const ConvGemmDev& d, int B, hipStream_t s) {
                 e.Tm = (d.M + 127) / 128; e.Tn = (d.N + 127) / 128; e.RT = B * e.Tm;
                 e.RC = g_xcd_order ? (e.RT + 7) / 8 : 0;
                 dim3 g1(e.RC > 0 ? 8 * e.RC * e.Tn : e.RT * e.Tn, d.G);
-                hipLaunchKernelGGL((conv_gemm_dma_kernel<T, TO>), g1, blk, 0, s, e);
+                if (e.lds_epi) hipLaunchKernelGGL((conv_gemm_dma_kernel<T, TO, true>), g1, blk, 0, s, e);
+                else hipLaunchKernelGGL((conv_gemm_dma_kernel<T, TO, false>), g1, blk, 0, s, e);
                 MI_HIP(hipGetLastError());
                 return;
             }
@@ -657,6 +750,7 @@ void launch_conv_gemm(const ConvGemm& p, hipStream_t s) {
             const char* y = std::getenv("MI355TTS_NO_DMA3_GEMM"); g_use_dma3 = !(y && y[0] == '1');
             const char* z = std::getenv("MI355TTS_NO_BIG_TILES"); g_big_tiles = !(z && z[0] == '1');
             if (const char* m = std::getenv("MI355TTS_BIG_TILE_MIN")) g_big_min = std::atol(m);
+            if (const char* m = std::getenv("MI355TTS_DMA3_K_MIN")) g_k_min = std::atol(m);
             if (const char* n = std::getenv("MI355TTS_NO_N192")) g_n192 = !(n[0] == '1');
             env_read = true; }
         int dev = 0;
@@ -666,6 +760,14 @@ void launch_conv_gemm(const ConvGemm& p, hipStream_t s) {
         d.zero = z.p;
         const char* dm = std::getenv("MI355TTS_GEMM_DBG");
         d.dbg = dm ? std::atoi(dm) : 0;
+        static int no_lds_epi = -1;
+        if (no_lds_epi < 0) { const char* q = std::getenv("MI355TTS_NO_LDS_EPI"); no_lds_epi = (q && q[0] == '1') ? 1 : 0; }
+        const int ch = 16 / (int)dtype_size(odt);
+        // measured: +8-14 % on the K = 1024 DiT linears in the 2-blocks-per-CU 128x128 kernel, a loss on the conv shapes
+        // (N <= 768) and in the one-block-per-CU 8-wave kernels, so it is used for wide linear layers only
+        d.lds_epi = !no_lds_epi && p.epi == EPI_PLAIN && p.taps == 1 && p.N >= 1024 && p.N % ch == 0 && p.out_rstride % ch == 0 &&
+                    p.out_bstride % ch == 0 && ((uintptr_t)p.out % 16) == 0 && (!p.res || ((uintptr_t)p.res % 16) == 0) &&
+                    (p.epi != EPI_CONVT || p.Cout % ch == 0);
     }
     if (p.epi == EPI_CONVT) MI_REQUIRE(p.Cout > 0 && p.N == p.u * p.Cout, "conv_gemm: convT shape");
     if (p.epi == EPI_QKV_ROPE)
