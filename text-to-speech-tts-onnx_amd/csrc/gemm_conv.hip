@@ -662,7 +662,12 @@ static void dispatch_tiles(const ConvGemmDev& d, int B, hipStream_t s) {
         if constexpr (sizeof(T) == 2) {
             // measured on gfx950 (tools/gemm_bench.py): with <= 32 K-chunks the 4-wave 128x128 kernel (two workgroups
             // per CU, short prologue/epilogue) wins; deeper K favours the 8-wave 256-row tiles.
-            if (g_use_dma3 && g_n192 && d.Cin % 8 == 0 && d.K % d.Cin == 0 && d.M > 128 && d.N % 192 == 0 && d.N % 256 != 0 &&
+            // N divisible by both 192 and 256 (BigVGAN stage 0, N = 768 at B = 8: 192 tiles of 256x256 leave a quarter of
+            // the CUs idle for the whole launch, 256 tiles of 256x192 fill the chip): compare rounds x tile width
+            const long rt256 = (long)B * ((d.M + 255) / 256);
+            const long rounds192 = (rt256 * (d.N / 192) + 255) / 256, rounds256 = (rt256 * ((d.N + 255) / 256) + 255) / 256;
+            const bool n192_wins = d.N % 256 != 0 || rounds192 * 192 < rounds256 * 256;
+            if (g_use_dma3 && g_n192 && d.Cin % 8 == 0 && d.K % d.Cin == 0 && d.M > 128 && d.N % 192 == 0 && n192_wins &&
                 d.K >= 576 && (long)B * ((d.M + 255) / 256) * (d.N / 192) >= g_n192_min) {
                 // N = 192 / 384 (BigVGAN stages 2 and 1): a 192-wide tile has no padded columns (128-wide tiles waste 25 %
                 // of the MFMAs and DMA bytes at N = 192) and the fewest DMA bytes per useful flop after 256x256
