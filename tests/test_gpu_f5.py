@@ -148,6 +148,32 @@ def test_attention_against_oracle_ragged_lengths(small):
     eng.close()
 
 
+@pytest.mark.parametrize("dtype,tol", [("f16", 1.5e-2), ("bf16", 8e-2)])
+def test_dit_16bit_ragged_batch_against_oracle(dtype, tol):
+    """16-bit DiT evaluation, two utterances flattened into the GEMM M axis with an odd token count: the LDS-staged QKV
+    epilogue (RoPE on 8-column chunks, V written transposed with lane = key) sees item boundaries inside its 64-row
+    tiles and key offsets that are not multiples of 8."""
+    cfg = F5Config(dim=256, depth=2, heads=4, dim_head=64, text_dim=64, text_num_embeds=40, conv_layers=1,
+                   pos_conv_groups=4, vocos_dim=64, vocos_intermediate=128, vocos_layers=1, nfe_step=4)
+    raw = W.synth_state(W.f5_spec(cfg), 7)
+    st = W.fold_f5(cfg, raw)
+    eng = F5Engine(cfg, raw, dtype=dtype)
+    tables = O.time_tables(cfg, st)
+    for N in (67, 131, 257):
+        noise = np.stack([W.synth_normal(3 + u, f"n{N}", (N, cfg.mel_dim)) for u in range(2)])
+        cmt = np.stack([W.synth_normal(14 + u, f"c{N}", (N, cfg.mel_dim + cfg.text_dim), std=0.7) for u in range(2)])
+        cmtd = np.stack([W.synth_normal(25 + u, f"d{N}", (N, cfg.mel_dim + cfg.text_dim), std=0.7) for u in range(2)])
+        cos, sin = O.rope_tables(N, 64)
+        pred = eng.dit_eval(noise, cmt, cmtd, 1)
+        for u in range(2):
+            ref = O.dit_forward(cfg, st, noise[u], cmt[u], cmtd[u], tables[2][1], cos, sin)
+            got = pred[2 * u:2 * u + 2]
+            assert got.shape == ref.shape
+            assert rms(got - ref) / rms(ref) < tol, (N, u, rms(got - ref) / rms(ref))
+            assert np.abs(got - ref).max() < 12 * tol * rms(ref), (N, u)
+    eng.close()
+
+
 def test_bad_arguments(small):
     cfg, st, eng = small
     with pytest.raises(ValueError):

@@ -257,6 +257,100 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x16 (&acc)[TM][TN], const C
     }
 }
 
+// LDS-staged variant of the fused QKV epilogue for the 128x128 DMA kernel (head_dim 64, one (q|k|v, head) slice per
+// 64-column wave tile).  q / k: rows leave as 16-byte stores into [b*H + h][token][64] with the interleaved-pair RoPE
+// applied on the 8-column chunk a lane holds.  V (transposed for the attention kernel, [b*H + h][d][key]): the tile is
+// read back column-wise with lane = key, so every store instruction writes 32 consecutive keys of one d (64 contiguous
+// bytes) instead of 64 two-byte writes to 64 different rows.
+template <typename TO>
+__device__ __forceinline__ void gemm_epilogue_qkv_lds(f32x16 (&acc)[2][2], const ConvGemmDev& p, int m0, int n0, int b,
+                                                      int wm, int wn, int lr, int lk, float* stage) {
+    const int lane = lk * 32 + lr;
+    const int dm = p.heads * 64;
+    const int nbase = n0 + wn * 64;
+    const int which = nbase / dm, hh = (nbase - which * dm) >> 6;           // wave-uniform
+    const int Mb = p.Mb > 0 ? p.Mb : p.M;
+    const int mbase = m0 + wm * 64;
+    const int bi0 = mbase / Mb, mloc0 = mbase - bi0 * Mb;
+    const bool vt = which == 2 && p.v_ld > 0;
+    TO* base = (TO*)(which == 0 ? p.out : which == 1 ? p.out2 : p.out3);
+    struct alignas(16) Pk { TO v[8]; };
+    if (!vt) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float bv = p.bias ? p.bias[nbase + j * 32 + lr] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    stage[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * 64 + j * 32 + lr] = acc[i][j][r] + bv;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int c8 = (lane & 7) * 8;
+        for (int rr = lane >> 3; rr < 64; rr += 8) {
+            if (mbase + rr >= p.M) continue;
+            int m = mloc0 + rr, bi = bi0;
+            if (m >= Mb) { m -= Mb; ++bi; }
+            float x[8];
+#pragma unroll
+            for (int q = 0; q < 8; q += 4) {
+                const float4 t = *reinterpret_cast<const float4*>(&stage[rr * 64 + c8 + q]);
+                x[q] = t.x; x[q + 1] = t.y; x[q + 2] = t.z; x[q + 3] = t.w;
+            }
+            if (which < 2) {
+                float c[8], sn[8];
+#pragma unroll
+                for (int q = 0; q < 8; q += 4) {
+                    const float4 tc = *reinterpret_cast<const float4*>(p.rope_cos + (long)m * 64 + c8 + q);
+                    const float4 ts = *reinterpret_cast<const float4*>(p.rope_sin + (long)m * 64 + c8 + q);
+                    c[q] = tc.x; c[q + 1] = tc.y; c[q + 2] = tc.z; c[q + 3] = tc.w;
+                    sn[q] = ts.x; sn[q + 1] = ts.y; sn[q + 2] = ts.z; sn[q + 3] = ts.w;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; q += 2) {
+                    const float e = x[q], o = x[q + 1];
+                    x[q] = e * c[q] - o * sn[q];
+                    x[q + 1] = o * c[q + 1] + e * sn[q + 1];
+                }
+            }
+            Pk o8;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) o8.v[q] = from_f32<TO>(x[q]);
+            *reinterpret_cast<Pk*>(base + (((long)b + bi) * p.heads + hh) * Mb * 64 + (long)m * 64 + c8) = o8;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        const int row = lane & 31, dh = lane >> 5;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float bv = p.bias ? p.bias[nbase + j * 32 + lr] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    stage[((r & 3) + 8 * (r >> 2) + 4 * lk) * 65 + j * 32 + lr] = acc[i][j][r] + bv;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int rr = i * 32 + row;
+            const bool ok = mbase + rr < p.M;
+            int m = mloc0 + rr, bi = bi0;
+            if (m >= Mb) { m -= Mb; ++bi; }
+            TO* dst = base + (((long)b + bi) * p.heads + hh) * 64 * p.v_ld + m;
+#pragma unroll 8
+            for (int d = 0; d < 32; ++d) {
+                const int dd = dh * 32 + d;
+                const float v = stage[row * 65 + dd];
+                if (ok) dst[(long)dd * p.v_ld] = from_f32<TO>(v);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 template <typename T, typename TO, int BM, int BN, int WGM, int WGN, int KC>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmDev p) {
     using MF = Mfma<T>;
@@ -498,8 +592,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvGemmDev
     }
     if constexpr (LEPI) {
         constexpr int ERT = (WN <= 64 && TM % 2 == 0) ? 2 : 1;
-        gemm_epilogue_lds<TO, TM, TN, WM, WN>(acc, p, m0, n0, b, g, wm, wn, lr, lk,
-                                              reinterpret_cast<float*>(smem) + wave * (ERT * 32 * WN));
+        float* stage = reinterpret_cast<float*>(smem) + wave * (ERT * 32 * WN);
+        if constexpr (sizeof(TO) == 2) {
+            if (p.epi == EPI_QKV_ROPE) { gemm_epilogue_qkv_lds<TO>(acc, p, m0, n0, b, wm, wn, lr, lk, stage); return; }
+        }
+        gemm_epilogue_lds<TO, TM, TN, WM, WN>(acc, p, m0, n0, b, g, wm, wn, lr, lk, stage);
     } else {
         gemm_epilogue<TO, TM, TN, WM, WN>(acc, p, m0, n0, b, g, wm, wn, lr, lk);
     }
@@ -666,7 +763,7 @@ static void dispatch_tiles(const ConvGemmDev& d, int B, hipStream_t s) {
             // the CUs idle for the whole launch, 256 tiles of 256x192 fill the chip): compare rounds x tile width
             const long rt256 = (long)B * ((d.M + 255) / 256);
             const long rounds192 = (rt256 * (d.N / 192) + 255) / 256, rounds256 = (rt256 * ((d.N + 255) / 256) + 255) / 256;
-            const bool n192_wins = d.N % 256 != 0 || rounds192 * 192 < rounds256 * 256;
+            const bool n192_wins = d.N % 256 != 0 || (d.K > g_k_min && rounds192 * 192 < rounds256 * 256);
             if (g_use_dma3 && g_n192 && d.Cin % 8 == 0 && d.K % d.Cin == 0 && d.M > 128 && d.N % 192 == 0 && n192_wins &&
                 d.K >= 576 && (long)B * ((d.M + 255) / 256) * (d.N / 192) >= g_n192_min) {
                 // N = 192 / 384 (BigVGAN stages 2 and 1): a 192-wide tile has no padded columns (128-wide tiles waste 25 %
@@ -770,6 +867,11 @@ void launch_conv_gemm(const ConvGemm& p, hipStream_t s) {
         const int ch = 16 / (int)dtype_size(odt);
         // measured: +8-14 % on the K = 1024 DiT linears in the 2-blocks-per-CU 128x128 kernel, a loss on the conv shapes
         // (N <= 768) and in the one-block-per-CU 8-wave kernels, so it is used for wide linear layers only
+        const bool qkv_lds = p.epi == EPI_QKV_ROPE && p.head_dim == 64 && dtype_size(odt) == 2 && p.G == 1 &&
+                             (p.rows_per_item == 0 ? p.M : p.rows_per_item) >= 64 && ((uintptr_t)p.out % 16) == 0 &&
+                             ((uintptr_t)p.out2 % 16) == 0;
+        d.lds_epi = !no_lds_epi && qkv_lds;
+        if (!qkv_lds)
         d.lds_epi = !no_lds_epi && p.epi == EPI_PLAIN && p.taps == 1 && p.N >= 1024 && p.N % ch == 0 && p.out_rstride % ch == 0 &&
                     p.out_bstride % ch == 0 && ((uintptr_t)p.out % 16) == 0 && (!p.res || ((uintptr_t)p.res % 16) == 0) &&
                     (p.epi != EPI_CONVT || p.Cout % ch == 0);
