@@ -425,6 +425,91 @@ __global__ __launch_bounds__(512) void gpt_attn_kernel(const T* __restrict__ qkv
     }
 }
 
+// decode-step attention (one new row per sentence, no mask): one block of 4 waves per (head, slot).  Each wave owns
+// every fourth 64-key pass and runs its own online softmax (lane = key for the scores, 16-byte K loads against the
+// packed q; the pass's V rows are fetched before the softmax so their latency overlaps it), so the block needs ONE
+// barrier: the four (max, sum, O) partials meet in LDS at the end.  The general kernel above (scores for all keys in
+// LDS, three block-wide reductions) took 6.5 us per launch at 100-300 keys; this is the latency-critical launch of a
+// decode step (24 per token).
+template <typename T>
+__global__ __launch_bounds__(256) void gpt_attn1_kernel(const T* __restrict__ qkv, const T* __restrict__ kc,
+                                                        const T* __restrict__ vc, T* __restrict__ out,
+                                                        const int* __restrict__ st, int hidden, int max_seq, int batched,
+                                                        size_t slot_stride) {
+    constexpr int V = Pack16<T>::N;            // elements per 16 bytes
+    constexpr int CH = 64 / V;                 // 16-byte chunks per 64-wide row
+    constexpr int KPI = 64 / CH;               // value rows per wave instruction
+    constexpr int NIT = 64 / KPI;              // instructions per 64-key pass
+    __shared__ float part[4][66];
+    const int head = blockIdx.x, slot = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (batched) { st += slot * GS_WORDS; kc += (size_t)slot * slot_stride; vc += (size_t)slot * slot_stride; }
+    const int kv = min(st[GS_HIST] + 1, max_seq);
+    Pack16<T> q[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) q[c] = ld16(qkv + (size_t)slot * 3 * hidden + head * 64 + c * V);
+    const T* kb = kc + (size_t)head * max_seq * 64;
+    const T* vb = vc + (size_t)head * max_seq * 64;
+    const int g = lane / CH, c = lane % CH;
+    float m_run = -INFINITY, l_run = 0.f, acc[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[e] = 0.f;
+    for (int base = wave * 64; base < kv; base += 256) {
+        const int j = base + lane;
+        const bool kok = j < kv;
+        Pack16<T> kp[CH], vp[NIT];
+        const T* kr = kb + (size_t)(kok ? j : base) * 64;
+#pragma unroll
+        for (int cc = 0; cc < CH; ++cc) kp[cc] = ld16(kr + cc * V);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int jj = base + it * KPI + g;
+            vp[it] = ld16(vb + (size_t)(jj < kv ? jj : base) * 64 + c * V);
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int cc = 0; cc < CH; ++cc) s = dot_pack(kp[cc], q[cc], s);
+        s = kok ? s : -INFINITY;
+        float mw = s;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mw = fmaxf(mw, __shfl_xor(mw, o, 64));
+        const float m_new = fmaxf(m_run, mw);              // finite: the pass holds at least one key
+        const float pj = kok ? __expf(s - m_new) : 0.f;
+        const float corr = __expf(m_run - m_new);          // exp(-inf) = 0 on the first pass
+        l_run = l_run * corr + wave_sum(pj);
+        m_run = m_new;
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] *= corr;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const float pk = __shfl(pj, it * KPI + g, 64);  // 0 for keys beyond kv
+#pragma unroll
+            for (int e = 0; e < V; ++e) acc[e] = fmaf(pk, (float)vp[it].v[e], acc[e]);
+        }
+    }
+#pragma unroll
+    for (int o = CH; o < 64; o <<= 1)
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
+    if (lane == 0) { part[wave][0] = m_run; part[wave][1] = l_run; }
+    if (g == 0)
+#pragma unroll
+        for (int e = 0; e < V; ++e) part[wave][2 + c * V + e] = acc[e];
+    __syncthreads();
+    if (wave == 0) {
+        float M = part[0][0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) M = fmaxf(M, part[w][0]);
+        float L = 0.f, o = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float f = __expf(part[w][0] - M);        // waves without keys: exp(-inf) = 0
+            L = fmaf(part[w][1], f, L);
+            o = fmaf(part[w][2 + lane], f, o);
+        }
+        out[(size_t)slot * hidden + head * 64 + lane] = (T)(o / L);
+    }
+}
+
 __global__ __launch_bounds__(256) void gpt_text_embed_kernel(const int* __restrict__ ids, const float* __restrict__ emb,
                                                              const float* __restrict__ pos, float* __restrict__ out,
                                                              int n, int hidden, int vocab) {
@@ -699,7 +784,9 @@ void Gpt::forward_rows(int rows, int flag, int slot) {
         {
             ProfScope ps(FAM_ATTN, s, 2.0 * (double)h * (history + rows) * es, 4.0 * (double)h * rows * (history + rows));
 #define ATT(T, ...) hipLaunchKernelGGL(gpt_attn_kernel<T>, dim3(c.heads, rows), dim3(512), lds, s, (const T*)qkv.p, (const T*)kcl, (const T*)vcl, (T*)att.p, st, rows, flag, h, S, 0, (size_t)0)
-            GPT_DISPATCH(ATT, 0);
+#define ATT1(T, ...) hipLaunchKernelGGL(gpt_attn1_kernel<T>, dim3(c.heads, 1), dim3(256), 0, s, (const T*)qkv.p, (const T*)kcl, (const T*)vcl, (T*)att.p, st, h, S, 0, (size_t)0)
+            if (rows == 1 && !flag) GPT_DISPATCH(ATT1, 0); else GPT_DISPATCH(ATT, 0);
+#undef ATT1
 #undef ATT
         }
         if (rows == 1) {
@@ -784,7 +871,6 @@ void Gpt::decode_batch_eager(int nb) {
     const int h = c.hidden, S = c.max_seq;
     hipStream_t s = stream;
     const size_t es = dtype_size(dtype);
-    const int lds = (S + 64 + 512) * 4;
     float* x = Xd.as<float>();
     hipLaunchKernelGGL(gpt_embed_state_kernel, dim3(nb), dim3(256), 0, s, state.as<int>(), mel_emb.as<float>(),
                        mel_pos.as<float>(), x, h, c.mel_codes, c.max_mel_pos, -1, -1);
@@ -797,7 +883,7 @@ void Gpt::decode_batch_eager(int nb) {
         gemv_b(l.qkv, xnd.p, nb, qkvd.p, dtype, ACT_NONE, nullptr, kcl, vcl);
         {
             ProfScope ps(FAM_ATTN, s, 0.0, 0.0);
-#define ATT(T, ...) hipLaunchKernelGGL(gpt_attn_kernel<T>, dim3(c.heads, nb), dim3(512), lds, s, (const T*)qkvd.p, (const T*)kcl, (const T*)vcl, (T*)attd.p, state.as<int>(), 1, 0, h, S, 1, slot_cache_elems())
+#define ATT(T, ...) hipLaunchKernelGGL(gpt_attn1_kernel<T>, dim3(c.heads, nb), dim3(256), 0, s, (const T*)qkvd.p, (const T*)kcl, (const T*)vcl, (T*)attd.p, state.as<int>(), h, S, 1, slot_cache_elems())
             GPT_DISPATCH(ATT, 0);
 #undef ATT
         }
