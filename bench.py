@@ -366,6 +366,21 @@ def run_indextts(args, world, rank, local, dev, dist, torch):
     gpt.close(); voc.close()
 
 
+def pmc_traffic_per_launch(args, ixf):
+    """HBM-side bytes per launch of the conv family from the committed PMC passes (profiles/r1/, same command as this
+    run under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`, FETCH doubled per MI355X_MICROARCH.md; tools/
+    pmc_traffic.py).  Counters cannot be collected from inside the timed run, so the figure is only reported for the
+    configuration those passes were taken on (the default one); otherwise null."""
+    if ixf or args.dtype != "f16" or args.batch != 8 or args.frames != 512:
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1", "final_bigvgan_pmc_hbm_traffic.json")) as f:
+            t = json.load(f)["_conv_family"]
+        return t["traffic_GB_per_forward"] * 1e9 / t["launches_per_forward"]
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tokens", type=int, default=256, help="indextts: mel codes decoded per sentence")
@@ -502,7 +517,8 @@ def main():
                        "whole_forward_achieved_GBps": bigvgan_algorithmic_bytes(cfg, B, F, esz) / (dt / args.steps) / 1e9},
             "roofline": {"bound": "hbm", "kernel": "conv_gemm_kernel (implicit-GEMM Conv1d/ConvTranspose1d family)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "launches_per_step": prof["launches"] / args.steps,
+                         "traffic": pmc_traffic_per_launch(args, ixf), "launches_per_step": prof["launches"] / args.steps,
+                         "algorithmic_bytes_per_launch": prof["bytes"] / max(prof["launches"], 1),
                          "avg_launch_ms": k_ms, "family_ms_per_step": prof["ms"] / args.steps,
                          "tflops": prof["flops"] / (prof["ms"] * 1e-3) / 1e12 if prof["ms"] > 0 else 0.0,
                          "mfma_peak_tflops": MFMA_F32_PEAK_TF if args.dtype == "f32" else MFMA_F16_PEAK_TF,
