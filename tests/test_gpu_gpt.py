@@ -330,3 +330,47 @@ def test_generate_batch_f16_tracks_single(small):
         agree += k
     assert agree >= 30          # 16-bit rounding differs between the fused-LN GEMV and the batched GEMV; ties are rare
     e.close()
+
+
+def _teacher_forced_hidden(cfg, st, prompt, toks):
+    """Oracle hidden states when it is fed the ENGINE's tokens (no divergence: 16-bit engines may legitimately pick a
+    different near-tie token than the fp32 oracle)."""
+    keys = [np.zeros((cfg.heads, 64, 0), np.float32)] * cfg.layers
+    vals = [np.zeros((cfg.heads, 0, 64), np.float32)] * cfg.layers
+    pen = np.ones((1, cfg.mel_codes), np.float32)
+    folds = [O.fold_layer(cfg, st, i) for i in range(cfg.layers)]
+    keys, vals, kvl, last, _, logits = O.graph_e(cfg, st, keys, vals, 0, pen, prompt.shape[1], prompt, 1, folds)
+    out, lg = [last], [logits]
+    gl = np.array([1])
+    for t in toks[:-1]:
+        hs, gl = O.graph_c(cfg, st, [[int(t)]], gl)
+        keys, vals, kvl, last, _, logits = O.graph_e(cfg, st, keys, vals, int(kvl[0]), pen, 1, hs, 0, folds)
+        out.append(last); lg.append(logits)
+    return np.concatenate(out, 0), np.concatenate(lg, 0)
+
+
+@pytest.mark.parametrize("dtype,tol", [("f16", 4e-2), ("bf16", 2.5e-1)])
+@pytest.mark.parametrize("nb", [3, 9, 16])
+def test_generate_batch_matrix_core_path(dtype, tol, nb):
+    """16-bit engines with >= 9 sentences (threshold lowered to 3 here) run the decode-step linears as v_mfma_f32_16x16x32 skinny GEMMs (hidden 256 and
+    320: one and five 64-wide K blocks per wave; inner 1280 takes the 8-way K split).  Checked against the oracle fed with
+    the engine's own tokens."""
+    _lib.set_option("gpt_mfma_min", 3)
+    for hidden, heads, inner in ((256, 4, 1024), (320, 5, 2560)):
+        cfg = IndexGPTConfig(hidden=hidden, layers=2, heads=heads, inner=inner, mel_codes=301, text_tokens=64, max_mel_pos=80,
+                             max_text_pos=80, max_seq=96, max_batch=16, start_mel_token=299, stop_mel_token=300)
+        st = W.synth_state(W.gpt_spec(cfg), 13)
+        e = IndexGPT(cfg, st, dtype=dtype)
+        items = [_prompt(e, cfg, 20 + b, 3 + (b * 5) % 9, n_cond=6) for b in range(nb)]
+        limits = [5 + (b * 3) % 6 for b in range(nb)]
+        res, _ = e.generate_batch([it[2] for it in items], limits, stop_tokens=[], repeat_value=1.0)
+        for b in (0, nb // 2, nb - 1):
+            toks, hid = res[b]
+            assert len(toks) == limits[b]
+            ohid, ologits = _teacher_forced_hidden(cfg, st, items[b][2], toks)
+            np.testing.assert_allclose(hid, ohid, rtol=0, atol=tol)
+            # the chosen token is (near-)maximal in the oracle's logits
+            for k, t in enumerate(toks):
+                assert ologits[k, t] >= ologits[k].max() - 6 * tol, (b, k)
+        e.close()
+    _lib.set_option("gpt_mfma_min", 9)

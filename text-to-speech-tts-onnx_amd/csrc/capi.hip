@@ -598,7 +598,7 @@ int mi_bench_conv_gemm(int dtype, int B, int T, int Cin, int N, int taps, int di
 int mi_set_option(const char* key, int64_t value) {
     return guard([&] {
         MI_REQUIRE(key != nullptr, "mi_set_option: null key");
-        MI_REQUIRE(gemm_set_option(key, (long)value), "mi_set_option: unknown key");
+        MI_REQUIRE(gemm_set_option(key, (long)value) || gpt_set_option(key, (long)value), "mi_set_option: unknown key");
     });
 }
 

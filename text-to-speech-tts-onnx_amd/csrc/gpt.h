@@ -13,6 +13,7 @@ struct GptCfg {
 };
 GptCfg parse_gpt_cfg(const int32_t* ci, int ni);
 int64_t gpt_param_count(const GptCfg& c);
+bool gpt_set_option(const char* key, long v);     // "gpt_mfma_min": sentences from which the batched step uses MFMA
 
 // device-side decode state (one int32 array; kernels read it so that a decode step has no host-dependent argument
 // and can be captured once into a hipGraph)

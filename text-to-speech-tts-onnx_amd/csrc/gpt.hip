@@ -14,9 +14,16 @@
 // every weight byte is read once per token), so the GEMV kernel is a plain coalesced 16-byte-per-lane dot product,
 // not an MFMA tile; the prompt pass (ids_len rows at once) goes through the MFMA implicit-GEMM kernel instead.
 #include "gpt.h"
+#include "mfma.h"
 #include <cstdlib>
 
 namespace mi {
+
+static long g_gpt_mfma_min = 9;
+bool gpt_set_option(const char* key, long v) {
+    if (std::string(key) == "gpt_mfma_min") { g_gpt_mfma_min = v; return true; }
+    return false;
+}
 
 GptCfg parse_gpt_cfg(const int32_t* ci, int ni) {
     MI_REQUIRE(ci && (ni == 9 || ni == 10), "gpt cfg: expected 9 or 10 ints");
@@ -320,6 +327,88 @@ __global__ __launch_bounds__(512) void gemv_b_kernel(const T* __restrict__ w, co
             if (!to_cache) {
                 if (out_f32) ((float*)out)[(size_t)b * N + n] = v; else ((T*)out)[(size_t)b * N + n] = (T)v;
             }
+        }
+    }
+}
+
+// Batched decode step on the matrix cores (16-bit engines, 9..16 sentences; option "gpt_mfma_min" moves the threshold): out[b][n] = sum_k w[n][k] x[b][k] as
+// v_mfma_f32_16x16x32 with the WEIGHT rows as the A operand (16 rows per wave) and the sentences as the 16 B columns,
+// so one pass over a weight row serves every sentence at full rate (the v_dot2 GEMV above costs ~1 us per sentence per
+// launch).  A wave owns 16 weight rows x K/KS of the K axis; within each 64-wide K block lane group g = lane>>4 takes
+// k = 16g .. 16g+15 for BOTH operands (the contraction is order-free), so a lane's two 16-byte loads are adjacent and
+// the four groups cover one full 128-byte line of the row.  The KS partial tiles meet in LDS.  x (<= 16 x K) is read
+// from L2 by every wave: as many bytes as the weights, but they never leave the chip.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+template <typename T> struct Mfma16;
+template <> struct Mfma16<f16> {
+    using Frag = f16x8;
+    static __device__ __forceinline__ f32x4_t mma(Frag a, Frag b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+template <> struct Mfma16<bf16> {
+    using Frag = bf16x8;
+    static __device__ __forceinline__ f32x4_t mma(Frag a, Frag b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+
+template <typename T, bool QKV, int UNR>
+__global__ __launch_bounds__(512) void gemm_skinny_kernel(const T* __restrict__ w, const T* __restrict__ x,
+                                                          const float* __restrict__ bias, const float* res, void* out,
+                                                          int out_f32, int act, int N, int K, int nb, int KS,
+                                                          T* __restrict__ kc, T* __restrict__ vc,
+                                                          const int* __restrict__ st, int max_seq, size_t slot_stride) {
+    using MF = Mfma16<T>;
+    using Frag = typename MF::Frag;
+    __shared__ __attribute__((aligned(16))) float red[8][256];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+    const int TR = 8 / KS, tile = wave / KS, ks = wave - tile * KS;
+    const int n0 = (blockIdx.x * TR + tile) * 16;
+    const int kw = K / KS;
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    if (n0 < N) {
+        const T* wr = w + (size_t)min(n0 + i, N - 1) * K + ks * kw + g * 16;
+        const T* xr = x + (size_t)min(i, nb - 1) * K + ks * kw + g * 16;
+        // UNR 64-wide K blocks per trip: all 4 * UNR loads are issued before the first MFMA
+        for (int kb = 0; kb < kw; kb += 64 * UNR) {
+            Frag a[2 * UNR], bq[2 * UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                a[2 * u] = *reinterpret_cast<const Frag*>(wr + kb + 64 * u);
+                a[2 * u + 1] = *reinterpret_cast<const Frag*>(wr + kb + 64 * u + 8);
+                bq[2 * u] = *reinterpret_cast<const Frag*>(xr + kb + 64 * u);
+                bq[2 * u + 1] = *reinterpret_cast<const Frag*>(xr + kb + 64 * u + 8);
+            }
+#pragma unroll
+            for (int u = 0; u < 2 * UNR; ++u) acc = MF::mma(a[u], bq[u], acc);
+        }
+    }
+    *reinterpret_cast<f32x4_t*>(&red[wave][lane * 4]) = acc;
+    __syncthreads();
+    if (ks != 0 || n0 >= N) return;
+    for (int q = 1; q < KS; ++q) {
+        const f32x4_t o = *reinterpret_cast<const f32x4_t*>(&red[wave + q][lane * 4]);
+        acc += o;
+    }
+    const int b = i;                                    // D layout: column = lane & 15 (sentence), rows 4*(lane>>4) + r
+    if (b >= nb) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int n = n0 + 4 * g + r;
+        if (n >= N) continue;
+        float v = acc[r] + (bias ? bias[n] : 0.f);
+        if (act == ACT_GELU_TANH) v = gelu_new(v);
+        if (res) v += res[(size_t)b * N + n];
+        bool to_cache = false;
+        if (QKV) {
+            const int hidden = N / 3;
+            if (n >= hidden) {
+                const int c = n - hidden, which = c / hidden, cc = c % hidden;
+                const int pos = st[b * GS_WORDS + GS_HIST];
+                if (pos < max_seq)
+                    (which ? vc : kc)[(size_t)b * slot_stride + ((size_t)(cc >> 6) * max_seq + pos) * 64 + (cc & 63)] = (T)v;
+                to_cache = true;
+            }
+        }
+        if (!to_cache) {
+            if (out_f32) ((float*)out)[(size_t)b * N + n] = v; else ((T*)out)[(size_t)b * N + n] = (T)v;
         }
     }
 }
@@ -846,9 +935,29 @@ void Gpt::gemv_b(const GLin& l, const void* x, int nb, void* out, int odt, int a
     MI_REQUIRE(of || odt == dtype, "gemv_b: output dtype");
     const int BB = nb <= 2 ? 2 : nb <= 4 ? 4 : nb <= 8 ? 8 : 16;
     const int R = l.n >= 4096 ? 2 : 1;
-    const dim3 grid((unsigned)((l.n + 8 * R - 1) / (8 * R)));
     ProfScope ps(FAM_CONV_GEMM, stream, (double)l.n * l.k * dtype_size(dtype), 2.0 * l.n * l.k * nb);
     const size_t sstride = slot_cache_elems();
+    {   // matrix-core path: 16-bit engines, nine or more sentences, K splits into 64-wide blocks per wave
+        static int no_mfma = -1;
+        if (no_mfma < 0) { const char* e = std::getenv("MI355TTS_GPT_NO_MFMA"); no_mfma = (e && e[0] == '1') ? 1 : 0; }
+        const int KS = l.k > 2048 ? 8 : 4;
+        // measured (1280-wide model): the MFMA kernel costs ~9.5 us per launch whatever the batch, the v_dot2 GEMV
+        // 10 / 12.7 / 20 us at 4 / 8 / 16 sentences
+        if (!no_mfma && dtype != MI_F32 && nb >= g_gpt_mfma_min && nb <= 16 && l.k % (KS * 64) == 0) {
+            const int TR = 8 / KS;
+            const dim3 gs((unsigned)((l.n + 16 * TR - 1) / (16 * TR)));
+            const bool u5 = (l.k / KS) % 320 == 0;
+#define GS1(T, QK, U) hipLaunchKernelGGL((gemm_skinny_kernel<T, QK, U>), gs, dim3(512), 0, stream, (const T*)l.w.p, (const T*)x, l.b.as<float>(), res, out, of, act, l.n, l.k, nb, KS, (T*)kcl, (T*)vcl, state.as<int>(), cfg.max_seq, sstride)
+#define GS(T, QK) do { if (u5) GS1(T, QK, 5); else GS1(T, QK, 1); } while (0)
+            if (dtype == MI_F16) { if (kcl) GS(f16, true); else GS(f16, false); }
+            else { if (kcl) GS(bf16, true); else GS(bf16, false); }
+#undef GS
+#undef GS1
+            MI_HIP(hipGetLastError());
+            return;
+        }
+    }
+    const dim3 grid((unsigned)((l.n + 8 * R - 1) / (8 * R)));
 #define GB(T, RR, B_, QK) hipLaunchKernelGGL((gemv_b_kernel<T, RR, B_, QK>), grid, dim3(512), 0, stream, (const T*)l.w.p, (const T*)x, l.b.as<float>(), res, out, of, act, l.n, l.k, nb, (T*)kcl, (T*)vcl, state.as<int>(), cfg.max_seq, sstride)
 #define GB_B(T, RR, QK) do { if (BB == 2) GB(T, RR, 2, QK); else if (BB == 4) GB(T, RR, 4, QK); else if (BB == 8) GB(T, RR, 8, QK); else GB(T, RR, 16, QK); } while (0)
 #define GB_T(T)                                                                 \
