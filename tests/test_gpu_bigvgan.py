@@ -234,7 +234,7 @@ def test_bad_inputs_raise(small_voc):
 # only when the launch fills the chip) and compared with the oracle
 # ---------------------------------------------------------------------------------------------
 _DEFAULTS = {"gemm_big_tile_min": 160, "gemm_n192_min": 160, "gemm_mid_tile_min": 160, "gemm_dma3_k_min": 2048,
-             "gemm_use_dma3": 1, "gemm_use_dma": 1, "gemm_big_tiles": 1, "gemm_n192": 1}
+             "gemm_use_dma3": 1, "gemm_use_dma": 1, "gemm_big_tiles": 1, "gemm_n192": 1, "gemm_pp": 0, "gemm_f32_dma": 1}
 
 
 @pytest.fixture
@@ -246,6 +246,11 @@ def gemm_options():
 
 
 @pytest.mark.parametrize("cfg_name,opts,Ci,Co,k,d,T,B", [
+    ("256x256/ping-pong", {"gemm_pp": 1, "gemm_big_tile_min": 1, "gemm_dma3_k_min": 0}, 768, 768, 7, 3, 700, 2),
+    ("256x256/ping-pong ragged N, Cin tail", {"gemm_pp": 1, "gemm_big_tile_min": 1, "gemm_dma3_k_min": 0}, 248, 1000, 3, 1, 333, 1),
+    ("256x256/ping-pong one chunk", {"gemm_pp": 1, "gemm_big_tile_min": 1, "gemm_dma3_k_min": 0}, 24, 300, 1, 1, 257, 1),
+    ("256x192/ping-pong", {"gemm_pp": 1, "gemm_n192_min": 1}, 192, 192, 11, 5, 900, 2),
+    ("256x192/ping-pong N=384", {"gemm_pp": 1, "gemm_n192_min": 1}, 384, 384, 3, 1, 515, 1),
     ("256x256/2-stage", {"gemm_big_tile_min": 1, "gemm_dma3_k_min": 0}, 768, 768, 7, 3, 700, 2),
     ("256x256/2-stage ragged N", {"gemm_big_tile_min": 1, "gemm_dma3_k_min": 0}, 256, 1000, 3, 1, 333, 1),
     ("256x192/2-stage", {"gemm_n192_min": 1}, 192, 192, 11, 5, 900, 2),
@@ -268,6 +273,21 @@ def test_gemm_tile_configs_vs_oracle(gemm_options, cfg_name, opts, Ci, Co, k, d,
     assert rms(y - ref) / rms(ref) < tol, cfg_name
     # element-wise too (a transposed or shifted tile would pass an RMS-of-noise check only by accident)
     assert np.abs(y - ref).max() < 40 * tol * rms(ref), cfg_name
+
+
+@pytest.mark.parametrize("f32_dma", [1, 0])
+def test_f32_gemm_dma_and_register_staged_agree_with_oracle(gemm_options, f32_dma):
+    # fp32 linears / convs with N > 64 run on the 128x128 LDS-DMA kernel (32-float chunks, k pairs (e, e+4) per MFMA);
+    # gemm_f32_dma = 0 keeps the register-staged kernel covered
+    gemm_options("gemm_f32_dma", f32_dma)
+    for Ci, Co, k, d, T, B in [(384, 384, 7, 3, 300, 2), (100, 200, 3, 1, 129, 1), (1024, 3072, 1, 1, 140, 1)]:
+        x = W.synth_normal(31, f"fx{Ci}{k}", (B, Ci, T))
+        w = W.synth_normal(32, f"fw{Ci}{Co}{k}", (Co, Ci, k), std=1.0 / np.sqrt(Ci * k))
+        b = W.synth_normal(33, "fb", (Co,), std=0.1)
+        pad = (k * d - d) // 2
+        ref = O.conv1d(x, w, b, dilation=d, padding=pad)
+        y = BV.conv1d(x, w, b, dilation=d, padding=pad)
+        np.testing.assert_allclose(y, ref, atol=2e-5, rtol=1e-5)
 
 
 # ---------------------------------------------------------------------------------------------

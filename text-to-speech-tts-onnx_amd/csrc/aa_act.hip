@@ -19,6 +19,7 @@
 // result goes back through LDS so the HBM store is again 16-byte coalesced.
 #include "common.h"
 #include "aa_math.h"
+#include <cstdlib>
 
 namespace mi {
 
@@ -138,7 +139,9 @@ static void launch_t(const AAAct& p, hipStream_t s) {
             if (p.C % cand == 0 && cand % VEC == 0) { CT = cand; break; }
         MI_REQUIRE(CT > 0, "aa_act: unsupported channel count");
     }
-    int TT = (8192 / CT) / R * R;
+    static int tt_elems = 0;                                // tile size in elements (rows x channels); tuning: MI355TTS_AA_TILE
+    if (!tt_elems) { const char* e = std::getenv("MI355TTS_AA_TILE"); tt_elems = e ? std::atoi(e) : 8192; }
+    int TT = (tt_elems / CT) / R * R;
     if (TT < R) TT = R;
     if (TT > 512) TT = 512;
     const int shift = p.post ? 15 : 0, ext = p.post ? 20 : 0;

@@ -561,6 +561,7 @@ int mi_bench_conv_gemm(int dtype, int B, int T, int Cin, int N, int taps, int di
         auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 65536.0f - 0.5f; };
         for (auto& v : hx) v = rnd();
         for (auto& v : hw) v = rnd() * 0.1f;
+        if (const char* z = std::getenv("MI355TTS_BENCH_ZERO")) if (z[0] == '1') { std::fill(hx.begin(), hx.end(), 0.f); std::fill(hw.begin(), hw.end(), 0.f); }   // data-dependent power / clock check
         // MI355TTS_BENCH_WSETS=n: cycle through n copies of the weights (n * bytes > 256 MiB MALL => every launch
         // streams cold weights from HBM, like consecutive layers of a real model)
         int nsets = 1;

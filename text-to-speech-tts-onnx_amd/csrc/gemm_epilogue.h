@@ -1,0 +1,340 @@
+// gemm_epilogue.h — device-side argument block and the shared epilogues of the implicit-GEMM kernels
+// (gemm_conv.hip: register-staged and LDS-DMA kernels; gemm_pp.hip: the ping-pong 256-row kernel).
+#pragma once
+#include "common.h"
+#include "mfma.h"
+
+namespace mi {
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    switch (act) {
+        case ACT_GELU_TANH: {
+            const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+            return 0.5f * v * (1.f + tanhf(k0 * (v + k1 * v * v * v)));
+        }
+        case ACT_GELU_ERF: return 0.5f * v * (1.f + erff(v * 0.7071067811865476f));
+        case ACT_MISH: {
+            float sp = v > 20.f ? v : log1pf(expf(v));
+            return v * tanhf(sp);
+        }
+        case ACT_SILU: return v / (1.f + expf(-v));
+        default: return v;
+    }
+}
+
+struct ConvGemmDev {
+    const void* x; const void* w; const float* bias; void* out; const void* res; const float* gate;
+    long gate_bstride;
+    int G, T_in, M, N, Cin, K, dil, pad;
+    long x_bstride, x_rstride, out_bstride, out_rstride, x_goff;
+    int act; float alpha; int accumulate; int epi;
+    int u, Cout, padT, T_out;
+    const float* rope_cos; const float* rope_sin; int heads, head_dim; void* out2; void* out3;
+    long v_ld; int Mb;
+    const void* zero;      // >= 16 bytes of zeros: source for out-of-range / K-tail vectors of the LDS-DMA path
+    int dbg;               // tuning only: 1 = no DMA in the main loop, 2 = no ds_read/MFMA in the main loop
+    int lds_epi;           // 1: outputs leave through the LDS-staged, 16-byte-store epilogue (alignment checked on the host)
+    int Tm, Tn, RT, RC;    // XCD-aware tile order (DMA kernel): M-tiles per batch item, N-tiles, row tiles (B*Tm), rows per XCD
+};
+
+// Shared epilogue: 32x32 accumulator tiles -> bias / activation / gate / residual / alpha / accumulate -> HBM,
+// with the ConvTranspose1d index map and the fused QKV bias+RoPE+head-scatter variants.
+// All wave-uniform decisions (activation kind, residual, accumulate, index map) are taken ONCE per 32x32 tile, not
+// per element: the first version branched per element and cost ~5 us per tile (~20 us fixed per launch).
+template <int ACT>
+__device__ __forceinline__ void act16(float (&v)[16]) {
+    // four values at a time: letting the scheduler interleave all 16 transcendental expansions costs ~90 VGPRs
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[q * 4 + r] = act_apply(v[q * 4 + r], ACT);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <typename TO, int TM, int TN, int WM, int WN>
+__device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], const ConvGemmDev& p, int m0, int n0, int b, int g,
+                                              int wm, int wn, int lr, int lk) {
+    if (p.epi == EPI_QKV_ROPE) {
+        // fused bias + interleaved-pair RoPE + head scatter (AttnProcessor, modules.py:459-466, 421-438):
+        //   column n -> (which = q|k|v, head, d) ; q,k: z*cos + rot(z)*sin with rot(z)[2j] = -z[2j+1],
+        //   rot(z)[2j+1] = z[2j] (the pair partner lives in lane^1 of the accumulator tile) ;
+        //   destination layout [b*H + head][token][head_dim] for the attention kernel.
+        const int dm = p.heads * p.head_dim;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * WN + j * 32 + lr;        // N % 32 == 0 is required: no lane drops out
+            const int which = n / dm;
+            const int rem = n - which * dm;
+            const int hh = rem / p.head_dim, dd = rem - hh * p.head_dim;
+            const float bv = p.bias ? p.bias[n] : 0.f;
+            const float sgn = (dd & 1) ? 1.f : -1.f;
+            const bool vt = which == 2 && p.v_ld > 0;         // V transposed: [bh][d][key]
+            TO* base = (TO*)(which == 0 ? p.out : which == 1 ? p.out2 : p.out3);
+            const long mstride = vt ? 1 : p.head_dim;
+            const int Mb = p.Mb > 0 ? p.Mb : p.M;             // tokens per batch item (batch may be flattened into M)
+            const long item_stride = vt ? (long)p.heads * p.head_dim * p.v_ld : (long)p.heads * Mb * p.head_dim;
+            const long head_off = vt ? ((long)hh * p.head_dim + dd) * p.v_ld : (long)hh * Mb * p.head_dim + dd;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int mb = m0 + wm * WM + i * 32 + 4 * lk;
+                const int bi0 = p.Mb > 0 ? mb / Mb : 0;                    // one division per 32-row tile (Mb >= 32)
+                const int mloc0 = mb - bi0 * Mb;
+                TO* dst0 = base + ((long)b + bi0) * item_stride + head_off;        // this tile touches at most two items
+                TO* dst1 = dst0 + item_stride;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int off = (r & 3) + 8 * (r >> 2);
+                    const int mg = mb + off;                               // row in the (possibly flattened) M axis
+                    float v = acc[i][j][r] + bv;
+                    const float partner = __shfl_xor(v, 1);
+                    int m = mloc0 + off, bi = bi0;                         // token position inside its batch item
+                    if (m >= Mb) { m -= Mb; ++bi; }
+                    if (mg >= p.M) { m = 0; bi = 0; }
+                    const float c = which < 2 ? p.rope_cos[(long)m * p.head_dim + dd] : 1.f;
+                    const float sn = which < 2 ? p.rope_sin[(long)m * p.head_dim + dd] : 0.f;
+                    v = v * c + sgn * partner * sn;
+                    if (mg < p.M) (bi == bi0 ? dst0 : dst1)[(long)m * mstride] = from_f32<TO>(v);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        return;
+    }
+    TO* outp = (TO*)p.out + (long)b * p.out_bstride;
+    const TO* resp = p.res ? (const TO*)p.res + (long)b * p.out_bstride : nullptr;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WN + j * 32 + lr;
+        const bool nok = n < p.N;
+        const int nc = nok ? n : 0;
+        int col, ph = 0;
+        if (p.epi == EPI_CONVT) { ph = nc / p.Cout; col = nc - ph * p.Cout; }
+        else col = g * p.N + nc;
+        const float bv = p.bias ? p.bias[col] : 0.f;
+        const float gv = p.gate ? p.gate[(long)b * p.gate_bstride + col] : 1.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mb = m0 + wm * WM + i * 32 + 4 * lk;
+            float v[16];
+            // element r -> output row; recomputed where needed instead of kept in 32 registers
+            auto row_of = [&](int r, bool& o) -> long {
+                const int m = mb + (r & 3) + 8 * (r >> 2);
+                long row = m;
+                o = nok && m < p.M;
+                if (p.epi == EPI_CONVT) { row = (long)m * p.u + ph - p.padT; o = o && row >= 0 && row < p.T_out; }
+                return (o ? row : 0) * p.out_rstride + col;
+            };
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r] + bv;
+            switch (p.act) {                                  // wave-uniform, once per tile
+                case ACT_GELU_TANH: act16<ACT_GELU_TANH>(v); break;
+                case ACT_GELU_ERF: act16<ACT_GELU_ERF>(v); break;
+                case ACT_MISH: act16<ACT_MISH>(v); break;
+                case ACT_SILU: act16<ACT_SILU>(v); break;
+                default: break;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] *= gv;
+            if (resp) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { bool o; const long ix = row_of(r, o); v[r] += o ? to_f32(resp[ix]) : 0.f; }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] *= p.alpha;
+            if (p.accumulate) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { bool o; const long ix = row_of(r, o); v[r] += o ? to_f32(outp[ix]) : 0.f; }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { bool o; const long ix = row_of(r, o); if (o) outp[ix] = from_f32<TO>(v[r]); }
+            __builtin_amdgcn_sched_barrier(0);                // keep one tile's addresses live at a time
+        }
+    }
+}
+
+// LDS-staged epilogue for the DMA kernels (EPI_PLAIN / EPI_CONVT): the accumulator layout gives every lane ONE output
+// column, so the direct epilogue above leaves the chip as 2- or 4-byte stores (a 256x256 bf16 tile = 128 store
+// instructions of 128 bytes per wave; measured: 25-35 us of fixed cost per block wave, more than the K loop of a
+// K = 1024 GEMM).  Here each wave parks 32*RT rows x WN columns of fp32 results (bias / activation / gate applied) in
+// its own slice of the now idle operand ring, then reads them back row-wise and leaves with 16-byte stores (residual
+// and accumulate operands are fetched with 16-byte loads in the same layout).  Wave-local: no block barrier.
+template <typename TO, int TM, int TN, int WM, int WN>
+__device__ __forceinline__ void gemm_epilogue_lds(f32x16 (&acc)[TM][TN], const ConvGemmDev& p, int m0, int n0, int b, int g,
+                                                  int wm, int wn, int lr, int lk, float* stage) {
+    constexpr int CH = sizeof(TO) == 2 ? 8 : 4;            // columns per lane: one 16-byte store
+    constexpr int LPR = WN / CH;                            // lanes per output row
+    constexpr int RPI = 64 / LPR;                           // rows per wave instruction
+    constexpr int RT = (WN <= 64 && TM % 2 == 0) ? 2 : 1;   // 32-row tiles per pass (<= 16 KB of fp32 per wave)
+    const int lane = lk * 32 + lr;
+    TO* outp = (TO*)p.out + (long)b * p.out_bstride;
+    const TO* resp = p.res ? (const TO*)p.res + (long)b * p.out_bstride : nullptr;
+    const int cl = (lane % LPR) * CH, rl0 = lane / LPR;
+    const int nchunk = n0 + wn * WN + cl;                   // first of this lane's CH columns
+    int ccol = g * p.N + nchunk, cph = 0;
+    if (p.epi == EPI_CONVT) { cph = nchunk / p.Cout; ccol = nchunk - cph * p.Cout; }
+    const bool cok = nchunk < p.N && lane < RPI * LPR;
+#pragma unroll
+    for (int i0 = 0; i0 < TM; i0 += RT) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * WN + j * 32 + lr;
+            const int nc = n < p.N ? n : 0;
+            const int col = p.epi == EPI_CONVT ? nc % p.Cout : g * p.N + nc;
+            const float bv = p.bias ? p.bias[col] : 0.f;
+            const float gv = p.gate ? p.gate[(long)b * p.gate_bstride + col] : 1.f;
+#pragma unroll
+            for (int ii = 0; ii < RT; ++ii) {
+                float v[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = acc[i0 + ii][j][r] + bv;
+                switch (p.act) {
+                    case ACT_GELU_TANH: act16<ACT_GELU_TANH>(v); break;
+                    case ACT_GELU_ERF: act16<ACT_GELU_ERF>(v); break;
+                    case ACT_MISH: act16<ACT_MISH>(v); break;
+                    case ACT_SILU: act16<ACT_SILU>(v); break;
+                    default: break;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    stage[(ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * WN + j * 32 + lr] = v[r] * gv;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int rr = rl0; rr < RT * 32; rr += RPI) {
+            const int m = m0 + wm * WM + i0 * 32 + rr;
+            long row = m;
+            bool ok = cok && m < p.M;
+            if (p.epi == EPI_CONVT) { row = (long)m * p.u + cph - p.padT; ok = ok && row >= 0 && row < p.T_out; }
+            if (!ok) continue;
+            float x[CH];
+#pragma unroll
+            for (int q = 0; q < CH; q += 4) {
+                const float4 t = *reinterpret_cast<const float4*>(&stage[rr * WN + cl + q]);
+                x[q] = t.x; x[q + 1] = t.y; x[q + 2] = t.z; x[q + 3] = t.w;
+            }
+            const long ix = row * p.out_rstride + ccol;
+            struct alignas(16) Pk { TO v[CH]; };
+            if (resp) {
+                const Pk rv = *reinterpret_cast<const Pk*>(resp + ix);
+#pragma unroll
+                for (int q = 0; q < CH; ++q) x[q] += to_f32(rv.v[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < CH; ++q) x[q] *= p.alpha;
+            if (p.accumulate) {
+                const Pk ov = *reinterpret_cast<const Pk*>(outp + ix);
+#pragma unroll
+                for (int q = 0; q < CH; ++q) x[q] += to_f32(ov.v[q]);
+            }
+            Pk o;
+#pragma unroll
+            for (int q = 0; q < CH; ++q) o.v[q] = from_f32<TO>(x[q]);
+            *reinterpret_cast<Pk*>(outp + ix) = o;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// LDS-staged variant of the fused QKV epilogue for the 128x128 DMA kernel (head_dim 64, one (q|k|v, head) slice per
+// 64-column wave tile).  q / k: rows leave as 16-byte stores into [b*H + h][token][64] with the interleaved-pair RoPE
+// applied on the 8-column chunk a lane holds.  V (transposed for the attention kernel, [b*H + h][d][key]): the tile is
+// read back column-wise with lane = key, so every store instruction writes 32 consecutive keys of one d (64 contiguous
+// bytes) instead of 64 two-byte writes to 64 different rows.
+template <typename TO>
+__device__ __forceinline__ void gemm_epilogue_qkv_lds(f32x16 (&acc)[2][2], const ConvGemmDev& p, int m0, int n0, int b,
+                                                      int wm, int wn, int lr, int lk, float* stage) {
+    const int lane = lk * 32 + lr;
+    const int dm = p.heads * 64;
+    const int nbase = n0 + wn * 64;
+    const int which = nbase / dm, hh = (nbase - which * dm) >> 6;           // wave-uniform
+    const int Mb = p.Mb > 0 ? p.Mb : p.M;
+    const int mbase = m0 + wm * 64;
+    const int bi0 = mbase / Mb, mloc0 = mbase - bi0 * Mb;
+    const bool vt = which == 2 && p.v_ld > 0;
+    TO* base = (TO*)(which == 0 ? p.out : which == 1 ? p.out2 : p.out3);
+    struct alignas(16) Pk { TO v[8]; };
+    if (!vt) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float bv = p.bias ? p.bias[nbase + j * 32 + lr] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    stage[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * 64 + j * 32 + lr] = acc[i][j][r] + bv;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int c8 = (lane & 7) * 8;
+        for (int rr = lane >> 3; rr < 64; rr += 8) {
+            if (mbase + rr >= p.M) continue;
+            int m = mloc0 + rr, bi = bi0;
+            if (m >= Mb) { m -= Mb; ++bi; }
+            float x[8];
+#pragma unroll
+            for (int q = 0; q < 8; q += 4) {
+                const float4 t = *reinterpret_cast<const float4*>(&stage[rr * 64 + c8 + q]);
+                x[q] = t.x; x[q + 1] = t.y; x[q + 2] = t.z; x[q + 3] = t.w;
+            }
+            if (which < 2) {
+                float c[8], sn[8];
+#pragma unroll
+                for (int q = 0; q < 8; q += 4) {
+                    const float4 tc = *reinterpret_cast<const float4*>(p.rope_cos + (long)m * 64 + c8 + q);
+                    const float4 ts = *reinterpret_cast<const float4*>(p.rope_sin + (long)m * 64 + c8 + q);
+                    c[q] = tc.x; c[q + 1] = tc.y; c[q + 2] = tc.z; c[q + 3] = tc.w;
+                    sn[q] = ts.x; sn[q + 1] = ts.y; sn[q + 2] = ts.z; sn[q + 3] = ts.w;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; q += 2) {
+                    const float e = x[q], o = x[q + 1];
+                    x[q] = e * c[q] - o * sn[q];
+                    x[q + 1] = o * c[q + 1] + e * sn[q + 1];
+                }
+            }
+            Pk o8;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) o8.v[q] = from_f32<TO>(x[q]);
+            *reinterpret_cast<Pk*>(base + (((long)b + bi) * p.heads + hh) * Mb * 64 + (long)m * 64 + c8) = o8;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        const int row = lane & 31, dh = lane >> 5;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float bv = p.bias ? p.bias[nbase + j * 32 + lr] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    stage[((r & 3) + 8 * (r >> 2) + 4 * lk) * 65 + j * 32 + lr] = acc[i][j][r] + bv;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int rr = i * 32 + row;
+            const bool ok = mbase + rr < p.M;
+            int m = mloc0 + rr, bi = bi0;
+            if (m >= Mb) { m -= Mb; ++bi; }
+            TO* dst = base + (((long)b + bi) * p.heads + hh) * 64 * p.v_ld + m;
+#pragma unroll 8
+            for (int d = 0; d < 32; ++d) {
+                const int dd = dh * 32 + d;
+                const float v = stage[row * 65 + dd];
+                if (ok) dst[(long)dd * p.v_ld] = from_f32<TO>(v);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+typedef __attribute__((address_space(3))) void lds_void;
+
+// gemm_pp.hip: ping-pong 256x256 (bn = 256) / 256x192 (bn = 192) kernel, 16-bit operands only
+template <typename T, typename TO> void launch_conv_gemm_pp(const ConvGemmDev& d, int B, int bn, hipStream_t s);
+
+}  // namespace mi
