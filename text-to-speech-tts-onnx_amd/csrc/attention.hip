@@ -24,7 +24,7 @@
 namespace mi {
 
 template <typename T>
-__global__ __launch_bounds__(256) void attn_kernel(const T* __restrict__ q, const T* __restrict__ k,
+__global__ __launch_bounds__(256, 3) void attn_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                    const T* __restrict__ v, T* __restrict__ o, int H, int N) {
     using MF = Mfma<T>;
     constexpr int KP = MF::KP;
@@ -115,71 +115,88 @@ __global__ __launch_bounds__(256) void attn_kernel(const T* __restrict__ q, cons
     __syncthreads();
     for (int st = 0; st < nstage; ++st) {
         if (st + 1 < nstage) load_regs((st + 1) * KT);
-#pragma unroll
-        for (int kt = 0; kt < KT / 32; ++kt) {
+        auto tile = [&](int kt) {                                        // one 32-key tile
             const int key0 = st * KT + kt * 32;
-            if (key0 < N) {                                            // wave-uniform
-                // ---- S^T tile: 32 keys x 32 queries ----------------------------------------------
-                f32x16 sacc;
+            // ---- S^T tile: 32 keys x 32 queries ----------------------------------------------
+            f32x16 sacc;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+            for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    const typename MF::Frag a =
-                        *reinterpret_cast<const typename MF::Frag*>(Ks + (kt * 32 + lr) * LDK + ks * 2 * KP + hi * KP);
-                    sacc = MF::mma(a, qf[ks], sacc);
-                }
-                // ---- online softmax (per lane = per query) -----------------------------------------
-                float mloc = -INFINITY;
+            for (int ks = 0; ks < KS; ++ks) {
+                const typename MF::Frag a =
+                    *reinterpret_cast<const typename MF::Frag*>(Ks + (kt * 32 + lr) * LDK + ks * 2 * KP + hi * KP);
+                sacc = MF::mma(a, qf[ks], sacc);
+            }
+            // ---- online softmax (per lane = per query) -----------------------------------------
+            // only the tile that straddles N needs the key >= N select (2 VALU issues per score, a third of the
+            // softmax's VALU time when done on every tile): wave-uniform branch around it
+            if (key0 + 32 > N) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                     if (key >= N) sacc[r] = -INFINITY;
-                    mloc = fmaxf(mloc, sacc[r]);
                 }
-                mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-                // lazy rescale: keep the old reference max while it is within 2^8 of the new one (P <= 256, exact in
-                // fp32 accumulation); rescale O and l only when some query of the wave needs it (wave-uniform branch)
-                float alpha = 1.f;
-                if (!__all(mloc - m_run <= 8.0f)) {
-                    const float m_new = fmaxf(m_run, mloc);
-                    alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-                    m_run = m_new;
+            }
+            float mloc = -INFINITY;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
+            for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, sacc[r]);
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+            // lazy rescale: keep the old reference max while it is within 2^8 of the new one (P <= 256, exact in
+            // fp32 accumulation); rescale O and l only when some query of the wave needs it (wave-uniform branch)
+            float alpha = 1.f;
+            if (!__all(mloc - m_run <= 8.0f)) {
+                const float m_new = fmaxf(m_run, mloc);
+                alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                m_run = m_new;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
+            }
+            // score - max and the row sum as packed fp32 pairs (v_pk_add_f32: two per VALU issue)
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            float p[16];
+            f2 ls2 = f2{0.f, 0.f};
+            const f2 m2 = f2{m_run, m_run};
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const f2 d = f2{sacc[r], sacc[r + 1]} - m2;
+                const f2 e = f2{__builtin_amdgcn_exp2f(d.x), __builtin_amdgcn_exp2f(d.y)};
+                p[r] = e.x; p[r + 1] = e.y;
+                ls2 += e;
+            }
+            float lsum = ls2.x + ls2.y;
+            lsum += __shfl_xor(lsum, 32);
+            l_run = l_run * alpha + lsum;
+            // ---- O^T += V^T P^T ------------------------------------------------------------------
+            if constexpr (KP == 1) {
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const int kk = kt * 32 + (s & 3) + 8 * (s >> 2) + 4 * hi;
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt)
+                        oacc[dt] = MF::mma(reinterpret_cast<const float*>(Vs)[kk * LDV + dt * 32 + lr], p[s], oacc[dt]);
                 }
-                float p[16], lsum = 0.f;
+            } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_exp2f(sacc[r] - m_run); lsum += p[r]; }
-                lsum += __shfl_xor(lsum, 32);
-                l_run = l_run * alpha + lsum;
-                // ---- O^T += V^T P^T ------------------------------------------------------------------
-                if constexpr (KP == 1) {
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    T pb[8];
 #pragma unroll
-                    for (int s = 0; s < 16; ++s) {
-                        const int kk = kt * 32 + (s & 3) + 8 * (s >> 2) + 4 * hi;
+                    for (int e = 0; e < 8; ++e) pb[e] = from_f32<T>(p[8 * s2 + e]);
+                    const typename MF::Frag bfrag = *reinterpret_cast<const typename MF::Frag*>(pb);
 #pragma unroll
-                        for (int dt = 0; dt < 2; ++dt)
-                            oacc[dt] = MF::mma(reinterpret_cast<const float*>(Vs)[kk * LDV + dt * 32 + lr], p[s], oacc[dt]);
-                    }
-                } else {
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) {
-                        T pb[8];
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) pb[e] = from_f32<T>(p[8 * s2 + e]);
-                        const typename MF::Frag bfrag = *reinterpret_cast<const typename MF::Frag*>(pb);
-#pragma unroll
-                        for (int dt = 0; dt < 2; ++dt) {
-                            const T* row = Vs + (dt * 32 + lr) * LDV + kt * 32 + 16 * s2 + 4 * hi;
-                            uint2 a2[2];
-                            a2[0] = *reinterpret_cast<const uint2*>(row);
-                            a2[1] = *reinterpret_cast<const uint2*>(row + 8);
-                            oacc[dt] = MF::mma(*reinterpret_cast<const typename MF::Frag*>(a2), bfrag, oacc[dt]);
-                        }
+                    for (int dt = 0; dt < 2; ++dt) {
+                        const T* row = Vs + (dt * 32 + lr) * LDV + kt * 32 + 16 * s2 + 4 * hi;
+                        uint2 a2[2];
+                        a2[0] = *reinterpret_cast<const uint2*>(row);
+                        a2[1] = *reinterpret_cast<const uint2*>(row + 8);
+                        oacc[dt] = MF::mma(*reinterpret_cast<const typename MF::Frag*>(a2), bfrag, oacc[dt]);
                     }
                 }
             }
+        };
+#pragma unroll
+        for (int kt = 0; kt < KT / 32; ++kt) {
+            const int key0 = st * KT + kt * 32;
+            if (key0 < N) tile(kt);                                      // wave-uniform
         }
         __syncthreads();
         if (st + 1 < nstage) {
