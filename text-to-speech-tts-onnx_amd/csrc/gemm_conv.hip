@@ -164,14 +164,15 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmDev p) 
 //     16-lane group instead of 8-way for the linear image).
 //   * the loads of chunk c+1 are in flight while the 16 MFMAs per wave of chunk c run.
 // ---------------------------------------------------------------------------------------------------
-template <typename T, typename TO, bool LEPI>
+template <typename T, typename TO, bool LEPI, int NST = 2>
 __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvGemmDev p) {
     using MF = Mfma<T>;
     // a tile row is always 128 bytes = eight 16-byte k-vectors: 64 halfs / bf16s or 32 floats per K chunk
     constexpr int VEC = 16 / (int)sizeof(T), KC = 8 * VEC;
     constexpr int BM = 128, BN = 128, WM = 64, WN = 64, TM = 2, TN = 2;
     constexpr int TILE = (BM + BN) * KC;                  // elements per buffer
-    __shared__ __attribute__((aligned(1024))) T smem[2 * TILE];
+    static_assert(NST == 2 || NST == 4, "two buffers, or the four-stage ring for one-round launches");
+    __shared__ __attribute__((aligned(1024))) T smem[NST * TILE];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lk = lane >> 5;
@@ -234,14 +235,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvGemmDev
 
     int tap = 0, c0 = 0;
     const int ntaps = p.K / p.Cin;
-    issue(0, 0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
-        const int buf = c & 1;
-        int ntap = tap + 1, nc0 = c0;                      // K order = (channel chunk, tap): see launch_conv_gemm
-        if (ntap >= ntaps) { ntap = 0; nc0 += KC; }
-        if (c + 1 < nchunks) issue(buf ^ 1, ntap, nc0);
+    auto compute = [&](int buf) {
         const T* As = smem + buf * TILE;
         const T* Bs = As + BM * KC;
 #pragma unroll
@@ -289,9 +283,43 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvGemmDev
                     }
             }
         }
+    };
+    if constexpr (NST == 2) {
+        issue(0, 0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        tap = ntap; c0 = nc0;
+        for (int c = 0; c < nchunks; ++c) {
+            const int buf = c & 1;
+            int ntap = tap + 1, nc0 = c0;                  // K order = (channel chunk, tap): see launch_conv_gemm
+            if (ntap >= ntaps) { ntap = 0; nc0 += KC; }
+            if (c + 1 < nchunks) issue(buf ^ 1, ntap, nc0);
+            compute(buf);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            tap = ntap; c0 = nc0;
+        }
+    } else {
+        // One-round launches (<= one workgroup per CU, e.g. the DiT O / FF2 projections of a single utterance: 144 tiles):
+        // nothing else runs on the CU, so the two-buffer loop above exposes a full L2 / HBM round trip per 64-deep chunk
+        // (measured ~1700 cycles per chunk against 512 cycles of MFMA).  Here the whole LDS is one ring of four stages:
+        // chunk c+3 is issued before chunk c is computed, the wait is the COUNTED s_waitcnt vmcnt(16) (= this wave's 2 x 8
+        // DMA instructions of chunks c+2, c+3 may stay in flight) and the barrier is the raw s_barrier, so three chunks
+        // are in flight at any time.  Chunks past the end of K fetch the zero page (c0 >= Cin) to keep the count uniform.
+        auto advance = [&]() { if (++tap >= ntaps) { tap = 0; c0 += KC; } };
+        issue(0, tap, c0); advance();
+        issue(1, tap, c0); advance();
+        issue(2, tap, c0); advance();
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        for (int c = 0; c < nchunks; ++c) {
+            issue((c + 3) & 3, tap, c0); advance();         // overwrites the stage read in iteration c-1 (all waves passed its barrier)
+            compute(c & 3);
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // chunk c+1 has landed (this wave's share)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the trailing zero-page chunks must not land on the epilogue's staging
+        __builtin_amdgcn_s_barrier();
     }
     if constexpr (LEPI) {
         constexpr int ERT = (WN <= 64 && TM % 2 == 0) ? 2 : 1;
@@ -445,7 +473,8 @@ __global__ __launch_bounds__(512) void conv_gemm_dma3_kernel(const ConvGemmDev p
 
 static bool g_use_dma = true, g_xcd_order = false, g_use_dma3 = true, g_big_tiles = true;
 static long g_big_min = 160, g_n192_min = 160, g_mid_min = 160, g_k_min = 2048;
-static bool g_n192 = true, g_f32_dma = true, g_pp = false;
+static bool g_n192 = true, g_f32_dma = true, g_pp = false, g_ring4 = true;
+static long g_ring4_max = 256;
 static DevBuf g_zero_page[16];
 
 template <typename T, typename TO>
@@ -507,7 +536,13 @@ static void dispatch_tiles(const ConvGemmDev& d, int B, hipStream_t s) {
                 e.Tm = (d.M + 127) / 128; e.Tn = (d.N + 127) / 128; e.RT = B * e.Tm;
                 e.RC = g_xcd_order ? (e.RT + 7) / 8 : 0;
                 dim3 g1(e.RC > 0 ? 8 * e.RC * e.Tn : e.RT * e.Tn, d.G);
-                if (e.lds_epi) hipLaunchKernelGGL((conv_gemm_dma_kernel<T, TO, true>), g1, blk, 0, s, e);
+                const int nchunks = (d.K / d.Cin) * ((d.Cin + 63) / 64);
+                if (g_ring4 && (long)g1.x * g1.y <= g_ring4_max && nchunks >= 6) {
+                    // at most one workgroup per CU: the four-stage ring hides the DMA round trip that the two-buffer
+                    // loop exposes when a CU has no second workgroup to switch to
+                    if (e.lds_epi) hipLaunchKernelGGL((conv_gemm_dma_kernel<T, TO, true, 4>), g1, blk, 0, s, e);
+                    else hipLaunchKernelGGL((conv_gemm_dma_kernel<T, TO, false, 4>), g1, blk, 0, s, e);
+                } else if (e.lds_epi) hipLaunchKernelGGL((conv_gemm_dma_kernel<T, TO, true>), g1, blk, 0, s, e);
                 else hipLaunchKernelGGL((conv_gemm_dma_kernel<T, TO, false>), g1, blk, 0, s, e);
                 MI_HIP(hipGetLastError());
                 return;
@@ -544,6 +579,8 @@ bool gemm_set_option(const char* key, long v) {
     else if (k == "gemm_n192") g_n192 = v != 0;
     else if (k == "gemm_f32_dma") g_f32_dma = v != 0;
     else if (k == "gemm_pp") g_pp = v != 0;
+    else if (k == "gemm_ring4") g_ring4 = v != 0;
+    else if (k == "gemm_ring4_max") g_ring4_max = v;
     else return false;
     return true;
 }
@@ -576,6 +613,8 @@ void launch_conv_gemm(const ConvGemm& p, hipStream_t s) {
             if (const char* m = std::getenv("MI355TTS_DMA3_K_MIN")) g_k_min = std::atol(m);
             if (const char* n = std::getenv("MI355TTS_NO_N192")) g_n192 = !(n[0] == '1');
             if (const char* n = std::getenv("MI355TTS_PP")) g_pp = n[0] == '1';
+            if (const char* n = std::getenv("MI355TTS_NO_RING4")) g_ring4 = !(n[0] == '1');
+            if (const char* n = std::getenv("MI355TTS_RING4_MAX")) g_ring4_max = std::atol(n);
             env_read = true; }
         int dev = 0;
         MI_HIP(hipGetDevice(&dev));
