@@ -392,7 +392,7 @@ def main():
     ap.add_argument("--frames", type=int, default=512)
     ap.add_argument("--dtype", default=None, help="bigvgan: f16 (default) | f32 | bf16 ; f5: bf16 (default) | f32 | f16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=48)
+    ap.add_argument("--cpu-frames", type=int, default=128)
     args = ap.parse_args()
 
     import torch

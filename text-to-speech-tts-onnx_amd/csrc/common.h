@@ -126,6 +126,7 @@ struct ConvGemm {
     int u = 1, Cout = 0, padT = 0, T_out = 0;
     // EPI_QKV_ROPE (f5): see f5.hip
     const float* rope_cos = nullptr; const float* rope_sin = nullptr; int heads = 0, head_dim = 0;
+    const void* rope_pack = nullptr;   // optional: (cos, sin) half pairs [token][head_dim / 2] (values must equal the fp32 tables)
     void* out2 = nullptr; void* out3 = nullptr;
     int rows_per_item = 0;        // EPI_QKV_ROPE with the batch flattened into M: tokens per batch item (0: M)
     long v_ld = 0;                // > 0: V is written transposed, [b*H + h][head_dim][v_ld] (keys contiguous)

@@ -32,6 +32,7 @@ struct F5 {
     long mod_ld = 0;
     DevBuf delta_t;         // fp32 [nfe-1]
     DevBuf rope_cos, rope_sin;   // fp32 [max_len][dim_head] (rounded through fp16 like the export)
+    DevBuf rope_pack;            // the same values as (cos, sin) half pairs, [max_len][dim_head / 2]: 4x fewer table bytes for the QKV epilogue
     std::vector<float> h_time_expand, h_delta;
 
     // ---- front end (fp32) ----

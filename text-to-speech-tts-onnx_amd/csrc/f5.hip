@@ -207,6 +207,17 @@ F5::F5(const F5Cfg& c, const float* w, int64_t nw, int dt, int dev) : cfg(c), dt
             }
         upload_f32(rope_cos, rc.data(), rc.size(), s);
         upload_f32(rope_sin, rs.data(), rs.size(), s);
+        // packed copy: the table values ARE fp16 numbers and both elements of a rotation pair share one angle, so
+        // (cos, sin) as two halfs per pair holds the same information in a quarter of the bytes
+        std::vector<f16> pk((size_t)c.max_len * D);
+        for (int n = 0; n < c.max_len; ++n)
+            for (int j = 0; j < D / 2; ++j) {
+                pk[(size_t)n * D + 2 * j] = (f16)rc[(size_t)n * D + 2 * j];
+                pk[(size_t)n * D + 2 * j + 1] = (f16)rs[(size_t)n * D + 2 * j];
+            }
+        rope_pack.ensure(pk.size() * sizeof(f16));
+        MI_HIP(hipMemcpyAsync(rope_pack.p, pk.data(), pk.size() * sizeof(f16), hipMemcpyHostToDevice, s));
+        MI_HIP(hipStreamSynchronize(s));
     }
     // ---- STFT kernels (STFT_Process.py:86-98; fp32 evaluation order of torch) + HTK mel fbank ---------
     {
@@ -493,7 +504,7 @@ void F5::dit_eval(int U, int N, int k) {
             g.out = qb.p; g.out2 = kb.p; g.out3 = vb.p;
             g.B = 1; g.T_in = B * N; g.M = B * N; g.rows_per_item = N;       // batch flattened into M
             g.N = 3 * d; g.Cin = d; g.x_bstride = (long)B * N * d; g.x_rstride = d;
-            g.epi = EPI_QKV_ROPE; g.rope_cos = rope_cos.as<float>(); g.rope_sin = rope_sin.as<float>(); g.heads = H; g.head_dim = D;
+            g.epi = EPI_QKV_ROPE; g.rope_cos = rope_cos.as<float>(); g.rope_sin = rope_sin.as<float>(); g.rope_pack = rope_pack.p; g.heads = H; g.head_dim = D;
             g.v_ld = attention_v_ld(N, dtype);
             launch_conv_gemm(g, s);
         }

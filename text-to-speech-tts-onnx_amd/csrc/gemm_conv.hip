@@ -601,7 +601,7 @@ void launch_conv_gemm(const ConvGemm& p, hipStream_t s) {
     d.x_goff = p.x_goff;
     d.act = p.act; d.alpha = p.alpha; d.accumulate = p.accumulate; d.epi = p.epi;
     d.u = p.u; d.Cout = p.Cout; d.padT = p.padT; d.T_out = p.T_out;
-    d.rope_cos = p.rope_cos; d.rope_sin = p.rope_sin; d.heads = p.heads; d.head_dim = p.head_dim;
+    d.rope_cos = p.rope_cos; d.rope_sin = p.rope_sin; d.rope_pack = p.rope_pack; d.heads = p.heads; d.head_dim = p.head_dim;
     d.out2 = p.out2; d.out3 = p.out3; d.v_ld = p.v_ld; d.Mb = p.rows_per_item;
     {
         static bool env_read = false;

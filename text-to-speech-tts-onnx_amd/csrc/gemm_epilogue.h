@@ -29,7 +29,7 @@ struct ConvGemmDev {
     long x_bstride, x_rstride, out_bstride, out_rstride, x_goff;
     int act; float alpha; int accumulate; int epi;
     int u, Cout, padT, T_out;
-    const float* rope_cos; const float* rope_sin; int heads, head_dim; void* out2; void* out3;
+    const float* rope_cos; const float* rope_sin; const void* rope_pack; int heads, head_dim; void* out2; void* out3;
     long v_ld; int Mb;
     const void* zero;      // >= 16 bytes of zeros: source for out-of-range / K-tail vectors of the LDS-DMA path
     int dbg;               // tuning only: 1 = no DMA in the main loop, 2 = no ds_read/MFMA in the main loop
@@ -296,7 +296,18 @@ __device__ __forceinline__ void gemm_epilogue_qkv_lds(f32x16 (&acc)[2][2], const
                 const float4 t = *reinterpret_cast<const float4*>(&stage[rr * 64 + c8 + q]);
                 x[q] = t.x; x[q + 1] = t.y; x[q + 2] = t.z; x[q + 3] = t.w;
             }
-            if (which < 2) {
+            if (which < 2 && p.rope_pack) {
+                // four (cos, sin) half pairs = one 16-byte load for the lane's eight columns
+                struct alignas(16) H8 { f16 v[8]; };
+                const H8 cs = *reinterpret_cast<const H8*>((const f16*)p.rope_pack + (long)m * 64 + c8);
+#pragma unroll
+                for (int q = 0; q < 8; q += 2) {
+                    const float cc = (float)cs.v[q], ss = (float)cs.v[q + 1];
+                    const float e = x[q], o = x[q + 1];
+                    x[q] = e * cc - o * ss;
+                    x[q + 1] = o * cc + e * ss;
+                }
+            } else if (which < 2) {
                 float c[8], sn[8];
 #pragma unroll
                 for (int q = 0; q < 8; q += 4) {
