@@ -183,3 +183,51 @@ def test_bad_arguments(small):
         eng.preprocess(np.zeros(8192, np.int16), np.zeros(4, np.int32), 8)
     with pytest.raises(MiError):                       # text id outside the embedding table
         eng.preprocess(np.zeros(8192, np.int16), np.full(4, 10 ** 6, np.int32), 60)
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json size (F5Config(): 22 DiT blocks, N = 1126 frames from 6 s of reference audio): the numpy oracle needs
+# ~8 minutes for the 31 evaluations, so the full size is held by size-independent properties instead:
+#   * utterances are independent: a batch of two different utterances == the two run alone,
+#     which exercises the batch-flattened GEMMs, the per-(item, head) attention grid and the ragged 1126 = 8 x 128 + 102
+#     tile tails at the real shape;
+#   * the same call twice is bit-identical (first call eager, later calls replay the captured hipGraph);
+#   * the bf16 engine (16-bit LDS-DMA GEMMs, fast GELU, packed RoPE table, 16-bit attention) stays inside the stated
+#     low-precision gate of the fp32 engine's waveform.
+# ---------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def full():
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import f5_synthetic_inputs
+    cfg = F5Config()
+    raw = W.synth_state(W.f5_spec(cfg), 9527)
+    audio, ids, N, noise = f5_synthetic_inputs(cfg, 2, 0)
+    return cfg, raw, audio, ids, N, noise
+
+
+def test_full_size_batch_invariance_determinism_and_lowp_gate(full):
+    cfg, raw, audio, ids, N, noise = full
+    assert N == 1126 and audio.shape == (2, 144000)
+    e32 = F5Engine(cfg, raw, dtype="f32")
+    w_pair = e32.synthesize(audio, ids, N, noise=noise)
+    assert w_pair.shape == (2, 1, (N - 563 - 1) * cfg.hop_length) and w_pair.dtype == np.int16
+    w0 = e32.synthesize(audio[:1], ids[:1], N, noise=noise[:1])
+    w1 = e32.synthesize(audio[1:], ids[1:], N, noise=noise[1:])
+    # fp32, same kernels and tile shapes per row: identical up to the int16 truncation boundary
+    for wp, ws in ((w_pair[0], w0[0]), (w_pair[1], w1[0])):
+        d = np.abs(wp.astype(np.int32) - ws.astype(np.int32))
+        assert d.max() <= 2 and (d > 0).mean() < 0.01
+    assert rms(w0) > 300 and not np.array_equal(w0, w1)                  # neither silent nor saturated, and really different
+    assert np.abs(w0.astype(np.int32)).max() < 32767
+    w0b = e32.synthesize(audio[:1], ids[:1], N, noise=noise[:1])          # replayed hipGraph
+    w0c = e32.synthesize(audio[:1], ids[:1], N, noise=noise[:1])
+    assert np.array_equal(w0b, w0c)
+    d = np.abs(w0.astype(np.int32) - w0b.astype(np.int32))
+    assert d.max() <= 2
+    e32.close()
+    e16 = F5Engine(cfg, raw, dtype="bf16")
+    wb = e16.synthesize(audio[:1], ids[:1], N, noise=noise[:1])
+    err = rms((wb.astype(np.float64) - w0.astype(np.float64)) / 32767.0)
+    assert err < 3e-2, err
+    e16.close()
