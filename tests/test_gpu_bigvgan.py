@@ -234,7 +234,7 @@ def test_bad_inputs_raise(small_voc):
 # only when the launch fills the chip) and compared with the oracle
 # ---------------------------------------------------------------------------------------------
 _DEFAULTS = {"gemm_big_tile_min": 160, "gemm_n192_min": 160, "gemm_mid_tile_min": 160, "gemm_dma3_k_min": 2048,
-             "gemm_use_dma3": 1, "gemm_use_dma": 1, "gemm_big_tiles": 1, "gemm_n192": 1, "gemm_pp": 0, "gemm_f32_dma": 1, "gemm_ring4": 1, "gemm_ring4_max": 256}
+             "gemm_use_dma3": 1, "gemm_use_dma": 1, "gemm_big_tiles": 1, "gemm_n192": 1, "gemm_pp": 0, "gemm_f32_dma": 1, "gemm_ring4": 1, "gemm_ring4_max": 256, "gemm_buf": 1}
 
 
 @pytest.fixture
@@ -260,6 +260,9 @@ def gemm_options():
     ("128x128/4-stage ring", {"gemm_use_dma3": 0}, 768, 768, 3, 1, 300, 1),
     ("128x128/4-stage ring, Cin tail, ragged", {"gemm_use_dma3": 0}, 200, 300, 7, 2, 333, 2),
     ("128x128/2-stage dma (many tiles)", {"gemm_use_dma3": 0, "gemm_ring4_max": 4}, 768, 768, 3, 1, 300, 1),
+    ("128x128 flat-address DMA (no buffer descriptors)", {"gemm_use_dma3": 0, "gemm_buf": 0}, 768, 768, 3, 1, 300, 1),
+    ("128x128 ring, flat-address DMA", {"gemm_use_dma3": 0, "gemm_buf": 0, "gemm_ring4_max": 4096}, 768, 768, 7, 3, 600, 2),
+    ("256-row tiles need whole chunks: Cin = 200 falls back", {"gemm_big_tile_min": 1, "gemm_dma3_k_min": 0}, 200, 768, 7, 1, 700, 2),
     ("register-staged", {"gemm_use_dma3": 0, "gemm_use_dma": 0}, 192, 192, 7, 3, 300, 1),
 ])
 @pytest.mark.parametrize("dtype,tol", [("f16", 6e-3), ("bf16", 4e-2)])

@@ -201,8 +201,38 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvGemmDev
     const int cpt = (p.Cin + KC - 1) / KC;                // chunks per tap
     const int nchunks = (p.K / p.Cin) * cpt;
 
+    // p.use_buf: DMA through buffer descriptors — out-of-range lanes get zeros from the hardware range check, the per-lane
+    // offsets are loop-invariant (see conv_gemm_dma3_kernel); the flat-address form below stays for Cin tails.
+#if defined(__HIP_DEVICE_COMPILE__)
+    __amdgpu_buffer_rsrc_t rsa, rsb;
+    int avo[4], bvo[4];
+    if (p.use_buf) {
+        rsa = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, (int)((((long)p.T_in - 1) * p.x_rstride + p.Cin) * (long)sizeof(T)), 0x00020000);
+        rsb = __builtin_amdgcn_make_buffer_rsrc((void*)wg, 0, (int)((long)p.N * p.K * (long)sizeof(T)), 0x00020000);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int R0 = (wave * 4 + j) * 8;
+            const long n = n0 + R0 + lrow;
+            avo[j] = (int)(((long)(m0 + R0 + lrow) * p.x_rstride + kvl * VEC) * (long)sizeof(T));
+            bvo[j] = n < p.N ? (int)((n * p.K + kvl * VEC) * (long)sizeof(T)) : 0x7fffff00;
+        }
+    }
+#endif
     auto issue = [&](int buf, int tap, int c0) {
         T* base = smem + buf * TILE;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (p.use_buf) {
+            const int ca = (int)(((long)(tap * p.dil - p.pad) * p.x_rstride + c0) * (long)sizeof(T));
+            const int cb = (tap * p.Cin + c0) * (int)sizeof(T);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lds_void*)(base + (wave * 4 + j) * 8 * KC), 16, avo[j] + ca, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb, (lds_void*)(base + (BM + (wave * 4 + j) * 8) * KC), 16, bvo[j] + cb, 0, 0, 0);
+            return;
+        }
+#endif
         const int ci = c0 + kvl * VEC;
         const bool kval = ci < p.Cin;
         const int toff = tap * p.dil - p.pad;
@@ -343,16 +373,20 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvGemmDev
 // Swizzle: slot = kv ^ ((row >> 1) & 7): rows of equal parity inside every ds_read_b128 lane group get eight
 // distinct slots => conflict-free fragment reads.
 // ---------------------------------------------------------------------------------------------------
-template <typename T, typename TO, int BM, int BN, int WM, int WN, int NST>
-__global__ __launch_bounds__(512) void conv_gemm_dma3_kernel(const ConvGemmDev p) {
+template <typename T, typename TO, int BM, int BN, int WM, int WN, int NST, bool BUF = false>
+__global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void conv_gemm_dma3_kernel(const ConvGemmDev p) {
     using MF = Mfma<T>;
     // two configurations: 256x128 tile / 64x64 per wave / 3-stage ring (default) and 256x256 tile / 128x64 per wave /
     // 2-stage ring (1.5x fewer DMA bytes per flop, for problems that fill every CU: the per-CU L2->LDS fill rate,
     // ~22 B/cycle measured, is what bounds this kernel)
     constexpr int KC = 64, TM = WM / 32, TN = WN / 32, WGN = BN / WN;
-    static_assert((BM / WM) * WGN == 8, "eight waves");
+    // NW = 8 waves (two per SIMD), or NW = 4 waves of 128x128 (one per SIMD, 256 accumulator registers: a third fewer
+    // LDS fragment bytes per MFMA than the 128x64 wave tile)
+    constexpr int NW = (BM / WM) * WGN;
+    static_assert(NW == 8 || NW == 4, "eight or four waves");
     constexpr int TILE = (BM + BN) * KC;
-    constexpr int AJ = BM / 64, BJ = BN / 64, PERW = AJ + BJ;     // 8-row DMA groups per wave per chunk
+    constexpr int AJ = BM / 8 / NW, BJ = BN / 8 / NW, PERW = AJ + BJ;     // 8-row DMA groups per wave per chunk
+    static_assert(NST == 2 || PERW == 6 || PERW == 8, "counted vmcnt immediates of the 3-stage ring");
     __shared__ __attribute__((aligned(1024))) T smem[NST * TILE];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -372,8 +406,49 @@ __global__ __launch_bounds__(512) void conv_gemm_dma3_kernel(const ConvGemmDev p
     const int kv1 = (lane & 7) ^ ((4 + (lane >> 4)) & 7);         // odd 8-row groups
     const int nchunks = (p.K / p.Cin) * ((p.Cin + KC - 1) / KC);
 
+    // BUF: the DMA goes through buffer descriptors (buffer_load_dwordx4 ... lds).  A lane whose offset falls outside
+    // [0, num_records) gets ZEROS written to its LDS slot by the hardware range check (tools/ubench/bufload_lds.hip), so
+    // the time padding (t < 0 or t >= T_in) and the N tail need no per-lane select, and the per-lane part of the address
+    // (row * stride + swizzled k-vector) is loop-invariant: one v_add per DMA instruction instead of ~20 VALU / SALU
+    // instructions (two 64-bit multiply-adds, three compares, exec masking) of the flat-address form.  Requires
+    // Cin % 64 == 0 (a K tail inside a valid row would read the neighbouring row) — checked by the dispatcher.
+    // (the buffer-resource type and builtins exist in the device pass only: the host pass, which just needs the launch
+    // stub, must not see them)
+#if defined(__HIP_DEVICE_COMPILE__)
+    __amdgpu_buffer_rsrc_t rsa, rsb;
+    int avo[AJ], bvo[BJ];                                         // per-lane byte offsets, loop-invariant
+    if constexpr (BUF) {
+        rsa = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, (int)((((long)p.T_in - 1) * p.x_rstride + p.Cin) * (long)sizeof(T)), 0x00020000);
+        rsb = __builtin_amdgcn_make_buffer_rsrc((void*)wg, 0, (int)((long)p.N * p.K * (long)sizeof(T)), 0x00020000);
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            const int R0 = (wave * AJ + j) * 8;
+            avo[j] = (int)(((long)(m0 + R0 + lrow) * p.x_rstride + (((wave * AJ + j) & 1) ? kv1 : kv0) * 8) * (long)sizeof(T));
+        }
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) {
+            const int R0 = (wave * BJ + j) * 8;
+            const long n = n0 + R0 + lrow;
+            // rows past N: any offset >= num_records (a clamped product cannot wrap into range)
+            bvo[j] = n < p.N ? (int)((n * p.K + (((wave * BJ + j) & 1) ? kv1 : kv0) * 8) * (long)sizeof(T)) : 0x7fffff00;
+        }
+    }
+#endif
     auto issue = [&](int st, int tap, int c0) {
         T* base = smem + st * TILE;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (BUF) {
+            const int ca = (int)(((long)(tap * p.dil - p.pad) * p.x_rstride + c0) * (long)sizeof(T));
+            const int cb = (tap * p.Cin + c0) * (int)sizeof(T);
+#pragma unroll
+            for (int j = 0; j < AJ; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lds_void*)(base + (wave * AJ + j) * 8 * KC), 16, avo[j] + ca, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < BJ; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb, (lds_void*)(base + (BM + (wave * BJ + j) * 8) * KC), 16, bvo[j] + cb, 0, 0, 0);
+            return;
+        }
+#endif
         const int toff = tap * p.dil - p.pad;
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
@@ -477,6 +552,13 @@ static bool g_n192 = true, g_f32_dma = true, g_pp = false, g_ring4 = true;
 static long g_ring4_max = 256;
 static DevBuf g_zero_page[16];
 
+// buffer-descriptor DMA (BUF kernels): whole 64-deep chunks only, and every byte offset must fit the 32-bit range check
+static bool g_buf = true;
+static bool buf_ok(const ConvGemmDev& d, int esz = 2) {
+    const long a_bytes = (((long)d.T_in - 1) * d.x_rstride + d.Cin) * esz, b_bytes = (long)d.N * d.K * esz;
+    return g_buf && d.Cin % (128 / esz) == 0 && a_bytes + (long)512 * d.x_rstride * esz < 0x7fff0000L && b_bytes < 0x7fff0000L;
+}
+
 template <typename T, typename TO>
 static void dispatch_tiles(const ConvGemmDev& d, int B, hipStream_t s) {
     constexpr int KC = sizeof(T) == 4 ? 16 : 64;
@@ -497,14 +579,14 @@ static void dispatch_tiles(const ConvGemmDev& d, int B, hipStream_t s) {
             const long rt256 = (long)B * ((d.M + 255) / 256);
             const long rounds192 = (rt256 * (d.N / 192) + 255) / 256, rounds256 = (rt256 * ((d.N + 255) / 256) + 255) / 256;
             const bool n192_wins = d.N % 256 != 0 || (d.K > g_k_min && rounds192 * 192 < rounds256 * 256);
-            if (g_use_dma3 && g_n192 && d.Cin % 8 == 0 && d.K % d.Cin == 0 && d.M > 128 && d.N % 192 == 0 && n192_wins &&
+            if (g_use_dma3 && g_n192 && buf_ok(d) && d.K % d.Cin == 0 && d.M > 128 && d.N % 192 == 0 && n192_wins &&
                 d.K >= 576 && (long)B * ((d.M + 255) / 256) * (d.N / 192) >= g_n192_min) {
                 // N = 192 / 384 (BigVGAN stages 2 and 1): a 192-wide tile has no padded columns (128-wide tiles waste 25 %
                 // of the MFMAs and DMA bytes at N = 192) and the fewest DMA bytes per useful flop after 256x256
                 if (g_pp) { launch_conv_gemm_pp<T, TO>(d, B, 192, s); return; }
                 ConvGemmDev e = d;
                 e.RC = 0; e.Tm = (d.M + 255) / 256; e.Tn = d.N / 192; e.RT = B * e.Tm;
-                hipLaunchKernelGGL((conv_gemm_dma3_kernel<T, TO, 256, 192, 64, 96, 2>), dim3(e.RT * e.Tn, d.G), dim3(512), 0, s, e);
+                hipLaunchKernelGGL((conv_gemm_dma3_kernel<T, TO, 256, 192, 64, 96, 2, true>), dim3(e.RT * e.Tn, d.G), dim3(512), 0, s, e);
                 MI_HIP(hipGetLastError());
                 return;
             }
@@ -515,11 +597,11 @@ static void dispatch_tiles(const ConvGemmDev& d, int B, hipStream_t s) {
                 const long blocks_256x128 = (long)B * ((d.M + 255) / 256) * ((d.N + 127) / 128);
                 const long blocks_256x256 = (long)B * ((d.M + 255) / 256) * ((d.N + 255) / 256);
                 const int n_waste_256 = ((d.N + 255) / 256) * 256 - d.N;
-                if (g_big_tiles && blocks_256x256 >= g_big_min && n_waste_256 * 4 <= d.N) {
+                if (g_big_tiles && buf_ok(d) && blocks_256x256 >= g_big_min && n_waste_256 * 4 <= d.N) {
                     // every CU busy for >= 2 rounds: the tile with the fewest DMA bytes per flop
                     if (g_pp) { launch_conv_gemm_pp<T, TO>(d, B, 256, s); return; }
                     e.Tm = (d.M + 255) / 256; e.Tn = (d.N + 255) / 256; e.RT = B * e.Tm;
-                    hipLaunchKernelGGL((conv_gemm_dma3_kernel<T, TO, 256, 256, 128, 64, 2>), dim3(e.RT * e.Tn, d.G), dim3(512), 0, s, e);
+                    hipLaunchKernelGGL((conv_gemm_dma3_kernel<T, TO, 256, 256, 128, 64, 2, true>), dim3(e.RT * e.Tn, d.G), dim3(512), 0, s, e);
                     MI_HIP(hipGetLastError());
                     return;
                 }
@@ -535,6 +617,7 @@ static void dispatch_tiles(const ConvGemmDev& d, int B, hipStream_t s) {
                 ConvGemmDev e = d;
                 e.Tm = (d.M + 127) / 128; e.Tn = (d.N + 127) / 128; e.RT = B * e.Tm;
                 e.RC = g_xcd_order ? (e.RT + 7) / 8 : 0;
+                e.use_buf = buf_ok(d, 2);
                 dim3 g1(e.RC > 0 ? 8 * e.RC * e.Tn : e.RT * e.Tn, d.G);
                 const int nchunks = (d.K / d.Cin) * ((d.Cin + 63) / 64);
                 if (g_ring4 && (long)g1.x * g1.y <= g_ring4_max && nchunks >= 6) {
@@ -554,6 +637,7 @@ static void dispatch_tiles(const ConvGemmDev& d, int B, hipStream_t s) {
                 ConvGemmDev e = d;
                 e.Tm = (d.M + 127) / 128; e.Tn = (d.N + 127) / 128; e.RT = B * e.Tm;
                 e.RC = g_xcd_order ? (e.RT + 7) / 8 : 0;
+                e.use_buf = buf_ok(d, 4);
                 dim3 g1(e.RC > 0 ? 8 * e.RC * e.Tn : e.RT * e.Tn, d.G);
                 if (e.lds_epi) hipLaunchKernelGGL((conv_gemm_dma_kernel<T, TO, true>), g1, blk, 0, s, e);
                 else hipLaunchKernelGGL((conv_gemm_dma_kernel<T, TO, false>), g1, blk, 0, s, e);
@@ -580,6 +664,7 @@ bool gemm_set_option(const char* key, long v) {
     else if (k == "gemm_f32_dma") g_f32_dma = v != 0;
     else if (k == "gemm_pp") g_pp = v != 0;
     else if (k == "gemm_ring4") g_ring4 = v != 0;
+    else if (k == "gemm_buf") g_buf = v != 0;
     else if (k == "gemm_ring4_max") g_ring4_max = v;
     else return false;
     return true;
@@ -603,6 +688,7 @@ void launch_conv_gemm(const ConvGemm& p, hipStream_t s) {
     d.u = p.u; d.Cout = p.Cout; d.padT = p.padT; d.T_out = p.T_out;
     d.rope_cos = p.rope_cos; d.rope_sin = p.rope_sin; d.rope_pack = p.rope_pack; d.heads = p.heads; d.head_dim = p.head_dim;
     d.out2 = p.out2; d.out3 = p.out3; d.v_ld = p.v_ld; d.Mb = p.rows_per_item;
+    d.use_buf = 0;
     {
         static bool env_read = false;
         if (!env_read) { const char* e = std::getenv("MI355TTS_NO_DMA_GEMM"); g_use_dma = !(e && e[0] == '1');
@@ -614,6 +700,7 @@ void launch_conv_gemm(const ConvGemm& p, hipStream_t s) {
             if (const char* n = std::getenv("MI355TTS_NO_N192")) g_n192 = !(n[0] == '1');
             if (const char* n = std::getenv("MI355TTS_PP")) g_pp = n[0] == '1';
             if (const char* n = std::getenv("MI355TTS_NO_RING4")) g_ring4 = !(n[0] == '1');
+            if (const char* n = std::getenv("MI355TTS_NO_BUF")) g_buf = !(n[0] == '1');
             if (const char* n = std::getenv("MI355TTS_RING4_MAX")) g_ring4_max = std::atol(n);
             env_read = true; }
         int dev = 0;

@@ -34,6 +34,7 @@ struct ConvGemmDev {
     const void* zero;      // >= 16 bytes of zeros: source for out-of-range / K-tail vectors of the LDS-DMA path
     int dbg;               // tuning only: 1 = no DMA in the main loop, 2 = no ds_read/MFMA in the main loop
     int lds_epi;           // 1: outputs leave through the LDS-staged, 16-byte-store epilogue (alignment checked on the host)
+    int use_buf;           // 128x128 DMA kernel: 1 = LDS-DMA through buffer descriptors (whole K chunks, offsets fit 31 bits)
     int Tm, Tn, RT, RC;    // XCD-aware tile order (DMA kernel): M-tiles per batch item, N-tiles, row tiles (B*Tm), rows per XCD
 };
 
