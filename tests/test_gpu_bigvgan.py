@@ -234,7 +234,7 @@ def test_bad_inputs_raise(small_voc):
 # only when the launch fills the chip) and compared with the oracle
 # ---------------------------------------------------------------------------------------------
 _DEFAULTS = {"gemm_big_tile_min": 160, "gemm_n192_min": 160, "gemm_mid_tile_min": 160, "gemm_dma3_k_min": 2048,
-             "gemm_use_dma3": 1, "gemm_use_dma": 1, "gemm_big_tiles": 1, "gemm_n192": 1, "gemm_pp": 0, "gemm_f32_dma": 1, "gemm_ring4": 1, "gemm_ring4_max": 256, "gemm_buf": 1}
+             "gemm_use_dma3": 1, "gemm_use_dma": 1, "gemm_big_tiles": 1, "gemm_n192": 1, "gemm_pp": 0, "gemm_f32_dma": 1, "gemm_ring4": 1, "gemm_ring4_max": 256, "gemm_buf": 1, "gemm_f32_small": 1, "gemm_f32_small_max": 1024}
 
 
 @pytest.fixture
@@ -281,11 +281,14 @@ def test_gemm_tile_configs_vs_oracle(gemm_options, cfg_name, opts, Ci, Co, k, d,
     assert np.abs(y - ref).max() < 40 * tol * rms(ref), cfg_name
 
 
-@pytest.mark.parametrize("f32_dma", [1, 0])
-def test_f32_gemm_dma_and_register_staged_agree_with_oracle(gemm_options, f32_dma):
-    # fp32 linears / convs with N > 64 run on the 128x128 LDS-DMA kernel (32-float chunks, k pairs (e, e+4) per MFMA);
+@pytest.mark.parametrize("f32_dma,small,buf", [(1, 1, 1), (1, 0, 1), (1, 1, 0), (1, 0, 0), (0, 1, 1)])
+def test_f32_gemm_dma_and_register_staged_agree_with_oracle(gemm_options, f32_dma, small, buf):
+    # fp32 linears / convs with N > 64 run on the LDS-DMA kernel (32-float chunks, k pairs (e, e+4) per MFMA): 64x64 tiles
+    # when there are few 128x128 tiles (gemm_f32_small), buffer-descriptor or flat-address DMA (gemm_buf);
     # gemm_f32_dma = 0 keeps the register-staged kernel covered
     gemm_options("gemm_f32_dma", f32_dma)
+    gemm_options("gemm_f32_small", small)
+    gemm_options("gemm_buf", buf)
     for Ci, Co, k, d, T, B in [(384, 384, 7, 3, 300, 2), (100, 200, 3, 1, 129, 1), (1024, 3072, 1, 1, 140, 1)]:
         x = W.synth_normal(31, f"fx{Ci}{k}", (B, Ci, T))
         w = W.synth_normal(32, f"fw{Ci}{Co}{k}", (Co, Ci, k), std=1.0 / np.sqrt(Ci * k))

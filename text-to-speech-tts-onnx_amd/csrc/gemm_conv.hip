@@ -164,12 +164,16 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmDev p) 
 //     16-lane group instead of 8-way for the linear image).
 //   * the loads of chunk c+1 are in flight while the 16 MFMAs per wave of chunk c run.
 // ---------------------------------------------------------------------------------------------------
-template <typename T, typename TO, bool LEPI, int NST = 2>
+template <typename T, typename TO, bool LEPI, int NST = 2, int BT = 128>
 __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvGemmDev p) {
     using MF = Mfma<T>;
     // a tile row is always 128 bytes = eight 16-byte k-vectors: 64 halfs / bf16s or 32 floats per K chunk
     constexpr int VEC = 16 / (int)sizeof(T), KC = 8 * VEC;
-    constexpr int BM = 128, BN = 128, WM = 64, WN = 64, TM = 2, TN = 2;
+    // BT = 128: the 128x128 tile (64x64 per wave).  BT = 64: 64x64 tiles (32x32 per wave) for fp32 problems with too few
+    // 128-row tiles to balance 256 CUs — fp32 MFMAs are slow enough (64 cycles) that the doubled fragment traffic is free
+    constexpr int BM = BT, BN = BT, WM = BT / 2, WN = BT / 2, TM = WM / 32, TN = WN / 32;
+    constexpr int DJ = BT / 32;                           // 8-row DMA groups per wave per operand per chunk
+    static_assert(BT == 128 || BT == 64, "tile");
     constexpr int TILE = (BM + BN) * KC;                  // elements per buffer
     static_assert(NST == 2 || NST == 4, "two buffers, or the four-stage ring for one-round launches");
     __shared__ __attribute__((aligned(1024))) T smem[NST * TILE];
@@ -205,13 +209,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvGemmDev
     // offsets are loop-invariant (see conv_gemm_dma3_kernel); the flat-address form below stays for Cin tails.
 #if defined(__HIP_DEVICE_COMPILE__)
     __amdgpu_buffer_rsrc_t rsa, rsb;
-    int avo[4], bvo[4];
+    int avo[DJ], bvo[DJ];
     if (p.use_buf) {
         rsa = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, (int)((((long)p.T_in - 1) * p.x_rstride + p.Cin) * (long)sizeof(T)), 0x00020000);
         rsb = __builtin_amdgcn_make_buffer_rsrc((void*)wg, 0, (int)((long)p.N * p.K * (long)sizeof(T)), 0x00020000);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int R0 = (wave * 4 + j) * 8;
+        for (int j = 0; j < DJ; ++j) {
+            const int R0 = (wave * DJ + j) * 8;
             const long n = n0 + R0 + lrow;
             avo[j] = (int)(((long)(m0 + R0 + lrow) * p.x_rstride + kvl * VEC) * (long)sizeof(T));
             bvo[j] = n < p.N ? (int)((n * p.K + kvl * VEC) * (long)sizeof(T)) : 0x7fffff00;
@@ -225,11 +229,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvGemmDev
             const int ca = (int)(((long)(tap * p.dil - p.pad) * p.x_rstride + c0) * (long)sizeof(T));
             const int cb = (tap * p.Cin + c0) * (int)sizeof(T);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lds_void*)(base + (wave * 4 + j) * 8 * KC), 16, avo[j] + ca, 0, 0, 0);
+            for (int j = 0; j < DJ; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lds_void*)(base + (wave * DJ + j) * 8 * KC), 16, avo[j] + ca, 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb, (lds_void*)(base + (BM + (wave * 4 + j) * 8) * KC), 16, bvo[j] + cb, 0, 0, 0);
+            for (int j = 0; j < DJ; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb, (lds_void*)(base + (BM + (wave * DJ + j) * 8) * KC), 16, bvo[j] + cb, 0, 0, 0);
             return;
         }
 #endif
@@ -238,16 +242,16 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvGemmDev
         const int toff = tap * p.dil - p.pad;
         const long wk = (long)tap * p.Cin + ci;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int R0 = (wave * 4 + j) * 8;
+        for (int j = 0; j < DJ; ++j) {
+            const int R0 = (wave * DJ + j) * 8;
             const int t = m0 + R0 + lrow + toff;
             const T* src = (kval && t >= 0 && t < p.T_in) ? xb + (long)t * p.x_rstride + ci : zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (lds_void*)(base + R0 * KC), 16, 0, 0);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int R0 = (wave * 4 + j) * 8;
+        for (int j = 0; j < DJ; ++j) {
+            const int R0 = (wave * DJ + j) * 8;
             const int n = n0 + R0 + lrow;
             const T* src = (kval && n < p.N) ? wg + (long)n * p.K + wk : zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -339,6 +343,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvGemmDev
         issue(0, tap, c0); advance();
         issue(1, tap, c0); advance();
         issue(2, tap, c0); advance();
+        static_assert(BT == 128, "the ring's vmcnt(16) assumes eight DMA instructions per wave per chunk");
         asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         for (int c = 0; c < nchunks; ++c) {
@@ -354,7 +359,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvGemmDev
     if constexpr (LEPI) {
         constexpr int ERT = (WN <= 64 && TM % 2 == 0) ? 2 : 1;
         float* stage = reinterpret_cast<float*>(smem) + wave * (ERT * 32 * WN);
-        if constexpr (sizeof(TO) == 2) {
+        if constexpr (sizeof(TO) == 2 && BT == 128) {
             if (p.epi == EPI_QKV_ROPE) { gemm_epilogue_qkv_lds<TO>(acc, p, m0, n0, b, wm, wn, lr, lk, stage); return; }
         }
         gemm_epilogue_lds<TO, TM, TN, WM, WN>(acc, p, m0, n0, b, g, wm, wn, lr, lk, stage);
@@ -548,7 +553,8 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void conv_gemm_dma3_ker
 
 static bool g_use_dma = true, g_xcd_order = false, g_use_dma3 = true, g_big_tiles = true;
 static long g_big_min = 160, g_n192_min = 160, g_mid_min = 160, g_k_min = 2048;
-static bool g_n192 = true, g_f32_dma = true, g_pp = false, g_ring4 = true;
+static bool g_n192 = true, g_f32_dma = true, g_pp = false, g_ring4 = true, g_f32_small = true;
+static long g_f32_small_max = 1024;
 static long g_ring4_max = 256;
 static DevBuf g_zero_page[16];
 
@@ -638,6 +644,16 @@ static void dispatch_tiles(const ConvGemmDev& d, int B, hipStream_t s) {
                 e.Tm = (d.M + 127) / 128; e.Tn = (d.N + 127) / 128; e.RT = B * e.Tm;
                 e.RC = g_xcd_order ? (e.RT + 7) / 8 : 0;
                 e.use_buf = buf_ok(d, 4);
+                if (g_f32_small && (long)e.RT * e.Tn * d.G < g_f32_small_max) {
+                    // fewer than a few 128x128 tiles per CU (one utterance: 144 / 288 / 432 tiles on 256 CUs): 64x64 tiles
+                    // balance the chip (O projection 144 -> 576 workgroups: makespan 3 quarter-tiles instead of 4)
+                    e.Tm = (d.M + 63) / 64; e.Tn = (d.N + 63) / 64; e.RT = B * e.Tm; e.RC = 0;
+                    dim3 g2(e.RT * e.Tn, d.G);
+                    if (e.lds_epi) hipLaunchKernelGGL((conv_gemm_dma_kernel<T, TO, true, 2, 64>), g2, blk, 0, s, e);
+                    else hipLaunchKernelGGL((conv_gemm_dma_kernel<T, TO, false, 2, 64>), g2, blk, 0, s, e);
+                    MI_HIP(hipGetLastError());
+                    return;
+                }
                 dim3 g1(e.RC > 0 ? 8 * e.RC * e.Tn : e.RT * e.Tn, d.G);
                 if (e.lds_epi) hipLaunchKernelGGL((conv_gemm_dma_kernel<T, TO, true>), g1, blk, 0, s, e);
                 else hipLaunchKernelGGL((conv_gemm_dma_kernel<T, TO, false>), g1, blk, 0, s, e);
@@ -665,6 +681,8 @@ bool gemm_set_option(const char* key, long v) {
     else if (k == "gemm_pp") g_pp = v != 0;
     else if (k == "gemm_ring4") g_ring4 = v != 0;
     else if (k == "gemm_buf") g_buf = v != 0;
+    else if (k == "gemm_f32_small") g_f32_small = v != 0;
+    else if (k == "gemm_f32_small_max") g_f32_small_max = v;
     else if (k == "gemm_ring4_max") g_ring4_max = v;
     else return false;
     return true;
@@ -701,6 +719,8 @@ void launch_conv_gemm(const ConvGemm& p, hipStream_t s) {
             if (const char* n = std::getenv("MI355TTS_PP")) g_pp = n[0] == '1';
             if (const char* n = std::getenv("MI355TTS_NO_RING4")) g_ring4 = !(n[0] == '1');
             if (const char* n = std::getenv("MI355TTS_NO_BUF")) g_buf = !(n[0] == '1');
+            if (const char* n = std::getenv("MI355TTS_NO_F32_SMALL")) g_f32_small = !(n[0] == '1');
+            if (const char* n = std::getenv("MI355TTS_F32_SMALL_MAX")) g_f32_small_max = std::atol(n);
             if (const char* n = std::getenv("MI355TTS_RING4_MAX")) g_ring4_max = std::atol(n);
             env_read = true; }
         int dev = 0;
