@@ -363,6 +363,9 @@ __device__ __forceinline__ void gemm_epilogue_qkv_lds(f32x16 (&acc)[2][2], const
 
 typedef __attribute__((address_space(3))) void lds_void;
 
+// gemm_dma3.hip: the 8-wave 256-row kernels (bn = 192 / 256: buffer-descriptor DMA, bn = 128: three-stage ring)
+template <typename T, typename TO> void launch_conv_gemm_dma3(const ConvGemmDev& e, int bn, hipStream_t s);
+
 // gemm_pp.hip: ping-pong 256x256 (bn = 256) / 256x192 (bn = 192) kernel, 16-bit operands only
 template <typename T, typename TO> void launch_conv_gemm_pp(const ConvGemmDev& d, int B, int bn, hipStream_t s);
 
