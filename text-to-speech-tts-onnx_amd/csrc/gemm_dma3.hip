@@ -137,6 +137,56 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void conv_gemm_dma3_ker
     else wait_next(false);
     __builtin_amdgcn_s_barrier();
 
+    if constexpr (NST == 2) {
+        // Two stages, software-pipelined ACROSS chunks: the wait + barrier that publish chunk c+1 sit before the LAST k-step
+        // of chunk c (whose fragments are already in registers), so the first fragments of chunk c+1 are fetched, and the
+        // DMA of chunk c+2 is issued into chunk c's stage, under MFMAs that are ready to issue — the lockstep form left
+        // an LDS round trip (and the barrier skew) exposed in front of the first MFMA of every chunk.
+        typename MF::Frag fa[2][TM], fb[2][TN];
+        auto ldfrag = [&](const T* As, int ks, int set) {
+            const T* Bs = As + BM * KC;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = wm * WM + i * 32 + lr;
+                fa[set][i] = *reinterpret_cast<const typename MF::Frag*>(As + row * KC + (((ks * 2 + lk) ^ ((row >> 1) & 7)) << 3));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row = wn * WN + j * 32 + lr;
+                fb[set][j] = *reinterpret_cast<const typename MF::Frag*>(Bs + row * KC + (((ks * 2 + lk) ^ ((row >> 1) & 7)) << 3));
+            }
+        };
+        auto mmas = [&](int set) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma(fa[set][i], fb[set][j], acc[i][j]);
+        };
+        if (nchunks > 1) { issue(1, itap, ic0); advance(); }
+        ldfrag(smem, 0, 0);
+        for (int c = 0; c < nchunks; ++c) {
+            const T* As = smem + (c & 1) * TILE;
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) {
+                ldfrag(As, ks + 1, (ks + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);                // keep the next k-step's reads AHEAD of these MFMAs
+                mmas(ks & 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (c + 1 < nchunks) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // chunk c+1 (issued a chunk period ago) has landed
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");// every read of chunk c's stage has retired
+                __builtin_amdgcn_s_barrier();
+                if (c + 2 < nchunks) { issue(c & 1, itap, ic0); advance(); }
+                ldfrag(smem + ((c + 1) & 1) * TILE, 0, 0);        // register set 0 is free: k-step 3 runs from set 1
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mmas(1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        gemm_epilogue<TO, TM, TN, WM, WN>(acc, p, m0, n0, b, g, wm, wn, lr, lk);
+        return;
+    }
     int st = 0;
     for (int c = 0; c < nchunks; ++c) {
         const bool pre = c + AHEAD < nchunks;
