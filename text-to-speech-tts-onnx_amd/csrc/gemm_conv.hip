@@ -318,7 +318,61 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvGemmDev
             }
         }
     };
-    if constexpr (NST == 2) {
+    if constexpr (NST == 2 && sizeof(T) == 2) {
+        // 16-bit, two stages: fragments one k-step ahead in two register sets, and the chunk boundary software-pipelined
+        // as in conv_gemm_dma3_kernel — the wait + barrier that publish chunk c+1 sit before the LAST k-step of chunk c,
+        // so the first fragments of chunk c+1 and the DMA of chunk c+2 are issued under MFMAs
+        typename MF::Frag fa[2][TM], fb[2][TN];
+        auto ldfrag = [&](int buf, int ks, int set) {
+            const T* As = smem + buf * TILE;
+            const T* Bs = As + BM * KC;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = wm * WM + i * 32 + lr;
+                fa[set][i] = *reinterpret_cast<const typename MF::Frag*>(As + row * KC + (((ks * 2 + lk) ^ (row & 7)) * VEC));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row = wn * WN + j * 32 + lr;
+                fb[set][j] = *reinterpret_cast<const typename MF::Frag*>(Bs + row * KC + (((ks * 2 + lk) ^ (row & 7)) * VEC));
+            }
+        };
+        auto mmas = [&](int set) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma(fa[set][i], fb[set][j], acc[i][j]);
+        };
+        auto advance = [&]() { if (++tap >= ntaps) { tap = 0; c0 += KC; } };
+        issue(0, tap, c0); advance();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (nchunks > 1) { issue(1, tap, c0); advance(); }
+        ldfrag(0, 0, 0);
+        for (int c = 0; c < nchunks; ++c) {
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) {
+                ldfrag(c & 1, ks + 1, (ks + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mmas(ks & 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (c + 1 < nchunks) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // chunk c+1 has landed (this wave's share)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // every read of chunk c's stage has retired
+                __builtin_amdgcn_s_barrier();
+                if (c + 2 < nchunks) { issue(c & 1, tap, c0); advance(); }
+                ldfrag((c + 1) & 1, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mmas(1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (LEPI) {                                      // the staging epilogue reuses the stages: all reads must be done
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    } else if constexpr (NST == 2) {
         issue(0, 0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
