@@ -158,10 +158,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmDev p) 
 //   * a K chunk is (tap, 64 input channels): A rows are x[m + tap*dil - pad][c0 .. c0+64), B rows are
 //     w[n][tap*Cin + c0 .. +64).  Vectors that fall outside the tensor (time padding, Cin tail, N tail) are
 //     fetched from a page of zeros, so the DMA needs no predication and the MFMA loop no masking.
-//   * LDS image: row r holds its eight 16-byte k-vectors at slot (kv ^ (r & 7)).  The DMA writes lane-linear
-//     (lane l -> row R0 + l/8, slot l%8), so lane l simply FETCHES k-vector (l%8) ^ (l/8); fragment reads apply
-//     the same XOR.  8 consecutive rows then cover all 64 banks for a ds_read_b128 (2-way at worst in a
-//     16-lane group instead of 8-way for the linear image).
+//   * LDS image: row r holds its eight 16-byte k-vectors at slot (kv ^ ((r >> 1) & 7)).  The DMA writes lane-linear
+//     (lane l -> row R0 + l/8, slot l%8), so lane l simply FETCHES the k-vector its slot must hold; fragment reads apply
+//     the same XOR.  Every ds_read_b128 lane group then covers all 64 banks exactly once (conflict-free).
 //   * the loads of chunk c+1 are in flight while the 16 MFMAs per wave of chunk c run.
 // ---------------------------------------------------------------------------------------------------
 template <typename T, typename TO, bool LEPI, int NST = 2, int BT = 128>
@@ -200,7 +199,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvGemmDev
     const T* wg = (const T*)p.w + (long)g * p.N * p.K;
     const T* zero = (const T*)p.zero;
 
-    const int kvl = (lane & 7) ^ (lane >> 3);             // logical k-vector this lane fetches
+    // logical k-vector this lane fetches: physical slot (lane & 7) of row R0 + lrow holds k-vector slot ^ ((row >> 1) & 7).
+    // (row >> 1, not row: the hardware serves a ds_read_b128 in lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ...;
+    // with `row & 7` rows 0 / 24, 1 / 25, ... of a group share a slot: SQ_LDS_BANK_CONFLICT was 47 % of the LDS-active
+    // cycles of this kernel (0 % in the 256-row kernels, which always used the `row >> 1` form).)
+    const int kvl0 = (lane & 7) ^ ((lane >> 4) & 7);              // even 8-row DMA groups
+    const int kvl1 = (lane & 7) ^ ((4 + (lane >> 4)) & 7);        // odd 8-row DMA groups
     const int lrow = lane >> 3;                           // row inside an 8-row DMA group
     const int cpt = (p.Cin + KC - 1) / KC;                // chunks per tap
     const int nchunks = (p.K / p.Cin) * cpt;
@@ -217,6 +221,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvGemmDev
         for (int j = 0; j < DJ; ++j) {
             const int R0 = (wave * DJ + j) * 8;
             const long n = n0 + R0 + lrow;
+            const int kvl = (j & 1) ? kvl1 : kvl0;                 // (wave * DJ + j) & 1 == j & 1: DJ is even
             avo[j] = (int)(((long)(m0 + R0 + lrow) * p.x_rstride + kvl * VEC) * (long)sizeof(T));
             bvo[j] = n < p.N ? (int)((n * p.K + kvl * VEC) * (long)sizeof(T)) : 0x7fffff00;
         }
@@ -237,23 +242,22 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvGemmDev
             return;
         }
 #endif
-        const int ci = c0 + kvl * VEC;
-        const bool kval = ci < p.Cin;
         const int toff = tap * p.dil - p.pad;
-        const long wk = (long)tap * p.Cin + ci;
 #pragma unroll
         for (int j = 0; j < DJ; ++j) {
             const int R0 = (wave * DJ + j) * 8;
+            const int ci = c0 + ((j & 1) ? kvl1 : kvl0) * VEC;
             const int t = m0 + R0 + lrow + toff;
-            const T* src = (kval && t >= 0 && t < p.T_in) ? xb + (long)t * p.x_rstride + ci : zero;
+            const T* src = (ci < p.Cin && t >= 0 && t < p.T_in) ? xb + (long)t * p.x_rstride + ci : zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (lds_void*)(base + R0 * KC), 16, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < DJ; ++j) {
             const int R0 = (wave * DJ + j) * 8;
+            const int ci = c0 + ((j & 1) ? kvl1 : kvl0) * VEC;
             const int n = n0 + R0 + lrow;
-            const T* src = (kval && n < p.N) ? wg + (long)n * p.K + wk : zero;
+            const T* src = (ci < p.Cin && n < p.N) ? wg + (long)n * p.K + (long)tap * p.Cin + ci : zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (lds_void*)(base + (BM + R0) * KC), 16, 0, 0);
         }
@@ -279,12 +283,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvGemmDev
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     const int row = wm * WM + i * 32 + lr;
-                    a[i] = *reinterpret_cast<const typename MF::Frag*>(As + row * KC + (((ks * 2 + lk) ^ (row & 7)) * VEC));
+                    a[i] = *reinterpret_cast<const typename MF::Frag*>(As + row * KC + (((ks * 2 + lk) ^ ((row >> 1) & 7)) * VEC));
                 }
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int row = wn * WN + j * 32 + lr;
-                    bb[j] = *reinterpret_cast<const typename MF::Frag*>(Bs + row * KC + (((ks * 2 + lk) ^ (row & 7)) * VEC));
+                    bb[j] = *reinterpret_cast<const typename MF::Frag*>(Bs + row * KC + (((ks * 2 + lk) ^ ((row >> 1) & 7)) * VEC));
                 }
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
@@ -299,12 +303,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvGemmDev
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     const int row = wm * WM + i * 32 + lr;
-                    a[i] = *reinterpret_cast<const float4*>(As + row * KC + (((ks * 2 + lk) ^ (row & 7)) * VEC));
+                    a[i] = *reinterpret_cast<const float4*>(As + row * KC + (((ks * 2 + lk) ^ ((row >> 1) & 7)) * VEC));
                 }
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int row = wn * WN + j * 32 + lr;
-                    bb[j] = *reinterpret_cast<const float4*>(Bs + row * KC + (((ks * 2 + lk) ^ (row & 7)) * VEC));
+                    bb[j] = *reinterpret_cast<const float4*>(Bs + row * KC + (((ks * 2 + lk) ^ ((row >> 1) & 7)) * VEC));
                 }
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
@@ -329,12 +333,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvGemmDev
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int row = wm * WM + i * 32 + lr;
-                fa[set][i] = *reinterpret_cast<const typename MF::Frag*>(As + row * KC + (((ks * 2 + lk) ^ (row & 7)) * VEC));
+                fa[set][i] = *reinterpret_cast<const typename MF::Frag*>(As + row * KC + (((ks * 2 + lk) ^ ((row >> 1) & 7)) * VEC));
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int row = wn * WN + j * 32 + lr;
-                fb[set][j] = *reinterpret_cast<const typename MF::Frag*>(Bs + row * KC + (((ks * 2 + lk) ^ (row & 7)) * VEC));
+                fb[set][j] = *reinterpret_cast<const typename MF::Frag*>(Bs + row * KC + (((ks * 2 + lk) ^ ((row >> 1) & 7)) * VEC));
             }
         };
         auto mmas = [&](int set) {
