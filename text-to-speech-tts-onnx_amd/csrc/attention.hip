@@ -20,10 +20,16 @@
 #include "common.h"
 #include "mfma.h"
 #include "f5_kernels.h"
+#include <cstdlib>
 
 namespace mi {
 
-template <typename T>
+// SPLIT2 = false: workgroup = 4 waves x 32 queries, every wave walks all keys.
+// SPLIT2 = true : workgroup = 2 x 32 queries; waves (2g, 2g+1) share query group g and take the even / odd 32-key tile of
+//                 every 64-key stage, then wave 2g+1 hands its (max, sum, O) to wave 2g through LDS.  Twice as many, half
+//                 as long workgroups: the fp32 kernel is MFMA-bound, and one utterance is 9 x 32 = 288 workgroups on 256
+//                 CUs, so the CUs that got two workgroups set the makespan (2 units); 576 half-size ones finish in 1.5.
+template <typename T, bool SPLIT2 = false>
 __global__ __launch_bounds__(256, 3) void attn_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                    const T* __restrict__ v, T* __restrict__ o, int H, int N) {
     using MF = Mfma<T>;
@@ -40,7 +46,7 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const T* __restrict__ q, c
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, hi = lane >> 5;
     const int bh = blockIdx.y;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = SPLIT2 ? blockIdx.x * 64 + (wave >> 1) * 32 : blockIdx.x * 128 + wave * 32;
     const T* qb = q + (long)bh * N * D;
     const T* kb = k + (long)bh * N * D;
     const long vld = sizeof(T) == 4 ? 0 : (long)((N + 7) / 8 * 8);
@@ -193,10 +199,14 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const T* __restrict__ q, c
                 }
             }
         };
+        if constexpr (SPLIT2) {
+            if (st * KT + (wave & 1) * 32 < N) tile(wave & 1);           // this wave's half of the stage
+        } else {
 #pragma unroll
-        for (int kt = 0; kt < KT / 32; ++kt) {
-            const int key0 = st * KT + kt * 32;
-            if (key0 < N) tile(kt);                                      // wave-uniform
+            for (int kt = 0; kt < KT / 32; ++kt) {
+                const int key0 = st * KT + kt * 32;
+                if (key0 < N) tile(kt);                                  // wave-uniform
+            }
         }
         __syncthreads();
         if (st + 1 < nstage) {
@@ -205,6 +215,32 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const T* __restrict__ q, c
         }
     }
 
+    if constexpr (SPLIT2) {
+        // ---- merge the two key halves: m = max(m0, m1) ; l = l0 2^(m0-m) + l1 2^(m1-m) ; O likewise ----------------------
+        __syncthreads();                                            // every wave is done with the K / V stage
+        float* comb = reinterpret_cast<float*>(smem);               // [2 groups][32 accumulator registers][64 lanes]
+        float* stats = comb + 2 * 32 * 64;                          // [2 groups][64 lanes][m, l]
+        static_assert(sizeof(smem) >= (2 * 32 * 64 + 2 * 64 * 2) * sizeof(float), "merge buffer fits the stage");
+        const int grp = wave >> 1;
+        if (wave & 1) {
+            stats[(grp * 64 + lane) * 2] = m_run; stats[(grp * 64 + lane) * 2 + 1] = l_run;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) comb[((grp * 2 + dt) * 16 + r) * 64 + lane] = oacc[dt][r];
+        }
+        __syncthreads();
+        if (wave & 1) return;
+        const float m1 = stats[(grp * 64 + lane) * 2], l1 = stats[(grp * 64 + lane) * 2 + 1];
+        const float m = fmaxf(m_run, m1);
+        const float s0 = m_run == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m_run - m);
+        const float s1 = m1 == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m1 - m);
+        l_run = l_run * s0 + l1 * s1;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[dt][r] = oacc[dt][r] * s0 + comb[((grp * 2 + dt) * 16 + r) * 64 + lane] * s1;
+    }
     // ---- normalise + store o[b][n][h*64 + d] ---------------------------------------------------------
     const int qr = q0 + lr;
     if (qr < N) {
@@ -227,12 +263,18 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const T* __restrict__ q, c
 
 void launch_attention(const void* q, const void* k, const void* v, void* o, int BH, int H, int N, int dtype, hipStream_t s) {
     MI_REQUIRE(BH % H == 0 && N > 0, "attention: bad shape");
-    dim3 grid((N + 127) / 128, BH);
     const double esz = (double)dtype_size(dtype);
     ProfScope ps(FAM_ATTN, s, 4.0 * BH * N * 64.0 * esz, 4.0 * BH * (double)N * N * 64.0);
-    if (dtype == MI_F32) hipLaunchKernelGGL(attn_kernel<float>, grid, dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N);
-    else if (dtype == MI_F16) hipLaunchKernelGGL(attn_kernel<f16>, grid, dim3(256), 0, s, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)o, H, N);
-    else hipLaunchKernelGGL(attn_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, H, N);
+    if (dtype == MI_F32) {
+        // few 128-query workgroups (one or two utterances): halve them along the keys, see attn_kernel
+        static int split = -1;
+        if (split < 0) { const char* e = std::getenv("MI355TTS_ATTN_NO_SPLIT"); split = (e && e[0] == '1') ? 0 : 1; }
+        if (split && (long)((N + 127) / 128) * BH < 1024 && N >= 64)
+            hipLaunchKernelGGL((attn_kernel<float, true>), dim3((N + 63) / 64, BH), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N);
+        else
+            hipLaunchKernelGGL((attn_kernel<float, false>), dim3((N + 127) / 128, BH), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N);
+    } else if (dtype == MI_F16) hipLaunchKernelGGL((attn_kernel<f16, false>), dim3((N + 127) / 128, BH), dim3(256), 0, s, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)o, H, N);
+    else hipLaunchKernelGGL((attn_kernel<bf16, false>), dim3((N + 127) / 128, BH), dim3(256), 0, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, H, N);
     MI_HIP(hipGetLastError());
 }
 
