@@ -179,7 +179,7 @@ int         mi_bench_conv_gemm(int dtype, int B, int T, int Cin, int N, int taps
                                double* ms);
 
 /* test / tuning hook: tile-dispatch thresholds of the implicit-GEMM kernel ("gemm_big_tile_min", "gemm_n192_min",
- * "gemm_mid_tile_min", "gemm_dma3_k_min", "gemm_use_dma3", "gemm_use_dma", "gemm_big_tiles", "gemm_n192", "gemm_pp", "gemm_f32_dma", "gemm_ring4", "gemm_ring4_max", "gemm_buf", "gemm_f32_small", "gemm_f32_small_max"), and
+ * "gemm_mid_tile_min", "gemm_dma3_k_min", "gemm_use_dma3", "gemm_use_dma", "gemm_big_tiles", "gemm_n192", "gemm_pp", "gemm_f32_dma", "gemm_ring4", "gemm_ring4_max", "gemm_buf", "gemm_f32_small", "gemm_f32_small_max", "gemm_small16_max"), and
  * "gpt_mfma_min" (sentences from which mi_gpt_generate_batch runs its linears on MFMA; default 9).              */
 int         mi_set_option(const char* key, int64_t value);
 

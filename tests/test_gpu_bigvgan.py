@@ -234,7 +234,7 @@ def test_bad_inputs_raise(small_voc):
 # only when the launch fills the chip) and compared with the oracle
 # ---------------------------------------------------------------------------------------------
 _DEFAULTS = {"gemm_big_tile_min": 160, "gemm_n192_min": 160, "gemm_mid_tile_min": 160, "gemm_dma3_k_min": 2048,
-             "gemm_use_dma3": 1, "gemm_use_dma": 1, "gemm_big_tiles": 1, "gemm_n192": 1, "gemm_pp": 0, "gemm_f32_dma": 1, "gemm_ring4": 1, "gemm_ring4_max": 256, "gemm_buf": 1, "gemm_f32_small": 1, "gemm_f32_small_max": 1024}
+             "gemm_use_dma3": 1, "gemm_use_dma": 1, "gemm_big_tiles": 1, "gemm_n192": 1, "gemm_pp": 0, "gemm_f32_dma": 1, "gemm_ring4": 1, "gemm_ring4_max": 256, "gemm_buf": 1, "gemm_f32_small": 1, "gemm_f32_small_max": 1024, "gemm_small16_max": 256}
 
 
 @pytest.fixture
@@ -256,12 +256,14 @@ def gemm_options():
     ("256x192/2-stage", {"gemm_n192_min": 1}, 192, 192, 11, 5, 900, 2),
     ("256x192/2-stage N=384", {"gemm_n192_min": 1}, 384, 384, 3, 1, 515, 1),
     ("256x128/3-stage", {"gemm_big_tiles": 0, "gemm_n192": 0, "gemm_mid_tile_min": 1, "gemm_dma3_k_min": 0}, 384, 384, 7, 1, 600, 2),
-    ("128x128/2-stage dma", {"gemm_use_dma3": 0, "gemm_ring4": 0}, 768, 768, 3, 1, 300, 1),
-    ("128x128/4-stage ring", {"gemm_use_dma3": 0}, 768, 768, 3, 1, 300, 1),
-    ("128x128/4-stage ring, Cin tail, ragged", {"gemm_use_dma3": 0}, 200, 300, 7, 2, 333, 2),
-    ("128x128/2-stage dma (many tiles)", {"gemm_use_dma3": 0, "gemm_ring4_max": 4}, 768, 768, 3, 1, 300, 1),
-    ("128x128 flat-address DMA (no buffer descriptors)", {"gemm_use_dma3": 0, "gemm_buf": 0}, 768, 768, 3, 1, 300, 1),
-    ("128x128 ring, flat-address DMA", {"gemm_use_dma3": 0, "gemm_buf": 0, "gemm_ring4_max": 4096}, 768, 768, 7, 3, 600, 2),
+    ("128x128/2-stage dma", {"gemm_use_dma3": 0, "gemm_ring4": 0, "gemm_small16_max": 0}, 768, 768, 3, 1, 300, 1),
+    ("128x128/4-stage ring", {"gemm_use_dma3": 0, "gemm_small16_max": 0}, 768, 768, 3, 1, 300, 1),
+    ("128x128/4-stage ring, Cin tail, ragged", {"gemm_use_dma3": 0, "gemm_small16_max": 0}, 200, 300, 7, 2, 333, 2),
+    ("64x64 tiles (16-bit, few tiles)", {"gemm_use_dma3": 0}, 768, 768, 3, 1, 300, 1),
+    ("64x64 tiles, Cin tail, ragged", {"gemm_use_dma3": 0}, 200, 300, 7, 2, 333, 2),
+    ("128x128/2-stage dma (many tiles)", {"gemm_use_dma3": 0, "gemm_ring4_max": 4, "gemm_small16_max": 0}, 768, 768, 3, 1, 300, 1),
+    ("128x128 flat-address DMA (no buffer descriptors)", {"gemm_use_dma3": 0, "gemm_buf": 0, "gemm_small16_max": 0}, 768, 768, 3, 1, 300, 1),
+    ("128x128 ring, flat-address DMA", {"gemm_use_dma3": 0, "gemm_buf": 0, "gemm_ring4_max": 4096, "gemm_small16_max": 0}, 768, 768, 7, 3, 600, 2),
     ("256-row tiles need whole chunks: Cin = 200 falls back", {"gemm_big_tile_min": 1, "gemm_dma3_k_min": 0}, 200, 768, 7, 1, 700, 2),
     ("register-staged", {"gemm_use_dma3": 0, "gemm_use_dma": 0}, 192, 192, 7, 3, 300, 1),
 ])

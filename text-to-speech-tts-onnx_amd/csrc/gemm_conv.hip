@@ -429,7 +429,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvGemmDev
 static bool g_use_dma = true, g_xcd_order = false, g_use_dma3 = true, g_big_tiles = true;
 static long g_big_min = 160, g_n192_min = 160, g_mid_min = 160, g_k_min = 2048;
 static bool g_n192 = true, g_f32_dma = true, g_pp = false, g_ring4 = true, g_f32_small = true;
-static long g_f32_small_max = 1024;
+static long g_f32_small_max = 1024, g_small16_max = 256;
 static long g_ring4_max = 256;
 static DevBuf g_zero_page[16];
 
@@ -501,6 +501,17 @@ static void dispatch_tiles(const ConvGemmDev& d, int B, hipStream_t s) {
                 e.use_buf = buf_ok(d, 2);
                 dim3 g1(e.RC > 0 ? 8 * e.RC * e.Tn : e.RT * e.Tn, d.G);
                 const int nchunks = (d.K / d.Cin) * ((d.Cin + 63) / 64);
+                if (d.epi == EPI_PLAIN && (long)g1.x * g1.y <= g_small16_max) {
+                    // at most one 128x128 tile per CU (the O / FF2 projections of one utterance: 144 tiles): 64x64 tiles put
+                    // four times as many, shorter workgroups on ALL CUs (O 15.6 -> 12.1 us, FF2 24.6 -> 21.4 us; with 288
+                    // tiles, FF1, the doubled DMA bytes per flop already cost more than the balance gains)
+                    e.Tm = (d.M + 63) / 64; e.Tn = (d.N + 63) / 64; e.RT = B * e.Tm; e.RC = 0;
+                    dim3 g2(e.RT * e.Tn, d.G);
+                    if (e.lds_epi) hipLaunchKernelGGL((conv_gemm_dma_kernel<T, TO, true, 2, 64>), g2, blk, 0, s, e);
+                    else hipLaunchKernelGGL((conv_gemm_dma_kernel<T, TO, false, 2, 64>), g2, blk, 0, s, e);
+                    MI_HIP(hipGetLastError());
+                    return;
+                }
                 if (g_ring4 && (long)g1.x * g1.y <= g_ring4_max && nchunks >= 6) {
                     // at most one workgroup per CU: the four-stage ring hides the DMA round trip that the two-buffer
                     // loop exposes when a CU has no second workgroup to switch to
@@ -558,6 +569,7 @@ bool gemm_set_option(const char* key, long v) {
     else if (k == "gemm_buf") g_buf = v != 0;
     else if (k == "gemm_f32_small") g_f32_small = v != 0;
     else if (k == "gemm_f32_small_max") g_f32_small_max = v;
+    else if (k == "gemm_small16_max") g_small16_max = v;
     else if (k == "gemm_ring4_max") g_ring4_max = v;
     else return false;
     return true;
@@ -596,6 +608,7 @@ void launch_conv_gemm(const ConvGemm& p, hipStream_t s) {
             if (const char* n = std::getenv("MI355TTS_NO_BUF")) g_buf = !(n[0] == '1');
             if (const char* n = std::getenv("MI355TTS_NO_F32_SMALL")) g_f32_small = !(n[0] == '1');
             if (const char* n = std::getenv("MI355TTS_F32_SMALL_MAX")) g_f32_small_max = std::atol(n);
+            if (const char* n = std::getenv("MI355TTS_SMALL16_MAX")) g_small16_max = std::atol(n);
             if (const char* n = std::getenv("MI355TTS_RING4_MAX")) g_ring4_max = std::atol(n);
             env_read = true; }
         int dev = 0;
