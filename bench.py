@@ -81,24 +81,8 @@ def f5_flops_per_eval(cfg, N: int) -> float:
 
 
 def f5_synthetic_inputs(cfg, U: int, rank: int):
-    """6.0 s reference audio (144000 samples -> 563 frames), equal-length
-    ~15-word ASCII ref/gen texts (-> N = 1126), char-level ids against a synthetic vocab."""
     from mi355tts import weights as W
-    L = 144000
-    ref_text = "Some call me nature, others call me mother nature, I am the breeze and rain. "
-    gen_text = "The quick brown fox jumps over the lazy dog while seven wizards brew a potion"
-    gen_text = (gen_text + " " * len(ref_text))[:len(ref_text)]
-    vocab = W.synth_vocab(cfg.text_num_embeds)
-    ids = np.asarray([vocab.get(c, 0) for c in (ref_text + gen_text)], dtype=np.int32)
-    ref_frames = L // cfg.hop_length + 1
-    N = ref_frames + int(ref_frames / len(ref_text.encode()) * len(gen_text.encode()) / 1.0)
-    audio = np.empty((U, L), np.int16)
-    tt = np.arange(L) / cfg.sample_rate
-    for u in range(U):
-        a = 0.1 * 32767 * np.sin(2 * np.pi * 220 * tt) + W.synth_normal(9527 + 64 * rank + u, "audio", (L,), std=500.0)
-        audio[u] = np.clip(np.round(a), -32768, 32767).astype(np.int16)
-    noise = np.stack([W.synth_normal(9527 + 64 * rank + u, "noise", (N, cfg.mel_dim)) for u in range(U)])
-    return audio, np.tile(ids[None], (U, 1)), N, noise
+    return W.f5_synthetic_inputs(cfg, U, rank)
 
 
 def cpu_baseline_f5(cfg, raw_state, audio, ids, N, noise):
@@ -469,8 +453,7 @@ def main():
         conds = torch.from_numpy(W.synth_normal(100 + rank, "conds", (ncond,), std=0.2)).to(dev)
         step = lambda: voc.run_latent_torch(latent, conds, out)
     else:
-        mel = torch.from_numpy(W.synth_normal(100 + rank, "mel", (B, cfg.num_mels, F), std=2.0, mean=-2.0)
-                               .clip(-11.5, 2.5)).to(dev)
+        mel = torch.from_numpy(W.bigvgan_synthetic_mel(cfg, B, F, rank)).to(dev)
         step = lambda: voc.run_torch(mel, out)
 
     for _ in range(args.warmup):

@@ -106,6 +106,9 @@ int         mi_f5_preprocess(mi_f5* h, const int16_t* audio, int64_t L, const in
                              int64_t max_duration, const float* noise_in, uint64_t seed, float* noise,
                              float* rope_cos, float* rope_sin, float* cat_mel_text, float* cat_mel_text_drop,
                              int64_t* ref_signal_len, int mem);
+/* unit-level entry (tests): STFT-B of graph A alone (F5_TTS/STFT_Process.py:144-157, reflect padding): audio (L) int16 ->
+ * spec (L/hop + 1, 2*(n_fft/2+1)) fp32, row f = [re(0..n_fft/2) | im(0..n_fft/2)] of frame f.                          */
+int         mi_f5_stft(mi_f5* h, const int16_t* audio, int64_t L, float* spec, int mem);
 /* graph B, one call = `fuse` Euler/CFG steps starting at *time_step (host int); noise (U,N,100) is
  * updated in place, *time_step += fuse.  cat_mel_text(_drop): (U,N,612).                              */
 int         mi_f5_transformer_step(mi_f5* h, float* noise, const float* cat_mel_text, const float* cat_mel_text_drop,
@@ -179,7 +182,7 @@ int         mi_bench_conv_gemm(int dtype, int B, int T, int Cin, int N, int taps
                                double* ms);
 
 /* test / tuning hook: tile-dispatch thresholds of the implicit-GEMM kernel ("gemm_big_tile_min", "gemm_n192_min",
- * "gemm_mid_tile_min", "gemm_dma3_k_min", "gemm_use_dma3", "gemm_use_dma", "gemm_big_tiles", "gemm_n192", "gemm_pp", "gemm_f32_dma", "gemm_ring4", "gemm_ring4_max", "gemm_buf", "gemm_f32_small", "gemm_f32_small_max", "gemm_small16_max"), and
+ * "gemm_mid_tile_min", "gemm_dma3_k_min", "gemm_use_dma3", "gemm_use_dma", "gemm_big_tiles", "gemm_n192", "gemm_f32_dma", "gemm_ring4", "gemm_ring4_max", "gemm_buf", "gemm_f32_small", "gemm_f32_small_max", "gemm_small16_max"), and
  * "gpt_mfma_min" (sentences from which mi_gpt_generate_batch runs its linears on MFMA; default 9).              */
 int         mi_set_option(const char* key, int64_t value);
 

@@ -218,6 +218,39 @@ def test_full_size_properties(full_state):
     v.close()
 
 
+def test_full_size_reference_fixture(full_state, golden_dir):
+    """BASELINE configs[0] / [1] against the REFERENCE generator + int16 wrapper run at the real shape
+    (tests/golden/make_golden_full.py: BigVGAN/modeling_modified/bigvgan.py:384-410 through Export_BigVGAN.py:37-49 on
+    mel (1,100,512)).  fp32: the north-star gate (1e-3 RMS) with headroom + int16 within the truncation boundary;
+    fp16 B=8 (configs[1]): item 0 of the bench batch is the fixture's mel, the same mel tiled 8 times must give 8 equal
+    waveforms, gate 2e-2 RMS (stated, storage rounded to fp16 after every layer)."""
+    cfg, st = full_state
+    gf = np.load(os.path.join(golden_dir, "bigvgan_full.npz"))
+    ref = gf["wav_i16"].astype(np.float64)
+    assert ref.shape == (131102,) and rms(ref) > 1000
+    mel8 = W.bigvgan_synthetic_mel(cfg, 8, 512, 0)
+    v = BV.BigVGANVocoder(cfg, st, dtype="f32")
+    w = v.run(mel8[:1])
+    d = np.abs(w[0, 0].astype(np.int32) - gf["wav_i16"].astype(np.int32))
+    err32 = rms((w[0, 0] - ref) / 32767.0)
+    assert err32 < 1e-4, err32                                       # north-star gate 1e-3
+    assert d.max() <= 4 and (d > 1).mean() < 1e-3, (d.max(), (d > 1).mean())
+    ones = v.run(np.ones((1, cfg.num_mels, 64), np.float32))       # the reference's own smoke input (Export_BigVGAN.py:165)
+    assert np.abs(ones[0, 0].astype(np.int32) - gf["ones64_i16"].astype(np.int32)).max() <= 2
+    v.close()
+    v = BV.BigVGANVocoder(cfg, st, dtype="f16")
+    w8 = v.run(mel8)
+    assert w8.shape == (8, 1, 131102)
+    err16 = rms((w8[0, 0] - ref) / 32767.0)
+    assert err16 < 2e-2, err16
+    wt = v.run(np.repeat(mel8[:1], 8, axis=0))
+    for b in range(8):
+        assert np.array_equal(wt[b], wt[0])
+    assert np.array_equal(wt[0], w8[0])                              # batch position does not change an item's result
+    v.close()
+    print(f"BigVGAN full size vs reference: fp32 rms {err32:.2e} (max |d| {d.max()} LSB), fp16 B=8 rms {err16:.2e}")
+
+
 def test_bad_inputs_raise(small_voc):
     cfg, st, v = small_voc
     with pytest.raises(ValueError):
@@ -234,7 +267,7 @@ def test_bad_inputs_raise(small_voc):
 # only when the launch fills the chip) and compared with the oracle
 # ---------------------------------------------------------------------------------------------
 _DEFAULTS = {"gemm_big_tile_min": 160, "gemm_n192_min": 160, "gemm_mid_tile_min": 160, "gemm_dma3_k_min": 2048,
-             "gemm_use_dma3": 1, "gemm_use_dma": 1, "gemm_big_tiles": 1, "gemm_n192": 1, "gemm_pp": 0, "gemm_f32_dma": 1, "gemm_ring4": 1, "gemm_ring4_max": 256, "gemm_buf": 1, "gemm_f32_small": 1, "gemm_f32_small_max": 1024, "gemm_small16_max": 256}
+             "gemm_use_dma3": 1, "gemm_use_dma": 1, "gemm_big_tiles": 1, "gemm_n192": 1, "gemm_f32_dma": 1, "gemm_ring4": 1, "gemm_ring4_max": 256, "gemm_buf": 1, "gemm_f32_small": 1, "gemm_f32_small_max": 1024, "gemm_small16_max": 256}
 
 
 @pytest.fixture
@@ -246,11 +279,6 @@ def gemm_options():
 
 
 @pytest.mark.parametrize("cfg_name,opts,Ci,Co,k,d,T,B", [
-    ("256x256/ping-pong", {"gemm_pp": 1, "gemm_big_tile_min": 1, "gemm_dma3_k_min": 0}, 768, 768, 7, 3, 700, 2),
-    ("256x256/ping-pong ragged N, Cin tail", {"gemm_pp": 1, "gemm_big_tile_min": 1, "gemm_dma3_k_min": 0}, 248, 1000, 3, 1, 333, 1),
-    ("256x256/ping-pong one chunk", {"gemm_pp": 1, "gemm_big_tile_min": 1, "gemm_dma3_k_min": 0}, 24, 300, 1, 1, 257, 1),
-    ("256x192/ping-pong", {"gemm_pp": 1, "gemm_n192_min": 1}, 192, 192, 11, 5, 900, 2),
-    ("256x192/ping-pong N=384", {"gemm_pp": 1, "gemm_n192_min": 1}, 384, 384, 3, 1, 515, 1),
     ("256x256/2-stage", {"gemm_big_tile_min": 1, "gemm_dma3_k_min": 0}, 768, 768, 7, 3, 700, 2),
     ("256x256/2-stage ragged N", {"gemm_big_tile_min": 1, "gemm_dma3_k_min": 0}, 256, 1000, 3, 1, 333, 1),
     ("256x192/2-stage", {"gemm_n192_min": 1}, 192, 192, 11, 5, 900, 2),

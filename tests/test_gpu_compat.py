@@ -53,6 +53,45 @@ def test_f5_driver_sequence_through_facade(tmp_path, golden_dir):
     assert np.array_equal(w2, wav)
 
 
+def test_f5_facade_fuse_nfe_seed_and_rope_inputs(tmp_path, golden_dir):
+    """FUSE_NFE > 1 (`for i in range(0, NFE_STEP - 1, FUSE_NFE)`, F5-TTS-ONNX-Inference.py:291): the transformer graph advances
+    fuse_step Euler steps per run; repeated preprocess runs draw fresh noise like ORT's generator; RoPE feeds that are not
+    graph A's tables are refused instead of silently ignored."""
+    import dataclasses
+    g = np.load(os.path.join(golden_dir, "f5_small.npz"))
+    base = F5Config.small()
+    cfg = dataclasses.replace(base, nfe_step=7, fuse_step=2)       # 6 Euler steps = 3 runs of 2
+    st = W.synth_state(W.f5_spec(cfg), 9527)
+    wfile = tmp_path / "f5_weights.npy"
+    np.save(wfile, W.pack_f5(cfg, st))
+    pa = onnxruntime.save_model(str(tmp_path / "A.mi355.json"), "F5_Preprocess", cfg, str(wfile), "f32")
+    pb = onnxruntime.save_model(str(tmp_path / "B.mi355.json"), "F5_Transformer", cfg, str(wfile), "f32")
+    onnxruntime.set_seed(9527)
+    A, B = onnxruntime.InferenceSession(pa), onnxruntime.InferenceSession(pb)
+    in_A, out_A = [a.name for a in A.get_inputs()], [a.name for a in A.get_outputs()]
+    in_B, out_B = [a.name for a in B.get_inputs()], [a.name for a in B.get_outputs()]
+    feedA = {in_A[0]: g["pre_audio"].reshape(1, 1, -1), in_A[1]: g["pre_text_ids"].reshape(1, -1),
+             in_A[2]: np.array([int(g["pre_N"])], dtype=np.int64)}
+    n1, cq, sq, ck, sk, cmt, cmtd, rsl = A.run(out_A, feedA)
+    n2 = A.run(out_A, feedA)[0]
+    assert not np.array_equal(n1, n2)                           # the generator advanced
+    onnxruntime.set_seed(9527)
+    assert np.array_equal(A.run(out_A, feedA)[0], n1)           # and is reproducible from the seed
+    noise, time_step = g["dit_noise"][None].copy(), np.array([0], dtype=np.int32)
+    NFE_STEP, FUSE_NFE, runs = cfg.nfe_step, cfg.fuse_step, 0
+    for i in range(0, NFE_STEP - 1, FUSE_NFE):
+        noise, time_step = B.run(out_B, {in_B[0]: noise, in_B[1]: cq, in_B[2]: sq, in_B[3]: ck, in_B[4]: sk, in_B[5]: cmt,
+                                         in_B[6]: cmtd, in_B[7]: time_step})
+        runs += 1
+    assert runs == 3 and int(time_step[0]) == 6
+    eng = B._eng
+    want = eng.sample(g["dit_noise"][None], cmt, cmtd)
+    assert np.array_equal(noise, want)                          # 3 fused runs == the 6-step device loop
+    with pytest.raises(onnxruntime.InvalidArgument):
+        B.run(out_B, {in_B[0]: noise, in_B[1]: cq * 0.5, in_B[2]: sq, in_B[3]: ck, in_B[4]: sk, in_B[5]: cmt, in_B[6]: cmtd,
+                      in_B[7]: np.array([0], dtype=np.int32)})
+
+
 def test_bigvgan_session_like_the_reference_smoke_run(tmp_path, golden_dir):
     g = np.load(os.path.join(golden_dir, "bigvgan_small.npz"))
     cfg = BigVGANConfig.small()

@@ -411,3 +411,26 @@ def test_full_size_gpt_teacher_forced_and_batch_equals_single():
             k += 1
         assert k >= n_new // 2, (b, k)                                # 16-bit rounding order differs between the two GEMV forms
     e.close()
+
+
+def test_repeat_penalty_change_on_one_handle_reaches_the_replayed_graph():
+    """The decode step is captured into a hipGraph on first use; REPEAT_PENALITY is a device scalar so that a later call with
+    another value is honoured by every replayed token (it used to be baked into the captured kernel arguments)."""
+    from mi355tts.config import IndexGPTConfig
+    from mi355tts.indextts import IndexGPT
+    from oracle import gpt_np as G
+    cfg = IndexGPTConfig.small()
+    st = W.synth_state(W.gpt_spec(cfg), 9527)
+    conds = W.synth_normal(9527, "rp.conds", (1, 4, cfg.hidden), std=0.5)
+    text = np.array([[5, 17, 3, 22, 9, 30]], np.int32)
+    gpt = IndexGPT(cfg, st, dtype="f32")
+    outs = {}
+    for rep in (0.7, 0.2, 0.7):
+        ones = np.ones((1, cfg.mel_codes), np.float32)
+        toks, hid, _ = gpt.generate(conds, text, max_generate_length=13 + 14, stop_tokens=[], repeat_value=rep, repeat_penality=ones)
+        otoks, _, _ = G.generate(cfg, st, conds, text, max_generate_length=13 + 14, stop_tokens=[], repeat_value=rep)
+        assert toks.tolist() == otoks, rep
+        outs.setdefault(rep, toks.tolist())
+        assert outs[rep] == toks.tolist()
+    assert outs[0.7] != outs[0.2]                 # the two penalties really give different token streams
+    gpt.close()

@@ -131,3 +131,25 @@ def test_indextts_graph_f_io_names_match_the_export():
     assert n_spec == sum(int(np.prod(s)) for _, s, _ in W.bigvgan_spec(BigVGANConfig(
         num_mels=1280, upsample_rates=cfg.upsample_rates, upsample_kernel_sizes=cfg.upsample_kernel_sizes,
         use_bias_at_final=True))) + 2 * 1280
+
+
+def test_ascii_segmentation_follows_jieba_block_rules():
+    """jieba.cut on pure-ASCII text (un-vendored; restated in mi355tts.text): blocks of [a-zA-Z0-9+#&._%-] go through the DAG
+    + finalseg's `[a-zA-Z0-9]+(?:\\.\\d+)?%?` split, so decimals, percentages and punctuation runs are single multi-character
+    tokens — and convert_char_to_pinyin (F5-TTS-ONNX-Inference.py:116-119) puts a space in front of those."""
+    from mi355tts import text as T
+    seg = T._segment
+    assert seg("wait... ok") == ["wait", "...", " ", "ok"]
+    assert seg("pi is 3.14") == ["pi", " ", "is", " ", "3.14"]
+    assert seg("C++ and c#") == ["C++", " ", "and", " ", "c#"]
+    assert seg("a--b") == ["a", "--", "b"]
+    assert seg("50% off, AT&T.") == ["50%", " ", "off", ",", " ", "AT&T", "."]
+    assert seg("I'm") == ["I", "'", "m"]
+    assert seg("a\r\nb") == ["a", "\r\n", "b"]
+    j = lambda t: "".join(T.convert_char_to_pinyin([t])[0])
+    assert j("wait... ok") == "wait ... ok"
+    assert j("pi is 3.14") == "pi is 3.14"
+    assert j("a... b") == "a ... b"
+    assert j("C++") == "C++" and j("use C++") == "use C++"
+    assert j("x;y") == "x,y"
+    assert j("Hello, world!") == "Hello, world!"

@@ -242,6 +242,8 @@ void BigVGAN::run_latent(const float* latent, int T_codes, const float* conds, l
     MI_REQUIRE(cfg.pre_ln && cfg.cond, "bigvgan_forward_latent: handle was not created with the IndexTTS graph-F flags");
     MI_REQUIRE(latent && conds && T_codes >= 3 && (out_f32 || out_i16), "bigvgan_forward_latent: bad arguments (needs >= 3 latent rows)");
     MI_REQUIRE(n_conds == total_cond(), "bigvgan_forward_latent: conditioning vector length");
+    // the LayerNorm below writes rows of num_mels elements; conv_pre reads them with row stride mel_pad
+    MI_REQUIRE(mel_pad == cfg.num_mels, "bigvgan_forward_latent: the latent width must be a multiple of the 16-byte vector");
     MI_HIP(hipSetDevice(device));
     const int F = T_codes - 2;                          // the reference drops the last two latent rows
     ensure_workspace(1, F);

@@ -192,7 +192,7 @@ int mi_f5_preprocess(mi_f5* h, const int16_t* audio, int64_t L, const int32_t* t
         MI_REQUIRE(max_duration > 0 && max_duration <= e.cfg.max_len && T >= 0 && T < (1 << 20) && L > 0 && L < (1L << 31),
                    "mi_f5_preprocess: sizes");
         const int N = (int)max_duration;
-        const int R = e.preprocess(0, 1, audio, L, text_ids, (int)T, N, noise_in, seed, mem);
+        const int R = e.preprocess(1, audio, L, text_ids, (int)T, N, noise_in, seed, mem);
         hipStream_t s = e.stream;
         const size_t cd = e.cfg.cond_dim(), D = e.cfg.dim_head;
         copy_out(noise, e.d_noise.p, (size_t)N * e.cfg.mel * 4, mem, s);
@@ -201,6 +201,7 @@ int mi_f5_preprocess(mi_f5* h, const int16_t* audio, int64_t L, const int32_t* t
         copy_out(cat_mel_text, e.d_cmt.p, (size_t)N * cd * 4, mem, s);
         copy_out(cat_mel_text_drop, e.d_cmtd.p, (size_t)N * cd * 4, mem, s);
         MI_HIP(hipStreamSynchronize(s));
+        e.check_text_ids();
         if (ref_signal_len) *ref_signal_len = R;
     });
 }
@@ -270,16 +271,33 @@ int mi_f5_synthesize(mi_f5* h, int U, const int16_t* audio, int64_t L, const int
         MI_REQUIRE(audio && text_ids && out && U >= 1 && max_duration > 0, "mi_f5_synthesize: bad arguments");
         F5& e = *h->impl;
         const int N = (int)max_duration;
-        int R = 0;
-        for (int u = 0; u < U; ++u)
-            R = e.preprocess(u, U, audio + (size_t)u * L, L, text_ids + (size_t)u * T, (int)T, N,
-                             noise_in ? noise_in + (size_t)u * N * e.cfg.mel : nullptr, seed, mem);
+        const int R = e.preprocess(U, audio, L, text_ids, (int)T, N, noise_in, seed, mem);
         e.build_cat_cond(U, N);
         e.steps(U, N, 0, e.cfg.nfe - 1);
         const long len = e.decode(e.d_noise.as<float>(), U, N, R, nullptr, e.v_outi.as<int16_t>());
         copy_out(out, e.v_outi.p, (size_t)U * len * 2, mem, e.stream);
         MI_HIP(hipStreamSynchronize(e.stream));
+        e.check_text_ids();
         if (out_len) *out_len = len;
+    });
+}
+
+int mi_f5_stft(mi_f5* h, const int16_t* audio, int64_t L, float* spec, int mem) {
+    return guard([&] {
+        F5_CHECK(h, mem, "mi_f5_stft");
+        F5& e = *h->impl;
+        MI_REQUIRE(audio && spec && L >= e.cfg.n_fft / 2 + 1 && L < (1L << 31), "mi_f5_stft: bad arguments");
+        MI_HIP(hipSetDevice(e.device));
+        const int nf = e.cfg.n_fft, nb = e.cfg.nb(), R = (int)(L / e.cfg.hop) + 1;
+        e.p_audio.ensure((size_t)L * 2); e.p_pad.ensure((size_t)(L + nf) * 4 + 64); e.p_spec.ensure((size_t)R * 2 * nb * 4);
+        const int16_t* da = audio;
+        if (mem == MI_HOST) {
+            MI_HIP(hipMemcpyAsync(e.p_audio.p, audio, (size_t)L * 2, hipMemcpyHostToDevice, e.stream));
+            da = e.p_audio.as<int16_t>();
+        }
+        e.stft(da, 1, L);
+        copy_out(spec, e.p_spec.p, (size_t)R * 2 * nb * 4, mem, e.stream);
+        MI_HIP(hipStreamSynchronize(e.stream));
     });
 }
 
@@ -450,7 +468,7 @@ int mi_gpt_generate(mi_gpt* h, const float* prompt, int P, int max_new, const in
             MI_HIP(hipMemcpyAsync(e.pen.p, ones.data(), ones.size() * 4, hipMemcpyHostToDevice, s));
             MI_HIP(hipStreamSynchronize(s));
         }
-        e.rep_value = repeat_value;
+        e.set_rep_value(repeat_value);
         std::vector<int32_t> w(GS_WORDS, 0);
         w[GS_GEN_LEN] = 0; w[GS_NSTOP] = n_stop; w[GS_RANGE] = penalty_range; w[GS_UPDATE_PEN] = 1;
         if (mem == MI_HOST) for (int i = 0; i < n_stop; ++i) w[GS_STOP0 + i] = stop_ids[i];
@@ -505,7 +523,7 @@ int mi_gpt_generate_batch(mi_gpt* h, int nb, const float* prompts, const int32_t
             MI_HIP(hipMemcpyAsync(e.pen.p, ones.data(), ones.size() * 4, hipMemcpyHostToDevice, s));
             MI_HIP(hipStreamSynchronize(s));
         }
-        e.rep_value = repeat_value;
+        e.set_rep_value(repeat_value);
         bool any = false;
         for (int b = 0; b < nb; ++b) {                               // prompt passes, one sentence at a time
             std::vector<int32_t> w(GS_WORDS, 0);
@@ -600,6 +618,7 @@ int mi_set_option(const char* key, int64_t value) {
     return guard([&] {
         MI_REQUIRE(key != nullptr, "mi_set_option: null key");
         MI_REQUIRE(gemm_set_option(key, (long)value) || gpt_set_option(key, (long)value), "mi_set_option: unknown key");
+        option_epoch_bump();
     });
 }
 

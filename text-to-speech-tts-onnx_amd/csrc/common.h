@@ -23,6 +23,9 @@ struct Error : std::runtime_error {
     Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
 };
 void set_last_error(const std::string& m);
+// bumped by every mi_set_option: handles drop their captured hipGraphs when it moved (a graph bakes the dispatch in)
+long option_epoch();
+void option_epoch_bump();
 
 #define MI_HIP(expr)                                                                              \
     do {                                                                                          \

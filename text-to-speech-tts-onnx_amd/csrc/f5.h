@@ -50,13 +50,15 @@ struct F5 {
     struct GraphEntry { hipGraphExec_t exec = nullptr; int uses = 0; };
     std::map<std::vector<int>, GraphEntry> graphs;
     bool use_graph = true;          // MI355TTS_NO_GRAPH=1 disables
+    long graph_epoch = 0;           // option_epoch() the cached graphs were captured under
     void drop_graphs();
     void steps_eager(int U, int N, int k0, int nsteps);
 
     // ---- workspace ----
     int ws_U = 0, ws_N = 0;
     DevBuf d_noise, d_cmt, d_cmtd, cat, h32, hT, c1, X, Ub, qb, kb, vb, Ob, Hff, pred;
-    DevBuf p_audio, p_pad, p_spec, p_mag, p_mel, p_ids, p_tx, p_ty, p_ty2, p_ss;
+    DevBuf p_audio, p_pad, p_spec, p_mag, p_mel, p_ids, p_tid, p_err, p_tx, p_ty, p_ty2, p_ss;
+    std::vector<float> h_noise;
     DevBuf v_h, v_z, v_z2, v_s, v_c, v_fr, v_outf, v_outi;
 
     F5(const F5Cfg& c, const float* w, int64_t nw, int dt, int dev);
@@ -64,9 +66,11 @@ struct F5 {
     void ensure_workspace(int U, int N);
     void gemm(int dt, const void* x, long xb, long xr, int K, const Lin& L, void* out, int odt, long ob, long orr,
               int B, int M, int act = ACT_NONE, const void* res = nullptr, const float* gate = nullptr);
-    // fills d_noise[u], d_cmt[u], d_cmtd[u]; returns ref_signal_len
-    int preprocess(int u, int U, const int16_t* audio, long L, const int32_t* text_ids, int T, int N,
+    // fills d_noise, d_cmt, d_cmtd for U utterances (asynchronous on `stream`); returns ref_signal_len
+    int preprocess(int U, const int16_t* audio, long L, const int32_t* text_ids, int T, int N,
                    const float* noise_in, uint64_t seed, int mem);
+    void stft(const int16_t* audio_dev, int U, long L);     // -> p_spec [u][frame][re | im]
+    void check_text_ids();
     void load_cond(const float* noise, const float* cmt, const float* cmtd, int U, int N, int mem);
     void build_cat_cond(int U, int N);
     void dit_eval(int U, int N, int k);                 // pred <- DiT(noise, cond, t_k)

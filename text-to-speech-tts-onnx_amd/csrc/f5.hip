@@ -322,15 +322,15 @@ void F5::ensure_workspace(int U, int N) {
     {   // V may be stored transposed with the key axis padded to a multiple of 8; the pad columns are read (and
         // multiplied by exactly-zero probabilities), so they must hold finite values: zero the buffer once
         const size_t vbytes = (size_t)2 * Um * (size_t)(Nm + 8) * c.dim * es;
-        if (vbytes > vb.bytes) { vb.ensure(vbytes); MI_HIP(hipMemset(vb.p, 0, vbytes)); }
+        if (vbytes > vb.bytes) { vb.ensure(vbytes); MI_HIP(hipMemsetAsync(vb.p, 0, vbytes, stream)); }
     }
     Hff.ensure(rows * c.ff() * es);
     pred.ensure(rows * c.mel * 4);
-    // preprocess temporaries (one utterance at a time)
+    // preprocess temporaries
     const int ti = c.text_dim * c.conv_mult;
-    p_ids.ensure((size_t)Nm * 4);
-    p_tx.ensure((size_t)2 * Nm * c.text_dim * 4); p_ty.ensure((size_t)2 * Nm * c.text_dim * 4);
-    p_ty2.ensure((size_t)2 * Nm * ti * 4); p_ss.ensure((size_t)2 * ti * 4);
+    p_ids.ensure((size_t)Um * Nm * 4);
+    p_tx.ensure((size_t)2 * Um * Nm * c.text_dim * 4); p_ty.ensure((size_t)2 * Um * Nm * c.text_dim * 4);
+    p_ty2.ensure((size_t)2 * Um * Nm * ti * 4); p_ss.ensure((size_t)2 * Um * ti * 4);
     // decode temporaries
     const size_t fr = (size_t)Um * Nm;
     v_h.ensure(fr * c.vd * 4); v_z.ensure(fr * c.vd * 4); v_z2.ensure(fr * c.vi * 4);
@@ -369,82 +369,99 @@ static void host_normal(float* out, size_t n, uint64_t seed) {
     }
 }
 
-int F5::preprocess(int u, int U, const int16_t* audio, long L, const int32_t* text_ids, int T, int N,
+// Graph A for U utterances at once (audio (U,L), text_ids (U,T), noise_in (U,N,mel) or null): every stage is one launch
+// over the batch, nothing waits for the host.  Text ids are validated on the host when they live there; device-resident
+// ids are checked by the kernel (flag in p_err, read at the caller's next synchronisation via check_text_ids()).
+int F5::preprocess(int U, const int16_t* audio, long L, const int32_t* text_ids, int T, int N,
                    const float* noise_in, uint64_t seed, int mem) {
     const F5Cfg& c = cfg;
-    MI_REQUIRE(audio && text_ids && L >= c.n_fft / 2 + 1 && T >= 0, "f5_preprocess: bad arguments");
+    MI_REQUIRE(audio && text_ids && U >= 1 && L >= c.n_fft / 2 + 1 && T >= 0, "f5_preprocess: bad arguments");
     const int R = (int)(L / c.hop) + 1;
     MI_REQUIRE(N >= R && N >= T && N <= c.max_len, "f5_preprocess: max_duration must be >= ref frames, >= text length and <= max_signal_length");
+    if (mem == MI_HOST)
+        for (long i = 0; i < (long)U * T; ++i) {
+            const long id = (long)text_ids[i] + 1;
+            MI_REQUIRE(id >= 0 && id <= c.vocab, "f5_preprocess: text id out of range");
+        }
     MI_HIP(hipSetDevice(device));
     ensure_workspace(U, N);
     hipStream_t s = stream;
     const int nf = c.n_fft, nb = c.nb(), ldm = rup(nb, 8), cd = c.cond_dim();
-    float* cmt = d_cmt.as<float>() + (size_t)u * N * cd;
-    float* cmtd = d_cmtd.as<float>() + (size_t)u * N * cd;
+    const long Lp = L + nf;
     // ---- audio -> STFT -> |.| -> mel -> log ---------------------------------------------------------------
-    p_audio.ensure((size_t)L * 2); p_pad.ensure((size_t)(L + nf) * 4);
-    p_spec.ensure((size_t)R * 2 * nb * 4); p_mag.ensure((size_t)R * ldm * 4); p_mel.ensure((size_t)R * c.mel * 4);
+    p_audio.ensure((size_t)U * L * 2); p_pad.ensure((size_t)U * Lp * 4 + 64);
+    p_spec.ensure((size_t)U * R * 2 * nb * 4); p_mag.ensure((size_t)U * R * ldm * 4); p_mel.ensure((size_t)U * R * c.mel * 4);
+    p_tid.ensure((size_t)U * std::max(T, 1) * 4); p_err.ensure(4);
     const int16_t* da = audio;
+    const int32_t* dt_ids = text_ids;
     if (mem == MI_HOST) {
-        MI_HIP(hipMemcpyAsync(p_audio.p, audio, (size_t)L * 2, hipMemcpyHostToDevice, s));
+        MI_HIP(hipMemcpyAsync(p_audio.p, audio, (size_t)U * L * 2, hipMemcpyHostToDevice, s));
         da = p_audio.as<int16_t>();
+        if (T > 0) MI_HIP(hipMemcpyAsync(p_tid.p, text_ids, (size_t)U * T * 4, hipMemcpyHostToDevice, s));
+        dt_ids = p_tid.as<int32_t>();
     }
-    launch_pad_reflect(da, p_pad.as<float>(), L, nf / 2, s);
-    {
-        ConvGemm g;      // framed GEMM: row f = padded[f*hop : f*hop + n_fft]
-        g.dtype = MI_F32; g.x = p_pad.p; g.w = stft_w.p; g.out = p_spec.p;
-        g.B = 1; g.T_in = R; g.M = R; g.N = 2 * nb; g.Cin = nf; g.x_rstride = c.hop; g.x_bstride = 0;
-        g.out_rstride = 2 * nb; g.out_bstride = 0;
-        launch_conv_gemm(g, s);
-    }
-    launch_spec_mag(p_spec.as<float>(), p_mag.as<float>(), R, nb, ldm, s);
+    MI_HIP(hipMemsetAsync(p_err.p, 0, 4, s));
+    stft(da, U, L);
+    launch_spec_mag(p_spec.as<float>(), p_mag.as<float>(), U * R, nb, ldm, s);
     {
         ConvGemm g;
         g.dtype = MI_F32; g.x = p_mag.p; g.w = fbank.p; g.out = p_mel.p;
-        g.B = 1; g.T_in = R; g.M = R; g.N = c.mel; g.Cin = ldm; g.x_rstride = ldm; g.out_rstride = c.mel;
+        g.B = 1; g.T_in = U * R; g.M = U * R; g.N = c.mel; g.Cin = ldm; g.x_rstride = ldm; g.out_rstride = c.mel;
         launch_conv_gemm(g, s);
     }
-    launch_logmel(p_mel.as<float>(), cmt, cmtd, N, R, c.mel, cd, s);
-    // ---- text ids (+1, zero = filler) -> embedding + pos -> ConvNeXtV2 blocks (both branches as batch 2) ----
-    {
-        std::vector<int> ids(N, 0);
-        std::vector<int32_t> hti(T);
-        if (mem == MI_HOST) std::memcpy(hti.data(), text_ids, (size_t)T * 4);
-        else MI_HIP(hipMemcpy(hti.data(), text_ids, (size_t)T * 4, hipMemcpyDeviceToHost));
-        for (int i = 0; i < T; ++i) {
-            const long id = (long)hti[i] + 1;
-            MI_REQUIRE(id >= 0 && id <= c.vocab, "f5_preprocess: text id out of range");
-            ids[i] = (int)id;
-        }
-        MI_HIP(hipMemcpyAsync(p_ids.p, ids.data(), (size_t)N * 4, hipMemcpyHostToDevice, s));
-        MI_HIP(hipStreamSynchronize(s));
-    }
+    launch_logmel(p_mel.as<float>(), d_cmt.as<float>(), d_cmtd.as<float>(), U, N, R, c.mel, cd, s);
+    // ---- text ids (+1, zero = filler) -> embedding + pos -> ConvNeXtV2 blocks (text / drop branches of all utterances
+    //      as batch 2U: slab 2u = text, 2u+1 = drop) ---------------------------------------------------------------
     const int td = c.text_dim, ti = td * c.conv_mult;
-    const int* dids = p_ids.as<int>();
+    int* dids = p_ids.as<int>();
+    launch_text_ids(dt_ids, dids, U, T, N, c.vocab, p_err.as<int>(), s);
     float* tx = p_tx.as<float>(); float* ty = p_ty.as<float>(); float* ty2 = p_ty2.as<float>();
-    launch_text_gather(dids, text_emb.as<float>(), text_pos.as<float>(), tx, N, td, s);
+    launch_text_gather(dids, text_emb.as<float>(), text_pos.as<float>(), tx, U, N, td, s);
+    const int B2 = 2 * U;
     for (auto& tb : tblocks) {
-        launch_dwconv7(tx, ty, tb.dw_w.as<float>(), tb.dw_b.as<float>(), 2, N, td, s);
-        launch_rownorm(NORM_LN_AFFINE, ty, ty, MI_F32, tb.ln_w.as<float>(), tb.ln_b.as<float>(), 2L * N, td, 1e-6f, s);
-        gemm(MI_F32, ty, (long)N * td, td, td, tb.pw1, ty2, MI_F32, (long)N * ti, ti, 2, N, ACT_GELU_ERF);
-        launch_grn(ty2, p_ss.as<float>(), tb.grn_g.as<float>(), tb.grn_b.as<float>(), 2, N, ti, s);
-        gemm(MI_F32, ty2, (long)N * ti, ti, ti, tb.pw2, tx, MI_F32, (long)N * td, td, 2, N, ACT_NONE, tx);
-        launch_mask_rows(dids, tx, 2, N, td, s);
+        launch_dwconv7(tx, ty, tb.dw_w.as<float>(), tb.dw_b.as<float>(), B2, N, td, s);
+        launch_rownorm(NORM_LN_AFFINE, ty, ty, MI_F32, tb.ln_w.as<float>(), tb.ln_b.as<float>(), (long)B2 * N, td, 1e-6f, s);
+        gemm(MI_F32, ty, (long)N * td, td, td, tb.pw1, ty2, MI_F32, (long)N * ti, ti, B2, N, ACT_GELU_ERF);
+        launch_grn(ty2, p_ss.as<float>(), tb.grn_g.as<float>(), tb.grn_b.as<float>(), B2, N, ti, s);
+        gemm(MI_F32, ty2, (long)N * ti, ti, ti, tb.pw2, tx, MI_F32, (long)N * td, td, B2, N, ACT_NONE, tx);
+        launch_mask_rows(dids, tx, B2, N, td, s);
     }
-    launch_copy2d(tx, td, cmt + c.mel, cd, N, td, MI_F32, s);
-    launch_copy2d(tx + (size_t)N * td, td, cmtd + c.mel, cd, N, td, MI_F32, s);
+    for (int u = 0; u < U; ++u) {
+        launch_copy2d(tx + (size_t)(2 * u) * N * td, td, d_cmt.as<float>() + (size_t)u * N * cd + c.mel, cd, N, td, MI_F32, s);
+        launch_copy2d(tx + (size_t)(2 * u + 1) * N * td, td, d_cmtd.as<float>() + (size_t)u * N * cd + c.mel, cd, N, td, MI_F32, s);
+    }
     // ---- noise ------------------------------------------------------------------------------------------------
-    float* dn = d_noise.as<float>() + (size_t)u * N * c.mel;
+    const size_t nn = (size_t)N * c.mel;
     if (noise_in) {
-        MI_HIP(hipMemcpyAsync(dn, noise_in, (size_t)N * c.mel * 4, mem == MI_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, s));
+        MI_HIP(hipMemcpyAsync(d_noise.p, noise_in, (size_t)U * nn * 4, mem == MI_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, s));
     } else {
-        std::vector<float> hn((size_t)N * c.mel);
-        host_normal(hn.data(), hn.size(), seed + (uint64_t)u);
-        MI_HIP(hipMemcpyAsync(dn, hn.data(), hn.size() * 4, hipMemcpyHostToDevice, s));
-        MI_HIP(hipStreamSynchronize(s));
+        h_noise.resize((size_t)U * nn);                 // member: must outlive the asynchronous copy
+        for (int u = 0; u < U; ++u) host_normal(h_noise.data() + (size_t)u * nn, nn, seed + (uint64_t)u);
+        MI_HIP(hipMemcpyAsync(d_noise.p, h_noise.data(), h_noise.size() * 4, hipMemcpyHostToDevice, s));
     }
-    MI_HIP(hipStreamSynchronize(s));
     return R;
+}
+
+// STFT-B (STFT_Process.py:144-157): reflect pad n_fft/2, frames of n_fft at stride hop against the hann*cos / -hann*sin
+// kernels as one framed GEMM -> p_spec [u][frame][re(nb) | im(nb)]
+void F5::stft(const int16_t* audio_dev, int U, long L) {
+    const F5Cfg& c = cfg;
+    const int nf = c.n_fft, nb = c.nb(), R = (int)(L / c.hop) + 1;
+    const long Lp = L + nf;
+    launch_pad_reflect(audio_dev, p_pad.as<float>(), U, L, nf / 2, stream);
+    ConvGemm g;      // framed GEMM: row f = padded[f*hop : f*hop + n_fft]
+    g.dtype = MI_F32; g.x = p_pad.p; g.w = stft_w.p; g.out = p_spec.p;
+    g.B = U; g.T_in = R; g.M = R; g.N = 2 * nb; g.Cin = nf; g.x_rstride = c.hop; g.x_bstride = Lp;
+    g.out_rstride = 2 * nb; g.out_bstride = (long)R * 2 * nb;
+    launch_conv_gemm(g, stream);
+}
+
+// after a stream synchronisation: did the text-id kernel see an id outside the embedding table?
+void F5::check_text_ids() {
+    if (!p_err.p) return;
+    int flag = 0;
+    MI_HIP(hipMemcpy(&flag, p_err.p, 4, hipMemcpyDeviceToHost));
+    MI_REQUIRE(flag == 0, "f5_preprocess: text id out of range");
 }
 
 void F5::load_cond(const float* noise, const float* cmt, const float* cmtd, int U, int N, int mem) {
@@ -539,6 +556,7 @@ void F5::drop_graphs() {
 void F5::steps(int U, int N, int k0, int nsteps) {
     MI_REQUIRE(k0 >= 0 && nsteps >= 0 && k0 + nsteps <= cfg.nfe - 1, "f5: step range exceeds the NFE grid");
     if (!use_graph || prof_mask() != 0 || nsteps < 2) { steps_eager(U, N, k0, nsteps); return; }
+    if (graph_epoch != option_epoch()) { drop_graphs(); graph_epoch = option_epoch(); }
     GraphEntry& e = graphs[{U, N, k0, nsteps}];
     if (e.exec) { MI_HIP(hipGraphLaunch(e.exec, stream)); return; }
     if (e.uses++ == 0) { steps_eager(U, N, k0, nsteps); return; }      // first use: eager (also warms one-time allocations)

@@ -10,12 +10,14 @@ void launch_rownorm(int mode, const float* x, void* y, int out_dtype, const floa
                     float eps, hipStream_t s);
 void launch_dwconv7(const float* x, float* y, const float* w, const float* bias, int B, int T, int C, hipStream_t s);
 void launch_grn(float* y, float* ss_scratch, const float* gamma, const float* beta, int B, int T, int C, hipStream_t s);
-void launch_text_gather(const int* ids, const float* emb, const float* pos, float* out, int N, int C, hipStream_t s);
+// ids [U][N]; out slabs 2u (text) / 2u+1 (drop)
+void launch_text_gather(const int* ids, const float* emb, const float* pos, float* out, int U, int N, int C, hipStream_t s);
+void launch_text_ids(const int32_t* in, int* out, int U, int T, int N, int vocab, int* err, hipStream_t s);
 void launch_mask_rows(const int* ids, float* x, int V, int N, int C, hipStream_t s);
 void launch_copy2d(const float* src, long lds_, void* dst, long ldd, long rows, int cols, int out_dtype, hipStream_t s);
-void launch_pad_reflect(const int16_t* a, float* out, long L, int half, hipStream_t s);
+void launch_pad_reflect(const int16_t* a, float* out, int U, long L, int half, hipStream_t s);
 void launch_spec_mag(const float* spec, float* mag, int F, int nb, int ldm, hipStream_t s);
-void launch_logmel(const float* melraw, float* cmt, float* cmtd, int N, int R, int M, int ld, hipStream_t s);
+void launch_logmel(const float* melraw, float* cmt, float* cmtd, int U, int N, int R, int M, int ld, hipStream_t s);
 void launch_vocos_head(const float* sp, float* c, long rows, int nb, int ldc, hipStream_t s);
 void launch_istft_ola(const float* frames, const float* wsi, int U, int F, int nfft, int hop, float* out_f,
                       int16_t* out_i, hipStream_t s);

@@ -191,17 +191,35 @@ __global__ __launch_bounds__(256) void text_gather_kernel(const int* __restrict_
                                                           const float* __restrict__ pos, float* __restrict__ out,
                                                           int N, int C) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    const int v = blockIdx.y;
+    const int v = blockIdx.y, u = blockIdx.z;
     if (i >= (long)N * C) return;
     const int n = (int)(i / C), c = (int)(i - (long)n * C);
-    const int id = ids[n];
+    const int id = ids[(long)u * N + n];
     float r = 0.f;
     if (id != 0) r = emb[(long)(v == 0 ? id : 0) * C + c] + pos[(long)n * C + c];
-    out[((long)v * N + n) * C + c] = r;
+    out[((long)(2 * u + v) * N + n) * C + c] = r;
 }
-void launch_text_gather(const int* ids, const float* emb, const float* pos, float* out, int N, int C, hipStream_t s) {
+void launch_text_gather(const int* ids, const float* emb, const float* pos, float* out, int U, int N, int C, hipStream_t s) {
     const long n = (long)N * C;
-    hipLaunchKernelGGL(text_gather_kernel, dim3((unsigned)((n + 255) / 256), 2), dim3(256), 0, s, ids, emb, pos, out, N, C);
+    hipLaunchKernelGGL(text_gather_kernel, dim3((unsigned)((n + 255) / 256), 2, U), dim3(256), 0, s, ids, emb, pos, out, N, C);
+    MI_HIP(hipGetLastError());
+}
+
+// ids_out[u, n] = n < T ? ids_in[u, n] + 1 : 0 (text_ids + 1, zero = filler: Export_F5.py:136); ids outside the embedding
+// table raise *err (checked by the host at its next synchronisation point) and are clamped to the filler
+__global__ __launch_bounds__(256) void text_ids_kernel(const int32_t* __restrict__ in, int* __restrict__ out, int T, int N,
+                                                       int vocab, int* __restrict__ err) {
+    const int n = blockIdx.x * 256 + threadIdx.x, u = blockIdx.y;
+    if (n >= N) return;
+    int id = 0;
+    if (n < T) {
+        const long v = (long)in[(long)u * T + n] + 1;
+        if (v < 0 || v > vocab) atomicOr(err, 1); else id = (int)v;
+    }
+    out[(long)u * N + n] = id;
+}
+void launch_text_ids(const int32_t* in, int* out, int U, int T, int N, int vocab, int* err, hipStream_t s) {
+    hipLaunchKernelGGL(text_ids_kernel, dim3((unsigned)((N + 255) / 256), U), dim3(256), 0, s, in, out, T, N, vocab, err);
     MI_HIP(hipGetLastError());
 }
 
@@ -209,7 +227,7 @@ __global__ __launch_bounds__(256) void mask_rows_kernel(const int* __restrict__ 
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long)N * C) return;
     const int n = (int)(i / C);
-    if (ids[n] == 0) x[(long)blockIdx.y * N * C + i] = 0.f;
+    if (ids[(long)(blockIdx.y >> 1) * N + n] == 0) x[(long)blockIdx.y * N * C + i] = 0.f;       // slab 2u + v uses utterance u's ids
 }
 void launch_mask_rows(const int* ids, float* x, int V, int N, int C, hipStream_t s) {
     const long n = (long)N * C;
@@ -245,13 +263,14 @@ void launch_copy2d(const float* src, long lds_, void* dst, long ldd, long rows, 
 __global__ __launch_bounds__(256) void pad_reflect_kernel(const int16_t* __restrict__ a, float* __restrict__ out, long L, int half) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= L + 2 * half) return;
+    a += (long)blockIdx.y * L; out += (long)blockIdx.y * (L + 2 * half);
     long j = i - half;
     if (j < 0) j = -j;
     if (j >= L) j = 2 * (L - 1) - j;
     out[i] = (float)a[j] * (1.0f / 32768.0f);
 }
-void launch_pad_reflect(const int16_t* a, float* out, long L, int half, hipStream_t s) {
-    hipLaunchKernelGGL(pad_reflect_kernel, dim3((unsigned)((L + 2 * half + 255) / 256)), dim3(256), 0, s, a, out, L, half);
+void launch_pad_reflect(const int16_t* a, float* out, int U, long L, int half, hipStream_t s) {
+    hipLaunchKernelGGL(pad_reflect_kernel, dim3((unsigned)((L + 2 * half + 255) / 256), U), dim3(256), 0, s, a, out, L, half);
     MI_HIP(hipGetLastError());
 }
 
@@ -276,12 +295,14 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ m
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long)N * M) return;
     const int n = (int)(i / M), m = (int)(i - (long)n * M);
+    const long u = blockIdx.y;
+    melraw += u * R * M; cmt += u * N * ld; cmtd += u * N * ld;
     cmt[(long)n * ld + m] = n < R ? logf(fmaxf(melraw[(long)n * M + m], 1e-5f)) : 0.f;
     cmtd[(long)n * ld + m] = 0.f;
 }
-void launch_logmel(const float* melraw, float* cmt, float* cmtd, int N, int R, int M, int ld, hipStream_t s) {
+void launch_logmel(const float* melraw, float* cmt, float* cmtd, int U, int N, int R, int M, int ld, hipStream_t s) {
     const long n = (long)N * M;
-    hipLaunchKernelGGL(logmel_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, melraw, cmt, cmtd, N, R, M, ld);
+    hipLaunchKernelGGL(logmel_kernel, dim3((unsigned)((n + 255) / 256), U), dim3(256), 0, s, melraw, cmt, cmtd, N, R, M, ld);
     MI_HIP(hipGetLastError());
 }
 

@@ -20,6 +20,7 @@
 // tiles.  K is streamed in KC-wide chunks: global -> registers (next chunk, issued before the
 // MFMAs of the current one) -> LDS -> fragments.
 #include "common.h"
+#include <mutex>
 #include "mfma.h"
 #include "gemm_epilogue.h"
 #include <cstdlib>
@@ -428,7 +429,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvGemmDev
 
 static bool g_use_dma = true, g_xcd_order = false, g_use_dma3 = true, g_big_tiles = true;
 static long g_big_min = 160, g_n192_min = 160, g_mid_min = 160, g_k_min = 2048;
-static bool g_n192 = true, g_f32_dma = true, g_pp = false, g_ring4 = true, g_f32_small = true;
+static bool g_n192 = true, g_f32_dma = true, g_ring4 = true, g_f32_small = true;
 static long g_f32_small_max = 1024, g_small16_max = 256;
 static long g_ring4_max = 256;
 static DevBuf g_zero_page[16];
@@ -464,7 +465,6 @@ static void dispatch_tiles(const ConvGemmDev& d, int B, hipStream_t s) {
                 d.K >= 576 && (long)B * ((d.M + 255) / 256) * (d.N / 192) >= g_n192_min) {
                 // N = 192 / 384 (BigVGAN stages 2 and 1): a 192-wide tile has no padded columns (128-wide tiles waste 25 %
                 // of the MFMAs and DMA bytes at N = 192) and the fewest DMA bytes per useful flop after 256x256
-                if (g_pp) { launch_conv_gemm_pp<T, TO>(d, B, 192, s); return; }
                 ConvGemmDev e = d;
                 e.RC = 0; e.Tm = (d.M + 255) / 256; e.Tn = d.N / 192; e.RT = B * e.Tm;
                 launch_conv_gemm_dma3<T, TO>(e, 192, s);
@@ -480,7 +480,6 @@ static void dispatch_tiles(const ConvGemmDev& d, int B, hipStream_t s) {
                 const int n_waste_256 = ((d.N + 255) / 256) * 256 - d.N;
                 if (g_big_tiles && buf_ok(d) && blocks_256x256 >= g_big_min && n_waste_256 * 4 <= d.N) {
                     // every CU busy for >= 2 rounds: the tile with the fewest DMA bytes per flop
-                    if (g_pp) { launch_conv_gemm_pp<T, TO>(d, B, 256, s); return; }
                     e.Tm = (d.M + 255) / 256; e.Tn = (d.N + 255) / 256; e.RT = B * e.Tm;
                     launch_conv_gemm_dma3<T, TO>(e, 256, s);
                     MI_HIP(hipGetLastError());
@@ -564,7 +563,6 @@ bool gemm_set_option(const char* key, long v) {
     else if (k == "gemm_big_tiles") g_big_tiles = v != 0;
     else if (k == "gemm_n192") g_n192 = v != 0;
     else if (k == "gemm_f32_dma") g_f32_dma = v != 0;
-    else if (k == "gemm_pp") g_pp = v != 0;
     else if (k == "gemm_ring4") g_ring4 = v != 0;
     else if (k == "gemm_buf") g_buf = v != 0;
     else if (k == "gemm_f32_small") g_f32_small = v != 0;
@@ -595,27 +593,30 @@ void launch_conv_gemm(const ConvGemm& p, hipStream_t s) {
     d.out2 = p.out2; d.out3 = p.out3; d.v_ld = p.v_ld; d.Mb = p.rows_per_item;
     d.use_buf = 0;
     {
-        static bool env_read = false;
-        if (!env_read) { const char* e = std::getenv("MI355TTS_NO_DMA_GEMM"); g_use_dma = !(e && e[0] == '1');
+        static std::once_flag env_once;      // handles on different threads may launch concurrently
+        std::call_once(env_once, [] { const char* e = std::getenv("MI355TTS_NO_DMA_GEMM"); g_use_dma = !(e && e[0] == '1');
             const char* x = std::getenv("MI355TTS_XCD_ORDER"); g_xcd_order = x && x[0] == '1';
             const char* y = std::getenv("MI355TTS_NO_DMA3_GEMM"); g_use_dma3 = !(y && y[0] == '1');
             const char* z = std::getenv("MI355TTS_NO_BIG_TILES"); g_big_tiles = !(z && z[0] == '1');
             if (const char* m = std::getenv("MI355TTS_BIG_TILE_MIN")) g_big_min = std::atol(m);
             if (const char* m = std::getenv("MI355TTS_DMA3_K_MIN")) g_k_min = std::atol(m);
             if (const char* n = std::getenv("MI355TTS_NO_N192")) g_n192 = !(n[0] == '1');
-            if (const char* n = std::getenv("MI355TTS_PP")) g_pp = n[0] == '1';
             if (const char* n = std::getenv("MI355TTS_NO_RING4")) g_ring4 = !(n[0] == '1');
             if (const char* n = std::getenv("MI355TTS_NO_BUF")) g_buf = !(n[0] == '1');
             if (const char* n = std::getenv("MI355TTS_NO_F32_SMALL")) g_f32_small = !(n[0] == '1');
             if (const char* n = std::getenv("MI355TTS_F32_SMALL_MAX")) g_f32_small_max = std::atol(n);
             if (const char* n = std::getenv("MI355TTS_SMALL16_MAX")) g_small16_max = std::atol(n);
             if (const char* n = std::getenv("MI355TTS_RING4_MAX")) g_ring4_max = std::atol(n);
-            env_read = true; }
+        });
         int dev = 0;
         MI_HIP(hipGetDevice(&dev));
-        DevBuf& z = g_zero_page[dev & 15];
-        if (!z.p) { z.ensure(4096); MI_HIP(hipMemset(z.p, 0, 4096)); }
-        d.zero = z.p;
+        {
+            static std::mutex zero_mu;
+            std::lock_guard<std::mutex> lk(zero_mu);
+            DevBuf& z = g_zero_page[dev & 15];
+            if (!z.p) { z.ensure(4096); MI_HIP(hipMemset(z.p, 0, 4096)); MI_HIP(hipDeviceSynchronize()); }
+            d.zero = z.p;
+        }
         const char* dm = std::getenv("MI355TTS_GEMM_DBG");
         d.dbg = dm ? std::atoi(dm) : 0;
         // K-loop order of the DMA kernels is (channel chunk, tap), not (tap, channel chunk): sweeping all Cin channels

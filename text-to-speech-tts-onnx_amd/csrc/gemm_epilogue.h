@@ -1,5 +1,5 @@
 // gemm_epilogue.h — device-side argument block and the shared epilogues of the implicit-GEMM kernels
-// (gemm_conv.hip: register-staged and LDS-DMA kernels; gemm_pp.hip: the ping-pong 256-row kernel).
+// (gemm_conv.hip: register-staged and LDS-DMA kernels; gemm_dma3.hip: the 8-wave 256-row kernels).
 #pragma once
 #include "common.h"
 #include "mfma.h"
@@ -366,7 +366,5 @@ typedef __attribute__((address_space(3))) void lds_void;
 // gemm_dma3.hip: the 8-wave 256-row kernels (bn = 192 / 256: buffer-descriptor DMA, bn = 128: three-stage ring)
 template <typename T, typename TO> void launch_conv_gemm_dma3(const ConvGemmDev& e, int bn, hipStream_t s);
 
-// gemm_pp.hip: ping-pong 256x256 (bn = 256) / 256x192 (bn = 192) kernel, 16-bit operands only
-template <typename T, typename TO> void launch_conv_gemm_pp(const ConvGemmDev& d, int B, int bn, hipStream_t s);
 
 }  // namespace mi

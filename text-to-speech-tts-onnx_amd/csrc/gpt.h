@@ -39,11 +39,14 @@ struct Gpt {
     int MBp = 1;              // max_batch rounded up to a batched-GEMV template width
     std::map<int, hipGraphExec_t> batch_graphs;       // decode step over nb slots, keyed by nb
     DevBuf io_a, io_b;        // host<->device staging
-    float rep_value = 0.7f;
+    DevBuf rep_dev;           // REPEAT_PENALITY as a device scalar (read by gpt_pick_kernel, also inside replayed graphs)
+    void set_rep_value(float v);
     int history = 0;          // host mirror of state[GS_HIST] (valid outside generate())
 
     hipGraphExec_t step_graph = nullptr;
     bool use_graph = true;
+    long graph_epoch = 0;     // option_epoch() the captured graphs were taken under
+    void check_graph_epoch();
 
     Gpt(const GptCfg& c, const float* w, int64_t nw, int dt, int dev);
     ~Gpt();

@@ -624,7 +624,7 @@ __global__ __launch_bounds__(256) void gpt_embed_state_kernel(const int* __restr
 __global__ __launch_bounds__(1024) void gpt_pick_kernel(const float* __restrict__ logits, float* __restrict__ pen,
                                                         const float* __restrict__ last, int* __restrict__ st,
                                                         int* __restrict__ toks, float* __restrict__ hid, int codes,
-                                                        int hidden, int rows, float rep, int max_tok) {
+                                                        int hidden, int rows, const float* __restrict__ rep_dev, int max_tok) {
     __shared__ float bv[16];
     __shared__ int bi[16];
     __shared__ int slot;
@@ -662,7 +662,7 @@ __global__ __launch_bounds__(1024) void gpt_pick_kernel(const float* __restrict_
             for (int s = 0; s < st[GS_NSTOP]; ++s) stop |= (st[GS_STOP0 + s] == t);
             if (stop) st[GS_DONE] = 1;
             else if (st[GS_UPDATE_PEN]) {                     // Inference_IndexTTS_ONNX.py:768-772
-                pen[t] = rep;
+                pen[t] = rep_dev[0];      // device scalar: the captured decode graphs must see a changed REPEAT_PENALITY
                 const int r = st[GS_RESET];
                 if (n + 1 > st[GS_RANGE] && r < max_tok && toks[r] != t) { pen[toks[r]] = 1.f; st[GS_RESET] = r + 1; }
             }
@@ -748,7 +748,9 @@ Gpt::Gpt(const GptCfg& c, const float* w, int64_t nw, int dt, int dev) : cfg(c),
         MI_HIP(hipMemsetAsync(bfr->p, 0, bfr->bytes, s));
     std::vector<float> ones(P * c.mel_codes, 1.f);
     MI_HIP(hipMemcpyAsync(pen.p, ones.data(), ones.size() * 4, hipMemcpyHostToDevice, s));
+    rep_dev.ensure(4);
     MI_HIP(hipStreamSynchronize(s));
+    set_rep_value(0.7f);
     const char* ng = std::getenv("MI355TTS_NO_GRAPH");
     use_graph = !(ng && ng[0] == '1');
     // the attention kernel's score buffer is dynamic LDS: max_seq + 64 + 512 floats
@@ -894,8 +896,14 @@ void Gpt::forward_rows(int rows, int flag, int slot) {
     gemv(head, last_s, fn_w.as<float>(), fn_b.as<float>(), logits_s, MI_F32, ACT_NONE, nullptr, nullptr, nullptr);
     hipLaunchKernelGGL(gpt_pick_kernel, dim3(1), dim3(1024), 0, s, logits_s, pen.as<float>() + (size_t)slot * c.mel_codes,
                        last_s, state.as<int>() + (size_t)slot * GS_WORDS, toks.as<int>() + (size_t)slot * S,
-                       hid.as<float>() + (size_t)slot * S * h, c.mel_codes, h, rows, rep_value, S);
+                       hid.as<float>() + (size_t)slot * S * h, c.mel_codes, h, rows, rep_dev.as<float>(), S);
     MI_HIP(hipGetLastError());
+}
+
+void Gpt::set_rep_value(float v) {
+    // synchronous on purpose: `v` lives on the caller's stack
+    MI_HIP(hipMemcpyAsync(rep_dev.p, &v, 4, hipMemcpyHostToDevice, stream));
+    MI_HIP(hipStreamSynchronize(stream));
 }
 
 void Gpt::decode_step_eager() {
@@ -905,9 +913,18 @@ void Gpt::decode_step_eager() {
     forward_rows(1, 0);
 }
 
+void Gpt::check_graph_epoch() {
+    if (graph_epoch == option_epoch()) return;
+    if (step_graph) { (void)hipGraphExecDestroy(step_graph); step_graph = nullptr; }
+    for (auto& kv : batch_graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);
+    batch_graphs.clear();
+    graph_epoch = option_epoch();
+}
+
 void Gpt::decode_steps(int n) {
     if (n <= 0) return;
     if (!use_graph || prof_mask() != 0) { for (int i = 0; i < n; ++i) decode_step_eager(); return; }
+    check_graph_epoch();
     if (!step_graph) {
         decode_step_eager();                   // first step eager (one-time lazy initialisation stays out of the capture)
         --n;
@@ -1005,13 +1022,14 @@ void Gpt::decode_batch_eager(int nb) {
     launch_rownorm(NORM_LN_AFFINE, last.as<float>(), zd.p, dtype, fn_w.as<float>(), fn_b.as<float>(), nb, h, 1e-5f, s);
     gemv_b(head, zd.p, nb, logits.p, MI_F32, ACT_NONE, nullptr, nullptr, nullptr);
     hipLaunchKernelGGL(gpt_pick_kernel, dim3(nb), dim3(1024), 0, s, logits.as<float>(), pen.as<float>(), last.as<float>(),
-                       state.as<int>(), toks.as<int>(), hid.as<float>(), c.mel_codes, h, 1, rep_value, S);
+                       state.as<int>(), toks.as<int>(), hid.as<float>(), c.mel_codes, h, 1, rep_dev.as<float>(), S);
     MI_HIP(hipGetLastError());
 }
 
 void Gpt::decode_batch_steps(int nb, int n) {
     if (n <= 0) return;
     if (!use_graph || prof_mask() != 0) { for (int i = 0; i < n; ++i) decode_batch_eager(nb); return; }
+    check_graph_epoch();
     hipGraphExec_t& exec = batch_graphs[nb];
     if (!exec) {
         decode_batch_eager(nb);

@@ -1,12 +1,17 @@
 // runtime.hip — error state, uploads, and the event-based per-family kernel profiler.
 #include "common.h"
 #include <mutex>
+#include <atomic>
 
 namespace mi {
 
 static thread_local std::string g_err;
 void set_last_error(const std::string& m) { g_err = m; }
 const std::string& last_error() { return g_err; }
+
+static std::atomic<long> g_option_epoch{0};
+long option_epoch() { return g_option_epoch.load(); }
+void option_epoch_bump() { g_option_epoch.fetch_add(1); }
 
 void upload_f32(DevBuf& dst, const float* src, size_t n, hipStream_t s) {
     dst.ensure(n * 4);

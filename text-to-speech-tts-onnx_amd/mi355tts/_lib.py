@@ -69,6 +69,7 @@ def load() -> C.CDLL:
     L.mi_f5_preprocess.argtypes = [vp, vp, C.c_int64, vp, C.c_int64, C.c_int64, vp, C.c_uint64, vp, vp, vp, vp, vp,
                                    i64p, C.c_int]
     L.mi_f5_preprocess.restype = C.c_int
+    L.mi_f5_stft.argtypes = [vp, vp, C.c_int64, vp, C.c_int]; L.mi_f5_stft.restype = C.c_int
     L.mi_f5_transformer_step.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int64, i32p, C.c_int, C.c_int]
     L.mi_f5_transformer_step.restype = C.c_int
     L.mi_f5_sample.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int]

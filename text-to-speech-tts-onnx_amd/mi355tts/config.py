@@ -117,6 +117,7 @@ class F5Config:
     cfg_strength: float = 2.0
     sway_coef: float = -1.0
     max_signal_length: int = 4096
+    fuse_step: int = 1                   # FUSE_NFE: Euler steps per F5_Transformer.run (Export_F5.py:167-182, host-side only)
     # STFT / mel
     n_fft: int = 1024
     hop_length: int = 256

@@ -93,6 +93,17 @@ class F5Engine:
                 "rope_sin_k": sq.transpose(0, 1, 3, 2), "cat_mel_text": cmt, "cat_mel_text_drop": cmtd,
                 "ref_signal_len": np.int64(R.value)}
 
+    def stft(self, audio):
+        """STFT-B of graph A alone (STFT_Process.py:144-157): audio (L,) int16 -> (real, imag), each (n_fft/2+1, L//hop+1)."""
+        cfg = self.cfg
+        audio = np.ascontiguousarray(np.asarray(audio).reshape(-1))
+        if audio.dtype != np.int16:
+            raise ValueError("audio must be int16")
+        nb, R = cfg.n_fft // 2 + 1, audio.size // cfg.hop_length + 1
+        spec = np.empty((R, 2 * nb), np.float32)
+        _lib.check(_lib.load().mi_f5_stft(self._h, audio.ctypes.data, audio.size, spec.ctypes.data, _lib.MI_HOST), "mi_f5_stft")
+        return np.ascontiguousarray(spec[:, :nb].T), np.ascontiguousarray(spec[:, nb:].T)
+
     # ---- graph B ----------------------------------------------------------------------------------
     def _cond(self, noise, cmt, cmtd):
         cfg = self.cfg

@@ -29,6 +29,7 @@ import numpy as np
 from .config import BigVGANConfig, F5Config
 
 _SEED = [9527]
+_SEED_DRAWS = [0]          # preprocess calls since set_seed (onnxruntime's generator advances with every draw)
 PROVIDER = "MI355XExecutionProvider"
 
 
@@ -42,6 +43,7 @@ class Fail(RuntimeError):
 
 def set_seed(seed: int) -> None:
     _SEED[0] = int(seed)
+    _SEED_DRAWS[0] = 0
 
 
 def get_available_providers() -> List[str]:
@@ -332,6 +334,12 @@ class InferenceSession:
             raise InvalidArgument(f"Invalid rank for input: {name} Got: {a.ndim} Expected: {ndim}")
         return a
 
+    def _rope_table(self, N: int, cos: bool) -> np.ndarray:
+        D = self._cfg.dim_head
+        inv = (1.0 / (10000.0 ** (np.arange(0, D, 2, dtype=np.float32) / D))).astype(np.float32)
+        ang = np.repeat(np.outer(np.arange(N, dtype=np.float32), inv), 2, axis=1)
+        return (np.cos(ang) if cos else np.sin(ang)).astype(np.float16).astype(np.float32)
+
     def _run_gpt_e(self, feed):
         """graph E (IndexTTS/Export_IndexTTS.py:270-289).  Feed values are numpy arrays, OrtValues or the _KVRef
         objects a previous call returned."""
@@ -395,16 +403,27 @@ class InferenceSession:
             audio = self._chk(feed, "audio", np.int16, 3)
             ids = self._chk(feed, "text_ids", np.int32, 2)
             md = self._chk(feed, "max_duration", np.int64, 1)
-            return e.preprocess(audio, ids, md, noise=None, seed=_SEED[0])
+            seed = _SEED[0] + _SEED_DRAWS[0]              # ORT's generator advances: repeated runs draw fresh noise
+            _SEED_DRAWS[0] += 1
+            return e.preprocess(audio, ids, md, noise=None, seed=seed)
         if g == "F5_Transformer":
             noise = self._chk(feed, "noise", np.float32, 3)
             cmt = self._chk(feed, "cat_mel_text", np.float32, 3)
             cmtd = self._chk(feed, "cat_mel_text_drop", np.float32, 3)
             ts = self._chk(feed, "time_step", np.int32, 1)
-            for n in ("rope_cos_q", "rope_sin_q", "rope_cos_k", "rope_sin_k"):   # tables are regenerated on device
-                if np.asarray(feed[n]).ndim != 4:
+            # the engine keeps the RoPE tables on the device (the reference re-feeds 37 MB of them per call); a feed that is
+            # not graph A's table (Export_F5.py:107-112: cos/sin of n * 10000^(-2j/64), rounded through fp16) is rejected
+            N = noise.shape[1]
+            for n in ("rope_cos_q", "rope_sin_q", "rope_cos_k", "rope_sin_k"):
+                a = np.asarray(feed[n])
+                if a.ndim != 4:
                     raise InvalidArgument(f"Invalid rank for input: {n}")
-            x, t = e.transformer_step(noise, cmt, cmtd, ts, fuse=1)
+                want = self._rope_table(N, "cos" in n)
+                got = a[0, 0] if n.endswith("_q") else a[0, 0].T
+                if got.shape != want.shape or np.abs(got.astype(np.float32) - want).max() > 2e-3:
+                    raise InvalidArgument(f"{n}: not the RoPE table of F5_Preprocess (this engine regenerates the tables on "
+                                          f"the device and cannot honour modified ones)")
+            x, t = e.transformer_step(noise, cmt, cmtd, ts, fuse=max(1, int(getattr(self._cfg, "fuse_step", 1))))
             return {"denoised": x, "time_step": t}
         if g == "F5_Decode":
             den = self._chk(feed, "denoised", np.float32, 3)

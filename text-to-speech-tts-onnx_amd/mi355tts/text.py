@@ -11,6 +11,7 @@ characters; without them CJK input raises (no silent fallback).
 """
 from __future__ import annotations
 
+import math
 import re
 from typing import Dict, List, Sequence
 
@@ -27,11 +28,76 @@ def load_vocab(path: str) -> Dict[str, int]:
     return vocab
 
 
+# ---- jieba.cut(text) (cut_all=False, HMM=True) restated for pure-ASCII text -------------------------------------------
+# jieba (un-vendored, unpinned; behaviour of 0.42.1) splits the sentence into blocks with
+#   re_han_default = ([\u4E00-\u9FD5a-zA-Z0-9+#&\._%\-]+)
+# and, between blocks, re_skip_default = (\r\n|\s): whitespace tokens are yielded whole, everything else char by char.
+# A block goes through __cut_DAG: the max-probability route over dictionary words (dict.txt's only pure-ASCII entries are
+# AT&T, c#, C#, c++, C++, frequency 3 of 60101967), single-character routes are buffered and a buffer of two or more
+# characters that is not itself a dictionary word is handed to finalseg.cut, whose non-CJK branch splits on
+#   re_skip = ([a-zA-Z0-9]+(?:\.\d+)?%?)
+# keeping both the matches and the runs between them ("3.14", "50%", "..." and "--" are single tokens).
+_RE_BLOCK = re.compile(r"([a-zA-Z0-9+#&\._%\-]+)")
+_RE_SKIP_DEFAULT = re.compile(r"(\r\n|\s)")
+_RE_FINALSEG_SKIP = re.compile(r"([a-zA-Z0-9]+(?:\.\d+)?%?)")
+_ASCII_DICT = {"AT&T": 3, "c#": 3, "C#": 3, "c++": 3, "C++": 3}
+_LOG_TOTAL = math.log(60101967)
+
+
+def _cut_dag_ascii(blk: str) -> List[str]:
+    n = len(blk)
+    route = [(0.0, 0)] * (n + 1)
+    for i in range(n - 1, -1, -1):                       # Tokenizer.calc: best (log-probability, end index) from i
+        best = (-_LOG_TOTAL + route[i + 1][0], i)        # log(FREQ.get(char) or 1) = 0
+        for w, f in _ASCII_DICT.items():
+            if blk.startswith(w, i):
+                cand = (math.log(f) - _LOG_TOTAL + route[i + len(w)][0], i + len(w) - 1)
+                if cand > best:
+                    best = cand
+        route[i] = best
+    out: List[str] = []
+    buf = ""
+
+    def flush():
+        nonlocal buf
+        if buf:
+            if len(buf) == 1:
+                out.append(buf)
+            else:
+                out.extend(x for x in _RE_FINALSEG_SKIP.split(buf) if x)
+            buf = ""
+    x = 0
+    while x < n:
+        y = route[x][1] + 1
+        if y - x == 1:
+            buf += blk[x:y]
+        else:
+            flush()
+            out.append(blk[x:y])
+        x = y
+    flush()
+    return out
+
+
+def _segment_ascii(text: str) -> List[str]:
+    out: List[str] = []
+    for blk in _RE_BLOCK.split(text):
+        if not blk:
+            continue
+        if _RE_BLOCK.match(blk):
+            out.extend(_cut_dag_ascii(blk))
+        else:
+            for x in _RE_SKIP_DEFAULT.split(blk):
+                if _RE_SKIP_DEFAULT.match(x):
+                    out.append(x)
+                else:
+                    out.extend(x)
+    return out
+
+
 def _segment(text: str) -> List[str]:
     if all(ord(c) < 128 for c in text):
-        # jieba.cut on pure-ASCII text yields runs of [A-Za-z0-9] (its re_eng buffer) and every other
-        # character (punctuation, each whitespace char) as a single-character token
-        return re.findall(r"[a-zA-Z0-9]+|.", text, flags=re.S)
+        return _segment_ascii(text)
     try:
         import jieba
     except ImportError as e:                                 # pragma: no cover

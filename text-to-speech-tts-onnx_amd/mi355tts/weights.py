@@ -337,3 +337,35 @@ def synth_vocab(n: int = 2545) -> Dict[str, int]:
         chars.append(chr(i))
         i += 1
     return {c: k for k, c in enumerate(chars[:n])}
+
+
+# ---------------------------------------------------------------------------------------------
+# Synthetic workload inputs shared by bench.py, the -m gpu tests and the golden generators
+# ---------------------------------------------------------------------------------------------
+F5_BENCH_REF_TEXT = "Some call me nature, others call me mother nature, I am the breeze and rain. "
+F5_BENCH_GEN_TEXT = "The quick brown fox jumps over the lazy dog while seven wizards brew a potion"
+
+
+def f5_synthetic_inputs(cfg: F5Config, U: int, rank: int = 0):
+    """BASELINE configs[2]/[3]: 6.0 s reference audio (144000 samples -> 563 frames), equal-length ~15-word ASCII
+    ref/gen texts (-> N = 1126 by the duration formula of F5-TTS-ONNX-Inference.py:227-231), char-level ids against
+    the synthetic vocab, injected noise.  Returns (audio (U,L) i16, ids (U,T) i32, N, noise (U,N,mel) f32)."""
+    L = 144000
+    ref_text = F5_BENCH_REF_TEXT
+    gen_text = (F5_BENCH_GEN_TEXT + " " * len(ref_text))[:len(ref_text)]
+    vocab = synth_vocab(cfg.text_num_embeds)
+    ids = np.asarray([vocab.get(c, 0) for c in (ref_text + gen_text)], dtype=np.int32)
+    ref_frames = L // cfg.hop_length + 1
+    N = ref_frames + int(ref_frames / len(ref_text.encode()) * len(gen_text.encode()) / 1.0)
+    audio = np.empty((U, L), np.int16)
+    tt = np.arange(L) / cfg.sample_rate
+    for u in range(U):
+        a = 0.1 * 32767 * np.sin(2 * np.pi * 220 * tt) + synth_normal(9527 + 64 * rank + u, "audio", (L,), std=500.0)
+        audio[u] = np.clip(np.round(a), -32768, 32767).astype(np.int16)
+    noise = np.stack([synth_normal(9527 + 64 * rank + u, "noise", (N, cfg.mel_dim)) for u in range(U)])
+    return audio, np.tile(ids[None], (U, 1)), N, noise
+
+
+def bigvgan_synthetic_mel(cfg: BigVGANConfig, B: int, F: int, rank: int = 0) -> np.ndarray:
+    """BASELINE configs[0]/[1]: a log-mel shaped (B, num_mels, F) input, N(-2, 2) clipped to [-11.5, 2.5]."""
+    return synth_normal(100 + rank, "mel", (B, cfg.num_mels, F), std=2.0, mean=-2.0).clip(-11.5, 2.5)

@@ -5,7 +5,7 @@ import collections, csv, sys
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 for r in csv.DictReader(open(sys.argv[1])):
     name = r["Kernel_Name"]
-    for tag in ("conv_gemm_dma3", "conv_gemm_dma_kernel", "conv_gemm_pp", "conv_gemm_kernel", "aa_conv", "aa_act", "attn_kernel", "gpt_attn",
+    for tag in ("conv_gemm_dma3", "conv_gemm_dma_kernel", "conv_gemm_kernel", "aa_conv", "aa_act", "attn_kernel", "gpt_attn",
                 "gemv", "gemm_skinny", "rownorm", "conv_post"):
         if tag in name:
             name = tag
