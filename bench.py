@@ -3,17 +3,19 @@
 
     python bench.py --gpus N --steps K --warmup W [--workload bigvgan|f5|indextts_f|indextts]
 
-Workload (BASELINE.json configs[1]): BigVGAN-v2 24khz_100band_256x, fp16 HIP vocoder, mel (8,100,512)
-per GPU, synthetic seeded weights and mel already resident in HBM.  One step = one vocoder pass over
-the batch.  Metric = generated audio-seconds per wall second (whole job, all ranks); RTF = its
-inverse is reported in `config`.
+Default workload = BASELINE.json's metric: F5-TTS NFE=32 end to end (preprocess -> 31 DiT evaluations with CFG ->
+Vocos + ISTFT -> int16), synthetic seeded weights, 6 s reference audio + ~15-word texts (N = 1126 frames), inputs
+resident in HBM.  One GPU: configs[2] (fp32, one utterance — the precision the 1e-3 RMS parity gate is stated at);
+`--gpus N > 1`: the configs[3] shard (bf16, 8 utterances per GPU).  One step = one batch of utterances through the whole
+path.  Metric = generated audio-seconds per wall second over all ranks; RTF (= its inverse per GPU) is in `config`.
+On one GPU the line also carries `secondary`: configs[1] (BigVGAN-v2 fp16, mel (8,100,512)) and the configs[3] shard.
 
-Multi-GPU: one process per GPU (torchrun env), utterance batches are independent => weak scaling,
-no data-path collective; the packed weight blob is built on rank 0 and broadcast over RCCL.
+Multi-GPU: one process per GPU (torchrun env), utterances are independent => weak scaling, no data-path collective;
+the packed weight blob is built on rank 0, broadcast over RCCL and consumed by the engine from device memory.
 
-Adds `roofline` (dominant kernel family = the implicit-GEMM conv stack, HIP events on the engine's
-own stream, algorithmic bytes per SURVEY.md §8d) and `cpu_baseline` (numpy oracle on a bounded
-sample, rank 0, N=1 only).
+`roofline` = ONE kernel instantiation (the one with the largest event-timed total): its algorithmic flops (2*M*N*K) or
+bytes per launch / its average launch duration (HIP events on the engine's own stream) / the matching gfx950 peak.
+`cpu_baseline` = the numpy (OpenBLAS-threaded) oracle on a bounded sample of the same workload, rank 0, N=1 only.
 """
 from __future__ import annotations
 
@@ -111,95 +113,187 @@ def cpu_baseline_f5(cfg, raw_state, audio, ids, N, noise):
                       f"{t2 - t1:.1f} s (x{cfg.nfe_step - 1} extrapolated) + decode {t3 - t2:.1f} s for one {secs:.2f} s utterance"}
 
 
-def run_f5(args, world, rank, local, dev, dist, torch):
-    from mi355tts.config import F5Config
-    from mi355tts import weights as W
-    from mi355tts import _lib
-    from mi355tts.f5 import F5Engine
-    cfg = F5Config()
-    spec = W.f5_spec(cfg)
-    raw = None
-    nparam = sum(int(np.prod(sh)) for _, sh, _ in W.f5_packed_spec(cfg))
-    if rank == 0:
-        raw = W.synth_state(spec, 9527)
-        blob_t = torch.from_numpy(W.pack_f5(cfg, raw)).to(dev)
+def _cores() -> int:
+    try:
+        from threadpoolctl import threadpool_info
+        return int(max([p.get("num_threads", 1) for p in threadpool_info()] + [1]))
+    except Exception:
+        return os.cpu_count() or 1
+
+
+def dominant_kernel_roofline(kernels, steps: int, peak: float, bound: str, note: str):
+    """`roofline` of ONE kernel instantiation: the one with the largest event-timed total among `kernels`
+    (_lib.prof_kernels()).  achieved = its algorithmic flops (or bytes) per launch / its average launch duration."""
+    ks = [k for k in kernels if k["launches"] > 0]
+    if not ks:
+        return None
+    k = ks[0]
+    avg_ms = k["ms"] / k["launches"]
+    if bound == "mfma":
+        per_launch, unit = k["flops"] / k["launches"], "TFLOP/s"
+        achieved = per_launch / (avg_ms * 1e-3) / 1e12
     else:
-        blob_t = torch.empty(nparam, dtype=torch.float32, device=dev)
-    bcast_ms = 0.0
-    if world > 1:
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        per_launch, unit = k["bytes"] / k["launches"], "GB/s"
+        achieved = per_launch / (avg_ms * 1e-3) / 1e9
+    total = sum(x["ms"] for x in ks)
+    return {"bound": bound, "kernel": k["kernel"], "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak,
+            "traffic": None, "launches_per_step": k["launches"] / steps, "avg_launch_ms": avg_ms,
+            ("algorithmic_flops_per_launch" if bound == "mfma" else "algorithmic_bytes_per_launch"): per_launch,
+            "kernel_ms_per_step": k["ms"] / steps, "share_of_event_timed_ms": k["ms"] / total if total > 0 else 0.0,
+            "note": note,
+            "kernels": [{"kernel": x["kernel"], "launches_per_step": x["launches"] / steps, "ms_per_step": x["ms"] / steps,
+                         "avg_launch_us": x["ms"] / x["launches"] * 1e3,
+                         "tflops": x["flops"] / (x["ms"] * 1e-3) / 1e12 if x["ms"] > 0 else 0.0,
+                         "alg_GBps": x["bytes"] / (x["ms"] * 1e-3) / 1e9 if x["ms"] > 0 else 0.0} for x in ks[:8]]}
+
+
+def bcast_device_blob(torch, dist, blob_t):
+    """rank 0 -> all.  nccl (= RCCL over xGMI): the device buffer itself; gloo (the one-GPU plumbing test): staged through
+    host memory, because gloo's device-tensor support is not a given on ROCm builds."""
+    if dist.get_backend() == "nccl":
         dist.broadcast(blob_t, src=0)
-        torch.cuda.synchronize()
-        bcast_ms = (time.perf_counter() - t0) * 1e3
-    eng = F5Engine(cfg, blob=blob_t.cpu().numpy(), dtype=args.dtype, device=local)
-    del blob_t
-    U = args.batch
-    audio, ids, N, noise = f5_synthetic_inputs(cfg, U, rank)
-    R = audio.shape[1] // cfg.hop_length + 1
-    t_audio, t_ids, t_noise = torch.from_numpy(audio).to(dev), torch.from_numpy(ids).to(dev), torch.from_numpy(noise).to(dev)
-    out = torch.empty((U, 1, (N - R - 1) * cfg.hop_length), dtype=torch.int16, device=dev)
-    audio_s = U * out.shape[-1] / cfg.sample_rate
-    # the engine runs a shape eagerly once, captures the 31-step loop into a hipGraph on its second use and replays
-    # it afterwards: at least two untimed calls so the timed region is steady state
-    for _ in range(max(args.warmup, 2)):
-        eng.synthesize_torch(t_audio, t_ids, N, noise=t_noise, out=out)
+        return blob_t
+    h = blob_t.cpu()
+    dist.broadcast(h, src=0)
+    return h.to(blob_t.device)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
 
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
+def max_over_ranks(torch, dist, world, dt, dev):
+    if world <= 1:
+        return dt
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    return float(tt.item())
+
+
+class F5Bench:
+    """F5-TTS NFE=32 end to end (BASELINE configs[2] / [3]): the bracket of F5-TTS-ONNX-Inference.py:246-312 —
+    preprocess (graph A) -> 31 DiT evaluations with CFG (graph B x 31) -> Vocos + ISTFT -> int16 (graph C) — with the
+    audio / text ids / injected noise already resident in HBM and the int16 waveform left in HBM."""
+
+    def __init__(self, torch, dist, world, rank, local, dev):
+        from mi355tts.config import F5Config
+        from mi355tts import weights as W
+        self.torch, self.dist, self.world, self.rank, self.local, self.dev = torch, dist, world, rank, local, dev
+        # MI355TTS_BENCH_SMALL=1: reduced model + 1 s of audio, for the 2-rank plumbing test on a one-GPU box (its line
+        # says so in config.workload and is not a benchmark result)
+        self.small = os.environ.get("MI355TTS_BENCH_SMALL") == "1"
+        self.cfg = F5Config.small() if self.small else F5Config()
+        self.L = 24000 if self.small else 144000
+        self.W = W
+        self.raw = None
+        nparam = sum(int(np.prod(sh)) for _, sh, _ in W.f5_packed_spec(self.cfg))
+        if rank == 0:
+            self.raw = W.synth_state(W.f5_spec(self.cfg), 9527)
+            self.blob_t = torch.from_numpy(W.pack_f5(self.cfg, self.raw)).to(dev)
+        else:
+            self.blob_t = torch.empty(nparam, dtype=torch.float32, device=dev)
+        self.bcast_ms = 0.0
+        self.dump_dir = None
+        if world > 1:                       # the one collective of the path: weights rank 0 -> all, RCCL over xGMI
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            self.blob_t = bcast_device_blob(torch, dist, self.blob_t)
+            torch.cuda.synchronize()
+            self.bcast_ms = (time.perf_counter() - t0) * 1e3
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def measure(self, dtype: str, U: int, steps: int, warmup: int):
+        from mi355tts import _lib
+        from mi355tts.f5 import F5Engine
+        torch, cfg, dev = self.torch, self.cfg, self.dev
+        eng = F5Engine(cfg, blob_device=self.blob_t, dtype=dtype, device=self.local)
+        audio, ids, N, noise = self.W.f5_synthetic_inputs(cfg, U, self.rank, L=self.L)
+        R = audio.shape[1] // cfg.hop_length + 1
+        t_audio, t_ids, t_noise = torch.from_numpy(audio).to(dev), torch.from_numpy(ids).to(dev), torch.from_numpy(noise).to(dev)
+        out = torch.empty((U, 1, (N - R - 1) * cfg.hop_length), dtype=torch.int16, device=dev)
+        audio_s = U * out.shape[-1] / cfg.sample_rate
+        # the engine runs a shape eagerly once, captures the 31-step loop into a hipGraph on its second use and replays
+        # it afterwards: at least two untimed calls so the timed region is steady state
+        for _ in range(max(warmup, 2)):
+            eng.synthesize_torch(t_audio, t_ids, N, noise=t_noise, out=out)
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.synthesize_torch(t_audio, t_ids, N, noise=t_noise, out=out)
+        self.barrier()
+        dt = time.perf_counter() - t0
+        # roofline leg: ONE more pass with HIP events (on the engine's own stream) around every launch of the GEMM and
+        # attention families, attributed per kernel instantiation.  Events force the eager (un-graphed) launch path, so
+        # this pass is separate from the timed region and not part of `value`.
+        _lib.prof_reset()
+        _lib.prof_enable(["conv_gemm", "attn", "norm", "other"])
         eng.synthesize_torch(t_audio, t_ids, N, noise=t_noise, out=out)
-    barrier()
-    dt = time.perf_counter() - t0
-    # roofline leg: one more pass with HIP events around every GEMM / attention launch (the events force the eager,
-    # un-graphed launch path, so this pass is timed separately and is NOT part of `value`)
-    _lib.prof_reset()
-    _lib.prof_enable(["conv_gemm", "attn"])
-    eng.synthesize_torch(t_audio, t_ids, N, noise=t_noise, out=out)
-    torch.cuda.synchronize()
-    _lib.prof_enable(())
-    pg, pa = _lib.prof_get("conv_gemm"), _lib.prof_get("attn")
-    prof_steps = 1
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    if rank != 0:
+        torch.cuda.synchronize()
+        _lib.prof_enable(())
+        kernels = _lib.prof_kernels()
+        dt = max_over_ranks(torch, self.dist, self.world, dt, dev)
+        if self.dump_dir:
+            np.save(os.path.join(self.dump_dir, f"f5_{dtype}_u{U}_rank{self.rank}.npy"), out.cpu().numpy())
         eng.close()
+        peak = MFMA_F32_PEAK_TF if dtype == "f32" else MFMA_F16_PEAK_TF
+        gemm_like = [k for k in kernels if k["family"] in ("conv_gemm", "attn")]
+        roof = dominant_kernel_roofline(
+            gemm_like, 1, peak, "mfma",
+            "HIP events on the engine's stream around every launch, one separate eager pass after the timed region (the timed "
+            "region replays a hipGraph; events cannot be recorded into it); flops = 2*M*N*K of the launch")
+        alg_flops = f5_flops_per_eval(cfg, N) * (cfg.nfe_step - 1) * U
+        ev_ms = sum(k["ms"] for k in kernels)
+        res = {"value": self.world * audio_s * steps / dt, "ms_per_step": dt / steps * 1e3, "dtype": dtype,
+               "rtf": dt / steps / audio_s, "utterances_per_gpu": U, "frames": N, "audio_seconds_per_step_per_gpu": audio_s,
+               "end_to_end_TFLOP_per_step": alg_flops / 1e12, "end_to_end_TFLOP_per_s": alg_flops / (dt / steps) / 1e12,
+               "event_timed_kernel_ms_in_eager_pass": ev_ms, "roofline": roof}
+        return res, (audio, ids, N, noise)
+
+
+def f5_workload_name(dtype, U, N, small=False):
+    if small:
+        return f"PLUMBING TEST ONLY (MI355TTS_BENCH_SMALL=1): reduced F5 model, {dtype}, {U} utterance(s) per GPU, N={N}"
+    which = "configs[2]" if (dtype == "f32" and U == 1) else "configs[3] shard" if (dtype == "bf16" and U == 8) else "configs[2]/[3] variant"
+    return (f"F5-TTS {dtype} NFE=32 (32-point grid = 31 DiT evaluations, CFG batch 2) + Vocos/ISTFT end to end, "
+            f"{U} utterance(s) per GPU, 6 s ref audio + ~15-word texts, N={N} frames (BASELINE {which})")
+
+
+def run_f5(args, world, rank, local, dev, dist, torch):
+    fb = F5Bench(torch, dist, world, rank, local, dev)
+    fb.dump_dir = args.dump_dir
+    res, (audio, ids, N, noise) = fb.measure(args.dtype, args.batch, args.steps, args.warmup)
+    secondary = {}
+    if fb.small:
+        args.no_secondary = args.no_cpu_baseline = True
+    if world == 1 and not args.no_secondary:
+        if not (args.dtype == "bf16" and args.batch == 8):
+            r2, _ = fb.measure("bf16", 8, 2, 2)
+            r2["workload"] = f5_workload_name("bf16", 8, N)
+            secondary["f5_bf16_u8"] = r2
+    del fb.blob_t
+    if rank != 0:
         return
-    peak = MFMA_F32_PEAK_TF if args.dtype == "f32" else MFMA_F16_PEAK_TF
-    achieved = pg["flops"] / (pg["ms"] * 1e-3) / 1e12 if pg["ms"] > 0 else 0.0
-    value = world * audio_s * args.steps / dt
-    alg_flops = f5_flops_per_eval(cfg, N) * (cfg.nfe_step - 1) * U
+    if world == 1 and not args.no_secondary:
+        secondary["bigvgan_f16_b8"] = measure_bigvgan(torch, dist, 1, 0, local, dev, "f16", 8, 512, 10, 3, False)[0]
     line = {
-        "metric": "audio_seconds_per_second", "value": value, "unit": "audio-s/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "metric": "audio_seconds_per_second", "value": res["value"], "unit": "audio-s/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"F5-TTS {args.dtype} NFE=32 (31 DiT evaluations, CFG batch 2) + Vocos/ISTFT end to end, "
-                               f"{U} utterance(s) per GPU, 6 s ref audio, N={N} frames (BASELINE configs[2]/[3])",
-                   "utterances_per_gpu": U, "frames": N, "audio_seconds_per_step_per_gpu": audio_s,
-                   "rtf": dt / args.steps / audio_s, "weights": "synthetic seeded (337 M DiT + 13.5 M Vocos params)",
-                   "weight_bcast_ms": bcast_ms, "end_to_end_TFLOPs_per_step": alg_flops / 1e12,
-                   "end_to_end_TFLOP_per_s": alg_flops / (dt / args.steps) / 1e12},
-        "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel (DiT linear layers, implicit-GEMM MFMA)", "achieved": achieved,
-                     "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
-                     "launches_per_step": pg["launches"] / prof_steps, "avg_launch_ms": pg["ms"] / max(pg["launches"], 1),
-                     "family_ms_per_step": pg["ms"] / prof_steps,
-                     "attn_ms_per_step": pa["ms"] / prof_steps,
-                     "note": "event-timed in a separate eager pass; the timed region replays a hipGraph",
-                     "attn_tflops": pa["flops"] / (pa["ms"] * 1e-3) / 1e12 if pa["ms"] > 0 else 0.0},
+        "config": {"workload": f5_workload_name(args.dtype, args.batch, N, fb.small),
+                   "utterances_per_gpu": args.batch, "frames": N,
+                   "audio_seconds_per_step_per_gpu": res["audio_seconds_per_step_per_gpu"], "rtf": res["rtf"],
+                   "weights": "synthetic seeded (337 M DiT + 13.5 M Vocos params)", "weight_bcast_ms": fb.bcast_ms,
+                   "end_to_end_TFLOP_per_step": res["end_to_end_TFLOP_per_step"],
+                   "end_to_end_TFLOP_per_s": res["end_to_end_TFLOP_per_s"],
+                   "inputs": "audio / text ids / injected noise resident in HBM, int16 waveform left in HBM",
+                   "reference_published": "README.md:29-30: 180 s (i7-1165G7, ORT CPU) / 62 s (MX150) per utterance"},
+        "roofline": res["roofline"],
     }
+    if secondary:
+        line["secondary"] = secondary
     if world == 1 and not args.no_cpu_baseline:
-        if raw is None:
-            raw = W.synth_state(spec, 9527)
-        line["cpu_baseline"] = cpu_baseline_f5(cfg, raw, audio[0], ids[0], N, noise[0])
+        line["cpu_baseline"] = cpu_baseline_f5(fb.cfg, fb.raw, audio[0], ids[0], N, noise[0])
     print(json.dumps(line), flush=True)
-    eng.close()
 
 
 def run_indextts(args, world, rank, local, dev, dist, torch):
@@ -226,16 +320,14 @@ def run_indextts(args, world, rank, local, dev, dist, torch):
     if world > 1:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        dist.broadcast(blob_t, src=0)
+        blob_t = bcast_device_blob(torch, dist, blob_t)
         torch.cuda.synchronize()
         bcast_ms = (time.perf_counter() - t0) * 1e3
-    blob = blob_t.cpu().numpy()
-    del blob_t
     NB = max(1, args.batch)
     gcfg.max_batch = NB
-    gpt = IndexGPT(gcfg, blob=blob[:ng], dtype=args.dtype, device=local)
-    voc = BigVGANVocoder(vcfg, blob=blob[ng:], dtype=args.dtype, device=local)
-    del blob
+    gpt = IndexGPT(gcfg, blob_device=blob_t[:ng].contiguous(), dtype=args.dtype, device=local)
+    voc = BigVGANVocoder(vcfg, blob_device=blob_t[ng:].contiguous(), dtype=args.dtype, device=local)
+    del blob_t
     n_text, n_cond, n_tok = 30, 32, args.tokens
     text = (np.arange(n_text, dtype=np.int32) * 37 + 11 * rank) % (gcfg.text_tokens - 2) + 2
     conds = W.synth_normal_fast(100 + rank, "conds_latent", (1, n_cond, gcfg.hidden), std=0.5)
@@ -298,10 +390,7 @@ def run_indextts(args, world, rank, local, dev, dist, torch):
     torch.cuda.synchronize()
     _lib.prof_enable(())
     pg, pa = _lib.prof_get("conv_gemm"), _lib.prof_get("attn")
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = max_over_ranks(torch, dist, world, dt, dev)
     if rank != 0:
         gpt.close(); voc.close()
         return
@@ -350,41 +439,106 @@ def run_indextts(args, world, rank, local, dev, dist, torch):
     gpt.close(); voc.close()
 
 
-def pmc_traffic_per_launch(args, ixf):
-    """HBM-side bytes per launch of the conv family from the committed PMC passes (profiles/r1/, same command as this
-    run under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`, FETCH doubled per MI355X_MICROARCH.md; tools/
-    pmc_traffic.py).  Counters cannot be collected from inside the timed run, so the figure is only reported for the
-    configuration those passes were taken on (the default one); otherwise null."""
-    if ixf or args.dtype != "f16" or args.batch != 8 or args.frames != 512:
-        return None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r1", "final_bigvgan_pmc_hbm_traffic.json")) as f:
-            t = json.load(f)["_conv_family"]
-        return t["traffic_GB_per_forward"] * 1e9 / t["launches_per_forward"]
-    except Exception:
-        return None
+def measure_bigvgan(torch, dist, world, rank, local, dev, dtype, B, F, steps, warmup, ixf):
+    """BigVGAN-v2 (BASELINE configs[0]/[1]) or IndexTTS graph F (`ixf`): one step = one vocoder pass over the batch, mel
+    resident in HBM.  HIP events sit inside the timed region (~230 event pairs per 17 ms forward, < 1 %)."""
+    from mi355tts.config import BigVGANConfig
+    from mi355tts import weights as W
+    from mi355tts import _lib
+    from mi355tts.bigvgan import BigVGANVocoder
+    cfg = BigVGANConfig.indextts() if ixf else BigVGANConfig()
+    spec = W.bigvgan_spec(cfg)
+    nparam = sum(int(np.prod(s)) for _, s, _ in spec)
+    state = None
+    if rank == 0:
+        state = W.synth_state(spec, 9527)
+        blob_t = torch.from_numpy(W.pack_bigvgan(cfg, state)).to(dev)
+    else:
+        blob_t = torch.empty(nparam, dtype=torch.float32, device=dev)
+    bcast_ms = 0.0
+    if world > 1:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        blob_t = bcast_device_blob(torch, dist, blob_t)
+        torch.cuda.synchronize()
+        bcast_ms = (time.perf_counter() - t0) * 1e3
+    voc = BigVGANVocoder(cfg, blob_device=blob_t, dtype=dtype, device=local)
+    del blob_t
+    out = torch.empty((B, 1, voc.out_len(F)), dtype=torch.int16, device=dev)
+    audio_s = B * voc.out_len(F) / cfg.sampling_rate
+    if ixf:
+        latent = torch.from_numpy(W.synth_normal(100 + rank, "latent", (F + 2, cfg.num_mels), std=1.5, mean=0.3)).to(dev)
+        ncond = cfg.upsample_initial_channel + sum(cfg.stage_channels(i) for i in range(cfg.num_upsamples))
+        conds = torch.from_numpy(W.synth_normal(100 + rank, "conds", (ncond,), std=0.2)).to(dev)
+        step = lambda: voc.run_latent_torch(latent, conds, out)
+    else:
+        mel = torch.from_numpy(W.bigvgan_synthetic_mel(cfg, B, F, rank)).to(dev)
+        step = lambda: voc.run_torch(mel, out)
+    for _ in range(warmup):
+        step()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    _lib.prof_reset()
+    _lib.prof_enable(["conv_gemm", "aa_act", "conv_post"])
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    _lib.prof_enable(())
+    kernels = _lib.prof_kernels()
+    dt = max_over_ranks(torch, dist, world, dt, dev)
+    voc.close()
+    esz = 4 if dtype == "f32" else 2
+    alg = bigvgan_algorithmic_bytes(cfg, B, F, esz)
+    # dominant kernel: the MFMA-bound implicit-GEMM of stages 0-2 when it leads, else the HBM-bound fused AA conv
+    roof = None
+    if kernels:
+        lead = kernels[0]
+        mfma_bound = lead["kernel"].startswith("conv_gemm")
+        roof = dominant_kernel_roofline(
+            kernels, steps, (MFMA_F32_PEAK_TF if dtype == "f32" else MFMA_F16_PEAK_TF) if mfma_bound else HBM_PEAK_GBS,
+            "mfma" if mfma_bound else "hbm",
+            "HIP events on the engine's stream around every launch inside the timed region; per-launch work = 2*M*N*K flops "
+            "(implicit GEMM) / layer-granular algorithmic bytes (x + w + out [+ res])")
+    res = {"value": world * audio_s * steps / dt, "ms_per_step": dt / steps * 1e3, "dtype": dtype,
+           "rtf": dt / steps / audio_s, "batch_per_gpu": B, "frames": F, "audio_seconds_per_step_per_gpu": audio_s,
+           "workload": (f"IndexTTS graph F (speaker-conditioned BigVGAN, 1024x) {dtype}, T_codes = {F + 2} (BASELINE configs[4] "
+                        f"vocoder leg)") if ixf else
+                       (f"BigVGAN-v2 24khz_100band_256x {dtype} vocoder, mel ({B},100,{F}) per GPU (BASELINE configs[1])"),
+           "weight_bcast_ms": bcast_ms, "whole_forward_algorithmic_GB": alg / 1e9,
+           "whole_forward_algorithmic_GBps": alg / (dt / steps) / 1e9,
+           "whole_forward_frac_of_hbm_peak": alg / (dt / steps) / 1e9 / HBM_PEAK_GBS, "roofline": roof}
+    return res, (cfg, state)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tokens", type=int, default=256, help="indextts: mel codes decoded per sentence")
-    ap.add_argument("--workload", default="bigvgan", choices=["bigvgan", "f5", "indextts_f", "indextts"])
+    ap.add_argument("--workload", default="f5", choices=["f5", "bigvgan", "indextts_f", "indextts"],
+                    help="f5 (default) = BASELINE.json's metric: F5-TTS NFE=32 end to end")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=None, help="mel batch (bigvgan, default 8) / utterances (f5, default 1) per GPU")
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--batch", type=int, default=None,
+                    help="f5: utterances per GPU (default 1 on one GPU = configs[2]; 8 with --gpus > 1 = configs[3] shard) / "
+                         "bigvgan: mel batch (default 8)")
     ap.add_argument("--frames", type=int, default=512)
-    ap.add_argument("--dtype", default=None, help="bigvgan: f16 (default) | f32 | bf16 ; f5: bf16 (default) | f32 | f16")
+    ap.add_argument("--dtype", default=None, help="f5: f32 on one GPU (configs[2]), bf16 with --gpus > 1 (configs[3]) | f16 ; "
+                                                  "bigvgan: f16 (default) | f32 | bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="f5 on one GPU: skip the configs[1] / configs[3]-shard blocks")
     ap.add_argument("--cpu-frames", type=int, default=128)
+    ap.add_argument("--dump-dir", default=None, help="f5: every rank saves its int16 waveforms there (tests)")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    from mi355tts.config import BigVGANConfig
-    from mi355tts import weights as W
-    from mi355tts import _lib
-    from mi355tts.bigvgan import BigVGANVocoder
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -402,120 +556,40 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    if args.steps is None:
-        args.steps = 20 if args.workload == "bigvgan" else 3
-    if args.batch is None:
-        args.batch = 8 if args.workload == "bigvgan" else 1
-    if args.dtype is None:
-        args.dtype = "f16" if args.workload == "bigvgan" else "bf16"
-    if args.workload == "indextts":
-        if args.dtype == "bf16" and "--dtype" not in " ".join(sys.argv):
-            args.dtype = "f16"
-        run_indextts(args, world, rank, local, dev, dist, torch)
-        if world > 1:
-            dist.destroy_process_group()
-        return
     if args.workload == "f5":
+        # one GPU: configs[2] (fp32, one utterance) — the config parity is gated on; N > 1: the configs[3] shard
+        if args.dtype is None:
+            args.dtype = "f32" if world == 1 else "bf16"
+        if args.batch is None:
+            args.batch = 1 if world == 1 else 8
+        if args.steps is None:
+            args.steps = 3
+        if args.warmup is None:
+            args.warmup = 2
         run_f5(args, world, rank, local, dev, dist, torch)
-        if world > 1:
-            dist.destroy_process_group()
-        return
-
-    ixf = args.workload == "indextts_f"        # BASELINE configs[4] vocoder leg: IndexTTS graph F, T_codes = 128
-    cfg = BigVGANConfig.indextts() if ixf else BigVGANConfig()
-    if ixf:
-        args.batch, args.frames = 1, 126
-    spec = W.bigvgan_spec(cfg)
-    # weights: rank 0 packs, everybody else receives the blob over RCCL (xGMI)
-    nparam = sum(int(np.prod(s)) for _, s, _ in spec)
-    state = None
-    if rank == 0:
-        state = W.synth_state(spec, 9527)
-        blob_t = torch.from_numpy(W.pack_bigvgan(cfg, state)).to(dev)
+    elif args.workload == "indextts":
+        args.steps = 3 if args.steps is None else args.steps
+        args.warmup = 3 if args.warmup is None else args.warmup
+        args.batch = 1 if args.batch is None else args.batch
+        args.dtype = "f16" if args.dtype is None else args.dtype
+        run_indextts(args, world, rank, local, dev, dist, torch)
     else:
-        blob_t = torch.empty(nparam, dtype=torch.float32, device=dev)
-    bcast_ms = 0.0
-    if world > 1:
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        dist.broadcast(blob_t, src=0)
-        torch.cuda.synchronize()
-        bcast_ms = (time.perf_counter() - t0) * 1e3
-    voc = BigVGANVocoder(cfg, blob=blob_t.cpu().numpy(), dtype=args.dtype, device=local)
-    del blob_t
-
-    B, F = args.batch, args.frames
-    out = torch.empty((B, 1, voc.out_len(F)), dtype=torch.int16, device=dev)
-    audio_s = B * voc.out_len(F) / cfg.sampling_rate
-    if ixf:
-        latent = torch.from_numpy(W.synth_normal(100 + rank, "latent", (F + 2, cfg.num_mels), std=1.5, mean=0.3)).to(dev)
-        ncond = cfg.upsample_initial_channel + sum(cfg.stage_channels(i) for i in range(cfg.num_upsamples))
-        conds = torch.from_numpy(W.synth_normal(100 + rank, "conds", (ncond,), std=0.2)).to(dev)
-        step = lambda: voc.run_latent_torch(latent, conds, out)
-    else:
-        mel = torch.from_numpy(W.bigvgan_synthetic_mel(cfg, B, F, rank)).to(dev)
-        step = lambda: voc.run_torch(mel, out)
-
-    for _ in range(args.warmup):
-        step()
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    _lib.prof_reset()
-    _lib.prof_enable(["conv_gemm"])
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    _lib.prof_enable(())
-    prof = _lib.prof_get("conv_gemm")
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-
-    if rank == 0:
-        esz = 4 if args.dtype == "f32" else 2
-        value = world * audio_s * args.steps / dt
-        k_ms = prof["ms"] / max(prof["launches"], 1)
-        achieved = prof["bytes"] / (prof["ms"] * 1e-3) / 1e9 if prof["ms"] > 0 else 0.0
-        line = {
-            "metric": "audio_seconds_per_second", "value": value, "unit": "audio-s/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
-            "data": "synthetic",
-            "config": {"workload": (f"IndexTTS graph F (speaker-conditioned BigVGAN, 1024x) {args.dtype}, T_codes = {F + 2} "
-                                    f"(BASELINE configs[4] vocoder leg)") if ixf else
-                                   (f"BigVGAN-v2 24khz_100band_256x {args.dtype} vocoder, mel ({B},100,{F}) per GPU "
-                                    f"(BASELINE configs[1])"),
-                       "batch_per_gpu": B, "frames": F, "audio_seconds_per_step_per_gpu": audio_s,
-                       "rtf": dt / args.steps / audio_s, "weights": "synthetic seeded (112.4 M params)",
-                       "weight_bcast_ms": bcast_ms,
-                       "whole_forward_algorithmic_GB": bigvgan_algorithmic_bytes(cfg, B, F, esz) / 1e9,
-                       "whole_forward_achieved_GBps": bigvgan_algorithmic_bytes(cfg, B, F, esz) / (dt / args.steps) / 1e9},
-            "roofline": {"bound": "hbm", "kernel": "conv_gemm_kernel (implicit-GEMM Conv1d/ConvTranspose1d family)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic_per_launch(args, ixf), "launches_per_step": prof["launches"] / args.steps,
-                         "algorithmic_bytes_per_launch": prof["bytes"] / max(prof["launches"], 1),
-                         "avg_launch_ms": k_ms, "family_ms_per_step": prof["ms"] / args.steps,
-                         "tflops": prof["flops"] / (prof["ms"] * 1e-3) / 1e12 if prof["ms"] > 0 else 0.0,
-                         "mfma_peak_tflops": MFMA_F32_PEAK_TF if args.dtype == "f32" else MFMA_F16_PEAK_TF,
-                         "mfma_frac": (prof["flops"] / (prof["ms"] * 1e-3) / 1e12 if prof["ms"] > 0 else 0.0) /
-                                      (MFMA_F32_PEAK_TF if args.dtype == "f32" else MFMA_F16_PEAK_TF),
-                         "note": "family = every implicit-GEMM launch of the forward (stages 0-2 are MFMA / LDS-fill bound, "
-                                 "stages 3-5 + fused AA are HBM bound); bytes are the layer-granular algorithmic count"},
-        }
-        if world == 1 and not args.no_cpu_baseline and not ixf:
-            if state is None:
-                state = W.synth_state(spec, 9527)
-            line["cpu_baseline"] = cpu_baseline_bigvgan(cfg, state, args.cpu_frames)
-        print(json.dumps(line), flush=True)
-    voc.close()
+        ixf = args.workload == "indextts_f"        # BASELINE configs[4] vocoder leg: IndexTTS graph F, T_codes = 128
+        args.steps = 20 if args.steps is None else args.steps
+        args.warmup = 3 if args.warmup is None else args.warmup
+        args.dtype = "f16" if args.dtype is None else args.dtype
+        B, F = (1, 126) if ixf else (8 if args.batch is None else args.batch, args.frames)
+        res, (cfg, state) = measure_bigvgan(torch, dist, world, rank, local, dev, args.dtype, B, F, args.steps, args.warmup, ixf)
+        if rank == 0:
+            line = {"metric": "audio_seconds_per_second", "value": res["value"], "unit": "audio-s/s", "n_gpus": world,
+                    "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True,
+                    "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+                    "config": {k: v for k, v in res.items() if k not in ("value", "ms_per_step", "dtype", "roofline")},
+                    "roofline": res["roofline"]}
+            line["config"]["weights"] = "synthetic seeded (112.4 M params)"
+            if world == 1 and not args.no_cpu_baseline and not ixf:
+                line["cpu_baseline"] = cpu_baseline_bigvgan(cfg, state, args.cpu_frames)
+            print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

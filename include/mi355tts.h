@@ -59,6 +59,12 @@ const char* mi_version(void);
 int64_t     mi_bigvgan_param_count(const int32_t* cfg, int n_cfg);
 mi_bigvgan* mi_bigvgan_create(const int32_t* cfg, int n_cfg, const float* weights, int64_t n_weights,
                               int dtype, int device);
+/* same, with the blob in host (MI_HOST) or device (MI_DEVICE) memory, e.g. the buffer an RCCL broadcast filled (the
+ * broadcast itself is torch.distributed's: SURVEY.md 8b `mi_bcast_weights` became "hand the engine the device buffer").
+ * BigVGAN / GPT re-lay their conv weights out in host code, so a device blob is read back once at load; F5 converts its
+ * matrices device-to-device (see mi_f5_create_mem).                                                                  */
+mi_bigvgan* mi_bigvgan_create_mem(const int32_t* cfg, int n_cfg, const float* weights, int64_t n_weights,
+                                  int dtype, int device, int mem);
 void        mi_bigvgan_destroy(mi_bigvgan* h);
 int64_t     mi_bigvgan_out_len(const mi_bigvgan* h, int frames);      /* frames*hop + 30 */
 /* mel: (B, num_mels, frames) fp32 channels-first (the ONNX `mel_features` layout; B>1 is this
@@ -95,6 +101,11 @@ int         mi_conv_transpose1d(const float* x, int B, int Cin, int T, const flo
 int64_t     mi_f5_param_count(const int32_t* cfg_i, int n_i, const float* cfg_f, int n_f);
 mi_f5*      mi_f5_create(const int32_t* cfg_i, int n_i, const float* cfg_f, int n_f, const float* weights,
                          int64_t n_weights, int dtype, int device);
+/* blob in host or device memory.  MI_DEVICE: every DiT / Vocos matrix (98 % of the blob) is converted to the engine
+ * dtype by a device kernel straight out of the caller's buffer — no host staging; only the tensors whose load-time tables
+ * are built by host code (time MLP, the two k31 grouped convs, the Vocos embed conv: ~6 M of 351 M floats) are read back. */
+mi_f5*      mi_f5_create_mem(const int32_t* cfg_i, int n_i, const float* cfg_f, int n_f, const float* weights,
+                             int64_t n_weights, int dtype, int device, int mem);
 void        mi_f5_destroy(mi_f5* h);
 /* load-time tables (tests): time_expand (nfe, dim), delta_t (nfe-1)   Export_F5.py:153-164          */
 int         mi_f5_tables(mi_f5* h, float* time_expand, float* delta_t);
@@ -139,6 +150,8 @@ int         mi_f5_synthesize(mi_f5* h, int U, const int16_t* audio, int64_t L, c
 typedef struct mi_gpt mi_gpt;
 int64_t     mi_gpt_param_count(const int32_t* cfg, int n_cfg);
 mi_gpt*     mi_gpt_create(const int32_t* cfg, int n_cfg, const float* weights, int64_t n_weights, int dtype, int device);
+mi_gpt*     mi_gpt_create_mem(const int32_t* cfg, int n_cfg, const float* weights, int64_t n_weights, int dtype, int device,
+                              int mem);
 void        mi_gpt_destroy(mi_gpt* h);
 /* graph B: text_ids (n) -> text_hidden_state (n + 2, hidden): start id 0 / end id 1 added, + position rows. */
 int         mi_gpt_text_embed(mi_gpt* h, const int32_t* text_ids, int n, float* out, int mem);
@@ -194,6 +207,12 @@ int         mi_set_option(const char* key, int64_t value);
 int         mi_prof_enable(int family_mask);
 int         mi_prof_reset(void);
 int         mi_prof_get(const char* family, double* ms, int64_t* launches, double* bytes, double* flops);
+/* The same accumulators per kernel instantiation (name = the template instantiation rocprofv3 --kernel-trace lists, e.g.
+ * "conv_gemm_dma_kernel<float, float, true, 2, 64>"; launches that do not name their kernel are filed under the family
+ * name).  index in [0, mi_prof_kernel_count()).                                                                        */
+int         mi_prof_kernel_count(void);
+int         mi_prof_kernel_get(int index, char* name, int name_cap, char* family, int family_cap, double* ms,
+                               int64_t* launches, double* bytes, double* flops);
 
 #ifdef __cplusplus
 }

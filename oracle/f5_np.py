@@ -260,20 +260,18 @@ def preprocess(cfg, st, audio_i16, text_ids, max_duration, noise):
 # DiT — dit.py:205-220, modules.py
 # ------------------------------------------------------------------------------------------------
 def grouped_conv31(x, w, b, groups):
-    """x (N, C) channels-last; w (C, C/g, k) ; zero pad k//2."""
+    """x (N, C) channels-last; w (C, C/g, k) ; zero pad k//2.  Per group: im2col (a strided window view of the padded,
+    contiguous group slab) and one sgemm against the (k*cg, cg) matrix of that group's taps."""
     N, C = x.shape
     k = w.shape[2]
     cg = C // groups
-    xp = np.zeros((N + k - 1, C), dtype=F32)
-    xp[k // 2:k // 2 + N] = x
-    y = np.zeros((N, C), dtype=F32)
+    y = np.empty((N, C), dtype=F32)
     for g in range(groups):
-        wg = w[g * cg:(g + 1) * cg]                                   # (cg_out, cg_in, k)
-        xg = xp[:, g * cg:(g + 1) * cg]
-        acc = np.zeros((N, cg), dtype=F32)
-        for j in range(k):
-            acc += xg[j:j + N] @ wg[:, :, j].T
-        y[:, g * cg:(g + 1) * cg] = acc
+        xg = np.zeros((N + k - 1, cg), dtype=F32)
+        xg[k // 2:k // 2 + N] = x[:, g * cg:(g + 1) * cg]
+        cols = np.lib.stride_tricks.as_strided(xg, shape=(N, k * cg), strides=(xg.strides[0], xg.strides[1]), writeable=False)
+        wg = np.ascontiguousarray(w[g * cg:(g + 1) * cg].transpose(2, 1, 0).reshape(k * cg, cg))   # [(tap, ci)][co]
+        y[:, g * cg:(g + 1) * cg] = np.ascontiguousarray(cols) @ wg      # materialise: overlapping strides are not BLAS-able
     return (y + b[None, :]).astype(F32)
 
 
@@ -296,7 +294,8 @@ def rope_apply(z, cos, sin):
 
 
 def attention(cfg, st, p, u, cos, sin):
-    """AttnProcessor.__call__ (modules.py:449-468); u (2, N, d).  q/k weights are pre-scaled."""
+    """AttnProcessor.__call__ (modules.py:449-468); u (2, N, d).  q/k weights are pre-scaled.  softmax(q k^T) v is formed one
+    (branch, head) at a time so that the N x N logits stay cache resident (same arithmetic as the batched form)."""
     B, N, d = u.shape
     H, D = cfg.heads, cfg.dim_head
     q = linear(u, st[p + "to_q.weight"], st[p + "to_q.bias"]).reshape(B, N, H, D).transpose(0, 2, 1, 3)
@@ -304,12 +303,15 @@ def attention(cfg, st, p, u, cos, sin):
     v = linear(u, st[p + "to_v.weight"], st[p + "to_v.bias"]).reshape(B, N, H, D).transpose(0, 2, 1, 3)
     q = rope_apply(q, cos, sin)
     k = rope_apply(k, cos, sin)
-    s = (q @ k.transpose(0, 1, 3, 2)).astype(F32)
-    s = s - s.max(axis=-1, keepdims=True)
-    e = np.exp(s)
-    a = (e / e.sum(axis=-1, keepdims=True)).astype(F32)
-    o = (a @ v).transpose(0, 2, 1, 3).reshape(B, N, H * D).astype(F32)
-    return linear(o, st[p + "to_out.0.weight"], st[p + "to_out.0.bias"])
+    o = np.empty((B, N, H, D), dtype=F32)
+    for bi in range(B):
+        for h in range(H):
+            s = q[bi, h] @ k[bi, h].T                                   # (N, N) fp32
+            s -= s.max(axis=-1, keepdims=True)
+            np.exp(s, out=s)
+            s /= s.sum(axis=-1, keepdims=True)
+            o[bi, :, h, :] = s @ np.ascontiguousarray(v[bi, h])
+    return linear(o.reshape(B, N, H * D), st[p + "to_out.0.weight"], st[p + "to_out.0.bias"])
 
 
 def dit_block(cfg, st, i, x, t_emb, cos, sin):

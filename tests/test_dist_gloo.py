@@ -81,3 +81,75 @@ def test_two_rank_broadcast_shard_gather():
     for u, w in enumerate(waves):                               # concatenation == single-rank result
         mel = W.synth_normal(100 + u, "mel", (1, cfg.num_mels, 6 + u))
         assert np.array_equal(np.asarray(w, np.int16), O.bigvgan_int16(cfg, st, mel)[0, 0])
+
+
+def _f5_utterances(cfg, n):
+    """n utterances with two different lengths (so that bucket_by_length has something to do)."""
+    utts = []
+    for u in range(n):
+        L = 2304 if u % 2 == 0 else 2816
+        a = (2000 * np.sin(np.arange(L) * (0.03 + 0.01 * u))).astype(np.int16)
+        ids = ((np.arange(5 + u % 2) * 7 + u) % cfg.text_num_embeds).astype(np.int32)
+        R = L // cfg.hop_length + 1
+        N = R + 6
+        utts.append((a, ids, N, W.synth_normal(300 + u, "noise", (N, cfg.mel_dim))))
+    return utts
+
+
+def _f5_run(cfg, st, utt):
+    from oracle import f5_np as F
+    a, ids, N, noise = utt
+    pre = F.preprocess(cfg, st, a, ids, N, noise)
+    return np.asarray(F.decode(cfg, st, F.sample(cfg, st, pre), pre["ref_signal_len"])).reshape(-1)
+
+
+def _f5_worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "text-to-speech-tts-onnx_amd")]
+    from mi355tts.config import F5Config
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = F5Config.small()
+    raw = W.synth_state(W.f5_spec(cfg), 9527)
+    blob = W.pack_f5(cfg, raw) if rank == 0 else 0
+    blob = S.broadcast_blob(blob, src=0)
+    assert blob.size == W.pack_f5(cfg, raw).size
+    st = W.fold_f5(cfg, raw)
+    utts = _f5_utterances(cfg, 5)
+    a, b = S.shard_range(len(utts), world, rank)
+    mine = list(range(a, b))
+    local = [None] * len(mine)
+    # the engine batches utterances of equal max_duration: one "engine call" per bucket
+    for bucket in S.bucket_by_length([utts[i][2] for i in mine], max_batch=8):
+        assert len({utts[mine[j]][2] for j in bucket}) == 1
+        for j in bucket:
+            local[j] = _f5_run(cfg, st, utts[mine[j]])
+    allw = S.gather_waveforms(local, dst=0)
+    if rank == 0:
+        q.put([w.tolist() for w in allw])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_f5_utterance_list_buckets_and_gather():
+    """The configs[3] partitioning on CPU: contiguous utterance slices per rank, length buckets inside a rank, gather in
+    the original order == the single-process results."""
+    from mi355tts.config import F5Config
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_f5_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    waves = q.get(timeout=500)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    cfg = F5Config.small()
+    st = W.fold_f5(cfg, W.synth_state(W.f5_spec(cfg), 9527))
+    utts = _f5_utterances(cfg, 5)
+    assert len(waves) == 5
+    for u, w in enumerate(waves):
+        assert np.array_equal(np.asarray(w), _f5_run(cfg, st, utts[u])), u

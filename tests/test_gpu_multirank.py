@@ -1,0 +1,85 @@
+"""GPU: the N > 1 path with the HIP engine.  Two ranks share the one GPU of the test box (backend gloo, because RCCL
+refuses two ranks on one device; MI355TTS_BENCH_ONE_GPU=1 maps both ranks to cuda:0) and run bench.py's own multi-rank
+branches — weight blob built on rank 0, broadcast, consumed from device memory, per-rank utterance shards, barrier + max
+over ranks timing, one JSON line from rank 0 — on the reduced model (MI355TTS_BENCH_SMALL=1).  The per-rank waveforms must
+equal what one process computes for the same utterances (utterances are independent, no data-path
+collective)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from mi355tts.config import F5Config
+from mi355tts import weights as W
+from mi355tts.f5 import F5Engine
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_on_one_gpu_equals_single_process(tmp_path):
+    env = dict(os.environ, MI355TTS_BENCH_BACKEND="gloo", MI355TTS_BENCH_ONE_GPU="1", MI355TTS_BENCH_SMALL="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--batch", "3", "--dtype", "f32", "--dump-dir", str(tmp_path)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=800, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                                   # exactly one JSON line, from rank 0
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0 and line["dtype"] == "f32"
+    assert "PLUMBING TEST ONLY" in line["config"]["workload"] and line["config"]["utterances_per_gpu"] == 3
+    assert line["config"]["weight_bcast_ms"] > 0
+    # value = audio of BOTH ranks / max-over-ranks time
+    per_gpu = line["config"]["audio_seconds_per_step_per_gpu"]
+    assert abs(line["value"] - 2 * per_gpu / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
+    cfg = F5Config.small()
+    eng = F5Engine(cfg, W.synth_state(W.f5_spec(cfg), 9527), dtype="f32")
+    for rank in range(2):
+        got = np.load(tmp_path / f"f5_f32_u3_rank{rank}.npy")
+        audio, ids, N, noise = W.f5_synthetic_inputs(cfg, 3, rank, L=24000)
+        want = eng.synthesize(audio, ids, N, noise=noise)
+        assert got.shape == want.shape and np.array_equal(got, want), rank
+        assert np.sqrt(np.mean(want.astype(np.float64) ** 2)) > 100
+    assert not np.array_equal(np.load(tmp_path / "f5_f32_u3_rank0.npy"), np.load(tmp_path / "f5_f32_u3_rank1.npy"))
+    eng.close()
+
+
+def test_engine_from_device_blob_equals_engine_from_host_blob():
+    """mi_f5_create_mem(MI_DEVICE) (device-to-device conversion of the DiT / Vocos matrices, bf16 rounding done by a kernel)
+    builds the same engine as the host-blob path, for every engine dtype."""
+    import torch
+    cfg = F5Config.small()
+    raw = W.synth_state(W.f5_spec(cfg), 9527)
+    blob = W.pack_f5(cfg, raw)
+    audio, ids, N, noise = W.f5_synthetic_inputs(cfg, 2, 0, L=24000)
+    for dtype in ("f32", "bf16", "f16"):
+        e_host = F5Engine(cfg, blob=blob, dtype=dtype)
+        e_dev = F5Engine(cfg, blob_device=torch.from_numpy(blob).cuda(), dtype=dtype)
+        a = e_host.synthesize(audio, ids, N, noise=noise)
+        b = e_dev.synthesize(audio, ids, N, noise=noise)
+        assert np.array_equal(a, b), dtype
+        e_host.close(); e_dev.close()
+    from mi355tts.config import BigVGANConfig
+    from mi355tts.bigvgan import BigVGANVocoder
+    vcfg = BigVGANConfig.small()
+    vblob = W.pack_bigvgan(vcfg, W.synth_state(W.bigvgan_spec(vcfg), 9527))
+    mel = W.synth_normal(5, "mel", (2, vcfg.num_mels, 9))
+    v1 = BigVGANVocoder(vcfg, blob=vblob, dtype="f16")
+    v2 = BigVGANVocoder(vcfg, blob_device=torch.from_numpy(vblob).cuda(), dtype="f16")
+    assert np.array_equal(v1.run(mel), v2.run(mel))
+    v1.close(); v2.close()

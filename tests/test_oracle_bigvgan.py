@@ -95,3 +95,17 @@ def test_indextts_graph_f_against_reference_wrapper(golden_dir):
     assert w.shape == g["wav_i16"].shape == (1, 1, 3 * 1024 + 30)
     assert np.abs(w.astype(np.int32) - g["wav_i16"].astype(np.int32)).max() <= 2
     assert np.sqrt(np.mean(g["wav_i16"].astype(np.float64) ** 2)) > 1000
+
+
+def test_oracle_full_architecture_against_reference_fixture(golden_dir):
+    """The FULL BigVGAN-v2 architecture (112 M parameters, 6 stages) through the oracle against the reference generator +
+    int16 wrapper run in the build container (tests/golden/make_golden_full.py), on the reference's own smoke input
+    np.ones (BigVGAN/Export_BigVGAN.py:165) at 64 frames — what pins the oracle at real widths."""
+    import os
+    from mi355tts.config import BigVGANConfig
+    g = np.load(os.path.join(golden_dir, "bigvgan_full.npz"))
+    cfg = BigVGANConfig()
+    st = W.synth_state(W.bigvgan_spec(cfg), 9527)
+    w = O.bigvgan_int16(cfg, st, np.ones((1, cfg.num_mels, 64), np.float32))
+    assert w.shape == (1, 1, 64 * 256 + 30)
+    assert np.abs(w[0, 0].astype(np.int32) - g["ones64_i16"].astype(np.int32)).max() <= 2

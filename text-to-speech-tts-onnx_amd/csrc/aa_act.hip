@@ -151,6 +151,7 @@ static void launch_t(const AAAct& p, hipStream_t s) {
     const double bytes = (double)p.B * p.C * ((double)p.T + Tout) * sizeof(T);
     const double flops = (double)p.B * p.C * Tout * 60.0;
     ProfScope ps(FAM_AA, s, bytes, flops);
+    prof_set_kernel("aa_act_kernel<T>", type_label<T>());
     hipLaunchKernelGGL((aa_act_kernel<T, R>), grid, dim3(256), lds, s, (const T*)p.x, (T*)p.y, p.alpha, p.inv_beta,
                        p.T, p.C, CT, TT, shift, ext);
     MI_HIP(hipGetLastError());

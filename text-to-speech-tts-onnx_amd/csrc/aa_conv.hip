@@ -289,6 +289,7 @@ static void launch_t(const AAConv& q, hipStream_t s) {
     do {                                                                                                         \
         auto kfn = aa_conv_kernel<T, BMv, TNv>;                                                                  \
         if (lds > 64 * 1024) MI_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        prof_set_kernel("aa_conv_kernel<T, " #BMv ", " #TNv ">", type_label<T>());                                \
         hipLaunchKernelGGL(kfn, grid, dim3(256), lds, s, d);                                                     \
     } while (0)
     if (BM == 256) { if (TN == 1) LAUNCH(256, 1); else LAUNCH(256, 2); }

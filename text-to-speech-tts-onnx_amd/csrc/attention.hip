@@ -265,27 +265,33 @@ void launch_attention(const void* q, const void* k, const void* v, void* o, int 
     MI_REQUIRE(BH % H == 0 && N > 0, "attention: bad shape");
     const double esz = (double)dtype_size(dtype);
     ProfScope ps(FAM_ATTN, s, 4.0 * BH * N * 64.0 * esz, 4.0 * BH * (double)N * N * 64.0);
+#define ATTN_LAUNCH(TT, SP, ...)                                                \
+    do {                                                                        \
+        prof_set_kernel("attn_kernel<T, " #SP ">", type_label<TT>());           \
+        hipLaunchKernelGGL((attn_kernel<TT, SP>), __VA_ARGS__);                 \
+    } while (0)
     static int split = -1;
     if (split < 0) { const char* e = std::getenv("MI355TTS_ATTN_NO_SPLIT"); split = (e && e[0] == '1') ? 0 : 1; }
     if (dtype == MI_F32) {
         // few 128-query workgroups (one or two utterances): halve them along the keys, see attn_kernel
         if (split && (long)((N + 127) / 128) * BH < 1024 && N >= 64)
-            hipLaunchKernelGGL((attn_kernel<float, true>), dim3((N + 63) / 64, BH), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N);
+            ATTN_LAUNCH(float, true, dim3((N + 63) / 64, BH), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N);
         else
-            hipLaunchKernelGGL((attn_kernel<float, false>), dim3((N + 127) / 128, BH), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N);
+            ATTN_LAUNCH(float, false, dim3((N + 127) / 128, BH), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N);
     } else {
         // 16-bit: the same split below 512 workgroups (one utterance: attention 24.3 -> 21.1 ms per step; at two utterances,
         // 576 workgroups, the 128-query form is already balanced and shares each K / V stage among more waves)
         const bool sp = split && (long)((N + 127) / 128) * BH < 512 && N >= 64;
         const dim3 grid(sp ? (N + 63) / 64 : (N + 127) / 128, BH);
         if (dtype == MI_F16) {
-            if (sp) hipLaunchKernelGGL((attn_kernel<f16, true>), grid, dim3(256), 0, s, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)o, H, N);
-            else hipLaunchKernelGGL((attn_kernel<f16, false>), grid, dim3(256), 0, s, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)o, H, N);
+            if (sp) ATTN_LAUNCH(f16, true, grid, dim3(256), 0, s, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)o, H, N);
+            else ATTN_LAUNCH(f16, false, grid, dim3(256), 0, s, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)o, H, N);
         } else {
-            if (sp) hipLaunchKernelGGL((attn_kernel<bf16, true>), grid, dim3(256), 0, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, H, N);
-            else hipLaunchKernelGGL((attn_kernel<bf16, false>), grid, dim3(256), 0, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, H, N);
+            if (sp) ATTN_LAUNCH(bf16, true, grid, dim3(256), 0, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, H, N);
+            else ATTN_LAUNCH(bf16, false, grid, dim3(256), 0, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, H, N);
         }
     }
+#undef ATTN_LAUNCH
     MI_HIP(hipGetLastError());
 }
 

@@ -64,5 +64,7 @@ void prof_enable(unsigned mask);
 void prof_reset();
 int prof_family(const char* name);
 void prof_get(int fam, double* ms, int64_t* launches, double* bytes, double* flops);
+int prof_kernel_count();
+bool prof_kernel_get(int idx, std::string* name, int* fam, double* ms, int64_t* launches, double* bytes, double* flops);
 
 }  // namespace mi

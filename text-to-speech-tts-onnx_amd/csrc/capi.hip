@@ -72,6 +72,30 @@ mi_bigvgan* mi_bigvgan_create(const int32_t* cfg, int n_cfg, const float* weight
     return rc == MI_OK ? h : nullptr;
 }
 
+// a device-resident blob whose re-layouts are host code (BigVGAN conv / GPT Conv1D transposes): read back once at load
+static std::vector<float> read_back(const float* dev, int64_t n, int device) {
+    MI_REQUIRE(n > 0, "create_mem: empty blob");
+    MI_HIP(hipSetDevice(device));
+    std::vector<float> h((size_t)n);
+    MI_HIP(hipMemcpy(h.data(), dev, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return h;
+}
+
+mi_bigvgan* mi_bigvgan_create_mem(const int32_t* cfg, int n_cfg, const float* weights, int64_t n_weights, int dtype,
+                                  int device, int mem) {
+    if (mem == MI_HOST) return mi_bigvgan_create(cfg, n_cfg, weights, n_weights, dtype, device);
+    mi_bigvgan* h = nullptr;
+    int rc = guard([&] {
+        MI_REQUIRE(weights != nullptr && mem == MI_DEVICE, "mi_bigvgan_create_mem: null weights / bad mem kind");
+        BigVGANCfg g = parse_bigvgan_cfg(cfg, n_cfg);
+        MI_REQUIRE(n_weights == bigvgan_param_count(g), "bigvgan: weight blob size does not match the config");
+        std::vector<float> hw = read_back(weights, n_weights, device);
+        BigVGAN* impl = new BigVGAN(g, hw.data(), n_weights, dtype, device);
+        h = new mi_bigvgan; h->impl = impl;
+    });
+    return rc == MI_OK ? h : nullptr;
+}
+
 void mi_bigvgan_destroy(mi_bigvgan* h) {
     if (!h) return;
     delete h->impl;
@@ -152,6 +176,18 @@ mi_f5* mi_f5_create(const int32_t* cfg_i, int n_i, const float* cfg_f, int n_f, 
         MI_REQUIRE(weights != nullptr, "mi_f5_create: null weights");
         F5Cfg c = parse_f5_cfg(cfg_i, n_i, cfg_f, n_f);
         F5* impl = new F5(c, weights, n_weights, dtype, device);
+        h = new mi_f5; h->impl = impl;
+    });
+    return rc == MI_OK ? h : nullptr;
+}
+
+mi_f5* mi_f5_create_mem(const int32_t* cfg_i, int n_i, const float* cfg_f, int n_f, const float* weights, int64_t n_weights,
+                        int dtype, int device, int mem) {
+    mi_f5* h = nullptr;
+    int rc = guard([&] {
+        MI_REQUIRE(weights != nullptr && (mem == MI_HOST || mem == MI_DEVICE), "mi_f5_create_mem: null weights / bad mem kind");
+        F5Cfg c = parse_f5_cfg(cfg_i, n_i, cfg_f, n_f);
+        F5* impl = new F5(c, weights, n_weights, dtype, device, mem);
         h = new mi_f5; h->impl = impl;
     });
     return rc == MI_OK ? h : nullptr;
@@ -316,6 +352,21 @@ mi_gpt* mi_gpt_create(const int32_t* cfg, int n_cfg, const float* weights, int64
         MI_REQUIRE(weights != nullptr, "mi_gpt_create: null weights");
         GptCfg c = parse_gpt_cfg(cfg, n_cfg);
         Gpt* impl = new Gpt(c, weights, n_weights, dtype, device);
+        h = new mi_gpt; h->impl = impl;
+    });
+    return rc == MI_OK ? h : nullptr;
+}
+
+mi_gpt* mi_gpt_create_mem(const int32_t* cfg, int n_cfg, const float* weights, int64_t n_weights, int dtype, int device,
+                          int mem) {
+    if (mem == MI_HOST) return mi_gpt_create(cfg, n_cfg, weights, n_weights, dtype, device);
+    mi_gpt* h = nullptr;
+    int rc = guard([&] {
+        MI_REQUIRE(weights != nullptr && mem == MI_DEVICE, "mi_gpt_create_mem: null weights / bad mem kind");
+        GptCfg c = parse_gpt_cfg(cfg, n_cfg);
+        MI_REQUIRE(n_weights == gpt_param_count(c), "gpt: weight blob size does not match the config");
+        std::vector<float> hw = read_back(weights, n_weights, device);
+        Gpt* impl = new Gpt(c, hw.data(), n_weights, dtype, device);
         h = new mi_gpt; h->impl = impl;
     });
     return rc == MI_OK ? h : nullptr;
@@ -624,6 +675,24 @@ int mi_set_option(const char* key, int64_t value) {
 
 int mi_prof_enable(int family_mask) { prof_enable((unsigned)family_mask); return MI_OK; }
 int mi_prof_reset(void) { return guard([&] { prof_reset(); }); }
+int mi_prof_kernel_count(void) { return prof_kernel_count(); }
+int mi_prof_kernel_get(int index, char* name, int name_cap, char* family, int family_cap, double* ms, int64_t* launches,
+                       double* bytes, double* flops) {
+    return guard([&] {
+        std::string n;
+        int f = 0;
+        double m = 0, b = 0, fl = 0;
+        int64_t l = 0;
+        MI_REQUIRE(name && name_cap > 1 && prof_kernel_get(index, &n, &f, &m, &l, &b, &fl), "mi_prof_kernel_get: bad index");
+        std::snprintf(name, (size_t)name_cap, "%s", n.c_str());
+        static const char* fams[] = {"conv_gemm", "aa_act", "conv_post", "attn", "norm", "other"};
+        if (family && family_cap > 1) std::snprintf(family, (size_t)family_cap, "%s", fams[f]);
+        if (ms) *ms = m;
+        if (launches) *launches = l;
+        if (bytes) *bytes = b;
+        if (flops) *flops = fl;
+    });
+}
 int mi_prof_get(const char* family, double* ms, int64_t* launches, double* bytes, double* flops) {
     return guard([&] {
         MI_REQUIRE(family != nullptr, "mi_prof_get: null family");

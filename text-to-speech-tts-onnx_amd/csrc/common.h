@@ -85,15 +85,41 @@ struct DevBuf {
 void upload_as(DevBuf& dst, const float* src, size_t n, int dt, hipStream_t s);
 void upload_f32(DevBuf& dst, const float* src, size_t n, hipStream_t s);
 
+// Reader of a packed fp32 weight blob that lives in host OR device memory (the `mem` flag of mi_*_create_mem; a blob that
+// arrived over RCCL stays on the device).  put(): blob range -> device tensor of dtype dt (device blobs: a conversion
+// kernel, no host staging).  host(): a host-visible copy of a range, for the few tensors whose load-time tables or
+// re-layouts are built by host code.
+struct BlobReader {
+    int mem; hipStream_t s;
+    std::vector<std::vector<float>> keep;
+    BlobReader(int mem_, hipStream_t s_) : mem(mem_), s(s_) {}
+    const float* host(const float* p, size_t n);
+    // dst must already hold >= (dst_off + n) elements when dst_off > 0; with dst_off == 0 it is (re)allocated to n
+    void put(DevBuf& dst, const float* p, size_t n, int dt, size_t dst_off = 0);
+};
+
 // ---------------------------------------------------------------------------------------------
 // profiling (bench roofline leg): HIP events around launches of a kernel family
 // ---------------------------------------------------------------------------------------------
 struct ProfScope {
-    int fam; hipStream_t s; hipEvent_t e0 = nullptr, e1 = nullptr; bool on;
+    int fam; hipStream_t s; hipEvent_t e0 = nullptr, e1 = nullptr; bool on; double bytes_ = 0, flops_ = 0;
     ProfScope(int family, hipStream_t stream, double bytes, double flops);
     ~ProfScope();
 };
 enum { FAM_CONV_GEMM = 0, FAM_AA = 1, FAM_CONV_POST = 2, FAM_ATTN = 3, FAM_NORM = 4, FAM_OTHER = 5, FAM_COUNT = 6 };
+// per-kernel attribution inside a family: the launcher names the template instantiation it is about to launch (the text
+// rocprofv3 --kernel-trace shows for it); the enclosing ProfScope files its elapsed time under that name.  No-op unless
+// profiling is on.
+void prof_set_kernel(const char* expr, const char* t = nullptr, const char* to = nullptr);
+template <typename T> inline const char* type_label();
+template <> inline const char* type_label<float>() { return "float"; }
+template <> inline const char* type_label<f16>() { return "_Float16"; }
+template <> inline const char* type_label<bf16>() { return "__bf16"; }
+#define MI_LAUNCH(K, T_, TO_, grid, blk, lds, s, ...)                                                  \
+    do {                                                                                               \
+        mi::prof_set_kernel(#K, mi::type_label<T_>(), mi::type_label<TO_>());                          \
+        hipLaunchKernelGGL(K, grid, blk, lds, s, __VA_ARGS__);                                         \
+    } while (0)
 void prof_collect();   // resolve pending events (synchronises)
 unsigned prof_mask();   // current family mask (0 = profiling off)
 

@@ -61,7 +61,7 @@ struct F5 {
     std::vector<float> h_noise;
     DevBuf v_h, v_z, v_z2, v_s, v_c, v_fr, v_outf, v_outi;
 
-    F5(const F5Cfg& c, const float* w, int64_t nw, int dt, int dev);
+    F5(const F5Cfg& c, const float* w, int64_t nw, int dt, int dev, int mem = MI_HOST);   // w: host or device blob
     ~F5();
     void ensure_workspace(int U, int N);
     void gemm(int dt, const void* x, long xb, long xr, int K, const Lin& L, void* out, int odt, long ob, long orr,

@@ -52,10 +52,15 @@ int64_t f5_param_count(const F5Cfg& c) {
     return n;
 }
 
-static void up_lin(Lin& L, const float* w, const float* b, int n, int k, int dt, hipStream_t s) {
+static void up_lin(Lin& L, const float* w, const float* b, int n, int k, int dt, hipStream_t s) {     // host sources
     L.n = n; L.k = k;
     upload_as(L.w, w, (size_t)n * k, dt, s);
     if (b) upload_f32(L.b, b, n, s);
+}
+static void put_lin(BlobReader& R, Lin& L, const float* w, const float* b, int n, int k, int dt) {     // blob sources
+    L.n = n; L.k = k;
+    R.put(L.w, w, (size_t)n * k, dt);
+    if (b) R.put(L.b, b, n, MI_F32);
 }
 // Conv1d weight (Co, Ci, k) -> [co][tap][ci]
 static std::vector<float> relayout(const float* w, int Co, int Ci, int k) {
@@ -68,7 +73,7 @@ static std::vector<float> relayout(const float* w, int Co, int Ci, int k) {
 static inline float siluf(float v) { return v / (1.f + expf(-v)); }
 static inline float round_f16(float v) { return (float)(f16)v; }
 
-F5::F5(const F5Cfg& c, const float* w, int64_t nw, int dt, int dev) : cfg(c), dtype(dt), device(dev) {
+F5::F5(const F5Cfg& c, const float* w, int64_t nw, int dt, int dev, int mem) : cfg(c), dtype(dt), device(dev) {
     MI_REQUIRE(dt == MI_F32 || dt == MI_F16 || dt == MI_BF16, "f5: bad dtype");
     MI_REQUIRE(nw == f5_param_count(c), "f5: weight blob size does not match the config");
     MI_HIP(hipSetDevice(dev));
@@ -77,11 +82,12 @@ F5::F5(const F5Cfg& c, const float* w, int64_t nw, int dt, int dev) : cfg(c), dt
     hipStream_t s = stream;
     const int d = c.dim, td = c.text_dim, ff = c.ff(), ti = td * c.conv_mult, cin = c.cat_dim();
     const float* p = w;
-    auto take = [&](size_t n) { const float* r = p; p += n; return r; };
+    auto take = [&](size_t n) { const float* r = p; p += n; return r; };          // blob ranges (host or device memory)
+    BlobReader R(mem, s);
 
     // ---- time MLP table (Export_F5.py:145-165), host fp32 -------------------------------------------
-    const float* tw0 = take((size_t)d * c.freq_dim); const float* tb0 = take(d);
-    const float* tw2 = take((size_t)d * d); const float* tb2 = take(d);
+    const float* tw0 = R.host(take((size_t)d * c.freq_dim), (size_t)d * c.freq_dim); const float* tb0 = R.host(take(d), d);
+    const float* tw2 = R.host(take((size_t)d * d), (size_t)d * d); const float* tb2 = R.host(take(d), d);
     const int steps = c.nfe, half = c.freq_dim / 2;
     std::vector<float> ts(steps);
     for (int i = 0; i < steps; ++i) {
@@ -113,7 +119,7 @@ F5::F5(const F5Cfg& c, const float* w, int64_t nw, int dt, int dev) : cfg(c), dt
         }
     }
     // ---- text embedding -----------------------------------------------------------------------------
-    upload_f32(text_emb, take((size_t)(c.vocab + 1) * td), (size_t)(c.vocab + 1) * td, s);
+    R.put(text_emb, take((size_t)(c.vocab + 1) * td), (size_t)(c.vocab + 1) * td, MI_F32);
     {   // precompute_freqs_cis(text_dim, max_len) (modules.py:196-207)
         std::vector<float> pos((size_t)c.max_len * td);
         std::vector<float> fr(td / 2);
@@ -127,26 +133,27 @@ F5::F5(const F5Cfg& c, const float* w, int64_t nw, int dt, int dev) : cfg(c), dt
     }
     tblocks.resize(c.conv_layers);
     for (auto& tb : tblocks) {
-        upload_f32(tb.dw_w, take((size_t)td * 7), (size_t)td * 7, s);
-        upload_f32(tb.dw_b, take(td), td, s);
-        upload_f32(tb.ln_w, take(td), td, s);
-        upload_f32(tb.ln_b, take(td), td, s);
+        R.put(tb.dw_w, take((size_t)td * 7), (size_t)td * 7, MI_F32);
+        R.put(tb.dw_b, take(td), td, MI_F32);
+        R.put(tb.ln_w, take(td), td, MI_F32);
+        R.put(tb.ln_b, take(td), td, MI_F32);
         const float* w1 = take((size_t)ti * td); const float* b1 = take(ti);
-        up_lin(tb.pw1, w1, b1, ti, td, MI_F32, s);
-        upload_f32(tb.grn_g, take(ti), ti, s);
-        upload_f32(tb.grn_b, take(ti), ti, s);
+        put_lin(R, tb.pw1, w1, b1, ti, td, MI_F32);
+        R.put(tb.grn_g, take(ti), ti, MI_F32);
+        R.put(tb.grn_b, take(ti), ti, MI_F32);
         const float* w2 = take((size_t)td * ti); const float* b2 = take(td);
-        up_lin(tb.pw2, w2, b2, td, ti, MI_F32, s);
+        put_lin(R, tb.pw2, w2, b2, td, ti, MI_F32);
     }
     // ---- input embedding -------------------------------------------------------------------------------
     {
         const float* pw = take((size_t)d * cin); const float* pb = take(d);
-        up_lin(in_proj, pw, pb, d, cin, dt, s);
+        put_lin(R, in_proj, pw, pb, d, cin, dt);
         const int cg = d / c.pos_g;
-        const float* w1 = take((size_t)d * cg * c.pos_k); const float* b1 = take(d);
+        const size_t gw = (size_t)d * cg * c.pos_k;                 // the k31 grouped convs are re-laid out by host code
+        const float* w1 = R.host(take(gw), gw); const float* b1 = R.host(take(d), d);
         auto r1 = relayout(w1, d, cg, c.pos_k);
         up_lin(gconv1, r1.data(), b1, d, cg * c.pos_k, dt, s);
-        const float* w2 = take((size_t)d * cg * c.pos_k); const float* b2 = take(d);
+        const float* w2 = R.host(take(gw), gw); const float* b2 = R.host(take(d), d);
         auto r2 = relayout(w2, d, cg, c.pos_k);
         up_lin(gconv2, r2.data(), b2, d, cg * c.pos_k, dt, s);
     }
@@ -160,8 +167,8 @@ F5::F5(const F5Cfg& c, const float* w, int64_t nw, int dt, int dev) : cfg(c), dt
         upload_f32(d_silu_t, st.data(), st.size(), s);
     }
     auto mod_gemm = [&](const float* mw, const float* mb, int n, long col) {
-        upload_f32(d_tmpw, mw, (size_t)n * d, s);
-        upload_f32(d_tmpb, mb, n, s);
+        R.put(d_tmpw, mw, (size_t)n * d, MI_F32);
+        R.put(d_tmpb, mb, n, MI_F32);
         ConvGemm g;
         g.dtype = MI_F32; g.x = d_silu_t.p; g.w = d_tmpw.p; g.bias = d_tmpb.as<float>(); g.out = mod.as<float>() + col;
         g.B = 1; g.T_in = steps; g.M = steps; g.N = n; g.Cin = d; g.x_rstride = d; g.x_bstride = (long)steps * d;
@@ -174,24 +181,25 @@ F5::F5(const F5Cfg& c, const float* w, int64_t nw, int dt, int dev) : cfg(c), dt
         Block& bk = blocks[i];
         const float* mw = take((size_t)6 * d * d); const float* mb = take((size_t)6 * d);
         mod_gemm(mw, mb, 6 * d, (long)i * 6 * d);
-        std::vector<float> wq((size_t)3 * d * d), bq((size_t)3 * d);
+        bk.qkv.n = 3 * d; bk.qkv.k = d;                              // q | k | v rows stacked into one GEMM weight
+        bk.qkv.w.ensure((size_t)3 * d * d * dtype_size(dt)); bk.qkv.b.ensure((size_t)3 * d * 4);
         for (int t3 = 0; t3 < 3; ++t3) {
-            std::memcpy(&wq[(size_t)t3 * d * d], take((size_t)d * d), (size_t)d * d * 4);
-            std::memcpy(&bq[(size_t)t3 * d], take(d), (size_t)d * 4);
+            const float* wt = take((size_t)d * d); const float* bt = take(d);
+            if (t3 == 0) { R.put(bk.qkv.w, wt, (size_t)d * d, dt, 0); R.put(bk.qkv.b, bt, d, MI_F32, 0); }
+            else { R.put(bk.qkv.w, wt, (size_t)d * d, dt, (size_t)t3 * d * d); R.put(bk.qkv.b, bt, d, MI_F32, (size_t)t3 * d); }
         }
-        up_lin(bk.qkv, wq.data(), bq.data(), 3 * d, d, dt, s);
         const float* wo = take((size_t)d * d); const float* bo = take(d);
-        up_lin(bk.o, wo, bo, d, d, dt, s);
+        put_lin(R, bk.o, wo, bo, d, d, dt);
         const float* w1 = take((size_t)ff * d); const float* b1 = take(ff);
-        up_lin(bk.ff1, w1, b1, ff, d, dt, s);
+        put_lin(R, bk.ff1, w1, b1, ff, d, dt);
         const float* w2 = take((size_t)d * ff); const float* b2 = take(d);
-        up_lin(bk.ff2, w2, b2, d, ff, dt, s);
+        put_lin(R, bk.ff2, w2, b2, d, ff, dt);
     }
     {
         const float* mw = take((size_t)2 * d * d); const float* mb = take((size_t)2 * d);
         mod_gemm(mw, mb, 2 * d, (long)c.depth * 6 * d);
         const float* pw = take((size_t)c.mel * d); const float* pb = take(c.mel);
-        up_lin(proj_out, pw, pb, c.mel, d, dt, s);
+        put_lin(R, proj_out, pw, pb, c.mel, d, dt);
     }
     // ---- RoPE tables, rounded through fp16 (Export_F5.py:107-112) --------------------------------------
     {
@@ -280,23 +288,25 @@ F5::F5(const F5Cfg& c, const float* w, int64_t nw, int dt, int dev) : cfg(c), dt
     // ---- Vocos ----------------------------------------------------------------------------------------------
     {
         const int vd = c.vd, vi = c.vi;
-        const float* ew = take((size_t)vd * c.mel * 7); const float* eb = take(vd);
+        const size_t ewn = (size_t)vd * c.mel * 7;
+        const float* ew = R.host(take(ewn), ewn); const float* eb = R.host(take(vd), vd);
         auto re = relayout(ew, vd, c.mel, 7);
         up_lin(v_embed, re.data(), eb, vd, c.mel * 7, MI_F32, s);
-        upload_f32(v_norm_w, take(vd), vd, s); upload_f32(v_norm_b, take(vd), vd, s);
+        R.put(v_norm_w, take(vd), vd, MI_F32); R.put(v_norm_b, take(vd), vd, MI_F32);
         vblocks.resize(c.vlayers);
         for (auto& vb_ : vblocks) {
-            upload_f32(vb_.dw_w, take((size_t)vd * 7), (size_t)vd * 7, s); upload_f32(vb_.dw_b, take(vd), vd, s);
-            upload_f32(vb_.n_w, take(vd), vd, s); upload_f32(vb_.n_b, take(vd), vd, s);
+            R.put(vb_.dw_w, take((size_t)vd * 7), (size_t)vd * 7, MI_F32); R.put(vb_.dw_b, take(vd), vd, MI_F32);
+            R.put(vb_.n_w, take(vd), vd, MI_F32); R.put(vb_.n_b, take(vd), vd, MI_F32);
             const float* w1 = take((size_t)vi * vd); const float* b1 = take(vi);
-            up_lin(vb_.pw1, w1, b1, vi, vd, MI_F32, s);
+            put_lin(R, vb_.pw1, w1, b1, vi, vd, MI_F32);
             const float* w2 = take((size_t)vd * vi); const float* b2 = take(vd);
-            up_lin(vb_.pw2, w2, b2, vd, vi, MI_F32, s);
+            put_lin(R, vb_.pw2, w2, b2, vd, vi, MI_F32);
         }
-        upload_f32(v_fnorm_w, take(vd), vd, s); upload_f32(v_fnorm_b, take(vd), vd, s);
+        R.put(v_fnorm_w, take(vd), vd, MI_F32); R.put(v_fnorm_b, take(vd), vd, MI_F32);
         const float* hw = take((size_t)(c.n_fft + 2) * vd); const float* hb = take(c.n_fft + 2);
-        up_lin(v_head, hw, hb, c.n_fft + 2, vd, MI_F32, s);
+        put_lin(R, v_head, hw, hb, c.n_fft + 2, vd, MI_F32);
     }
+    MI_HIP(hipStreamSynchronize(s));
     MI_REQUIRE(p - w == nw, "f5: weight walk mismatch");
 }
 

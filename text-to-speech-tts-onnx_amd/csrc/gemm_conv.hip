@@ -447,10 +447,10 @@ static void dispatch_tiles(const ConvGemmDev& d, int B, hipStream_t s) {
     dim3 blk(256);
     if (d.N <= 32) {
         dim3 grid((d.M + 255) / 256, (d.N + 31) / 32, B * d.G);
-        hipLaunchKernelGGL((conv_gemm_kernel<T, TO, 256, 32, 4, 1, KC>), grid, blk, 0, s, d);
+        MI_LAUNCH((conv_gemm_kernel<T, TO, 256, 32, 4, 1, KC>), T, TO, grid, blk, 0, s, d);
     } else if (d.N <= 64) {
         dim3 grid((d.M + 127) / 128, (d.N + 63) / 64, B * d.G);
-        hipLaunchKernelGGL((conv_gemm_kernel<T, TO, 128, 64, 2, 2, KC>), grid, blk, 0, s, d);
+        MI_LAUNCH((conv_gemm_kernel<T, TO, 128, 64, 2, 2, KC>), T, TO, grid, blk, 0, s, d);
     } else {
         dim3 grid((d.M + 127) / 128, (d.N + 127) / 128, B * d.G);
         if constexpr (sizeof(T) == 2) {
@@ -506,18 +506,18 @@ static void dispatch_tiles(const ConvGemmDev& d, int B, hipStream_t s) {
                     // tiles, FF1, the doubled DMA bytes per flop already cost more than the balance gains)
                     e.Tm = (d.M + 63) / 64; e.Tn = (d.N + 63) / 64; e.RT = B * e.Tm; e.RC = 0;
                     dim3 g2(e.RT * e.Tn, d.G);
-                    if (e.lds_epi) hipLaunchKernelGGL((conv_gemm_dma_kernel<T, TO, true, 2, 64>), g2, blk, 0, s, e);
-                    else hipLaunchKernelGGL((conv_gemm_dma_kernel<T, TO, false, 2, 64>), g2, blk, 0, s, e);
+                    if (e.lds_epi) MI_LAUNCH((conv_gemm_dma_kernel<T, TO, true, 2, 64>), T, TO, g2, blk, 0, s, e);
+                    else MI_LAUNCH((conv_gemm_dma_kernel<T, TO, false, 2, 64>), T, TO, g2, blk, 0, s, e);
                     MI_HIP(hipGetLastError());
                     return;
                 }
                 if (g_ring4 && (long)g1.x * g1.y <= g_ring4_max && nchunks >= 6) {
                     // at most one workgroup per CU: the four-stage ring hides the DMA round trip that the two-buffer
                     // loop exposes when a CU has no second workgroup to switch to
-                    if (e.lds_epi) hipLaunchKernelGGL((conv_gemm_dma_kernel<T, TO, true, 4>), g1, blk, 0, s, e);
-                    else hipLaunchKernelGGL((conv_gemm_dma_kernel<T, TO, false, 4>), g1, blk, 0, s, e);
-                } else if (e.lds_epi) hipLaunchKernelGGL((conv_gemm_dma_kernel<T, TO, true>), g1, blk, 0, s, e);
-                else hipLaunchKernelGGL((conv_gemm_dma_kernel<T, TO, false>), g1, blk, 0, s, e);
+                    if (e.lds_epi) MI_LAUNCH((conv_gemm_dma_kernel<T, TO, true, 4>), T, TO, g1, blk, 0, s, e);
+                    else MI_LAUNCH((conv_gemm_dma_kernel<T, TO, false, 4>), T, TO, g1, blk, 0, s, e);
+                } else if (e.lds_epi) MI_LAUNCH((conv_gemm_dma_kernel<T, TO, true>), T, TO, g1, blk, 0, s, e);
+                else MI_LAUNCH((conv_gemm_dma_kernel<T, TO, false>), T, TO, g1, blk, 0, s, e);
                 MI_HIP(hipGetLastError());
                 return;
             }
@@ -534,19 +534,19 @@ static void dispatch_tiles(const ConvGemmDev& d, int B, hipStream_t s) {
                     // balance the chip (O projection 144 -> 576 workgroups: makespan 3 quarter-tiles instead of 4)
                     e.Tm = (d.M + 63) / 64; e.Tn = (d.N + 63) / 64; e.RT = B * e.Tm; e.RC = 0;
                     dim3 g2(e.RT * e.Tn, d.G);
-                    if (e.lds_epi) hipLaunchKernelGGL((conv_gemm_dma_kernel<T, TO, true, 2, 64>), g2, blk, 0, s, e);
-                    else hipLaunchKernelGGL((conv_gemm_dma_kernel<T, TO, false, 2, 64>), g2, blk, 0, s, e);
+                    if (e.lds_epi) MI_LAUNCH((conv_gemm_dma_kernel<T, TO, true, 2, 64>), T, TO, g2, blk, 0, s, e);
+                    else MI_LAUNCH((conv_gemm_dma_kernel<T, TO, false, 2, 64>), T, TO, g2, blk, 0, s, e);
                     MI_HIP(hipGetLastError());
                     return;
                 }
                 dim3 g1(e.RC > 0 ? 8 * e.RC * e.Tn : e.RT * e.Tn, d.G);
-                if (e.lds_epi) hipLaunchKernelGGL((conv_gemm_dma_kernel<T, TO, true>), g1, blk, 0, s, e);
-                else hipLaunchKernelGGL((conv_gemm_dma_kernel<T, TO, false>), g1, blk, 0, s, e);
+                if (e.lds_epi) MI_LAUNCH((conv_gemm_dma_kernel<T, TO, true>), T, TO, g1, blk, 0, s, e);
+                else MI_LAUNCH((conv_gemm_dma_kernel<T, TO, false>), T, TO, g1, blk, 0, s, e);
                 MI_HIP(hipGetLastError());
                 return;
             }
         }
-        hipLaunchKernelGGL((conv_gemm_kernel<T, TO, 128, 128, 2, 2, KC>), grid, blk, 0, s, d);
+        MI_LAUNCH((conv_gemm_kernel<T, TO, 128, 128, 2, 2, KC>), T, TO, grid, blk, 0, s, d);
     }
     MI_HIP(hipGetLastError());
 }

@@ -244,9 +244,9 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void conv_gemm_dma3_ker
 template <typename T, typename TO>
 void launch_conv_gemm_dma3(const ConvGemmDev& e, int bn, hipStream_t s) {
     const dim3 grid(e.RT * e.Tn, e.G);
-    if (bn == 192) hipLaunchKernelGGL((conv_gemm_dma3_kernel<T, TO, 256, 192, 64, 96, 2, true>), grid, dim3(512), 0, s, e);
-    else if (bn == 256) hipLaunchKernelGGL((conv_gemm_dma3_kernel<T, TO, 256, 256, 128, 64, 2, true>), grid, dim3(512), 0, s, e);
-    else hipLaunchKernelGGL((conv_gemm_dma3_kernel<T, TO, 256, 128, 64, 64, 3>), grid, dim3(512), 0, s, e);
+    if (bn == 192) MI_LAUNCH((conv_gemm_dma3_kernel<T, TO, 256, 192, 64, 96, 2, true>), T, TO, grid, dim3(512), 0, s, e);
+    else if (bn == 256) MI_LAUNCH((conv_gemm_dma3_kernel<T, TO, 256, 256, 128, 64, 2, true>), T, TO, grid, dim3(512), 0, s, e);
+    else MI_LAUNCH((conv_gemm_dma3_kernel<T, TO, 256, 128, 64, 64, 3>), T, TO, grid, dim3(512), 0, s, e);
 }
 
 template void launch_conv_gemm_dma3<f16, f16>(const ConvGemmDev&, int, hipStream_t);

@@ -45,6 +45,8 @@ def load() -> C.CDLL:
     L.mi_bigvgan_param_count.argtypes = [i32p, C.c_int]; L.mi_bigvgan_param_count.restype = C.c_int64
     L.mi_bigvgan_create.argtypes = [i32p, C.c_int, f32p, C.c_int64, C.c_int, C.c_int]
     L.mi_bigvgan_create.restype = vp
+    L.mi_bigvgan_create_mem.argtypes = [i32p, C.c_int, vp, C.c_int64, C.c_int, C.c_int, C.c_int]
+    L.mi_bigvgan_create_mem.restype = vp
     L.mi_bigvgan_destroy.argtypes = [vp]; L.mi_bigvgan_destroy.restype = None
     L.mi_bigvgan_out_len.argtypes = [vp, C.c_int]; L.mi_bigvgan_out_len.restype = C.c_int64
     L.mi_bigvgan_forward.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int]; L.mi_bigvgan_forward.restype = C.c_int
@@ -64,6 +66,8 @@ def load() -> C.CDLL:
     L.mi_f5_param_count.argtypes = [i32p, C.c_int, f32p, C.c_int]; L.mi_f5_param_count.restype = C.c_int64
     L.mi_f5_create.argtypes = [i32p, C.c_int, f32p, C.c_int, f32p, C.c_int64, C.c_int, C.c_int]
     L.mi_f5_create.restype = vp
+    L.mi_f5_create_mem.argtypes = [i32p, C.c_int, f32p, C.c_int, vp, C.c_int64, C.c_int, C.c_int, C.c_int]
+    L.mi_f5_create_mem.restype = vp
     L.mi_f5_destroy.argtypes = [vp]; L.mi_f5_destroy.restype = None
     L.mi_f5_tables.argtypes = [vp, f32p, f32p]; L.mi_f5_tables.restype = C.c_int
     L.mi_f5_preprocess.argtypes = [vp, vp, C.c_int64, vp, C.c_int64, C.c_int64, vp, C.c_uint64, vp, vp, vp, vp, vp,
@@ -84,6 +88,8 @@ def load() -> C.CDLL:
     L.mi_gpt_param_count.argtypes = [C.POINTER(C.c_int32), C.c_int]; L.mi_gpt_param_count.restype = C.c_int64
     L.mi_gpt_create.argtypes = [C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_float), C.c_int64, C.c_int, C.c_int]
     L.mi_gpt_create.restype = C.c_void_p
+    L.mi_gpt_create_mem.argtypes = [C.POINTER(C.c_int32), C.c_int, vp, C.c_int64, C.c_int, C.c_int, C.c_int]
+    L.mi_gpt_create_mem.restype = C.c_void_p
     L.mi_gpt_destroy.argtypes = [vp]; L.mi_gpt_destroy.restype = None
     L.mi_gpt_text_embed.argtypes = [vp, vp, C.c_int, vp, C.c_int]; L.mi_gpt_text_embed.restype = C.c_int
     L.mi_gpt_mel_embed.argtypes = [vp, C.c_int32, C.c_int64, vp, C.c_int]; L.mi_gpt_mel_embed.restype = C.c_int
@@ -106,6 +112,10 @@ def load() -> C.CDLL:
     L.mi_prof_get.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                               C.POINTER(C.c_double)]
     L.mi_prof_get.restype = C.c_int
+    L.mi_prof_kernel_count.argtypes = []; L.mi_prof_kernel_count.restype = C.c_int
+    L.mi_prof_kernel_get.argtypes = [C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64),
+                                     C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.mi_prof_kernel_get.restype = C.c_int
     _lib = L
     return L
 
@@ -154,6 +164,19 @@ def prof_get(family: str) -> dict:
     ms, n, by, fl = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
     check(load().mi_prof_get(family.encode(), C.byref(ms), C.byref(n), C.byref(by), C.byref(fl)), "mi_prof_get")
     return {"ms": ms.value, "launches": n.value, "bytes": by.value, "flops": fl.value}
+
+
+def prof_kernels() -> list:
+    """Per-kernel-instantiation accumulators since the last prof_reset, sorted by total time (descending)."""
+    L = load()
+    out = []
+    for i in range(L.mi_prof_kernel_count()):
+        name, fam = C.create_string_buffer(256), C.create_string_buffer(32)
+        ms, by, fl, n = C.c_double(0), C.c_double(0), C.c_double(0), C.c_int64(0)
+        check(L.mi_prof_kernel_get(i, name, 256, fam, 32, C.byref(ms), C.byref(n), C.byref(by), C.byref(fl)), "mi_prof_kernel_get")
+        out.append({"kernel": name.value.decode(), "family": fam.value.decode(), "ms": ms.value, "launches": int(n.value),
+                    "bytes": by.value, "flops": fl.value})
+    return sorted(out, key=lambda k: -k["ms"])
 
 
 def bench_conv_gemm(dtype: str, B: int, T: int, Cin: int, N: int, taps: int = 1, dil: int = 1, with_res: bool = False,

@@ -18,13 +18,25 @@ from .weights import pack_bigvgan
 
 class BigVGANVocoder:
     def __init__(self, cfg: BigVGANConfig, state: Optional[dict] = None, *, blob: Optional[np.ndarray] = None,
-                 dtype: str = "f32", device: int = 0):
+                 blob_device=None, dtype: str = "f32", device: int = 0):
         self.cfg = cfg
         self.dtype = dtype
         self.device = device
         self._h = None
         L = _lib.load()
         _lib.init(device)
+        if blob_device is not None:          # packed fp32 blob as a CUDA tensor (e.g. filled by an RCCL broadcast)
+            import torch
+            t = blob_device
+            if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.device.index == device):
+                raise ValueError("blob_device must be a contiguous float32 CUDA tensor on the engine's device")
+            ci = np.asarray(cfg.to_int_array(), dtype=np.int32)
+            torch.cuda.current_stream(t.device).synchronize()
+            self._h = L.mi_bigvgan_create_mem(_lib.i32p(ci), len(ci), t.data_ptr(), t.numel(), _lib.DTYPES[dtype], device,
+                                              _lib.MI_DEVICE)
+            if not self._h:
+                raise _lib.MiError("mi_bigvgan_create_mem: " + L.mi_last_error().decode())
+            return
         if blob is None:
             if state is None:
                 raise ValueError("BigVGANVocoder needs a state dict or a packed blob")

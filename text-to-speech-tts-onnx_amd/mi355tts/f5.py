@@ -26,10 +26,28 @@ def _p(a):
 
 class F5Engine:
     def __init__(self, cfg: F5Config, state: Optional[dict] = None, *, blob: Optional[np.ndarray] = None,
-                 dtype: str = "f32", device: int = 0):
+                 blob_device=None, dtype: str = "f32", device: int = 0):
+        """`state`: upstream-named (unfolded) tensors | `blob`: packed fp32 numpy blob | `blob_device`: the same blob as a
+        float32 CUDA tensor on `device` (e.g. the buffer torch.distributed.broadcast filled) — consumed in place."""
         self.cfg, self.dtype, self.device, self._h = cfg, dtype, device, None
         L = _lib.load()
         _lib.init(device)
+        self._ci = np.asarray(cfg.to_int_array(), dtype=np.int32)
+        self._cf = np.asarray(cfg.to_float_array(), dtype=np.float32)
+        if blob_device is not None:
+            import torch
+            t = blob_device
+            if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.device.index == device):
+                raise ValueError("blob_device must be a contiguous float32 CUDA tensor on the engine's device")
+            expect = L.mi_f5_param_count(_lib.i32p(self._ci), len(self._ci), _lib.f32p(self._cf), len(self._cf))
+            if expect != t.numel():
+                raise _lib.MiError(f"weight blob has {t.numel()} floats, config needs {expect}")
+            torch.cuda.current_stream(t.device).synchronize()
+            self._h = L.mi_f5_create_mem(_lib.i32p(self._ci), len(self._ci), _lib.f32p(self._cf), len(self._cf),
+                                         t.data_ptr(), t.numel(), _lib.DTYPES[dtype], device, _lib.MI_DEVICE)
+            if not self._h:
+                raise _lib.MiError("mi_f5_create_mem: " + L.mi_last_error().decode())
+            return
         if blob is None:
             if state is None:
                 raise ValueError("F5Engine needs an (unfolded, upstream-named) state dict or a packed blob")

@@ -346,11 +346,11 @@ F5_BENCH_REF_TEXT = "Some call me nature, others call me mother nature, I am the
 F5_BENCH_GEN_TEXT = "The quick brown fox jumps over the lazy dog while seven wizards brew a potion"
 
 
-def f5_synthetic_inputs(cfg: F5Config, U: int, rank: int = 0):
+def f5_synthetic_inputs(cfg: F5Config, U: int, rank: int = 0, L: int = 144000):
     """BASELINE configs[2]/[3]: 6.0 s reference audio (144000 samples -> 563 frames), equal-length ~15-word ASCII
     ref/gen texts (-> N = 1126 by the duration formula of F5-TTS-ONNX-Inference.py:227-231), char-level ids against
-    the synthetic vocab, injected noise.  Returns (audio (U,L) i16, ids (U,T) i32, N, noise (U,N,mel) f32)."""
-    L = 144000
+    the synthetic vocab, injected noise.  Returns (audio (U,L) i16, ids (U,T) i32, N, noise (U,N,mel) f32).
+    (`L` other than 144000 is for reduced-size plumbing tests only.)"""
     ref_text = F5_BENCH_REF_TEXT
     gen_text = (F5_BENCH_GEN_TEXT + " " * len(ref_text))[:len(ref_text)]
     vocab = synth_vocab(cfg.text_num_embeds)
