@@ -83,6 +83,11 @@ int         mi_bigvgan_forward_latent(mi_bigvgan* h, const float* latent, int T_
  * channels-first host memory; post!=0 selects the pad-15 variant (out T+30).                   */
 int         mi_aa_activation1d(const float* x, int B, int C, int T, const float* alpha_log,
                                const float* beta_log, int logscale, int post, int dtype, float* y);
+/* unit-level entry (tests): the FUSED kernel of the low-channel stages — Activation1d(SnakeBeta) -> Conv1d(C, C, k, dilation,
+ * "same" padding) (+ res): `xt = c(a(x))` / `x = c2(a2(xt)) + x` of AMPBlock1.forward, BigVGAN/modeling_modified/
+ * bigvgan.py:132-140.  x, res, y: (B, C, T) fp32 channels-first host memory; w (C, C, k); C % 8 == 0, C <= 96.             */
+int         mi_aa_conv1d(const float* x, int B, int C, int T, const float* alpha_log, const float* beta_log, int logscale,
+                         const float* w, const float* bias, int k, int dilation, const float* res, int dtype, float* y);
 /* unit-level entry (tests): Conv1d / ConvTranspose1d on fp32 channels-first host tensors,
  * executed by the implicit-GEMM MFMA kernel in `dtype`.                                       */
 int         mi_conv1d(const float* x, int B, int Cin, int T, const float* w, const float* bias, int Cout,
@@ -196,7 +201,9 @@ int         mi_bench_conv_gemm(int dtype, int B, int T, int Cin, int N, int taps
 
 /* test / tuning hook: tile-dispatch thresholds of the implicit-GEMM kernel ("gemm_big_tile_min", "gemm_n192_min",
  * "gemm_mid_tile_min", "gemm_dma3_k_min", "gemm_use_dma3", "gemm_use_dma", "gemm_big_tiles", "gemm_n192", "gemm_f32_dma", "gemm_ring4", "gemm_ring4_max", "gemm_buf", "gemm_f32_small", "gemm_f32_small_max", "gemm_small16_max"), and
- * "gpt_mfma_min" (sentences from which mi_gpt_generate_batch runs its linears on MFMA; default 9).              */
+ * "gpt_mfma_min" (sentences from which mi_gpt_generate_batch runs its linears on MFMA; default 9), and
+ * "aa_conv_deterministic" (1: one workgroup per CU in the fused AA+conv kernel, which makes the 16-bit BigVGAN output
+ * bit-identical from run to run at +19 % forward time; default 0: a few of 10^7 samples may differ by one 16-bit ulp).   */
 int         mi_set_option(const char* key, int64_t value);
 
 /* ---- profiling hooks (bench.py roofline leg) -------------------------------------------------

@@ -124,6 +124,42 @@ def test_aa_vs_oracle_f32(C, T, B, post):
     np.testing.assert_allclose(y, ref, atol=1e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize("C,k,d,T,B", [(24, 3, 1, 700, 2), (24, 11, 5, 300, 1), (48, 7, 3, 515, 2), (96, 11, 5, 260, 1), (96, 3, 1, 130, 2),
+                                       (16, 7, 1, 40, 1), (8, 3, 1, 5, 3)])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_fused_aa_conv_vs_oracle_f32(C, k, d, T, B, with_res):
+    """The fused kernel of the low-channel stages alone (`xt = c(a(x))`, `x = c2(a2(xt)) + x`: one half of an AMPBlock1
+    iteration, bigvgan.py:132-140): tile halos across ragged T, every (k, dilation) of the model, residual on / off."""
+    x = W.synth_normal(5, f"ac{C}{T}", (B, C, T), std=1.5)
+    a = W.synth_normal(6, "a", (C,), std=0.3)
+    b = W.synth_normal(7, "b", (C,), std=0.3)
+    w = W.synth_normal(8, f"w{C}{k}", (C, C, k), std=1.0 / np.sqrt(C * k))
+    bias = W.synth_normal(9, "bias", (C,), std=0.1)
+    res = W.synth_normal(10, f"r{C}{T}", (B, C, T)) if with_res else None
+    ref = O.conv1d(O.activation1d(x, a, b, O.aa_filter()), w, bias, dilation=d, padding=O.get_padding(k, d))
+    if with_res:
+        ref = ref + res
+    y = BV.aa_conv1d(x, a, b, w, bias, dilation=d, res=res)
+    assert y.shape == ref.shape
+    np.testing.assert_allclose(y, ref, atol=3e-5, rtol=1e-5)
+
+
+def test_amp_block_golden_through_fused_kernels(g, small_voc):
+    """G8a: the three AMPBlock1 of the reference (BigVGAN/modeling_modified/bigvgan.py:132-140, k = 3 / 7 / 11, dilations 1,3,5)
+    rebuilt from six fused AA+conv launches each, against the reference's own block outputs `amp_y*`."""
+    cfg, st, v = small_voc
+    x = g["amp_x"]
+    for j, k in enumerate(cfg.resblock_kernel_sizes):
+        cur = x
+        for l, d in enumerate(cfg.resblock_dilation_sizes[j]):
+            p = f"resblocks.{j}."
+            t = BV.aa_conv1d(cur, st[p + f"activations.{2 * l}.act.alpha"], st[p + f"activations.{2 * l}.act.beta"],
+                             st[p + f"convs1.{l}.weight"], st[p + f"convs1.{l}.bias"], dilation=d)
+            cur = BV.aa_conv1d(t, st[p + f"activations.{2 * l + 1}.act.alpha"], st[p + f"activations.{2 * l + 1}.act.beta"],
+                               st[p + f"convs2.{l}.weight"], st[p + f"convs2.{l}.bias"], dilation=1, res=cur)
+        np.testing.assert_allclose(cur, g[f"amp_y{j}"], atol=3e-5)
+
+
 def test_aa_f16_storage():
     x = W.synth_normal(5, "aah", (2, 48, 500), std=1.5)
     a = W.synth_normal(6, "a", (48,), std=0.3)
@@ -243,10 +279,23 @@ def test_full_size_reference_fixture(full_state, golden_dir):
     assert w8.shape == (8, 1, 131102)
     err16 = rms((w8[0, 0] - ref) / 32767.0)
     assert err16 < 2e-2, err16
+    # batch position does not change an item's result: bit-identical with the reproducible tile policy (one workgroup per
+    # CU in the fused AA+conv kernel); the default policy (two per CU, 19 % faster) may flip a few of 10^7 intermediate
+    # values by one fp16 ulp (tools/ubench/aa_race.hip), i.e. a handful of output samples by a few LSB
+    from mi355tts import _lib
     wt = v.run(np.repeat(mel8[:1], 8, axis=0))
     for b in range(8):
-        assert np.array_equal(wt[b], wt[0])
-    assert np.array_equal(wt[0], w8[0])                              # batch position does not change an item's result
+        d = np.abs(wt[b, 0].astype(np.int32) - wt[0, 0].astype(np.int32))
+        assert d.max() <= 64 and (d > 0).mean() < 1e-2, (b, d.max(), (d > 0).mean())
+    _lib.set_option("aa_conv_deterministic", 1)
+    try:
+        wd = v.run(np.repeat(mel8[:1], 8, axis=0))
+        for b in range(8):
+            assert np.array_equal(wd[b], wd[0])
+        assert np.array_equal(wd, v.run(np.repeat(mel8[:1], 8, axis=0)))
+        assert rms((wd[0, 0] - ref) / 32767.0) < 2e-2
+    finally:
+        _lib.set_option("aa_conv_deterministic", 0)
     v.close()
     print(f"BigVGAN full size vs reference: fp32 rms {err32:.2e} (max |d| {d.max()} LSB), fp16 B=8 rms {err16:.2e}")
 

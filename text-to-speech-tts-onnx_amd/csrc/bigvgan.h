@@ -53,6 +53,8 @@ struct BigVGAN {
 
 void unit_aa_activation1d(const float* x, int B, int C, int T, const float* alpha_log, const float* beta_log,
                           int logscale, int post, int dtype, float* y);
+void unit_aa_conv1d(const float* x, int B, int C, int T, const float* alpha_log, const float* beta_log, int logscale,
+                    const float* w, const float* bias, int k, int dil, const float* res, int dtype, int repeat, float* y);
 void unit_conv1d(const float* x, int B, int Cin, int T, const float* w, const float* bias, int Cout, int k, int dil,
                  int padding, int groups, int dtype, float* y);
 void unit_conv_transpose1d(const float* x, int B, int Cin, int T, const float* w, const float* bias, int Cout, int k,

@@ -364,6 +364,34 @@ void unit_aa_activation1d(const float* x, int B, int C, int T, const float* alph
     MI_HIP(hipStreamSynchronize(ts.s));
 }
 
+// fused AA-SnakeBeta -> Conv1d(C, C, k, dil, "same") (+ residual): one half of an AMPBlock1 iteration (bigvgan.py:132-140)
+void unit_aa_conv1d(const float* x, int B, int C, int T, const float* alpha_log, const float* beta_log, int logscale,
+                    const float* w, const float* bias, int k, int dil, const float* res, int dtype, int repeat, float* y) {
+    TmpStream ts;
+    DevBuf dx, dxl, dw, db, da, dib, dr, drl, dyl, dy;
+    const size_t es = dtype_size(dtype), n = (size_t)B * C * T;
+    upload_f32(dx, x, n, ts.s);
+    dxl.ensure(n * es); dyl.ensure(n * es); dy.ensure(n * 4);
+    launch_ncl_to_nlc(dx.as<float>(), dxl.p, B, C, T, C, dtype, ts.s);
+    if (res) {
+        upload_f32(dr, res, n, ts.s);
+        drl.ensure(n * es);
+        launch_ncl_to_nlc(dr.as<float>(), drl.p, B, C, T, C, dtype, ts.s);
+    }
+    make_snake(alpha_log, beta_log, C, logscale, da, dib, ts.s);
+    std::vector<float> wl;
+    relayout_conv(w, C, C, k, C, wl);
+    upload_as(dw, wl.data(), wl.size(), dtype, ts.s);
+    upload_f32(db, bias, C, ts.s);
+    AAConv a;
+    a.dtype = dtype; a.x = dxl.p; a.w = dw.p; a.bias = db.as<float>(); a.snake_alpha = da.as<float>();
+    a.snake_inv_beta = dib.as<float>(); a.out = dyl.p; a.res = res ? drl.p : nullptr; a.B = B; a.T = T; a.C = C; a.k = k; a.dil = dil;
+    for (int r = 0; r < std::max(repeat, 1); ++r) launch_aa_conv(a, ts.s);      // repeat > 1: tuning / stress runs
+    launch_nlc_to_ncl(dyl.p, dy.as<float>(), B, C, T, dtype, ts.s);
+    MI_HIP(hipMemcpyAsync(y, dy.p, n * 4, hipMemcpyDeviceToHost, ts.s));
+    MI_HIP(hipStreamSynchronize(ts.s));
+}
+
 void unit_conv1d(const float* x, int B, int Cin, int T, const float* w, const float* bias, int Cout, int k, int dil,
                  int padding, int groups, int dtype, float* y) {
     MI_REQUIRE(Cin % groups == 0 && Cout % groups == 0, "conv1d: groups");

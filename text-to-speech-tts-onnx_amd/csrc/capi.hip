@@ -143,6 +143,15 @@ int mi_aa_activation1d(const float* x, int B, int C, int T, const float* alpha_l
     });
 }
 
+int mi_aa_conv1d(const float* x, int B, int C, int T, const float* alpha_log, const float* beta_log, int logscale,
+                 const float* w, const float* bias, int k, int dilation, const float* res, int dtype, float* y) {
+    return guard([&] {
+        MI_REQUIRE(x && y && w && bias && alpha_log && beta_log && B > 0 && C > 0 && T > 0 && k > 0 && (k & 1) && dilation > 0,
+                   "mi_aa_conv1d: bad arguments");
+        unit_aa_conv1d(x, B, C, T, alpha_log, beta_log, logscale, w, bias, k, dilation, res, dtype, 1, y);
+    });
+}
+
 int mi_conv1d(const float* x, int B, int Cin, int T, const float* w, const float* bias, int Cout, int k, int dilation,
               int padding, int groups, int dtype, float* y) {
     return guard([&] {
@@ -668,7 +677,7 @@ int mi_bench_conv_gemm(int dtype, int B, int T, int Cin, int N, int taps, int di
 int mi_set_option(const char* key, int64_t value) {
     return guard([&] {
         MI_REQUIRE(key != nullptr, "mi_set_option: null key");
-        MI_REQUIRE(gemm_set_option(key, (long)value) || gpt_set_option(key, (long)value), "mi_set_option: unknown key");
+        MI_REQUIRE(gemm_set_option(key, (long)value) || gpt_set_option(key, (long)value) || aa_conv_set_option(key, (long)value), "mi_set_option: unknown key");
         option_epoch_bump();
     });
 }

@@ -186,6 +186,7 @@ struct AAConv {
     float alpha = 1.f; int accumulate = 0;
 };
 void launch_aa_conv(const AAConv& p, hipStream_t s);
+bool aa_conv_set_option(const char* key, long v);
 
 // layout helpers (elementwise.hip)
 // (B,C,T) fp32 channels-first -> (B,T,Cpad) dtype channels-last (zero padded channels)

@@ -56,6 +56,8 @@ def load() -> C.CDLL:
     L.mi_bigvgan_forward_latent.restype = C.c_int
     L.mi_aa_activation1d.argtypes = [f32p, C.c_int, C.c_int, C.c_int, f32p, f32p, C.c_int, C.c_int, C.c_int, f32p]
     L.mi_aa_activation1d.restype = C.c_int
+    L.mi_aa_conv1d.argtypes = [f32p, C.c_int, C.c_int, C.c_int, f32p, f32p, C.c_int, f32p, f32p, C.c_int, C.c_int, f32p, C.c_int, f32p]
+    L.mi_aa_conv1d.restype = C.c_int
     L.mi_conv1d.argtypes = [f32p, C.c_int, C.c_int, C.c_int, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                             C.c_int, f32p]
     L.mi_conv1d.restype = C.c_int

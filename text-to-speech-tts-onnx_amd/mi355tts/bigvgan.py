@@ -165,6 +165,24 @@ def aa_activation1d(x, alpha_log, beta_log, *, post=False, logscale=True, dtype=
     return y
 
 
+def aa_conv1d(x, alpha_log, beta_log, w, b, *, dilation=1, res=None, logscale=True, dtype="f32"):
+    """The fused kernel of the low-channel stages: conv(Activation1d(x)) (+ res), "same" padding; C % 8 == 0, C <= 96."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    B, Cc, T = x.shape
+    if w.shape[0] != Cc or w.shape[1] != Cc:
+        raise ValueError("aa_conv1d: weight must be (C, C, k)")
+    a = np.ascontiguousarray(alpha_log, dtype=np.float32)
+    bb = np.ascontiguousarray(beta_log, dtype=np.float32)
+    bias = np.ascontiguousarray(b, dtype=np.float32)
+    r = np.ascontiguousarray(res, dtype=np.float32) if res is not None else None
+    y = np.empty_like(x)
+    _lib.check(_lib.load().mi_aa_conv1d(_lib.f32p(x), B, Cc, T, _lib.f32p(a), _lib.f32p(bb), int(logscale), _lib.f32p(w),
+                                        _lib.f32p(bias), w.shape[2], dilation, _lib.f32p(r) if r is not None else None,
+                                        _lib.DTYPES[dtype], _lib.f32p(y)), "mi_aa_conv1d")
+    return y
+
+
 def conv1d(x, w, b=None, *, dilation=1, padding=0, groups=1, dtype="f32"):
     x = np.ascontiguousarray(x, dtype=np.float32)
     w = np.ascontiguousarray(w, dtype=np.float32)
