@@ -200,7 +200,7 @@ int         mi_bench_conv_gemm(int dtype, int B, int T, int Cin, int N, int taps
                                double* ms);
 
 /* test / tuning hook: tile-dispatch thresholds of the implicit-GEMM kernel ("gemm_big_tile_min", "gemm_n192_min",
- * "gemm_mid_tile_min", "gemm_dma3_k_min", "gemm_use_dma3", "gemm_use_dma", "gemm_big_tiles", "gemm_n192", "gemm_f32_dma", "gemm_ring4", "gemm_ring4_max", "gemm_buf", "gemm_f32_small", "gemm_f32_small_max", "gemm_small16_max"), and
+ * "gemm_mid_tile_min", "gemm_dma3_k_min", "gemm_use_dma3", "gemm_use_dma", "gemm_big_tiles", "gemm_n192", "gemm_f32_dma", "gemm_ring4", "gemm_ring4_max", "gemm_buf", "gemm_f32_small", "gemm_f32_small_max", "gemm_small16_max", "gemm_sk" (stream-K linear layers: 0 off, 1 fp32, 2 also 16-bit), "gemm_sk_stages", "gemm_sk_max_tiles"), and
  * "gpt_mfma_min" (sentences from which mi_gpt_generate_batch runs its linears on MFMA; default 9), and
  * "aa_conv_deterministic" (1: one workgroup per CU in the fused AA+conv kernel, which makes the 16-bit BigVGAN output
  * bit-identical from run to run at +19 % forward time; default 0: a few of 10^7 samples may differ by one 16-bit ulp).   */

@@ -316,7 +316,7 @@ def test_bad_inputs_raise(small_voc):
 # only when the launch fills the chip) and compared with the oracle
 # ---------------------------------------------------------------------------------------------
 _DEFAULTS = {"gemm_big_tile_min": 160, "gemm_n192_min": 160, "gemm_mid_tile_min": 160, "gemm_dma3_k_min": 2048,
-             "gemm_use_dma3": 1, "gemm_use_dma": 1, "gemm_big_tiles": 1, "gemm_n192": 1, "gemm_f32_dma": 1, "gemm_ring4": 1, "gemm_ring4_max": 256, "gemm_buf": 1, "gemm_f32_small": 1, "gemm_f32_small_max": 1024, "gemm_small16_max": 256}
+             "gemm_use_dma3": 1, "gemm_use_dma": 1, "gemm_big_tiles": 1, "gemm_n192": 1, "gemm_f32_dma": 1, "gemm_ring4": 1, "gemm_ring4_max": 256, "gemm_buf": 1, "gemm_f32_small": 1, "gemm_f32_small_max": 1024, "gemm_small16_max": 256, "gemm_sk": 1, "gemm_sk_stages": 0}
 
 
 @pytest.fixture
@@ -358,6 +358,35 @@ def test_gemm_tile_configs_vs_oracle(gemm_options, cfg_name, opts, Ci, Co, k, d,
     assert rms(y - ref) / rms(ref) < tol, cfg_name
     # element-wise too (a transposed or shifted tile would pass an RMS-of-noise check only by accident)
     assert np.abs(y - ref).max() < 40 * tol * rms(ref), cfg_name
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 0.0), ("f16", 6e-3), ("bf16", 4e-2)])
+@pytest.mark.parametrize("stages", [0, 2, 3, 4])
+@pytest.mark.parametrize("Ci,Co,T,B", [(256, 1000, 1500, 1), (512, 1024, 1126, 2), (128, 3072, 700, 2), (1024, 1024, 1126, 2)])
+def test_stream_k_linear_vs_oracle(gemm_options, dtype, tol, stages, Ci, Co, T, B):
+    """gemm_sk.hip: persistent workgroups over equal (tile, K chunk) ranges; tiles split between workgroups are summed in range
+    order by the owner of the tile's first chunk.  Ragged M / N tails, every ring depth, partial tiles of 2..many pieces, and
+    bit-identical results from run to run (the fix-up order is fixed)."""
+    from mi355tts import _lib
+    _lib.set_option("gemm_sk", 2)
+    _lib.set_option("gemm_sk_stages", stages)
+    x = W.synth_normal(1, f"skx{Ci}{T}", (B, Ci, T))
+    w = W.synth_normal(2, f"skw{Ci}{Co}", (Co, Ci, 1), std=1.0 / np.sqrt(Ci))
+    b = W.synth_normal(3, "skb", (Co,), std=0.1)
+    ref = O.conv1d(x, w, b)
+    y = BV.conv1d(x, w, b, dtype=dtype)
+    assert y.shape == ref.shape
+    if dtype == "f32":
+        np.testing.assert_allclose(y, ref, atol=3e-5, rtol=1e-5)
+    else:
+        assert rms(y - ref) / rms(ref) < tol
+    assert np.array_equal(y, BV.conv1d(x, w, b, dtype=dtype))
+    _lib.set_option("gemm_sk", 0)
+    y0 = BV.conv1d(x, w, b, dtype=dtype)                    # one tile per workgroup: same products, other summation split
+    if dtype == "f32":
+        np.testing.assert_allclose(y, y0, atol=3e-5, rtol=1e-5)
+    else:
+        assert rms(y - y0) / rms(ref) < tol
 
 
 @pytest.mark.parametrize("f32_dma,small,buf", [(1, 1, 1), (1, 0, 1), (1, 1, 0), (1, 0, 0), (0, 1, 1)])

@@ -417,6 +417,9 @@ void unit_conv1d(const float* x, int B, int Cin, int T, const float* w, const fl
     p.dtype = dtype; p.x = dxl.p; p.w = dw.p; p.bias = bias ? db.as<float>() : nullptr; p.out = dyl.p;
     p.B = B; p.G = groups; p.T_in = T; p.M = To; p.N = cog; p.Cin = cigp; p.taps = k; p.dil = dil; p.pad = padding;
     p.x_bstride = (long)T * Cp; p.x_rstride = Cp; p.x_goff = cigp; p.out_bstride = (long)To * Cout; p.out_rstride = Cout;
+    SkWorkspace skw;                                    // lets one-tap shapes reach the stream-K kernel (gemm_sk.hip)
+    skw.ensure(512, ts.s);
+    skw.attach(p);
     launch_conv_gemm(p, ts.s);
     launch_nlc_to_ncl(dyl.p, dy.as<float>(), B, Cout, To, dtype, ts.s);
     MI_HIP(hipMemcpyAsync(y, dy.p, (size_t)B * Cout * To * 4, hipMemcpyDeviceToHost, ts.s));

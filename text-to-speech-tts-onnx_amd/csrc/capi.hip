@@ -657,6 +657,9 @@ int mi_bench_conv_gemm(int dtype, int B, int T, int Cin, int N, int taps, int di
         p.dtype = dtype; p.x = x.p; p.w = w.p; p.bias = bias.as<float>(); p.out = o.p; p.res = with_res ? r.p : nullptr;
         p.B = B; p.T_in = T; p.M = T; p.N = N; p.Cin = Cin; p.taps = taps; p.dil = dil; p.pad = (taps * dil - dil) / 2;
         p.x_bstride = (long)T * Cin; p.x_rstride = Cin; p.out_bstride = (long)T * N; p.out_rstride = N;
+        SkWorkspace skw;
+        skw.ensure(512, s);
+        skw.attach(p);
         for (int i = 0; i < 3; ++i) launch_conv_gemm(p, s);
         hipEvent_t e0, e1;
         MI_HIP(hipEventCreate(&e0)); MI_HIP(hipEventCreate(&e1));

@@ -159,8 +159,17 @@ struct ConvGemm {
     void* out2 = nullptr; void* out3 = nullptr;
     int rows_per_item = 0;        // EPI_QKV_ROPE with the batch flattened into M: tokens per batch item (0: M)
     long v_ld = 0;                // > 0: V is written transposed, [b*H + h][head_dim][v_ld] (keys contiguous)
+    // stream-K workspace of the caller (gemm_sk.hip): sk_slots x 64 KB of partial tiles + sk_slots zero-initialised flags;
+    // null: plain linear layers run one tile per workgroup
+    float* sk_ws = nullptr; int* sk_flags = nullptr; int sk_slots = 0;
 };
 void launch_conv_gemm(const ConvGemm& p, hipStream_t s);
+// owner of a stream-K workspace (one per engine handle / stream)
+struct SkWorkspace {
+    DevBuf ws, flags; int slots = 0;
+    void ensure(int n_slots, hipStream_t s);
+    void attach(ConvGemm& g) const { g.sk_ws = ws.as<float>(); g.sk_flags = flags.as<int>(); g.sk_slots = slots; }
+};
 bool gemm_set_option(const char* key, long v);
 
 // anti-aliased SnakeBeta (aa_act.hip); channels-last (B,T,C) -> (B,T+2*shift,C)

@@ -55,6 +55,7 @@ struct F5 {
     void steps_eager(int U, int N, int k0, int nsteps);
 
     // ---- workspace ----
+    SkWorkspace sk;          // stream-K partial-tile slots of this handle's stream
     int ws_U = 0, ws_N = 0;
     DevBuf d_noise, d_cmt, d_cmtd, cat, h32, hT, c1, X, Ub, qb, kb, vb, Ob, Hff, pred;
     DevBuf p_audio, p_pad, p_spec, p_mag, p_mel, p_ids, p_tid, p_err, p_tx, p_ty, p_ty2, p_ss;

@@ -322,6 +322,7 @@ void F5::ensure_workspace(int U, int N) {
     const F5Cfg& c = cfg;
     const size_t es = dtype_size(dtype);
     const size_t rows = (size_t)2 * Um * Nm;
+    sk.ensure(512, stream);
     d_noise.ensure((size_t)Um * Nm * c.mel * 4);
     d_cmt.ensure((size_t)Um * Nm * c.cond_dim() * 4);
     d_cmtd.ensure((size_t)Um * Nm * c.cond_dim() * 4);
@@ -356,6 +357,7 @@ void F5::gemm(int dt, const void* x, long xb, long xr, int K, const Lin& L, void
     g.res = res; g.gate = gate; g.gate_bstride = 0;
     g.B = B; g.T_in = M; g.M = M; g.N = L.n; g.Cin = K; g.taps = 1;
     g.x_bstride = xb; g.x_rstride = xr; g.out_bstride = ob; g.out_rstride = orr; g.act = act;
+    sk.attach(g);
     if (B > 1 && xb == (long)M * xr && ob == (long)M * orr) {      // rows of all batch items are contiguous: one M axis
         g.B = 1; g.T_in = B * M; g.M = B * M;                      // (no per-item tile padding: 2252 rows -> 9 tiles, not 10)
     }
@@ -533,6 +535,7 @@ void F5::dit_eval(int U, int N, int k) {
             g.N = 3 * d; g.Cin = d; g.x_bstride = (long)B * N * d; g.x_rstride = d;
             g.epi = EPI_QKV_ROPE; g.rope_cos = rope_cos.as<float>(); g.rope_sin = rope_sin.as<float>(); g.rope_pack = rope_pack.p; g.heads = H; g.head_dim = D;
             g.v_ld = attention_v_ld(N, dtype);
+            sk.attach(g);
             launch_conv_gemm(g, s);
         }
         launch_attention(qb.p, kb.p, vb.p, Ob.p, B * H, H, N, dtype, s);

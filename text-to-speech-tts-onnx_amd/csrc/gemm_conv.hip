@@ -432,6 +432,12 @@ static long g_big_min = 160, g_n192_min = 160, g_mid_min = 160, g_k_min = 2048;
 static bool g_n192 = true, g_f32_dma = true, g_ring4 = true, g_f32_small = true;
 static long g_f32_small_max = 1024, g_small16_max = 256;
 static long g_ring4_max = 256;
+// stream-K (gemm_sk.hip): 0 off ; 1 fp32 linear layers ; 2 also 16-bit ; g_sk_stages: ring depth override (0 = automatic) ;
+// g_sk_max_tiles: only launches with at most this many 128x128 tiles (beyond that one tile per workgroup balances by itself)
+static long g_sk = 1, g_sk_stages = 0, g_sk_max_tiles = 2048, g_sk_order = -1;
+// fp32 QKV + RoPE: its scatter epilogue is slow and in a persistent launch every workgroup runs it at the same time at the
+// end (in-model 184 us against 138 us for the 64x64 tiles, whose epilogues overlap other workgroups' main loops): off
+static long g_sk_qkv32 = 0;
 static DevBuf g_zero_page[16];
 
 // buffer-descriptor DMA (BUF kernels): whole 64-deep chunks only, and every byte offset must fit the 32-bit range check
@@ -453,6 +459,20 @@ static void dispatch_tiles(const ConvGemmDev& d, int B, hipStream_t s) {
         MI_LAUNCH((conv_gemm_kernel<T, TO, 128, 64, 2, 2, KC>), T, TO, grid, blk, 0, s, d);
     } else {
         dim3 grid((d.M + 127) / 128, (d.N + 127) / 128, B * d.G);
+        {
+            // plain linear layer (one tap, one group, one M axis, whole K chunks): stream-K over persistent workgroups
+            constexpr int KCB = 128 / (int)sizeof(T);
+            const long tiles = (long)((d.M + 127) / 128) * ((d.N + 127) / 128);
+            if (g_sk >= (sizeof(T) == 4 ? 1 : 2) && d.sk_ws && d.sk_slots >= 256 && B == 1 && d.G == 1 && d.K == d.Cin && d.Cin % KCB == 0 &&
+                (d.epi == EPI_PLAIN || (d.epi == EPI_QKV_ROPE && (sizeof(T) == 2 || g_sk_qkv32))) && buf_ok(d, (int)sizeof(T)) && d.M > 128 && tiles >= 64 && tiles <= g_sk_max_tiles && d.pad == 0) {
+                ConvGemmDev e = d;
+                e.Tm = (d.M + 127) / 128; e.Tn = (d.N + 127) / 128; e.RT = e.Tm;
+                e.RC = d.M <= d.N ? 0 : 1;      // per-XCD groups: whole weight panels (x re-read 8x) when x is the smaller operand, else whole row tiles
+                if (g_sk_order >= 0) e.RC = (int)g_sk_order;
+                launch_linear_sk<T, TO>(e, (int)g_sk_stages, s);
+                return;
+            }
+        }
         if constexpr (sizeof(T) == 2) {
             // measured on gfx950 (tools/gemm_bench.py): with <= 32 K-chunks the 4-wave 128x128 kernel (two workgroups
             // per CU, short prologue/epilogue) wins; deeper K favours the 8-wave 256-row tiles.
@@ -569,11 +589,20 @@ bool gemm_set_option(const char* key, long v) {
     else if (k == "gemm_f32_small_max") g_f32_small_max = v;
     else if (k == "gemm_small16_max") g_small16_max = v;
     else if (k == "gemm_ring4_max") g_ring4_max = v;
+    else if (k == "gemm_sk") g_sk = v;
+    else if (k == "gemm_sk_stages") g_sk_stages = v;
+    else if (k == "gemm_sk_max_tiles") g_sk_max_tiles = v;
+    else if (k == "gemm_sk_qkv32") g_sk_qkv32 = v;
     else return false;
     return true;
 }
 
-void launch_conv_gemm(const ConvGemm& p, hipStream_t s) {
+void launch_conv_gemm(const ConvGemm& p_in, hipStream_t s) {
+    ConvGemm p = p_in;
+    if (p.B > 1 && p.taps == 1 && p.G == 1 && p.pad == 0 && p.epi == EPI_PLAIN && p.M == p.T_in && p.gate_bstride == 0 &&
+        p.x_bstride == (long)p.M * p.x_rstride && p.out_bstride == (long)p.M * p.out_rstride) {
+        p.T_in = p.M = p.B * p.M; p.B = 1;          // one-tap GEMM over contiguous batch items: a single M axis
+    }
     const int odt = p.out_dtype < 0 ? p.dtype : p.out_dtype;
     const int vec = 16 / (int)dtype_size(p.dtype);
     MI_REQUIRE(p.Cin % vec == 0, "conv_gemm: Cin must be a multiple of the 16-byte vector");
@@ -591,6 +620,7 @@ void launch_conv_gemm(const ConvGemm& p, hipStream_t s) {
     d.u = p.u; d.Cout = p.Cout; d.padT = p.padT; d.T_out = p.T_out;
     d.rope_cos = p.rope_cos; d.rope_sin = p.rope_sin; d.rope_pack = p.rope_pack; d.heads = p.heads; d.head_dim = p.head_dim;
     d.out2 = p.out2; d.out3 = p.out3; d.v_ld = p.v_ld; d.Mb = p.rows_per_item;
+    d.sk_ws = p.sk_ws; d.sk_flags = p.sk_flags; d.sk_slots = p.sk_slots;
     d.use_buf = 0;
     {
         static std::once_flag env_once;      // handles on different threads may launch concurrently
@@ -607,6 +637,9 @@ void launch_conv_gemm(const ConvGemm& p, hipStream_t s) {
             if (const char* n = std::getenv("MI355TTS_F32_SMALL_MAX")) g_f32_small_max = std::atol(n);
             if (const char* n = std::getenv("MI355TTS_SMALL16_MAX")) g_small16_max = std::atol(n);
             if (const char* n = std::getenv("MI355TTS_RING4_MAX")) g_ring4_max = std::atol(n);
+            if (const char* n = std::getenv("MI355TTS_SK")) g_sk = std::atol(n);
+            if (const char* n = std::getenv("MI355TTS_SK_STAGES")) g_sk_stages = std::atol(n);
+            if (const char* n = std::getenv("MI355TTS_SK_ORDER")) g_sk_order = std::atol(n);
         });
         int dev = 0;
         MI_HIP(hipGetDevice(&dev));
@@ -661,6 +694,15 @@ void launch_conv_gemm(const ConvGemm& p, hipStream_t s) {
         if (odt == MI_F32) dispatch_tiles<bf16, float>(d, p.B, s);
         else dispatch_tiles<bf16, bf16>(d, p.B, s);
     }
+}
+
+void SkWorkspace::ensure(int n_slots, hipStream_t s) {
+    if (n_slots <= slots) return;
+    ws.ensure((size_t)n_slots * 128 * 128 * 4);
+    flags.ensure((size_t)n_slots * 4);
+    MI_HIP(hipMemsetAsync(flags.p, 0, (size_t)n_slots * 4, s));
+    MI_HIP(hipStreamSynchronize(s));
+    slots = n_slots;
 }
 
 }  // namespace mi

@@ -36,6 +36,7 @@ struct ConvGemmDev {
     int lds_epi;           // 1: outputs leave through the LDS-staged, 16-byte-store epilogue (alignment checked on the host)
     int use_buf;           // 128x128 DMA kernel: 1 = LDS-DMA through buffer descriptors (whole K chunks, offsets fit 31 bits)
     int Tm, Tn, RT, RC;    // XCD-aware tile order (DMA kernel): M-tiles per batch item, N-tiles, row tiles (B*Tm), rows per XCD
+    float* sk_ws; int* sk_flags; int sk_slots;   // stream-K (gemm_sk.hip): 64 KB partial-tile slot + flag per persistent workgroup
 };
 
 // Shared epilogue: 32x32 accumulator tiles -> bias / activation / gate / residual / alpha / accumulate -> HBM,
@@ -365,6 +366,8 @@ typedef __attribute__((address_space(3))) void lds_void;
 
 // gemm_dma3.hip: the 8-wave 256-row kernels (bn = 192 / 256: buffer-descriptor DMA, bn = 128: three-stage ring)
 template <typename T, typename TO> void launch_conv_gemm_dma3(const ConvGemmDev& e, int bn, hipStream_t s);
+// gemm_sk.hip: stream-K 128x128 kernel for plain linear layers (stages: 0 = automatic)
+template <typename T, typename TO> void launch_linear_sk(const ConvGemmDev& e, int stages, hipStream_t s);
 
 
 }  // namespace mi
