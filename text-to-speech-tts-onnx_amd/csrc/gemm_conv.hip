@@ -438,6 +438,8 @@ static long g_sk = 1, g_sk_stages = 0, g_sk_max_tiles = 2048, g_sk_order = -1;
 // fp32 QKV + RoPE: its scatter epilogue is slow and in a persistent launch every workgroup runs it at the same time at the
 // end (in-model 184 us against 138 us for the 64x64 tiles, whose epilogues overlap other workgroups' main loops): off
 static long g_sk_qkv32 = 0;
+// 256x256 eight-phase kernel (gemm_ph8.hip) for 16-bit linear layers with at least g_ph8_min_tiles tiles of 256x256
+static long g_ph8 = 1, g_ph8_min_tiles = 200, g_ph8_order = 1;
 static DevBuf g_zero_page[16];
 
 // buffer-descriptor DMA (BUF kernels): whole 64-deep chunks only, and every byte offset must fit the 32-bit range check
@@ -459,6 +461,17 @@ static void dispatch_tiles(const ConvGemmDev& d, int B, hipStream_t s) {
         MI_LAUNCH((conv_gemm_kernel<T, TO, 128, 64, 2, 2, KC>), T, TO, grid, blk, 0, s, d);
     } else {
         dim3 grid((d.M + 127) / 128, (d.N + 127) / 128, B * d.G);
+        if constexpr (sizeof(T) == 2) {
+            // many row tiles (a batch of utterances): the 8-wave 256x256 eight-phase main loop
+            const long tiles256 = (long)((d.M + 255) / 256) * ((d.N + 255) / 256);
+            if (g_ph8 && B == 1 && d.G == 1 && d.K == d.Cin && d.Cin % 64 == 0 && d.pad == 0 && d.N % 64 == 0 && buf_ok(d, 2) &&
+                d.lds_epi && (d.epi == EPI_PLAIN || d.epi == EPI_QKV_ROPE) && tiles256 >= g_ph8_min_tiles) {
+                ConvGemmDev e = d;
+                e.Tm = (d.M + 255) / 256; e.Tn = (d.N + 255) / 256; e.RT = e.Tm; e.RC = (int)g_ph8_order;
+                launch_linear_ph8<T, TO>(e, s);
+                return;
+            }
+        }
         {
             // plain linear layer (one tap, one group, one M axis, whole K chunks): stream-K over persistent workgroups
             constexpr int KCB = 128 / (int)sizeof(T);
@@ -593,6 +606,9 @@ bool gemm_set_option(const char* key, long v) {
     else if (k == "gemm_sk_stages") g_sk_stages = v;
     else if (k == "gemm_sk_max_tiles") g_sk_max_tiles = v;
     else if (k == "gemm_sk_qkv32") g_sk_qkv32 = v;
+    else if (k == "gemm_ph8") g_ph8 = v;
+    else if (k == "gemm_ph8_min_tiles") g_ph8_min_tiles = v;
+    else if (k == "gemm_ph8_order") g_ph8_order = v;
     else return false;
     return true;
 }
@@ -640,6 +656,9 @@ void launch_conv_gemm(const ConvGemm& p_in, hipStream_t s) {
             if (const char* n = std::getenv("MI355TTS_SK")) g_sk = std::atol(n);
             if (const char* n = std::getenv("MI355TTS_SK_STAGES")) g_sk_stages = std::atol(n);
             if (const char* n = std::getenv("MI355TTS_SK_ORDER")) g_sk_order = std::atol(n);
+            if (const char* n = std::getenv("MI355TTS_PH8")) g_ph8 = std::atol(n);
+            if (const char* n = std::getenv("MI355TTS_PH8_MIN")) g_ph8_min_tiles = std::atol(n);
+            if (const char* n = std::getenv("MI355TTS_PH8_ORDER")) g_ph8_order = std::atol(n);
         });
         int dev = 0;
         MI_HIP(hipGetDevice(&dev));
