@@ -316,7 +316,7 @@ def test_bad_inputs_raise(small_voc):
 # only when the launch fills the chip) and compared with the oracle
 # ---------------------------------------------------------------------------------------------
 _DEFAULTS = {"gemm_big_tile_min": 160, "gemm_n192_min": 160, "gemm_mid_tile_min": 160, "gemm_dma3_k_min": 2048,
-             "gemm_use_dma3": 1, "gemm_use_dma": 1, "gemm_big_tiles": 1, "gemm_n192": 1, "gemm_f32_dma": 1, "gemm_ring4": 1, "gemm_ring4_max": 256, "gemm_buf": 1, "gemm_f32_small": 1, "gemm_f32_small_max": 1024, "gemm_small16_max": 256, "gemm_sk": 1, "gemm_sk_stages": 0, "gemm_ph8": 1, "gemm_ph8_min_tiles": 200, "gemm_ph8_order": 1}
+             "gemm_use_dma3": 1, "gemm_use_dma": 1, "gemm_big_tiles": 1, "gemm_n192": 1, "gemm_f32_dma": 1, "gemm_ring4": 1, "gemm_ring4_max": 256, "gemm_buf": 1, "gemm_f32_small": 1, "gemm_f32_small_max": 1024, "gemm_small16_max": 256, "gemm_sk": 1, "gemm_sk_stages": 0, "gemm_ph8": 1, "gemm_ph8_min_tiles": 200, "gemm_ph8_order": 1, "gemm_ph8_split_max": 4}
 
 
 @pytest.fixture
@@ -392,11 +392,13 @@ def test_stream_k_linear_vs_oracle(gemm_options, dtype, tol, stages, Ci, Co, T, 
 @pytest.mark.parametrize("dtype,tol", [("f16", 6e-3), ("bf16", 4e-2)])
 @pytest.mark.parametrize("order", [0, 1])
 @pytest.mark.parametrize("Ci,Co,T,B", [(1024, 1024, 1126, 2), (512, 3072, 700, 3), (64, 1280, 257, 1), (2048, 1024, 300, 1),
-                                        (256, 1088, 1500, 1), (192, 2048, 4100, 1)])
+                                        (256, 1088, 1500, 1), (192, 2048, 4100, 1), (1024, 2048, 9000, 1), (512, 1280, 14000, 1)])
 def test_eight_phase_256_tile_linear_vs_oracle(gemm_options, dtype, tol, order, Ci, Co, T, B):
     """gemm_ph8.hip: 256x256 tiles, two wave groups one barrier apart, half-tiles re-staged by counted LDS-DMA.  One K tile
     (the prologue alone), odd and even K tile counts, ragged M and N tails (out-of-range rows come back as zeros from the
-    buffer range check), both tile orders, run-to-run identity, and agreement with the 128x128 kernels on the same data."""
+    buffer range check), both tile orders, run-to-run identity, and agreement with the 128x128 kernels on the same data.
+    The last two shapes have more tiles than the chip has CUs (288 and 275): their tail tiles are cut into K slices whose
+    partial sums are added in slice order by the slice-0 workgroup (gemm_ph8_split_max = 1 switches that off)."""
     from mi355tts import _lib
     gemm_options("gemm_ph8", 1)
     gemm_options("gemm_ph8_min_tiles", 1)
@@ -411,6 +413,9 @@ def test_eight_phase_256_tile_linear_vs_oracle(gemm_options, dtype, tol, order, 
     assert np.abs(y - ref).max() < 40 * tol * rms(ref)
     for _ in range(3):
         assert np.array_equal(y, BV.conv1d(x, w, b, dtype=dtype))
+    gemm_options("gemm_ph8_split_max", 1)
+    y1 = BV.conv1d(x, w, b, dtype=dtype)                    # tail tiles unsplit: same products, other summation split
+    assert rms(y - y1) / rms(ref) < 1e-3 * tol + 1e-6
     gemm_options("gemm_ph8", 0)
     y0 = BV.conv1d(x, w, b, dtype=dtype)                    # 128x128 kernels: same products, same 64-deep fp32 accumulation order
     assert rms(y - y0) / rms(ref) < 1e-3 * tol + 1e-6

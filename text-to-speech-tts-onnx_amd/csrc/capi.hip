@@ -658,7 +658,7 @@ int mi_bench_conv_gemm(int dtype, int B, int T, int Cin, int N, int taps, int di
         p.B = B; p.T_in = T; p.M = T; p.N = N; p.Cin = Cin; p.taps = taps; p.dil = dil; p.pad = (taps * dil - dil) / 2;
         p.x_bstride = (long)T * Cin; p.x_rstride = Cin; p.out_bstride = (long)T * N; p.out_rstride = N;
         SkWorkspace skw;
-        skw.ensure(512, s);
+        skw.ensure(1024, s);
         skw.attach(p);
         for (int i = 0; i < 3; ++i) launch_conv_gemm(p, s);
         hipEvent_t e0, e1;

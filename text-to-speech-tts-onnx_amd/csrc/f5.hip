@@ -322,7 +322,7 @@ void F5::ensure_workspace(int U, int N) {
     const F5Cfg& c = cfg;
     const size_t es = dtype_size(dtype);
     const size_t rows = (size_t)2 * Um * Nm;
-    sk.ensure(512, stream);
+    sk.ensure(1024, stream);     // 64 MB: stream-K slots (64 KB) and the split-tail slabs of gemm_ph8.hip (256 KB)
     d_noise.ensure((size_t)Um * Nm * c.mel * 4);
     d_cmt.ensure((size_t)Um * Nm * c.cond_dim() * 4);
     d_cmtd.ensure((size_t)Um * Nm * c.cond_dim() * 4);

@@ -609,6 +609,7 @@ bool gemm_set_option(const char* key, long v) {
     else if (k == "gemm_ph8") g_ph8 = v;
     else if (k == "gemm_ph8_min_tiles") g_ph8_min_tiles = v;
     else if (k == "gemm_ph8_order") g_ph8_order = v;
+    else if (k == "gemm_ph8_split_max") ph8_set_split_max(v);
     else return false;
     return true;
 }
@@ -637,6 +638,7 @@ void launch_conv_gemm(const ConvGemm& p_in, hipStream_t s) {
     d.rope_cos = p.rope_cos; d.rope_sin = p.rope_sin; d.rope_pack = p.rope_pack; d.heads = p.heads; d.head_dim = p.head_dim;
     d.out2 = p.out2; d.out3 = p.out3; d.v_ld = p.v_ld; d.Mb = p.rows_per_item;
     d.sk_ws = p.sk_ws; d.sk_flags = p.sk_flags; d.sk_slots = p.sk_slots;
+    d.tail_tiles = 0; d.tail_split = 1;
     d.use_buf = 0;
     {
         static std::once_flag env_once;      // handles on different threads may launch concurrently
@@ -659,6 +661,7 @@ void launch_conv_gemm(const ConvGemm& p_in, hipStream_t s) {
             if (const char* n = std::getenv("MI355TTS_PH8")) g_ph8 = std::atol(n);
             if (const char* n = std::getenv("MI355TTS_PH8_MIN")) g_ph8_min_tiles = std::atol(n);
             if (const char* n = std::getenv("MI355TTS_PH8_ORDER")) g_ph8_order = std::atol(n);
+            if (const char* n = std::getenv("MI355TTS_PH8_SPLIT")) ph8_set_split_max(std::atol(n));
         });
         int dev = 0;
         MI_HIP(hipGetDevice(&dev));
