@@ -316,7 +316,7 @@ def test_bad_inputs_raise(small_voc):
 # only when the launch fills the chip) and compared with the oracle
 # ---------------------------------------------------------------------------------------------
 _DEFAULTS = {"gemm_big_tile_min": 160, "gemm_n192_min": 160, "gemm_mid_tile_min": 160, "gemm_dma3_k_min": 2048,
-             "gemm_use_dma3": 1, "gemm_use_dma": 1, "gemm_big_tiles": 1, "gemm_n192": 1, "gemm_f32_dma": 1, "gemm_ring4": 1, "gemm_ring4_max": 256, "gemm_buf": 1, "gemm_f32_small": 1, "gemm_f32_small_max": 1024, "gemm_small16_max": 256, "gemm_sk": 1, "gemm_sk_stages": 0, "gemm_ph8": 1, "gemm_ph8_min_tiles": 200, "gemm_ph8_order": 1, "gemm_ph8_split_max": 4}
+             "gemm_use_dma3": 1, "gemm_use_dma": 1, "gemm_big_tiles": 1, "gemm_n192": 1, "gemm_f32_dma": 1, "gemm_ring4": 1, "gemm_ring4_max": 256, "gemm_buf": 1, "gemm_f32_small": 1, "gemm_f32_small_max": 1024, "gemm_small16_max": 256, "gemm_sk": 1, "gemm_sk_stages": 0, "gemm_ph8": 1, "gemm_ph8_min_tiles": 200, "gemm_ph8_order": 1, "gemm_ph8_split_max": 2, "gemm_ph8_split_min_nk": 24}
 
 
 @pytest.fixture
@@ -403,6 +403,8 @@ def test_eight_phase_256_tile_linear_vs_oracle(gemm_options, dtype, tol, order, 
     gemm_options("gemm_ph8", 1)
     gemm_options("gemm_ph8_min_tiles", 1)
     gemm_options("gemm_ph8_order", order)
+    gemm_options("gemm_ph8_split_max", 4)
+    gemm_options("gemm_ph8_split_min_nk", 1)
     x = W.synth_normal(1, f"p8x{Ci}{T}", (B, Ci, T))
     w = W.synth_normal(2, f"p8w{Ci}{Co}", (Co, Ci, 1), std=1.0 / np.sqrt(Ci))
     b = W.synth_normal(3, "p8b", (Co,), std=0.1)

@@ -610,6 +610,7 @@ bool gemm_set_option(const char* key, long v) {
     else if (k == "gemm_ph8_min_tiles") g_ph8_min_tiles = v;
     else if (k == "gemm_ph8_order") g_ph8_order = v;
     else if (k == "gemm_ph8_split_max") ph8_set_split_max(v);
+    else if (k == "gemm_ph8_split_min_nk") ph8_set_split_min_nk(v);
     else return false;
     return true;
 }

@@ -372,6 +372,7 @@ template <typename T, typename TO> void launch_linear_sk(const ConvGemmDev& e, i
 // gemm_ph8.hip: 256x256 eight-phase kernel for 16-bit linear layers with many row tiles
 template <typename T, typename TO> void launch_linear_ph8(const ConvGemmDev& e, hipStream_t s);
 void ph8_set_split_max(long v);
+void ph8_set_split_min_nk(long v);
 
 
 }  // namespace mi

@@ -49,7 +49,7 @@ __device__ __forceinline__ void ph8_bufds16(RSRC rsrc, int voff, unsigned lds_ds
 #endif
 }
 
-template <typename T, typename TO>
+template <typename T, typename TO, bool SPLIT>
 __global__ __launch_bounds__(512, 1) void linear_ph8_kernel(const ConvGemmDev p) {
     using MF = Mfma<T>;
     using Frag = typename MF::Frag;
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(512, 1) void linear_ph8_kernel(const ConvGemmDev p)
     // ORDER, resets the flags and runs the epilogue.  Publishers get the lower workgroup ids, and all tail workgroups fit on
     // the chip together, so the wait cannot deadlock.
     const int nk_all = p.K / KC;
-    const int T_all = p.Tm * p.Tn, rem = p.tail_split > 1 ? p.tail_tiles : 0, S = rem > 0 ? p.tail_split : 1;
+    const int T_all = p.Tm * p.Tn, rem = (SPLIT && p.tail_split > 1) ? p.tail_tiles : 0, S = rem > 0 ? p.tail_split : 1;
     const int T_full = T_all - rem, G_full = 8 * ((T_full + 7) >> 3);
     int tile, slice = 0, kbeg = 0, kend = nk_all;
     if ((int)blockIdx.x < G_full) {
@@ -90,11 +90,13 @@ __global__ __launch_bounds__(512, 1) void linear_ph8_kernel(const ConvGemmDev p)
         const int q8 = T_full >> 3, r8 = T_full & 7;
         tile = (xg < r8 ? xg * (q8 + 1) : r8 * (q8 + 1) + (xg - r8) * q8) + j_in;
         if (j_in >= q8 + (xg < r8 ? 1 : 0)) return;
-    } else {
+    } else if constexpr (SPLIT) {
         const int u = (int)blockIdx.x - G_full;
         slice = S - 1 - u / rem;
         tile = T_full + u % rem;
         kbeg = slice * nk_all / S; kend = (slice + 1) * nk_all / S;
+    } else {
+        return;
     }
     int mt, nt;
     if (p.RC == 0) { nt = tile / p.Tm; mt = tile - nt * p.Tm; }
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(512, 1) void linear_ph8_kernel(const ConvGemmDev p)
 #undef PH8_BAR
     if (p.dbg & 4) return;
 
-    if (tile >= T_full && S > 1) {
+    if constexpr (SPLIT) if (tile >= T_full && S > 1) {
         const int ti = tile - T_full;
         int tidx = tid;
         asm volatile("" : "+v"(tidx));                          // keeps the 32 slab offsets from being hoisted above the K loop (they spilled an accumulator block there)
@@ -309,7 +311,8 @@ __global__ __launch_bounds__(512, 1) void linear_ph8_kernel(const ConvGemmDev p)
 #endif
 }
 
-static long g_ph8_split_max = 4;
+static long g_ph8_split_max = 2, g_ph8_split_min_nk = 24;      // measured: a gain only for the K = 2048 layer (FF2, 32 K tiles), two slices
+void ph8_set_split_min_nk(long v) { g_ph8_split_min_nk = v; }
 void ph8_set_split_max(long v) { g_ph8_split_max = v < 1 ? 1 : v > 4 ? 4 : v; }       // the kernel's fix-up is unrolled for at most 4 slices
 
 template <typename T, typename TO>
@@ -327,7 +330,7 @@ void launch_linear_ph8(const ConvGemmDev& e_in, hipStream_t s) {
     // (S - 1) * rem slabs of 256 KB in the workspace; worth it only when the tail round is mostly empty
     const int rem = T_all % cus;
     int S = 1;
-    if (T_all > cus && rem > 0 && rem * 2 <= cus && e.sk_ws && e.sk_flags) {
+    if (T_all > cus && rem > 0 && rem * 2 <= cus && e.sk_ws && e.sk_flags && nk >= g_ph8_split_min_nk) {
         for (int c = 2; c <= (int)g_ph8_split_max; ++c)
             if (rem * c <= cus && nk / c >= 4 && (long)rem * (c - 1) * 4 <= e.sk_slots) S = c;
     }
@@ -335,9 +338,16 @@ void launch_linear_ph8(const ConvGemmDev& e_in, hipStream_t s) {
     e.tail_split = S;
     const int T_full = T_all - e.tail_tiles;
     const dim3 grid(8 * ((T_full + 7) / 8) + e.tail_tiles * S);
-    auto kfn = linear_ph8_kernel<T, TO>;
-    prof_set_kernel("linear_ph8_kernel<T, TO>", type_label<T>(), type_label<TO>());
-    hipLaunchKernelGGL(kfn, grid, dim3(512), 0, s, e);
+    // the split-tail fix-up is a separate instantiation: its code costs the plain main loop ~7 % (register allocation)
+    if (S > 1) {
+        auto kfn = linear_ph8_kernel<T, TO, true>;
+        prof_set_kernel("linear_ph8_kernel<T, TO, true>", type_label<T>(), type_label<TO>());
+        hipLaunchKernelGGL(kfn, grid, dim3(512), 0, s, e);
+    } else {
+        auto kfn = linear_ph8_kernel<T, TO, false>;
+        prof_set_kernel("linear_ph8_kernel<T, TO, false>", type_label<T>(), type_label<TO>());
+        hipLaunchKernelGGL(kfn, grid, dim3(512), 0, s, e);
+    }
     MI_HIP(hipGetLastError());
 }
 
