@@ -222,36 +222,60 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x16 (&acc)[TM][TN], const C
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        for (int rr = rl0; rr < RT * 32; rr += RPI) {
-            const int m = m0 + wm * WM + i0 * 32 + rr;
-            long row = m;
-            bool ok = cok && m < p.M;
-            if (p.epi == EPI_CONVT) { row = (long)m * p.u + cph - p.padT; ok = ok && row >= 0 && row < p.T_out; }
-            if (!ok) continue;
-            float x[CH];
+        // Rows in groups of GRP: all residual / accumulate operands of a group are requested before the first is used, and
+        // out-of-range rows are handled by clamping the address and masking the store, not by branching.  (Before, every
+        // row was its own branch with load -> wait -> store inside: one 16-byte request in flight per lane, and a workgroup
+        // alone on its CU — the 256x256 kernel — spent longer in this loop than in its K loop: the DiT O projection of 8
+        // utterances ran 102 us in the model against 64 us without the residual.)
+        constexpr int NIT = (RT * 32 + RPI - 1) / RPI, GRP = NIT % 4 == 0 ? 4 : (NIT % 2 == 0 ? 2 : 1);     // 4 rows: 8 more registers per operand kind (8 rows spilled in the 256x256 kernel)
+        struct alignas(16) Pk { TO v[CH]; };
 #pragma unroll
-            for (int q = 0; q < CH; q += 4) {
-                const float4 t = *reinterpret_cast<const float4*>(&stage[rr * WN + cl + q]);
-                x[q] = t.x; x[q + 1] = t.y; x[q + 2] = t.z; x[q + 3] = t.w;
+        for (int it0 = 0; it0 < NIT; it0 += GRP) {
+            Pk rv[GRP], ov[GRP];
+            long ixv[GRP];
+            bool okv[GRP];
+#pragma unroll
+            for (int gi = 0; gi < GRP; ++gi) {
+                const int rr = rl0 + (it0 + gi) * RPI;
+                const int m = m0 + wm * WM + i0 * 32 + rr;
+                long row = m;
+                bool ok = cok && rr < RT * 32 && m < p.M;                 // (RPI need not divide the pass: 96-wide wave tiles)
+                if (p.epi == EPI_CONVT) { row = (long)m * p.u + cph - p.padT; ok = ok && row >= 0 && row < p.T_out; }
+                okv[gi] = ok;
+                ixv[gi] = ok ? row * p.out_rstride + ccol : 0;       // masked lanes read element 0 (always there) and store nothing
             }
-            const long ix = row * p.out_rstride + ccol;
-            struct alignas(16) Pk { TO v[CH]; };
             if (resp) {
-                const Pk rv = *reinterpret_cast<const Pk*>(resp + ix);
 #pragma unroll
-                for (int q = 0; q < CH; ++q) x[q] += to_f32(rv.v[q]);
+                for (int gi = 0; gi < GRP; ++gi) rv[gi] = *reinterpret_cast<const Pk*>(resp + ixv[gi]);
             }
-#pragma unroll
-            for (int q = 0; q < CH; ++q) x[q] *= p.alpha;
             if (p.accumulate) {
-                const Pk ov = *reinterpret_cast<const Pk*>(outp + ix);
 #pragma unroll
-                for (int q = 0; q < CH; ++q) x[q] += to_f32(ov.v[q]);
+                for (int gi = 0; gi < GRP; ++gi) ov[gi] = *reinterpret_cast<const Pk*>(outp + ixv[gi]);
             }
-            Pk o;
 #pragma unroll
-            for (int q = 0; q < CH; ++q) o.v[q] = from_f32<TO>(x[q]);
-            *reinterpret_cast<Pk*>(outp + ix) = o;
+            for (int gi = 0; gi < GRP; ++gi) {
+                const int rr = min(rl0 + (it0 + gi) * RPI, RT * 32 - 1);
+                float x[CH];
+#pragma unroll
+                for (int q = 0; q < CH; q += 4) {
+                    const float4 t = *reinterpret_cast<const float4*>(&stage[rr * WN + cl + q]);
+                    x[q] = t.x; x[q + 1] = t.y; x[q + 2] = t.z; x[q + 3] = t.w;
+                }
+                if (resp) {
+#pragma unroll
+                    for (int q = 0; q < CH; ++q) x[q] += to_f32(rv[gi].v[q]);
+                }
+#pragma unroll
+                for (int q = 0; q < CH; ++q) x[q] *= p.alpha;
+                if (p.accumulate) {
+#pragma unroll
+                    for (int q = 0; q < CH; ++q) x[q] += to_f32(ov[gi].v[q]);
+                }
+                Pk o;
+#pragma unroll
+                for (int q = 0; q < CH; ++q) o.v[q] = from_f32<TO>(x[q]);
+                if (okv[gi]) *reinterpret_cast<Pk*>(outp + ixv[gi]) = o;
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -289,47 +313,67 @@ __device__ __forceinline__ void gemm_epilogue_qkv_lds(f32x16 (&acc)[2][2], const
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const int c8 = (lane & 7) * 8;
-        for (int rr = lane >> 3; rr < 64; rr += 8) {
-            if (mbase + rr >= p.M) continue;
-            int m = mloc0 + rr, bi = bi0;
-            if (m >= Mb) { m -= Mb; ++bi; }
-            float x[8];
+        // rows in groups of four: the RoPE table rows of a group are requested before the first is used, out-of-range rows
+        // are clamped and their store masked (see gemm_epilogue_lds)
+        struct alignas(16) H8 { f16 v[8]; };
+        constexpr int GRP = 4;
 #pragma unroll
-            for (int q = 0; q < 8; q += 4) {
-                const float4 t = *reinterpret_cast<const float4*>(&stage[rr * 64 + c8 + q]);
-                x[q] = t.x; x[q + 1] = t.y; x[q + 2] = t.z; x[q + 3] = t.w;
+        for (int it0 = 0; it0 < 8; it0 += GRP) {
+            int mv[GRP], biv[GRP];
+            bool okv[GRP];
+            H8 cs[GRP];
+#pragma unroll
+            for (int gi = 0; gi < GRP; ++gi) {
+                const int rr = (lane >> 3) + (it0 + gi) * 8;
+                okv[gi] = mbase + rr < p.M;
+                int m = mloc0 + rr, bi = bi0;
+                if (m >= Mb) { m -= Mb; ++bi; }
+                if (!okv[gi]) { m = 0; bi = bi0; }
+                mv[gi] = m; biv[gi] = bi;
             }
             if (which < 2 && p.rope_pack) {
                 // four (cos, sin) half pairs = one 16-byte load for the lane's eight columns
-                struct alignas(16) H8 { f16 v[8]; };
-                const H8 cs = *reinterpret_cast<const H8*>((const f16*)p.rope_pack + (long)m * 64 + c8);
 #pragma unroll
-                for (int q = 0; q < 8; q += 2) {
-                    const float cc = (float)cs.v[q], ss = (float)cs.v[q + 1];
-                    const float e = x[q], o = x[q + 1];
-                    x[q] = e * cc - o * ss;
-                    x[q + 1] = o * cc + e * ss;
-                }
-            } else if (which < 2) {
-                float c[8], sn[8];
+                for (int gi = 0; gi < GRP; ++gi) cs[gi] = *reinterpret_cast<const H8*>((const f16*)p.rope_pack + (long)mv[gi] * 64 + c8);
+            }
+#pragma unroll
+            for (int gi = 0; gi < GRP; ++gi) {
+                const int rr = (lane >> 3) + (it0 + gi) * 8;
+                float x[8];
 #pragma unroll
                 for (int q = 0; q < 8; q += 4) {
-                    const float4 tc = *reinterpret_cast<const float4*>(p.rope_cos + (long)m * 64 + c8 + q);
-                    const float4 ts = *reinterpret_cast<const float4*>(p.rope_sin + (long)m * 64 + c8 + q);
-                    c[q] = tc.x; c[q + 1] = tc.y; c[q + 2] = tc.z; c[q + 3] = tc.w;
-                    sn[q] = ts.x; sn[q + 1] = ts.y; sn[q + 2] = ts.z; sn[q + 3] = ts.w;
+                    const float4 t = *reinterpret_cast<const float4*>(&stage[rr * 64 + c8 + q]);
+                    x[q] = t.x; x[q + 1] = t.y; x[q + 2] = t.z; x[q + 3] = t.w;
                 }
+                if (which < 2 && p.rope_pack) {
 #pragma unroll
-                for (int q = 0; q < 8; q += 2) {
-                    const float e = x[q], o = x[q + 1];
-                    x[q] = e * c[q] - o * sn[q];
-                    x[q + 1] = o * c[q + 1] + e * sn[q + 1];
+                    for (int q = 0; q < 8; q += 2) {
+                        const float cc = (float)cs[gi].v[q], ss = (float)cs[gi].v[q + 1];
+                        const float e = x[q], o = x[q + 1];
+                        x[q] = e * cc - o * ss;
+                        x[q + 1] = o * cc + e * ss;
+                    }
+                } else if (which < 2) {                          // fp32 tables (no packed table given): loaded row by row
+                    float c[8], sn[8];
+#pragma unroll
+                    for (int q = 0; q < 8; q += 4) {
+                        const float4 tc = *reinterpret_cast<const float4*>(p.rope_cos + (long)mv[gi] * 64 + c8 + q);
+                        const float4 ts = *reinterpret_cast<const float4*>(p.rope_sin + (long)mv[gi] * 64 + c8 + q);
+                        c[q] = tc.x; c[q + 1] = tc.y; c[q + 2] = tc.z; c[q + 3] = tc.w;
+                        sn[q] = ts.x; sn[q + 1] = ts.y; sn[q + 2] = ts.z; sn[q + 3] = ts.w;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; q += 2) {
+                        const float e = x[q], o = x[q + 1];
+                        x[q] = e * c[q] - o * sn[q];
+                        x[q + 1] = o * c[q + 1] + e * sn[q + 1];
+                    }
                 }
+                Pk o8;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) o8.v[q] = from_f32<TO>(x[q]);
+                if (okv[gi]) *reinterpret_cast<Pk*>(base + (((long)b + biv[gi]) * p.heads + hh) * Mb * 64 + (long)mv[gi] * 64 + c8) = o8;
             }
-            Pk o8;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) o8.v[q] = from_f32<TO>(x[q]);
-            *reinterpret_cast<Pk*>(base + (((long)b + bi) * p.heads + hh) * Mb * 64 + (long)m * 64 + c8) = o8;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();

@@ -15,7 +15,8 @@ MI_HOST, MI_DEVICE = 0, 1
 DTYPES = {"f32": MI_F32, "fp32": MI_F32, "float32": MI_F32, "f16": MI_F16, "fp16": MI_F16, "float16": MI_F16,
           "bf16": MI_BF16, "bfloat16": MI_BF16}
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmi355tts.so")
+# MI355TTS_LIB: another build of the same library (A/B measurements of kernel variants); the default is the in-tree build
+_LIB_PATH = os.environ.get("MI355TTS_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmi355tts.so")
 _lib = None
 
 
