@@ -21,6 +21,7 @@
 #include "mfma.h"
 #include "f5_kernels.h"
 #include <cstdlib>
+#include <algorithm>
 
 namespace mi {
 
@@ -31,7 +32,8 @@ namespace mi {
 //                 CUs, so the CUs that got two workgroups set the makespan (2 units); 576 half-size ones finish in 1.5.
 template <typename T, bool SPLIT2 = false>
 __global__ __launch_bounds__(256, 3) void attn_kernel(const T* __restrict__ q, const T* __restrict__ k,
-                                                   const T* __restrict__ v, T* __restrict__ o, int H, int N) {
+                                                   const T* __restrict__ v, T* __restrict__ o, int H, int N,
+                                                   float* __restrict__ ws, int* __restrict__ cnt) {
     using MF = Mfma<T>;
     constexpr int KP = MF::KP;
     constexpr int D = 64, KT = 64;
@@ -115,11 +117,17 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const T* __restrict__ q, c
     for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.f; oacc[1][r] = 0.f; }
     float m_run = -INFINITY, l_run = 0.f;
 
-    const int nstage = (N + KT - 1) / KT;
-    load_regs(0);
-    store_lds();
-    __syncthreads();
-    for (int st = 0; st < nstage; ++st) {
+    // gridDim.z > 1 (SPLIT2 only): the 64-key stages are cut into gridDim.z contiguous slices, one workgroup each; the
+    // slices of a query tile meet in `ws` and the LAST one to arrive merges them in slice order (see the end of the kernel)
+    const int nstage_all = (N + KT - 1) / KT;
+    const int st0 = SPLIT2 ? (int)((long)blockIdx.z * nstage_all / gridDim.z) : 0;
+    const int nstage = SPLIT2 ? (int)((long)(blockIdx.z + 1) * nstage_all / gridDim.z) : nstage_all;
+    if (st0 < nstage) {
+        load_regs(st0 * KT);
+        store_lds();
+        __syncthreads();
+    }
+    for (int st = st0; st < nstage; ++st) {
         if (st + 1 < nstage) load_regs((st + 1) * KT);
         auto tile = [&](int kt) {                                        // one 32-key tile
             const int key0 = st * KT + kt * 32;
@@ -215,14 +223,16 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const T* __restrict__ q, c
         }
     }
 
+    bool owner = true;                                              // this wave holds a finished 32-query result
     if constexpr (SPLIT2) {
         // ---- merge the two key halves: m = max(m0, m1) ; l = l0 2^(m0-m) + l1 2^(m1-m) ; O likewise ----------------------
         __syncthreads();                                            // every wave is done with the K / V stage
         float* comb = reinterpret_cast<float*>(smem);               // [2 groups][32 accumulator registers][64 lanes]
         float* stats = comb + 2 * 32 * 64;                          // [2 groups][64 lanes][m, l]
-        static_assert(sizeof(smem) >= (2 * 32 * 64 + 2 * 64 * 2) * sizeof(float), "merge buffer fits the stage");
+        static_assert(sizeof(smem) >= (2 * 32 * 64 + 2 * 64 * 2 + 4) * sizeof(float), "merge buffer fits the stage");
         const int grp = wave >> 1;
-        if (wave & 1) {
+        owner = !(wave & 1);
+        if (!owner) {
             stats[(grp * 64 + lane) * 2] = m_run; stats[(grp * 64 + lane) * 2 + 1] = l_run;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
@@ -230,17 +240,98 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const T* __restrict__ q, c
                 for (int r = 0; r < 16; ++r) comb[((grp * 2 + dt) * 16 + r) * 64 + lane] = oacc[dt][r];
         }
         __syncthreads();
-        if (wave & 1) return;
-        const float m1 = stats[(grp * 64 + lane) * 2], l1 = stats[(grp * 64 + lane) * 2 + 1];
-        const float m = fmaxf(m_run, m1);
-        const float s0 = m_run == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m_run - m);
-        const float s1 = m1 == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m1 - m);
-        l_run = l_run * s0 + l1 * s1;
+        if (owner) {
+            const float m1 = stats[(grp * 64 + lane) * 2], l1 = stats[(grp * 64 + lane) * 2 + 1];
+            const float m = fmaxf(m_run, m1);
+            const float s0 = m_run == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m_run - m);
+            const float s1 = m1 == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m1 - m);
+            l_run = l_run * s0 + l1 * s1;
+            m_run = m;
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
+            for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[dt][r] = oacc[dt][r] * s0 + comb[((grp * 2 + dt) * 16 + r) * 64 + lane] * s1;
+                for (int r = 0; r < 16; ++r) oacc[dt][r] = oacc[dt][r] * s0 + comb[((grp * 2 + dt) * 16 + r) * 64 + lane] * s1;
+        }
+        // ---- key slices (gridDim.z > 1).  One utterance in fp32 is 18 x 32 = 576 of these workgroups on 768 slots (three per
+        // CU): 2.25 per CU, so the CUs that got three set the makespan and a quarter of the chip idles.  With Z slices the
+        // work comes in pieces of 1 / Z (Z = 4: exactly 9 per CU).  Every slice publishes (m, l, O) of its keys with
+        // write-through stores, drains them, and takes a ticket (relaxed agent-scope fetch-add: the gemm_sk.hip hand-off);
+        // the workgroup that draws the last ticket adds the slices IN SLICE ORDER (its own from registers), so the result
+        // does not depend on which one that is, resets the ticket counter (hipGraph replays find it at zero) and stores.
+        // Nobody waits for anybody: there is no residency requirement. ---------------------------------------------------
+        const int Z = (int)gridDim.z;
+        if (Z > 1) {
+            const int z = (int)blockIdx.z;
+            const int unit = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+            constexpr int SLOT = 2 * 32 * 64 + 2 * 64 * 2;           // floats per (unit, slice)
+            // write-through (sc1) stores / sc1 loads through a buffer descriptor, as in gemm_sk.hip: no L2-wide write-back fence
+            typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+            typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+            __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)(ws + (long)unit * Z * SLOT), 0, Z * SLOT * 4, 0x00020000);
+            if (owner) {
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        u4 val;
+                        val.x = __float_as_uint(oacc[dt][4 * g4]); val.y = __float_as_uint(oacc[dt][4 * g4 + 1]);
+                        val.z = __float_as_uint(oacc[dt][4 * g4 + 2]); val.w = __float_as_uint(oacc[dt][4 * g4 + 3]);
+                        __builtin_amdgcn_raw_buffer_store_b128(val, rsw, (z * SLOT + (((grp * 2 + dt) * 4 + g4) * 64 + lane) * 4) * 4, 0, 16);
+                    }
+                u2 st2; st2.x = __float_as_uint(m_run); st2.y = __float_as_uint(l_run);
+                __builtin_amdgcn_raw_buffer_store_b64(st2, rsw, (z * SLOT + 2 * 32 * 64 + (grp * 64 + lane) * 2) * 4, 0, 16);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            int* ticket = reinterpret_cast<int*>(stats + 2 * 64 * 2);
+            if (tid == 0) *ticket = __hip_atomic_fetch_add(cnt + unit, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if (*ticket != Z - 1) return;                            // not the last slice of this query tile
+            if (tid == 0) __hip_atomic_store(cnt + unit, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!owner) return;
+            float mz[4], lz[4], M = -INFINITY;
+#pragma unroll
+            for (int zz = 0; zz < 4; ++zz) {
+                mz[zz] = -INFINITY; lz[zz] = 0.f;
+                if (zz < Z) {
+                    if (zz == z) { mz[zz] = m_run; lz[zz] = l_run; }
+                    else {
+                        const u2 st2 = __builtin_amdgcn_raw_buffer_load_b64(rsw, (zz * SLOT + 2 * 32 * 64 + (grp * 64 + lane) * 2) * 4, 0, 16);
+                        mz[zz] = __uint_as_float(st2.x); lz[zz] = __uint_as_float(st2.y);
+                    }
+                    M = fmaxf(M, mz[zz]);
+                }
+            }
+            f32x16 osum[2];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { osum[0][r] = 0.f; osum[1][r] = 0.f; }
+            float lsum = 0.f;
+#pragma unroll
+            for (int zz = 0; zz < 4; ++zz) {
+                if (zz >= Z) break;
+                const float sc = mz[zz] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mz[zz] - M);
+                lsum += lz[zz] * sc;
+                if (zz == z) {
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) osum[dt][r] += oacc[dt][r] * sc;
+                } else {
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            const u4 val = __builtin_amdgcn_raw_buffer_load_b128(rsw, (zz * SLOT + (((grp * 2 + dt) * 4 + g4) * 64 + lane) * 4) * 4, 0, 16);
+                            osum[dt][4 * g4] += __uint_as_float(val.x) * sc; osum[dt][4 * g4 + 1] += __uint_as_float(val.y) * sc;
+                            osum[dt][4 * g4 + 2] += __uint_as_float(val.z) * sc; osum[dt][4 * g4 + 3] += __uint_as_float(val.w) * sc;
+                        }
+                }
+            }
+            oacc[0] = osum[0]; oacc[1] = osum[1];
+            l_run = lsum;
+        }
     }
+    if (!owner) return;
     // ---- normalise + store o[b][n][h*64 + d] ---------------------------------------------------------
     const int qr = q0 + lr;
     if (qr < N) {
@@ -261,7 +352,8 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const T* __restrict__ q, c
     }
 }
 
-void launch_attention(const void* q, const void* k, const void* v, void* o, int BH, int H, int N, int dtype, hipStream_t s) {
+void launch_attention(const void* q, const void* k, const void* v, void* o, int BH, int H, int N, int dtype, hipStream_t s,
+                      float* ws, long ws_floats, int* cnt, long cnt_n) {
     MI_REQUIRE(BH % H == 0 && N > 0, "attention: bad shape");
     const double esz = (double)dtype_size(dtype);
     ProfScope ps(FAM_ATTN, s, 4.0 * BH * N * 64.0 * esz, 4.0 * BH * (double)N * N * 64.0);
@@ -270,25 +362,47 @@ void launch_attention(const void* q, const void* k, const void* v, void* o, int 
         prof_set_kernel("attn_kernel<T, " #SP ">", type_label<TT>());           \
         hipLaunchKernelGGL((attn_kernel<TT, SP>), __VA_ARGS__);                 \
     } while (0)
-    static int split = -1;
-    if (split < 0) { const char* e = std::getenv("MI355TTS_ATTN_NO_SPLIT"); split = (e && e[0] == '1') ? 0 : 1; }
+    static int split = -1, zmax = 4;
+    if (split < 0) {
+        const char* e = std::getenv("MI355TTS_ATTN_NO_SPLIT"); split = (e && e[0] == '1') ? 0 : 1;
+        if (const char* z = std::getenv("MI355TTS_ATTN_Z")) zmax = std::max(1, std::min(4, std::atoi(z)));
+    }
     if (dtype == MI_F32) {
         // few 128-query workgroups (one or two utterances): halve them along the keys, see attn_kernel
-        if (split && (long)((N + 127) / 128) * BH < 1024 && N >= 64)
-            ATTN_LAUNCH(float, true, dim3((N + 63) / 64, BH), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N);
-        else
-            ATTN_LAUNCH(float, false, dim3((N + 127) / 128, BH), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N);
+        if (split && (long)((N + 127) / 128) * BH < 1024 && N >= 64) {
+            // ... and cut the key range into Z slices when that evens out the workgroups per CU (three resident per CU):
+            // makespan(Z) = ceil(units * Z / CUs) / Z in units of one unsliced workgroup, + 6 % per extra slice for the
+            // prologue and the merge (measured, one utterance = 576 units: Z = 1 / 2 / 3 / 4 -> 135 / 122 / 121 / 126 us)
+            const long units = (long)((N + 63) / 64) * BH;
+            const int nstage = (N + 63) / 64;
+            int dev = 0, cus = 256;
+            MI_HIP(hipGetDevice(&dev));
+            {
+                static int cu_count[16] = {0};
+                if (!cu_count[dev & 15]) { hipDeviceProp_t pr; MI_HIP(hipGetDeviceProperties(&pr, dev)); cu_count[dev & 15] = pr.multiProcessorCount; }
+                cus = cu_count[dev & 15];
+            }
+            int Z = 1;
+            double best = 1e30;
+            for (int z = 1; z <= zmax; ++z) {
+                if (z > 1 && (!ws || !cnt || units * z * (2 * 32 * 64 + 2 * 64 * 2) > ws_floats || units > cnt_n || nstage < 2 * z)) break;
+                const double cost = (double)((units * z + cus - 1) / cus) / z * (1.0 + 0.06 * (z - 1));
+                if (cost < best - 1e-9) { best = cost; Z = z; }
+            }
+            ATTN_LAUNCH(float, true, dim3((N + 63) / 64, BH, Z), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt);
+        } else
+            ATTN_LAUNCH(float, false, dim3((N + 127) / 128, BH), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt);
     } else {
         // 16-bit: the same split below 512 workgroups (one utterance: attention 24.3 -> 21.1 ms per step; at two utterances,
         // 576 workgroups, the 128-query form is already balanced and shares each K / V stage among more waves)
         const bool sp = split && (long)((N + 127) / 128) * BH < 512 && N >= 64;
         const dim3 grid(sp ? (N + 63) / 64 : (N + 127) / 128, BH);
         if (dtype == MI_F16) {
-            if (sp) ATTN_LAUNCH(f16, true, grid, dim3(256), 0, s, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)o, H, N);
-            else ATTN_LAUNCH(f16, false, grid, dim3(256), 0, s, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)o, H, N);
+            if (sp) ATTN_LAUNCH(f16, true, grid, dim3(256), 0, s, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)o, H, N, ws, cnt);
+            else ATTN_LAUNCH(f16, false, grid, dim3(256), 0, s, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)o, H, N, ws, cnt);
         } else {
-            if (sp) ATTN_LAUNCH(bf16, true, grid, dim3(256), 0, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, H, N);
-            else ATTN_LAUNCH(bf16, false, grid, dim3(256), 0, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, H, N);
+            if (sp) ATTN_LAUNCH(bf16, true, grid, dim3(256), 0, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, H, N, ws, cnt);
+            else ATTN_LAUNCH(bf16, false, grid, dim3(256), 0, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, H, N, ws, cnt);
         }
     }
 #undef ATTN_LAUNCH

@@ -56,6 +56,8 @@ struct F5 {
 
     // ---- workspace ----
     SkWorkspace sk;          // stream-K partial-tile slots of this handle's stream
+    DevBuf attn_ws, attn_cnt; // key-sliced fp32 attention: partial (m, l, O) per 64-query tile and slice, ticket counters
+    long attn_ws_floats = 0, attn_cnt_n = 0;
     int ws_U = 0, ws_N = 0;
     DevBuf d_noise, d_cmt, d_cmtd, cat, h32, hT, c1, X, Ub, qb, kb, vb, Ob, Hff, pred;
     DevBuf p_audio, p_pad, p_spec, p_mag, p_mel, p_ids, p_tid, p_err, p_tx, p_ty, p_ty2, p_ss;

@@ -323,6 +323,18 @@ void F5::ensure_workspace(int U, int N) {
     const size_t es = dtype_size(dtype);
     const size_t rows = (size_t)2 * Um * Nm;
     sk.ensure(1024, stream);     // 64 MB: stream-K slots (64 KB) and the split-tail slabs of gemm_ph8.hip (256 KB)
+    if (dtype == MI_F32) {
+        // key-sliced attention (attention.hip): used while there are fewer than 1024 128-query workgroups, i.e. up to
+        // ~3 utterances; 4 slices x (8192 + 256) floats per 64-query tile
+        const long tiles = (long)((Nm + 63) / 64) * 2 * Um * c.heads;
+        if ((long)((Nm + 127) / 128) * 2 * Um * c.heads < 1024 && tiles > attn_cnt_n) {
+            attn_ws_floats = tiles * 4 * (2 * 32 * 64 + 2 * 64 * 2);
+            attn_ws.ensure((size_t)attn_ws_floats * 4);
+            attn_cnt.ensure((size_t)tiles * 4);
+            MI_HIP(hipMemsetAsync(attn_cnt.p, 0, (size_t)tiles * 4, stream));
+            attn_cnt_n = tiles;
+        }
+    }
     d_noise.ensure((size_t)Um * Nm * c.mel * 4);
     d_cmt.ensure((size_t)Um * Nm * c.cond_dim() * 4);
     d_cmtd.ensure((size_t)Um * Nm * c.cond_dim() * 4);
@@ -538,7 +550,7 @@ void F5::dit_eval(int U, int N, int k) {
             sk.attach(g);
             launch_conv_gemm(g, s);
         }
-        launch_attention(qb.p, kb.p, vb.p, Ob.p, B * H, H, N, dtype, s);
+        launch_attention(qb.p, kb.p, vb.p, Ob.p, B * H, H, N, dtype, s, attn_ws.as<float>(), attn_ws_floats, attn_cnt.as<int>(), attn_cnt_n);
         gemm(dtype, Ob.p, (long)N * d, d, d, bk.o, X.p, MI_F32, (long)N * d, d, B, N, ACT_NONE, X.p, m + 2 * d);
         launch_rownorm(NORM_LN_MOD, X.as<float>(), Ub.p, dtype, m + 4 * d, m + 3 * d, rows, d, 1e-6f, s);
         gemm(dtype, Ub.p, (long)N * d, d, d, bk.ff1, Hff.p, dtype, (long)N * ff, ff, B, N, ACT_GELU_TANH);

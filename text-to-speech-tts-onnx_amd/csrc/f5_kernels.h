@@ -27,7 +27,10 @@ void launch_cfg_update(float* noise, const float* pred, int U, int N, int M, flo
 // attention.hip: softmax_fp32(q k^T) v, no mask, no scale (q/k are pre-scaled): modules.py:467
 //   q,k [BH][N][64], v [BH][N][64] (fp32) or transposed [BH][64][v_ld] (16-bit, v_ld = attention_v_ld(N))
 //   -> o [B][N][H*64] (dtype), B = BH / H
-void launch_attention(const void* q, const void* k, const void* v, void* o, int BH, int H, int N, int dtype, hipStream_t s);
+// ws / cnt: optional workspace of the key-sliced fp32 kernel ((2*32*64 + 256) floats per 64-query tile and slice; one zeroed
+// counter per tile); without them every query tile is one workgroup
+void launch_attention(const void* q, const void* k, const void* v, void* o, int BH, int H, int N, int dtype, hipStream_t s,
+                      float* ws = nullptr, long ws_floats = 0, int* cnt = nullptr, long cnt_n = 0);
 inline long attention_v_ld(int N, int dtype) { return dtype == MI_F32 ? 0 : (long)((N + 7) / 8 * 8); }
 
 }  // namespace mi

@@ -659,6 +659,7 @@ void launch_conv_gemm(const ConvGemm& p_in, hipStream_t s) {
             if (const char* n = std::getenv("MI355TTS_SK")) g_sk = std::atol(n);
             if (const char* n = std::getenv("MI355TTS_SK_STAGES")) g_sk_stages = std::atol(n);
             if (const char* n = std::getenv("MI355TTS_SK_ORDER")) g_sk_order = std::atol(n);
+            if (const char* n = std::getenv("MI355TTS_SK_QKV32")) g_sk_qkv32 = std::atol(n);
             if (const char* n = std::getenv("MI355TTS_PH8")) g_ph8 = std::atol(n);
             if (const char* n = std::getenv("MI355TTS_PH8_MIN")) g_ph8_min_tiles = std::atol(n);
             if (const char* n = std::getenv("MI355TTS_PH8_ORDER")) g_ph8_order = std::atol(n);
