@@ -316,7 +316,7 @@ def test_bad_inputs_raise(small_voc):
 # only when the launch fills the chip) and compared with the oracle
 # ---------------------------------------------------------------------------------------------
 _DEFAULTS = {"gemm_big_tile_min": 160, "gemm_n192_min": 160, "gemm_mid_tile_min": 160, "gemm_dma3_k_min": 2048,
-             "gemm_use_dma3": 1, "gemm_use_dma": 1, "gemm_big_tiles": 1, "gemm_n192": 1, "gemm_f32_dma": 1, "gemm_ring4": 1, "gemm_ring4_max": 256, "gemm_buf": 1, "gemm_f32_small": 1, "gemm_f32_small_max": 1024, "gemm_small16_max": 256, "gemm_sk": 1, "gemm_sk_stages": 0, "gemm_ph8": 1, "gemm_ph8_min_tiles": 200, "gemm_ph8_order": 1, "gemm_ph8_split_max": 2, "gemm_ph8_split_min_nk": 24}
+             "gemm_use_dma3": 1, "gemm_use_dma": 1, "gemm_big_tiles": 1, "gemm_n192": 1, "gemm_f32_dma": 1, "gemm_ring4": 1, "gemm_ring4_max": 256, "gemm_buf": 1, "gemm_f32_small": 1, "gemm_f32_small_max": 1024, "gemm_small16_max": 256, "gemm_sk": 1, "gemm_sk_stages": 0, "gemm_ph8": 1, "gemm_ph8_min_tiles": 200, "gemm_ph8_order": 1, "gemm_ph8_split_max": 2, "gemm_ph8_split_min_nk": 24, "gemm_sk_hybrid": 0}
 
 
 @pytest.fixture
@@ -362,14 +362,17 @@ def test_gemm_tile_configs_vs_oracle(gemm_options, cfg_name, opts, Ci, Co, k, d,
 
 @pytest.mark.parametrize("dtype,tol", [("f32", 0.0), ("f16", 6e-3), ("bf16", 4e-2)])
 @pytest.mark.parametrize("stages", [0, 2, 3, 4])
-@pytest.mark.parametrize("Ci,Co,T,B", [(256, 1000, 1500, 1), (512, 1024, 1126, 2), (128, 3072, 700, 2), (1024, 1024, 1126, 2)])
+@pytest.mark.parametrize("Ci,Co,T,B", [(256, 1000, 1500, 1), (512, 1024, 1126, 2), (128, 3072, 700, 2), (1024, 1024, 1126, 2),
+                                        (256, 2048, 2252, 1), (128, 1280, 4000, 1)])
 def test_stream_k_linear_vs_oracle(gemm_options, dtype, tol, stages, Ci, Co, T, B):
     """gemm_sk.hip: persistent workgroups over equal (tile, K chunk) ranges; tiles split between workgroups are summed in range
     order by the owner of the tile's first chunk.  Ragged M / N tails, every ring depth, partial tiles of 2..many pieces, and
-    bit-identical results from run to run (the fix-up order is fixed)."""
+    bit-identical results from run to run (the fix-up order is fixed).  The last two shapes have more tiles than persistent
+    workgroups (288 / 320 tiles): whole tiles first, stream-K for the remainder (gemm_sk_hybrid)."""
     from mi355tts import _lib
     _lib.set_option("gemm_sk", 2)
     _lib.set_option("gemm_sk_stages", stages)
+    _lib.set_option("gemm_sk_hybrid", 1)
     x = W.synth_normal(1, f"skx{Ci}{T}", (B, Ci, T))
     w = W.synth_normal(2, f"skw{Ci}{Co}", (Co, Ci, 1), std=1.0 / np.sqrt(Ci))
     b = W.synth_normal(3, "skb", (Co,), std=0.1)
@@ -381,6 +384,12 @@ def test_stream_k_linear_vs_oracle(gemm_options, dtype, tol, stages, Ci, Co, T, 
     else:
         assert rms(y - ref) / rms(ref) < tol
     assert np.array_equal(y, BV.conv1d(x, w, b, dtype=dtype))
+    _lib.set_option("gemm_sk_hybrid", 0)
+    yh = BV.conv1d(x, w, b, dtype=dtype)                    # pure stream-K: same products, other summation split
+    if dtype == "f32":
+        np.testing.assert_allclose(y, yh, atol=3e-5, rtol=1e-5)
+    else:
+        assert rms(y - yh) / rms(ref) < tol
     _lib.set_option("gemm_sk", 0)
     y0 = BV.conv1d(x, w, b, dtype=dtype)                    # one tile per workgroup: same products, other summation split
     if dtype == "f32":

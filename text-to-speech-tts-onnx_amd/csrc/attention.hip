@@ -367,28 +367,36 @@ void launch_attention(const void* q, const void* k, const void* v, void* o, int 
         const char* e = std::getenv("MI355TTS_ATTN_NO_SPLIT"); split = (e && e[0] == '1') ? 0 : 1;
         if (const char* z = std::getenv("MI355TTS_ATTN_Z")) zmax = std::max(1, std::min(4, std::atoi(z)));
     }
+    // key slices for the SPLIT2 form (see attn_kernel): makespan(Z) = ceil(units * Z / CUs) / Z in units of one unsliced
+    // workgroup, + 6 % per extra slice for the prologue and the merge (measured, fp32, one utterance = 576 units:
+    // Z = 1 / 2 / 3 / 4 -> 135 / 122 / 121 / 126 us)
+    auto pick_z = [&](int zlimit16) -> int {
+        const long units = (long)((N + 63) / 64) * BH;
+        const int nstage = (N + 63) / 64;
+        int dev = 0, cus = 256;
+        MI_HIP(hipGetDevice(&dev));
+        {
+            static int cu_count[16] = {0};
+            if (!cu_count[dev & 15]) { hipDeviceProp_t pr; MI_HIP(hipGetDeviceProperties(&pr, dev)); cu_count[dev & 15] = pr.multiProcessorCount; }
+            cus = cu_count[dev & 15];
+        }
+        int Z = 1;
+        double best = 1e30;
+        const int zm = dtype == MI_F32 ? zmax : std::min(zmax, zlimit16);
+        for (int z = 1; z <= zm; ++z) {
+            if (z > 1 && (!ws || !cnt || units * z * (2 * 32 * 64 + 2 * 64 * 2) > ws_floats || units > cnt_n || nstage < 2 * z)) break;
+            const double cost = (double)((units * z + cus - 1) / cus) / z * (1.0 + 0.06 * (z - 1));
+            if (cost < best - 1e-9) { best = cost; Z = z; }
+        }
+        return Z;
+    };
+    static int z16 = -1;
+    if (z16 < 0) { const char* e = std::getenv("MI355TTS_ATTN_Z16"); z16 = e ? std::atoi(e) : 1; }
     if (dtype == MI_F32) {
         // few 128-query workgroups (one or two utterances): halve them along the keys, see attn_kernel
         if (split && (long)((N + 127) / 128) * BH < 1024 && N >= 64) {
-            // ... and cut the key range into Z slices when that evens out the workgroups per CU (three resident per CU):
-            // makespan(Z) = ceil(units * Z / CUs) / Z in units of one unsliced workgroup, + 6 % per extra slice for the
-            // prologue and the merge (measured, one utterance = 576 units: Z = 1 / 2 / 3 / 4 -> 135 / 122 / 121 / 126 us)
-            const long units = (long)((N + 63) / 64) * BH;
-            const int nstage = (N + 63) / 64;
-            int dev = 0, cus = 256;
-            MI_HIP(hipGetDevice(&dev));
-            {
-                static int cu_count[16] = {0};
-                if (!cu_count[dev & 15]) { hipDeviceProp_t pr; MI_HIP(hipGetDeviceProperties(&pr, dev)); cu_count[dev & 15] = pr.multiProcessorCount; }
-                cus = cu_count[dev & 15];
-            }
-            int Z = 1;
-            double best = 1e30;
-            for (int z = 1; z <= zmax; ++z) {
-                if (z > 1 && (!ws || !cnt || units * z * (2 * 32 * 64 + 2 * 64 * 2) > ws_floats || units > cnt_n || nstage < 2 * z)) break;
-                const double cost = (double)((units * z + cus - 1) / cus) / z * (1.0 + 0.06 * (z - 1));
-                if (cost < best - 1e-9) { best = cost; Z = z; }
-            }
+            // ... and cut the key range into Z slices when that evens out the workgroups per CU
+            const int Z = pick_z(1);
             ATTN_LAUNCH(float, true, dim3((N + 63) / 64, BH, Z), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt);
         } else
             ATTN_LAUNCH(float, false, dim3((N + 127) / 128, BH), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt);
@@ -396,7 +404,7 @@ void launch_attention(const void* q, const void* k, const void* v, void* o, int 
         // 16-bit: the same split below 512 workgroups (one utterance: attention 24.3 -> 21.1 ms per step; at two utterances,
         // 576 workgroups, the 128-query form is already balanced and shares each K / V stage among more waves)
         const bool sp = split && (long)((N + 127) / 128) * BH < 512 && N >= 64;
-        const dim3 grid(sp ? (N + 63) / 64 : (N + 127) / 128, BH);
+        const dim3 grid(sp ? (N + 63) / 64 : (N + 127) / 128, BH, sp ? pick_z(z16) : 1);
         if (dtype == MI_F16) {
             if (sp) ATTN_LAUNCH(f16, true, grid, dim3(256), 0, s, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)o, H, N, ws, cnt);
             else ATTN_LAUNCH(f16, false, grid, dim3(256), 0, s, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)o, H, N, ws, cnt);

@@ -323,8 +323,8 @@ void F5::ensure_workspace(int U, int N) {
     const size_t es = dtype_size(dtype);
     const size_t rows = (size_t)2 * Um * Nm;
     sk.ensure(1024, stream);     // 64 MB: stream-K slots (64 KB) and the split-tail slabs of gemm_ph8.hip (256 KB)
-    if (dtype == MI_F32) {
-        // key-sliced attention (attention.hip): used while there are fewer than 1024 128-query workgroups, i.e. up to
+    {
+        // key-sliced attention (attention.hip): used while there are fewer than 1024 (fp32) / 512 (16-bit) 128-query workgroups, i.e. up to
         // ~3 utterances; 4 slices x (8192 + 256) floats per 64-query tile
         const long tiles = (long)((Nm + 63) / 64) * 2 * Um * c.heads;
         if ((long)((Nm + 127) / 128) * 2 * Um * c.heads < 1024 && tiles > attn_cnt_n) {

@@ -435,6 +435,9 @@ static long g_ring4_max = 256;
 // stream-K (gemm_sk.hip): 0 off ; 1 fp32 linear layers ; 2 also 16-bit ; g_sk_stages: ring depth override (0 = automatic) ;
 // g_sk_max_tiles: only launches with at most this many 128x128 tiles (beyond that one tile per workgroup balances by itself)
 static long g_sk = 1, g_sk_stages = 0, g_sk_max_tiles = 2048, g_sk_order = -1;
+// whole tiles first, stream-K for the remainder only: measured SLOWER on the fp32 DiT layers (FF1 / FF2, 288 tiles: 87.0 vs
+// 83.7 us per launch — the remainder's eight-piece fix-ups cost more than the aligned K walk of the first phase gains): opt-in
+static long g_sk_hybrid = 0;
 // fp32 QKV + RoPE: its scatter epilogue is slow and in a persistent launch every workgroup runs it at the same time at the
 // end (in-model 184 us against 138 us for the 64x64 tiles, whose epilogues overlap other workgroups' main loops): off
 static long g_sk_qkv32 = 0;
@@ -482,6 +485,7 @@ static void dispatch_tiles(const ConvGemmDev& d, int B, hipStream_t s) {
                 e.Tm = (d.M + 127) / 128; e.Tn = (d.N + 127) / 128; e.RT = e.Tm;
                 e.RC = d.M <= d.N ? 0 : 1;      // per-XCD groups: whole weight panels (x re-read 8x) when x is the smaller operand, else whole row tiles
                 if (g_sk_order >= 0) e.RC = (int)g_sk_order;
+                e.tail_tiles = (int)g_sk_hybrid;   // whole tiles first, stream-K only for the remainder (gemm_sk.hip)
                 launch_linear_sk<T, TO>(e, (int)g_sk_stages, s);
                 return;
             }
@@ -606,6 +610,7 @@ bool gemm_set_option(const char* key, long v) {
     else if (k == "gemm_sk_stages") g_sk_stages = v;
     else if (k == "gemm_sk_max_tiles") g_sk_max_tiles = v;
     else if (k == "gemm_sk_qkv32") g_sk_qkv32 = v;
+    else if (k == "gemm_sk_hybrid") g_sk_hybrid = v;
     else if (k == "gemm_ph8") g_ph8 = v;
     else if (k == "gemm_ph8_min_tiles") g_ph8_min_tiles = v;
     else if (k == "gemm_ph8_order") g_ph8_order = v;
@@ -659,6 +664,7 @@ void launch_conv_gemm(const ConvGemm& p_in, hipStream_t s) {
             if (const char* n = std::getenv("MI355TTS_SK")) g_sk = std::atol(n);
             if (const char* n = std::getenv("MI355TTS_SK_STAGES")) g_sk_stages = std::atol(n);
             if (const char* n = std::getenv("MI355TTS_SK_ORDER")) g_sk_order = std::atol(n);
+            if (const char* n = std::getenv("MI355TTS_SK_HYBRID")) g_sk_hybrid = std::atol(n);
             if (const char* n = std::getenv("MI355TTS_SK_QKV32")) g_sk_qkv32 = std::atol(n);
             if (const char* n = std::getenv("MI355TTS_PH8")) g_ph8 = std::atol(n);
             if (const char* n = std::getenv("MI355TTS_PH8_MIN")) g_ph8_min_tiles = std::atol(n);

@@ -81,11 +81,18 @@ __global__ __launch_bounds__(256, NST <= 2 ? 2 : 1) void linear_sk_kernel(const 
     const int l = R - 1 - ((int)blockIdx.x >> 3);               // range index inside the group
     const int nch = p.K / KC;
     const int T_all = p.Tm * p.Tn;
-    const int tile_lo = (int)((long)xg * T_all / 8), tile_hi = (int)((long)(xg + 1) * T_all / 8);
+    const int tile_lo_g = (int)((long)xg * T_all / 8), tile_hi = (int)((long)(xg + 1) * T_all / 8);
+    // Hybrid (p.tail_tiles != 0): when a group holds at least one tile per workgroup, every workgroup first computes
+    // `full` WHOLE tiles (tile_lo_g + j*R + l), all of them starting at chunk 0 together — the 32 workgroups of an XCD then
+    // walk K in step and share their row / weight panels in L2 (pure stream-K ranges start at unrelated chunks: TCC hit
+    // rate 38 % against 82 % for one tile per workgroup) — and only the group's remaining tiles are stream-K'd.
+    const int full = p.tail_tiles ? (tile_hi - tile_lo_g) / R : 0;
+    const int tile_lo = tile_lo_g + full * R;                   // first stream-K'd tile of the group
     const long I = (long)(tile_hi - tile_lo) * nch;
     long it = (long)l * I / R;
     const long it1 = (long)(l + 1) * I / R;
     const int slot0 = xg * R;                                   // workspace slots / flags of this group
+    int dp_done = 0;
 
     const int kvl0 = (lane & 7) ^ ((lane >> 4) & 7);            // even 8-row DMA groups (swizzle: slot = kv ^ ((row >> 1) & 7))
     const int kvl1 = (lane & 7) ^ ((4 + (lane >> 4)) & 7);      // odd 8-row DMA groups
@@ -99,11 +106,12 @@ __global__ __launch_bounds__(256, NST <= 2 ? 2 : 1) void linear_sk_kernel(const 
     __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.sk_ws, 0, (int)((long)P * BM * BN * 4), 0x00020000);
     int* flags = p.sk_flags;
 
-    while (it < it1) {
-        const int tile_g = (int)(it / nch);                      // tile inside the group
-        const int cb = (int)(it - (long)tile_g * nch);
-        const int tile = tile_lo + tile_g;
-        const int n = (int)((it1 - it) < (long)(nch - cb) ? (it1 - it) : (long)(nch - cb));
+    while (dp_done < full || it < it1) {
+        const bool dp = dp_done < full;                          // a whole tile of the data-parallel phase
+        const int tile_g = dp ? 0 : (int)(it / nch);             // tile inside the stream-K'd part of the group
+        const int cb = dp ? 0 : (int)(it - (long)tile_g * nch);
+        const int tile = dp ? tile_lo_g + dp_done * R + l : tile_lo + tile_g;
+        const int n = dp ? nch : (int)((it1 - it) < (long)(nch - cb) ? (it1 - it) : (long)(nch - cb));
         const int ce = cb + n;
         int nt, mt;
         if (p.RC == 0) { nt = tile / p.Tm; mt = tile - nt * p.Tm; }   // row tiles fastest: a group = whole weight panels
@@ -244,7 +252,7 @@ __global__ __launch_bounds__(256, NST <= 2 ? 2 : 1) void linear_sk_kernel(const 
 
         // ---- partial tile: publish (tail / middle piece) or collect (head piece) -------------------------------------------
         const int slot_lane = (wave * 16) * 64 + lane;          // + (i*2+j)*4*64 + q*64 : 16-byte units inside a 64 KB slot
-        if (p.dbg & 4) { it += n; continue; }                    // tuning: no fix-up, no epilogue
+        if (p.dbg & 4) { if (dp) ++dp_done; else it += n; continue; }                    // tuning: no fix-up, no epilogue
         if (cb > 0) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -303,7 +311,7 @@ __global__ __launch_bounds__(256, NST <= 2 ? 2 : 1) void linear_sk_kernel(const 
             }
             __syncthreads();                                    // the staging epilogue read the ring's LDS
         }
-        it += n;
+        if (dp) ++dp_done; else it += n;
     }
 #endif
 }
