@@ -148,6 +148,42 @@ def test_attention_against_oracle_ragged_lengths(small):
     eng.close()
 
 
+@pytest.mark.parametrize("dtype,tol", [("f32", 3e-4), ("f16", 1.5e-2)])
+def test_attention_key_slices_agree(dtype, tol):
+    """Key-sliced attention (gridDim.z slices of the 64-key stages, last-arriver merge in slice order): every slice count,
+    including slices that get no stage at all, gives the unsliced result within rounding and is identical run to run."""
+    from mi355tts import _lib
+    cfg = F5Config(dim=256, depth=1, heads=4, dim_head=64, text_dim=64, text_num_embeds=40, conv_layers=1,
+                   pos_conv_groups=4, vocos_dim=64, vocos_intermediate=128, vocos_layers=1, nfe_step=4)
+    raw = W.synth_state(W.f5_spec(cfg), 7)
+    st = W.fold_f5(cfg, raw)
+    eng = F5Engine(cfg, raw, dtype=dtype)
+    tables = O.time_tables(cfg, st)
+    try:
+        for N in (130, 257, 700):                              # 3 / 5 / 11 stages of 64 keys: N = 130 leaves the fourth slice empty
+            noise = W.synth_normal(3, f"n{N}", (N, cfg.mel_dim))
+            cmt = W.synth_normal(4, f"c{N}", (N, cfg.mel_dim + cfg.text_dim), std=0.7)
+            cmtd = W.synth_normal(5, f"d{N}", (N, cfg.mel_dim + cfg.text_dim), std=0.7)
+            cos, sin = O.rope_tables(N, 64)
+            ref = O.dit_forward(cfg, st, noise, cmt, cmtd, tables[2][1], cos, sin)
+            outs = []
+            for z in (1, 2, 3, 4):
+                _lib.set_option("attn_z_force", z)
+                a = eng.dit_eval(noise[None], cmt[None], cmtd[None], 1)
+                for _ in range(3):
+                    assert np.array_equal(a, eng.dit_eval(noise[None], cmt[None], cmtd[None], 1)), (N, z)
+                if dtype == "f32":
+                    np.testing.assert_allclose(a, ref, atol=tol)
+                else:
+                    assert rms(a - ref) / rms(ref) < tol
+                outs.append(a)
+            for a in outs[1:]:
+                assert np.abs(a - outs[0]).max() < (1e-4 if dtype == "f32" else 0.1)
+    finally:
+        _lib.set_option("attn_z_force", 0)
+        eng.close()
+
+
 @pytest.mark.parametrize("dtype,tol", [("f16", 1.5e-2), ("bf16", 8e-2)])
 def test_dit_16bit_ragged_batch_against_oracle(dtype, tol):
     """16-bit DiT evaluation, two utterances flattened into the GEMM M axis with an odd token count: the LDS-staged QKV

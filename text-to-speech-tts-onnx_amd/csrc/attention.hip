@@ -21,6 +21,7 @@
 #include "mfma.h"
 #include "f5_kernels.h"
 #include <cstdlib>
+#include <string>
 #include <algorithm>
 
 namespace mi {
@@ -352,6 +353,17 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const T* __restrict__ q, c
     }
 }
 
+// key slices of the SPLIT2 form: at most g_attn_zmax for fp32, g_attn_z16 for 16-bit operands (1 = off: no gain measured)
+static int g_attn_zmax = 4, g_attn_z16 = 1, g_attn_zforce = 0;      // zforce (tests): exactly that many slices, even empty ones
+bool attn_set_option(const char* key, long v) {
+    const std::string k(key);
+    if (k == "attn_z_max") g_attn_zmax = (int)std::max(1L, std::min(4L, v));
+    else if (k == "attn_z16_max") g_attn_z16 = (int)std::max(1L, std::min(4L, v));
+    else if (k == "attn_z_force") g_attn_zforce = (int)std::max(0L, std::min(4L, v));
+    else return false;
+    return true;
+}
+
 void launch_attention(const void* q, const void* k, const void* v, void* o, int BH, int H, int N, int dtype, hipStream_t s,
                       float* ws, long ws_floats, int* cnt, long cnt_n) {
     MI_REQUIRE(BH % H == 0 && N > 0, "attention: bad shape");
@@ -362,11 +374,13 @@ void launch_attention(const void* q, const void* k, const void* v, void* o, int 
         prof_set_kernel("attn_kernel<T, " #SP ">", type_label<TT>());           \
         hipLaunchKernelGGL((attn_kernel<TT, SP>), __VA_ARGS__);                 \
     } while (0)
-    static int split = -1, zmax = 4;
+    static int split = -1;
     if (split < 0) {
         const char* e = std::getenv("MI355TTS_ATTN_NO_SPLIT"); split = (e && e[0] == '1') ? 0 : 1;
-        if (const char* z = std::getenv("MI355TTS_ATTN_Z")) zmax = std::max(1, std::min(4, std::atoi(z)));
+        if (const char* z = std::getenv("MI355TTS_ATTN_Z")) g_attn_zmax = std::max(1, std::min(4, std::atoi(z)));
+        if (const char* z = std::getenv("MI355TTS_ATTN_Z16")) g_attn_z16 = std::max(1, std::min(4, std::atoi(z)));
     }
+    const int zmax = g_attn_zmax;
     // key slices for the SPLIT2 form (see attn_kernel): makespan(Z) = ceil(units * Z / CUs) / Z in units of one unsliced
     // workgroup, + 6 % per extra slice for the prologue and the merge (measured, fp32, one utterance = 576 units:
     // Z = 1 / 2 / 3 / 4 -> 135 / 122 / 121 / 126 us)
@@ -380,6 +394,8 @@ void launch_attention(const void* q, const void* k, const void* v, void* o, int 
             if (!cu_count[dev & 15]) { hipDeviceProp_t pr; MI_HIP(hipGetDeviceProperties(&pr, dev)); cu_count[dev & 15] = pr.multiProcessorCount; }
             cus = cu_count[dev & 15];
         }
+        if (g_attn_zforce > 0)
+            return (ws && cnt && units * g_attn_zforce * (2 * 32 * 64 + 2 * 64 * 2) <= ws_floats && units <= cnt_n) ? g_attn_zforce : 1;
         int Z = 1;
         double best = 1e30;
         const int zm = dtype == MI_F32 ? zmax : std::min(zmax, zlimit16);
@@ -390,8 +406,7 @@ void launch_attention(const void* q, const void* k, const void* v, void* o, int 
         }
         return Z;
     };
-    static int z16 = -1;
-    if (z16 < 0) { const char* e = std::getenv("MI355TTS_ATTN_Z16"); z16 = e ? std::atoi(e) : 1; }
+    const int z16 = g_attn_z16;
     if (dtype == MI_F32) {
         // few 128-query workgroups (one or two utterances): halve them along the keys, see attn_kernel
         if (split && (long)((N + 127) / 128) * BH < 1024 && N >= 64) {

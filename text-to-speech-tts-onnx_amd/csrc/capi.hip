@@ -680,7 +680,8 @@ int mi_bench_conv_gemm(int dtype, int B, int T, int Cin, int N, int taps, int di
 int mi_set_option(const char* key, int64_t value) {
     return guard([&] {
         MI_REQUIRE(key != nullptr, "mi_set_option: null key");
-        MI_REQUIRE(gemm_set_option(key, (long)value) || gpt_set_option(key, (long)value) || aa_conv_set_option(key, (long)value), "mi_set_option: unknown key");
+        MI_REQUIRE(gemm_set_option(key, (long)value) || gpt_set_option(key, (long)value) || aa_conv_set_option(key, (long)value) ||
+                       attn_set_option(key, (long)value), "mi_set_option: unknown key");
         option_epoch_bump();
     });
 }

@@ -196,6 +196,7 @@ struct AAConv {
 };
 void launch_aa_conv(const AAConv& p, hipStream_t s);
 bool aa_conv_set_option(const char* key, long v);
+bool attn_set_option(const char* key, long v);
 
 // layout helpers (elementwise.hip)
 // (B,C,T) fp32 channels-first -> (B,T,Cpad) dtype channels-last (zero padded channels)

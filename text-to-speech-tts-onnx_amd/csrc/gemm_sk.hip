@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256, NST <= 2 ? 2 : 1) void linear_sk_kernel(const 
     int* flags = p.sk_flags;
 
     while (dp_done < full || it < it1) {
-        const bool dp = dp_done < full;                          // a whole tile of the data-parallel phase
+        const bool dp = p.tail_tiles == 2 ? !(it < it1) : dp_done < full;   // a whole tile of the data-parallel phase (mode 2: after the stream-K'd pieces, mode 1: before)
         const int tile_g = dp ? 0 : (int)(it / nch);             // tile inside the stream-K'd part of the group
         const int cb = dp ? 0 : (int)(it - (long)tile_g * nch);
         const int tile = dp ? tile_lo_g + dp_done * R + l : tile_lo + tile_g;
