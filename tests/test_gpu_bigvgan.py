@@ -316,7 +316,7 @@ def test_bad_inputs_raise(small_voc):
 # only when the launch fills the chip) and compared with the oracle
 # ---------------------------------------------------------------------------------------------
 _DEFAULTS = {"gemm_big_tile_min": 160, "gemm_n192_min": 160, "gemm_mid_tile_min": 160, "gemm_dma3_k_min": 2048,
-             "gemm_use_dma3": 1, "gemm_use_dma": 1, "gemm_big_tiles": 1, "gemm_n192": 1, "gemm_f32_dma": 1, "gemm_ring4": 1, "gemm_ring4_max": 256, "gemm_buf": 1, "gemm_f32_small": 1, "gemm_f32_small_max": 1024, "gemm_small16_max": 256, "gemm_sk": 1, "gemm_sk_stages": 0, "gemm_ph8": 1, "gemm_ph8_min_tiles": 200, "gemm_ph8_order": 1, "gemm_ph8_split_max": 2, "gemm_ph8_split_min_nk": 24, "gemm_sk_hybrid": 0}
+             "gemm_use_dma3": 1, "gemm_use_dma": 1, "gemm_big_tiles": 1, "gemm_n192": 1, "gemm_f32_dma": 1, "gemm_ring4": 1, "gemm_ring4_max": 256, "gemm_buf": 1, "gemm_f32_small": 1, "gemm_f32_small_max": 1024, "gemm_small16_max": 256, "gemm_sk": 1, "gemm_sk_stages": 0, "gemm_ph8": 1, "gemm_ph8_min_tiles": 200, "gemm_ph8_order": 1, "gemm_ph8_split_max": 2, "gemm_ph8_split_min_nk": 24, "gemm_sk_hybrid": 0, "gemm_sk_producer": 0}
 
 
 @pytest.fixture
@@ -384,6 +384,10 @@ def test_stream_k_linear_vs_oracle(gemm_options, dtype, tol, stages, Ci, Co, T, 
     else:
         assert rms(y - ref) / rms(ref) < tol
     assert np.array_equal(y, BV.conv1d(x, w, b, dtype=dtype))
+    if dtype == "f32" and stages in (0, 3):
+        _lib.set_option("gemm_sk_producer", 1)              # DMA issued by two extra waves: the same sums in the same order
+        assert np.array_equal(y, BV.conv1d(x, w, b, dtype=dtype))
+        _lib.set_option("gemm_sk_producer", 0)
     _lib.set_option("gemm_sk_hybrid", 0)
     yh = BV.conv1d(x, w, b, dtype=dtype)                    # pure stream-K: same products, other summation split
     if dtype == "f32":

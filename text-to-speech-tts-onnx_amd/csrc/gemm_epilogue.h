@@ -413,6 +413,7 @@ typedef __attribute__((address_space(3))) void lds_void;
 template <typename T, typename TO> void launch_conv_gemm_dma3(const ConvGemmDev& e, int bn, hipStream_t s);
 // gemm_sk.hip: stream-K 128x128 kernel for plain linear layers (stages: 0 = automatic)
 template <typename T, typename TO> void launch_linear_sk(const ConvGemmDev& e, int stages, hipStream_t s);
+void sk_set_producer(long v);
 // gemm_ph8.hip: 256x256 eight-phase kernel for 16-bit linear layers with many row tiles
 template <typename T, typename TO> void launch_linear_ph8(const ConvGemmDev& e, hipStream_t s);
 void ph8_set_split_max(long v);

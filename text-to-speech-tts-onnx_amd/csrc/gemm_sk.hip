@@ -52,14 +52,20 @@ __device__ __forceinline__ unsigned sk_lds_addr(const void* p) {
     return (unsigned)(unsigned long)(const __attribute__((address_space(3))) void*)p;
 }
 
-template <typename T, typename TO, bool LEPI, int NST>
-__global__ __launch_bounds__(256, NST <= 2 ? 2 : 1) void linear_sk_kernel(const ConvGemmDev p) {
+// PROD: two extra waves do nothing but issue the LDS-DMA (wave 4: the 16 x-row pieces of a chunk, wave 5: the 16 weight-row
+// pieces) and wait for it; the four MFMA waves
+// carry no VMEM instruction and no vmcnt wait.  Why: a DMA instruction costs its wave ~100 cycles of issue (M0 write, address
+// add, the instruction itself) during which that wave — alone on its SIMD — issues no MFMA: eight per 4096-cycle fp32 chunk
+// were the 18 % the "no DMA" ablation recovered.  The producer shares SIMD 0 with wave 0 and is paced by the same barriers.
+template <typename T, typename TO, bool LEPI, int NST, bool PROD = false>
+__global__ __launch_bounds__(PROD ? 384 : 256, NST <= 2 ? 2 : 1) void linear_sk_kernel(const ConvGemmDev p) {
     using MF = Mfma<T>;
     constexpr int VEC = 16 / (int)sizeof(T), KC = 8 * VEC;      // a tile row is 128 bytes: 64 halfs or 32 floats per K chunk
     constexpr int BM = 128, BN = 128, WM = 64, WN = 64, TM = 2, TN = 2, DJ = 4, PER = 2 * DJ;
     constexpr int TILE = (BM + BN) * KC;
     constexpr int AHEAD = NST - 1;                              // chunks in flight beyond the one being computed
     static_assert(NST >= 2 && NST <= 4, "ring depth");
+    static_assert(!PROD || NST == 3, "the producer wave runs two chunks ahead in a three-stage ring");
     // ONE static array (a dynamic `extern __shared__` block makes hipcc put s_waitcnt vmcnt(0) in front of every ds_read
     // that follows an LDS-DMA: the ring then drains every chunk — seen in the ISA, 56 % MFMA duty instead of ~90 %)
     __shared__ __attribute__((aligned(1024))) T smem[NST * TILE];
@@ -206,6 +212,69 @@ __global__ __launch_bounds__(256, NST <= 2 ? 2 : 1) void linear_sk_kernel(const 
         //      instructions with MFMA execution only if they sit BETWEEN MFMAs in program order, so every k-vector step is
         //      Q0 | fragment reads of the next step | Q1 | DMA | Q2 | DMA | Q3  (PMC before: 26 % of the busy cycles had no
         //      MFMA in flight, the eight address-computation + DMA blocks ran in front of the MFMA group) ---------------------
+        if constexpr (PROD) {
+            if (wave >= 4) {
+                const bool pa = wave == 4;                       // wave 4 stages the x rows, wave 5 the weight rows
+                // ---- producer: chunk c+2 goes out right after the barrier that ended the reads of chunk c-1 (same stage);
+                //      s_waitcnt vmcnt(16) = everything but this wave's newest chunk has landed; then the barrier that publishes
+                //      chunk c+1.  Rows past M / N are beyond num_records: the range check writes zeros.
+                const int a_ev = (int)(((long)(m0 + lrow) * p.x_rstride + kvl0 * VEC) * (long)sizeof(T));
+                const int a_od = (int)(((long)(m0 + 8 + lrow) * p.x_rstride + kvl1 * VEC) * (long)sizeof(T));
+                const int b_ev = (int)(((long)(n0 + lrow) * p.K + kvl0 * VEC) * (long)sizeof(T));
+                const int b_od = (int)(((long)(n0 + 8 + lrow) * p.K + kvl1 * VEC) * (long)sizeof(T));
+                const int a_step = (int)((long)16 * p.x_rstride * (long)sizeof(T)), b_step = (int)((long)16 * p.K * (long)sizeof(T));
+                auto issue_all = [&](int stg, int chunk) __attribute__((always_inline)) {
+                    if (p.dbg & 1) return;
+                    const unsigned base = __builtin_amdgcn_readfirstlane(smem_lds + (unsigned)(stg * TILE * (int)sizeof(T)));
+                    const int cbytes = chunk < ce ? chunk * KC * (int)sizeof(T) : OOB;
+                    if (pa) {
+#pragma unroll
+                        for (int g = 0; g < 8; ++g) {
+                            sk_bufds16(rsa, (int)((unsigned)a_ev + (unsigned)(g * a_step) + (unsigned)cbytes), base + (unsigned)((2 * g) * 8 * KC * (int)sizeof(T)));
+                            sk_bufds16(rsa, (int)((unsigned)a_od + (unsigned)(g * a_step) + (unsigned)cbytes), base + (unsigned)((2 * g + 1) * 8 * KC * (int)sizeof(T)));
+                        }
+                    } else {
+#pragma unroll
+                        for (int g = 0; g < 8; ++g) {
+                            sk_bufds16(rsb, (int)((unsigned)b_ev + (unsigned)(g * b_step) + (unsigned)cbytes), base + (unsigned)((BM + (2 * g) * 8) * KC * (int)sizeof(T)));
+                            sk_bufds16(rsb, (int)((unsigned)b_od + (unsigned)(g * b_step) + (unsigned)cbytes), base + (unsigned)((BM + (2 * g + 1) * 8) * KC * (int)sizeof(T)));
+                        }
+                    }
+                };
+                issue_all(0, cb); issue_all(1, cb + 1);
+                asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                int stp = 2;
+                for (int c = 0; c + 1 < n; ++c) {
+                    issue_all(stp, cb + c + 2);
+                    if (++stp == NST) stp = 0;
+                    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+            } else {
+                __builtin_amdgcn_s_barrier();                   // chunk cb has landed
+                ldfrag(0, 0, 0);
+                int st = 0;
+                for (int c = 0; c < n; ++c) {
+                    int stn = st + 1; if (stn == NST) stn = 0;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        const int set = ks & 1;
+                        if (ks == 3 && c + 1 < n) {
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            __builtin_amdgcn_s_barrier();       // chunk c+1 published, stage of chunk c released
+                        }
+                        SK_SB(); mma_q(set, 0); SK_SB();
+                        if (ks < 3) ldfrag(st, ks + 1, set ^ 1);
+                        else if (c + 1 < n) ldfrag(stn, 0, 0);
+                        SK_SB(); mma_q(set, 1); SK_SB();
+                        SK_SB(); mma_q(set, 2); SK_SB();
+                        SK_SB(); mma_q(set, 3); SK_SB();
+                    }
+                    st = stn;
+                }
+            }
+        } else {
 #pragma unroll
         for (int a = 0; a < AHEAD; ++a) issue(a, cb + a);
         wait_landed(true);
@@ -245,6 +314,7 @@ __global__ __launch_bounds__(256, NST <= 2 ? 2 : 1) void linear_sk_kernel(const 
             if (++st_issue == NST) st_issue = 0;
             st = stn;
         }
+        }
 #undef SK_SB
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // trailing dummies have landed: the ring may be reused
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -253,7 +323,9 @@ __global__ __launch_bounds__(256, NST <= 2 ? 2 : 1) void linear_sk_kernel(const 
         // ---- partial tile: publish (tail / middle piece) or collect (head piece) -------------------------------------------
         const int slot_lane = (wave * 16) * 64 + lane;          // + (i*2+j)*4*64 + q*64 : 16-byte units inside a 64 KB slot
         if (p.dbg & 4) { if (dp) ++dp_done; else it += n; continue; }                    // tuning: no fix-up, no epilogue
+        const bool worker = !PROD || wave < 4;                   // the producer wave only takes part in the barriers below
         if (cb > 0) {
+            if (worker)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -280,6 +352,7 @@ __global__ __launch_bounds__(256, NST <= 2 ? 2 : 1) void linear_sk_kernel(const 
                     }
                     __syncthreads();
                     sk_u4 v[TM * TN * 4];
+                    if (worker) {
 #pragma unroll
                     for (int u = 0; u < TM * TN * 4; ++u)
                         v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsw, ((slot0 + q_l) * (BM * BN / 4) + slot_lane + u * 64) * 16, 0, 16 /* sc1 */);
@@ -293,11 +366,13 @@ __global__ __launch_bounds__(256, NST <= 2 ? 2 : 1) void linear_sk_kernel(const 
                                 acc[i][j][4 * q] += __uint_as_float(w.x); acc[i][j][4 * q + 1] += __uint_as_float(w.y);
                                 acc[i][j][4 * q + 2] += __uint_as_float(w.z); acc[i][j][4 * q + 3] += __uint_as_float(w.w);
                             }
+                    }
                     __syncthreads();                            // every lane holds its share: the slot may be recycled
                     if (tid == 0) __hip_atomic_store(flags + slot0 + q_l, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     cov += (int)((q1 - q0) < (long)(nch - cov) ? (q1 - q0) : (long)(nch - cov));
                 }
             }
+            if (worker) {
             if constexpr (LEPI) {
                 constexpr int ERT = 2;
                 float* stage = reinterpret_cast<float*>(smem) + wave * (ERT * 32 * WN);
@@ -309,6 +384,7 @@ __global__ __launch_bounds__(256, NST <= 2 ? 2 : 1) void linear_sk_kernel(const 
             } else {
                 gemm_epilogue<TO, TM, TN, WM, WN>(acc, p, m0, n0, 0, 0, wm, wn, lr, lk);
             }
+            }
             __syncthreads();                                    // the staging epilogue read the ring's LDS
         }
         if (dp) ++dp_done; else it += n;
@@ -317,6 +393,11 @@ __global__ __launch_bounds__(256, NST <= 2 ? 2 : 1) void linear_sk_kernel(const 
 }
 
 // stages: 0 = automatic (fp32: three-stage ring, one workgroup per CU; 16-bit: two stages, two workgroups per CU)
+// measured on the fp32 DiT layers: interleaved DMA 83.9 us per launch, one producer wave 93.0 (it cannot issue 32 pieces in
+// the 3/4 chunk the MFMA waves leave it before the barrier), two producer waves 88.3 — the interleaved form stays the default
+static long g_sk_producer = 0;
+void sk_set_producer(long v) { g_sk_producer = v; }
+
 template <typename T, typename TO>
 void launch_linear_sk(const ConvGemmDev& e, int stages, hipStream_t s) {
     constexpr int KC = 128 / (int)sizeof(T);
@@ -337,6 +418,18 @@ void launch_linear_sk(const ConvGemmDev& e, int stages, hipStream_t s) {
         prof_set_kernel("linear_sk_kernel<T, TO, " #LE ", " #NS ">", type_label<T>(), type_label<TO>());               \
         hipLaunchKernelGGL(kfn, grid, dim3(256), 0, s, e);                                                             \
     } while (0)
+    if constexpr (sizeof(T) == 4) {
+        if (nst == 3 && g_sk_producer) {
+            auto launch_p = [&](auto kfn, const char* name) {
+                prof_set_kernel(name, type_label<T>(), type_label<TO>());
+                hipLaunchKernelGGL(kfn, grid, dim3(384), 0, s, e);
+            };
+            if (e.lds_epi) launch_p(linear_sk_kernel<T, TO, true, 3, true>, "linear_sk_kernel<T, TO, true, 3, producer>");
+            else launch_p(linear_sk_kernel<T, TO, false, 3, true>, "linear_sk_kernel<T, TO, false, 3, producer>");
+            MI_HIP(hipGetLastError());
+            return;
+        }
+    }
     if (e.lds_epi) { if (nst == 2) SK_LAUNCH(true, 2); else if (nst == 3) SK_LAUNCH(true, 3); else SK_LAUNCH(true, 4); }
     else { if (nst == 2) SK_LAUNCH(false, 2); else if (nst == 3) SK_LAUNCH(false, 3); else SK_LAUNCH(false, 4); }
 #undef SK_LAUNCH
