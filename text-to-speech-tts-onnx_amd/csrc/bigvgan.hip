@@ -420,6 +420,12 @@ void unit_conv1d(const float* x, int B, int Cin, int T, const float* w, const fl
     SkWorkspace skw;                                    // lets one-tap shapes reach the stream-K kernel (gemm_sk.hip)
     skw.ensure(512, ts.s);
     skw.attach(p);
+    DevBuf dw3;
+    if (dtype == MI_F32 && k == 1 && groups == 1 && gemm_x3_enabled()) {     // ... and the bf16x3 kernel (gemm_x3.hip)
+        dw3.ensure((size_t)3 * Cout * cigp * 2);
+        split3_planes(dw.as<float>(), dw3.p, (long)Cout * cigp, ts.s);
+        p.w3 = dw3.p;
+    }
     launch_conv_gemm(p, ts.s);
     launch_nlc_to_ncl(dyl.p, dy.as<float>(), B, Cout, To, dtype, ts.s);
     MI_HIP(hipMemcpyAsync(y, dy.p, (size_t)B * Cout * To * 4, hipMemcpyDeviceToHost, ts.s));

@@ -162,6 +162,8 @@ struct ConvGemm {
     // stream-K workspace of the caller (gemm_sk.hip): sk_slots x 64 KB of partial tiles + sk_slots zero-initialised flags;
     // null: plain linear layers run one tile per workgroup
     float* sk_ws = nullptr; int* sk_flags = nullptr; int sk_slots = 0;
+    // fp32 linear layers through the bf16 pipes (gemm_x3.hip): the weights split into three bf16 planes [3][N][K] (split3_planes)
+    const void* w3 = nullptr;
 };
 void launch_conv_gemm(const ConvGemm& p, hipStream_t s);
 // owner of a stream-K workspace (one per engine handle / stream)
@@ -197,6 +199,8 @@ struct AAConv {
 void launch_aa_conv(const AAConv& p, hipStream_t s);
 bool aa_conv_set_option(const char* key, long v);
 bool attn_set_option(const char* key, long v);
+void split3_planes(const float* w, void* planes, long n, hipStream_t s);   // gemm_x3.hip
+bool gemm_x3_enabled();
 
 // layout helpers (elementwise.hip)
 // (B,C,T) fp32 channels-first -> (B,T,Cpad) dtype channels-last (zero padded channels)

@@ -17,7 +17,7 @@ struct F5Cfg {
 F5Cfg parse_f5_cfg(const int32_t* ci, int ni, const float* cf, int nf);
 int64_t f5_param_count(const F5Cfg& c);
 
-struct Lin { DevBuf w, b; int n = 0, k = 0; };
+struct Lin { DevBuf w, b, w3; int n = 0, k = 0; };      // w3: fp32 engines, the three bf16 planes of w (gemm_x3.hip)
 
 struct F5 {
     F5Cfg cfg;

@@ -194,6 +194,13 @@ F5::F5(const F5Cfg& c, const float* w, int64_t nw, int dt, int dev, int mem) : c
         put_lin(R, bk.ff1, w1, b1, ff, d, dt);
         const float* w2 = take((size_t)d * ff); const float* b2 = take(d);
         put_lin(R, bk.ff2, w2, b2, d, ff, dt);
+        if (dt == MI_F32) {
+            // the four big matrices of the block once more as three bf16 planes each: fp32 products on the bf16 pipes
+            for (Lin* L : {&bk.qkv, &bk.o, &bk.ff1, &bk.ff2}) {
+                L->w3.ensure((size_t)3 * L->n * L->k * 2);
+                split3_planes(L->w.as<float>(), L->w3.p, (long)L->n * L->k, s);
+            }
+        }
     }
     {
         const float* mw = take((size_t)2 * d * d); const float* mb = take((size_t)2 * d);
@@ -365,7 +372,7 @@ void F5::ensure_workspace(int U, int N) {
 void F5::gemm(int dt, const void* x, long xb, long xr, int K, const Lin& L, void* out, int odt, long ob, long orr, int B,
               int M, int act, const void* res, const float* gate) {
     ConvGemm g;
-    g.dtype = dt; g.out_dtype = odt; g.x = x; g.w = L.w.p; g.bias = L.b.p ? L.b.as<float>() : nullptr; g.out = out;
+    g.dtype = dt; g.out_dtype = odt; g.x = x; g.w = L.w.p; g.w3 = L.w3.p; g.bias = L.b.p ? L.b.as<float>() : nullptr; g.out = out;
     g.res = res; g.gate = gate; g.gate_bstride = 0;
     g.B = B; g.T_in = M; g.M = M; g.N = L.n; g.Cin = K; g.taps = 1;
     g.x_bstride = xb; g.x_rstride = xr; g.out_bstride = ob; g.out_rstride = orr; g.act = act;
@@ -541,7 +548,7 @@ void F5::dit_eval(int U, int N, int k) {
         launch_rownorm(NORM_LN_MOD, X.as<float>(), Ub.p, dtype, m + d, m, rows, d, 1e-6f, s);
         {
             ConvGemm g;
-            g.dtype = dtype; g.x = Ub.p; g.w = bk.qkv.w.p; g.bias = bk.qkv.b.as<float>();
+            g.dtype = dtype; g.x = Ub.p; g.w = bk.qkv.w.p; g.w3 = bk.qkv.w3.p; g.bias = bk.qkv.b.as<float>();
             g.out = qb.p; g.out2 = kb.p; g.out3 = vb.p;
             g.B = 1; g.T_in = B * N; g.M = B * N; g.rows_per_item = N;       // batch flattened into M
             g.N = 3 * d; g.Cin = d; g.x_bstride = (long)B * N * d; g.x_rstride = d;

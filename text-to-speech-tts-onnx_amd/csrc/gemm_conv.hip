@@ -438,6 +438,9 @@ static long g_sk = 1, g_sk_stages = 0, g_sk_max_tiles = 2048, g_sk_order = -1;
 // whole tiles first, stream-K for the remainder only: measured SLOWER on the fp32 DiT layers (FF1 / FF2, 288 tiles: 87.0 vs
 // 83.7 us per launch — the remainder's eight-piece fix-ups cost more than the aligned K walk of the first phase gains): opt-in
 static long g_sk_hybrid = 0;
+// fp32 linear layers as six exact bf16 x bf16 partial products (gemm_x3.hip) when the caller supplies the weight planes
+static long g_x3 = 1;
+bool gemm_x3_enabled() { return g_x3 != 0; }
 // fp32 QKV + RoPE: its scatter epilogue is slow and in a persistent launch every workgroup runs it at the same time at the
 // end (in-model 184 us against 138 us for the 64x64 tiles, whose epilogues overlap other workgroups' main loops): off
 static long g_sk_qkv32 = 0;
@@ -472,6 +475,17 @@ static void dispatch_tiles(const ConvGemmDev& d, int B, hipStream_t s) {
                 ConvGemmDev e = d;
                 e.Tm = (d.M + 255) / 256; e.Tn = (d.N + 255) / 256; e.RT = e.Tm; e.RC = (int)g_ph8_order;
                 launch_linear_ph8<T, TO>(e, s);
+                return;
+            }
+        }
+        if constexpr (sizeof(T) == 4) {
+            const long tiles = (long)((d.M + 127) / 128) * ((d.N + 127) / 128);
+            if (d.w3 && B == 1 && tiles >= 64) {                // d.w3 is only kept when x3_eligible() said yes (launch_conv_gemm)
+                ConvGemmDev e = d;
+                e.Tm = (d.M + 127) / 128; e.Tn = (d.N + 127) / 128; e.RT = e.Tm;
+                e.RC = d.M <= d.N ? 0 : 1;
+                if (g_sk_order >= 0) e.RC = (int)g_sk_order;
+                launch_linear_x3(e, s);
                 return;
             }
         }
@@ -612,6 +626,7 @@ bool gemm_set_option(const char* key, long v) {
     else if (k == "gemm_sk_qkv32") g_sk_qkv32 = v;
     else if (k == "gemm_sk_hybrid") g_sk_hybrid = v;
     else if (k == "gemm_sk_producer") sk_set_producer(v);
+    else if (k == "gemm_f32_x3") g_x3 = v;
     else if (k == "gemm_ph8") g_ph8 = v;
     else if (k == "gemm_ph8_min_tiles") g_ph8_min_tiles = v;
     else if (k == "gemm_ph8_order") g_ph8_order = v;
@@ -619,6 +634,19 @@ bool gemm_set_option(const char* key, long v) {
     else if (k == "gemm_ph8_split_min_nk") ph8_set_split_min_nk(v);
     else return false;
     return true;
+}
+
+// the bf16x3 kernel (gemm_x3.hip) takes this launch: decided ONCE here, because the epilogue kind depends on it
+static bool x3_eligible(const ConvGemm& p) {
+    if (!g_x3 || !p.w3 || p.dtype != MI_F32 || (p.out_dtype >= 0 && p.out_dtype != MI_F32)) return false;
+    if (!p.sk_ws || !p.sk_flags || p.sk_slots < 256 || p.B != 1 || p.G != 1 || p.taps != 1 || p.pad != 0 || p.Cin % 32 != 0 || p.M <= 128) return false;
+    if (p.epi != EPI_PLAIN && p.epi != EPI_QKV_ROPE) return false;
+    if (p.epi == EPI_QKV_ROPE && !(p.head_dim == 64 && p.rope_pack && p.v_ld == 0 && (p.rows_per_item == 0 ? p.M : p.rows_per_item) >= 64 &&
+                                   ((uintptr_t)p.out % 16) == 0 && ((uintptr_t)p.out2 % 16) == 0 && ((uintptr_t)p.out3 % 16) == 0)) return false;
+    const long tiles = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    if (tiles < 64 || tiles > g_sk_max_tiles) return false;
+    const long a_bytes = (((long)p.T_in - 1) * p.x_rstride + p.Cin) * 4, b_bytes = (long)3 * p.N * p.Cin * 2;
+    return g_buf && a_bytes + (long)512 * p.x_rstride * 4 < 0x7fff0000L && b_bytes < 0x7fff0000L;
 }
 
 void launch_conv_gemm(const ConvGemm& p_in, hipStream_t s) {
@@ -645,6 +673,8 @@ void launch_conv_gemm(const ConvGemm& p_in, hipStream_t s) {
     d.rope_cos = p.rope_cos; d.rope_sin = p.rope_sin; d.rope_pack = p.rope_pack; d.heads = p.heads; d.head_dim = p.head_dim;
     d.out2 = p.out2; d.out3 = p.out3; d.v_ld = p.v_ld; d.Mb = p.rows_per_item;
     d.sk_ws = p.sk_ws; d.sk_flags = p.sk_flags; d.sk_slots = p.sk_slots;
+    const bool use_x3 = x3_eligible(p);
+    d.w3 = use_x3 ? p.w3 : nullptr;
     d.tail_tiles = 0; d.tail_split = 1;
     d.use_buf = 0;
     {
@@ -667,6 +697,7 @@ void launch_conv_gemm(const ConvGemm& p_in, hipStream_t s) {
             if (const char* n = std::getenv("MI355TTS_SK_ORDER")) g_sk_order = std::atol(n);
             if (const char* n = std::getenv("MI355TTS_SK_HYBRID")) g_sk_hybrid = std::atol(n);
             if (const char* n = std::getenv("MI355TTS_SK_PRODUCER")) sk_set_producer(std::atol(n));
+            if (const char* n = std::getenv("MI355TTS_F32_X3")) g_x3 = std::atol(n);
             if (const char* n = std::getenv("MI355TTS_SK_QKV32")) g_sk_qkv32 = std::atol(n);
             if (const char* n = std::getenv("MI355TTS_PH8")) g_ph8 = std::atol(n);
             if (const char* n = std::getenv("MI355TTS_PH8_MIN")) g_ph8_min_tiles = std::atol(n);
@@ -694,7 +725,9 @@ void launch_conv_gemm(const ConvGemm& p_in, hipStream_t s) {
         const int ch = 16 / (int)dtype_size(odt);
         // measured: +8-14 % on the K = 1024 DiT linears in the 2-blocks-per-CU 128x128 kernel, a loss on the conv shapes
         // (N <= 768) and in the one-block-per-CU 8-wave kernels, so it is used for wide linear layers only
-        const bool qkv_lds = p.epi == EPI_QKV_ROPE && p.head_dim == 64 && dtype_size(odt) == 2 && p.G == 1 &&
+        // (fp32 outputs: only the bf16x3 kernel has the staged QKV epilogue; rows leave as 32-byte stores, V untransposed)
+        const bool qkv_x3 = use_x3;
+        const bool qkv_lds = p.epi == EPI_QKV_ROPE && p.head_dim == 64 && (dtype_size(odt) == 2 || qkv_x3) && p.G == 1 &&
                              (p.rows_per_item == 0 ? p.M : p.rows_per_item) >= 64 && ((uintptr_t)p.out % 16) == 0 &&
                              ((uintptr_t)p.out2 % 16) == 0;
         d.lds_epi = !no_lds_epi && qkv_lds;

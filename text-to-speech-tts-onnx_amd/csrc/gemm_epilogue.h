@@ -37,6 +37,7 @@ struct ConvGemmDev {
     int use_buf;           // 128x128 DMA kernel: 1 = LDS-DMA through buffer descriptors (whole K chunks, offsets fit 31 bits)
     int Tm, Tn, RT, RC;    // XCD-aware tile order (DMA kernel): M-tiles per batch item, N-tiles, row tiles (B*Tm), rows per XCD
     float* sk_ws; int* sk_flags; int sk_slots;   // stream-K (gemm_sk.hip): 64 KB partial-tile slot + flag per persistent workgroup
+    const void* w3;                              // gemm_x3.hip: weight planes [3][N][K] bf16 (null: not available)
     int tail_tiles, tail_split;                  // gemm_ph8.hip: the last tail_tiles tiles are cut into tail_split K slices (0 / 1: none)
 };
 
@@ -414,6 +415,8 @@ template <typename T, typename TO> void launch_conv_gemm_dma3(const ConvGemmDev&
 // gemm_sk.hip: stream-K 128x128 kernel for plain linear layers (stages: 0 = automatic)
 template <typename T, typename TO> void launch_linear_sk(const ConvGemmDev& e, int stages, hipStream_t s);
 void sk_set_producer(long v);
+// gemm_x3.hip: fp32 linear layers as exact three-way bf16 splits on the stream-K frame
+void launch_linear_x3(const ConvGemmDev& e, hipStream_t s);
 // gemm_ph8.hip: 256x256 eight-phase kernel for 16-bit linear layers with many row tiles
 template <typename T, typename TO> void launch_linear_ph8(const ConvGemmDev& e, hipStream_t s);
 void ph8_set_split_max(long v);

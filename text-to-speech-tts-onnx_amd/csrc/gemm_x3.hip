@@ -1,0 +1,338 @@
+// gemm_x3.hip — fp32 linear layers on the 16-bit matrix cores by an exact three-way split ("bf16x3").
+//
+// Every fp32 operand value is written as the sum of three bf16 values  a = a1 + a2 + a3  (a1 = bf16(a), a2 = bf16(a - a1),
+// a3 = bf16(a - a1 - a2); the subtractions are exact in fp32, so the three pieces carry 24 significant bits: the whole
+// fp32 mantissa).  A product of two bf16 numbers is exact in fp32, and
+//     a * b = a1 b1 + (a1 b2 + a2 b1) + (a1 b3 + a2 b2 + a3 b1) + O(2^-24 |a b|),
+// so six v_mfma_f32_32x32x16_bf16 per 32x32x16 block, accumulated in fp32 exactly like v_mfma_f32_32x32x2_f32 accumulates,
+// reproduce the fp32 product to within the rounding of the fp32 accumulation itself: this is fp32 arithmetic carried by
+// the bf16 pipes, not a reduced-precision mode.  (The dropped terms a2 b3, a3 b2, a3 b3 are below 2^-24 of the product.)
+// Cost: 6 x 32 cycles per 32x32x16 block against 8 x 64 cycles for the native fp32 MFMA — 2.7x fewer matrix-core cycles,
+// and far fewer joules, which is what bounds the native fp32 kernels on this chip.
+//
+// The weights are split once at load ([3][N][K] bf16 planes, `split3_planes`); the activations arrive as fp32 rows,
+// are staged by LDS-DMA as fp32 (128-byte rows of 32 floats, the swizzle of the other kernels) and are split in
+// registers on their way from LDS to the MFMA (11 VALU instructions per pair of values, v_cvt_pk_bf16_f32 rounding to
+// nearest even), interleaved with the MFMAs of the previous fragment.
+//
+// Structure: the stream-K frame of gemm_sk.hip (one persistent workgroup per CU, three-stage LDS ring, equal (tile, K
+// chunk) ranges per XCD group, range-ordered fix-up through write-through slabs and relaxed flags), 128x128 tiles, 64x64
+// per wave, 32-deep K chunks.  LDS per stage: x rows 16 KB + 3 weight planes x 8 KB (64-byte rows, 16-byte slot
+// kv ^ ((row >> 2) & 3): a ds_read_b128 lane group covers the 64 banks once).
+#include "common.h"
+#include "mfma.h"
+#include "gemm_epilogue.h"
+
+namespace mi {
+
+typedef unsigned int x3_u4 __attribute__((ext_vector_type(4)));
+typedef float x3_f2 __attribute__((ext_vector_type(2)));
+typedef __bf16 x3_b2 __attribute__((ext_vector_type(2)));
+
+template <typename RSRC>
+__device__ __forceinline__ void x3_bufds16(RSRC rsrc, int voff, unsigned lds_dst) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst) : "memory");
+#endif
+}
+
+// two fp32 values -> three packed bf16 pairs (low half = x, high half = y)
+__device__ __forceinline__ void x3_split_pair(float x, float y, unsigned& p1, unsigned& p2, unsigned& p3) {
+    const x3_b2 b1 = __builtin_convertvector(x3_f2{x, y}, x3_b2);
+    p1 = __builtin_bit_cast(unsigned, b1);
+    const float rx = x - __uint_as_float(p1 << 16), ry = y - __uint_as_float(p1 & 0xffff0000u);
+    const x3_b2 b2 = __builtin_convertvector(x3_f2{rx, ry}, x3_b2);
+    p2 = __builtin_bit_cast(unsigned, b2);
+    const float sx = rx - __uint_as_float(p2 << 16), sy = ry - __uint_as_float(p2 & 0xffff0000u);
+    const x3_b2 b3 = __builtin_convertvector(x3_f2{sx, sy}, x3_b2);
+    p3 = __builtin_bit_cast(unsigned, b3);
+}
+
+// weights: fp32 [rows][K] -> planes [3][rows][K] bf16
+__global__ __launch_bounds__(256) void split3_planes_kernel(const float* __restrict__ w, __bf16* __restrict__ out, long n) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 2;
+    if (i >= n) return;
+    const float x = w[i], y = i + 1 < n ? w[i + 1] : 0.f;
+    unsigned p1, p2, p3;
+    x3_split_pair(x, y, p1, p2, p3);
+    unsigned short* o = reinterpret_cast<unsigned short*>(out);
+    o[i] = (unsigned short)(p1 & 0xffff); o[n + i] = (unsigned short)(p2 & 0xffff); o[2 * n + i] = (unsigned short)(p3 & 0xffff);
+    if (i + 1 < n) { o[i + 1] = (unsigned short)(p1 >> 16); o[n + i + 1] = (unsigned short)(p2 >> 16); o[2 * n + i + 1] = (unsigned short)(p3 >> 16); }
+}
+
+void split3_planes(const float* w, void* planes, long n, hipStream_t s) {
+    hipLaunchKernelGGL(split3_planes_kernel, dim3((unsigned)((n / 2 + 255) / 256 + 1)), dim3(256), 0, s, w, (__bf16*)planes, n);
+    MI_HIP(hipGetLastError());
+}
+
+template <typename TO, bool LEPI>
+__global__ __launch_bounds__(256, 1) void linear_x3_kernel(const ConvGemmDev p) {
+    using MF = Mfma<bf16>;
+    using Frag = typename MF::Frag;
+    constexpr int KC = 32;                                      // K chunk: 32 floats = 128 bytes of an x row
+    constexpr int BM = 128, BN = 128, WM = 64, WN = 64, TM = 2, TN = 2, NST = 3;
+    constexpr int A_BYTES = BM * KC * 4, BP_BYTES = BN * KC * 2, STAGE_BYTES = A_BYTES + 3 * BP_BYTES;     // 16 KB + 3 x 8 KB
+    constexpr int PER = 10;                                     // DMA instructions per wave per chunk: 4 (x rows) + 6 (weight planes)
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE_BYTES];
+    (void)smem;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lk = lane >> 5;
+    // ranges: see gemm_sk.hip (XCD groups of whole tiles; range r of a group on workgroup (R-1-r)*8 + xg)
+    const int P = (int)gridDim.x, R = P >> 3;
+    const int xg = (int)blockIdx.x & 7;
+    const int l = R - 1 - ((int)blockIdx.x >> 3);
+    const int nch = p.K / KC;
+    const int T_all = p.Tm * p.Tn;
+    const int tile_lo = (int)((long)xg * T_all / 8), tile_hi = (int)((long)(xg + 1) * T_all / 8);
+    const long I = (long)(tile_hi - tile_lo) * nch;
+    long it = (long)l * I / R;
+    const long it1 = (long)(l + 1) * I / R;
+    const int slot0 = xg * R;
+
+    const float* xb = (const float*)p.x;
+    __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, (int)((((long)p.T_in - 1) * p.x_rstride + p.Cin) * 4L), 0x00020000);
+    __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)p.w3, 0, (int)((long)3 * p.N * p.K * 2L), 0x00020000);
+    constexpr int OOB = 0x7fffff00;
+    const unsigned smem_lds = (unsigned)(unsigned long)(const __attribute__((address_space(3))) void*)smem;
+    __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.sk_ws, 0, (int)((long)P * BM * BN * 4), 0x00020000);
+    int* flags = p.sk_flags;
+
+    // x rows: lane -> row R0 + lane/8, 16-byte slot lane%8 holding k-vector slot ^ ((row >> 1) & 7)   (as gemm_sk.hip)
+    const int kvl0 = (lane & 7) ^ ((lane >> 4) & 7), kvl1 = (lane & 7) ^ ((4 + (lane >> 4)) & 7);
+    const int lrow = lane >> 3;
+    // weight planes: lane -> row R0 + lane/4 (16 rows per instruction), slot lane%4 holding k-vector slot ^ ((row >> 2) & 3)
+    const int kvb = (lane & 3) ^ ((lane >> 4) & 3);
+    const int brow = lane >> 2;
+
+    while (it < it1) {
+        const int tile_g = (int)(it / nch);
+        const int cb = (int)(it - (long)tile_g * nch);
+        const int tile = tile_lo + tile_g;
+        const int n = (int)((it1 - it) < (long)(nch - cb) ? (it1 - it) : (long)(nch - cb));
+        const int ce = cb + n;
+        int nt, mt;
+        if (p.RC == 0) { nt = tile / p.Tm; mt = tile - nt * p.Tm; }
+        else { mt = tile / p.Tn; nt = tile - mt * p.Tn; }
+        const int m0 = mt * BM, n0 = nt * BN;
+        int avo[4], bvo[2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int R0 = (wave * 4 + j) * 8;
+            avo[j] = (int)(((long)(m0 + R0 + lrow) * p.x_rstride + ((j & 1) ? kvl1 : kvl0) * 4) * 4L);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const long nn = n0 + (wave * 2 + h) * 16 + brow;
+            bvo[h] = nn < p.N ? (int)((nn * p.K + kvb * 8) * 2L) : OOB;
+        }
+        const int plane_bytes = (int)((long)p.N * p.K * 2L);
+        // j < 4: x row groups ; 4 <= j < 10: plane (j-4)/2, 16-row group (j-4)%2 of this wave
+        auto dma_one = [&](int st, int chunk, int j) __attribute__((always_inline)) {
+            if (p.dbg & 1) return;
+            const unsigned base = __builtin_amdgcn_readfirstlane(smem_lds + (unsigned)(st * STAGE_BYTES));
+            const bool live = chunk < ce;
+            if (j < 4) {
+                const int cbytes = live ? chunk * KC * 4 : OOB;
+                x3_bufds16(rsa, (int)((unsigned)avo[j] + (unsigned)cbytes), base + (unsigned)((wave * 4 + j) * 8 * KC * 4));
+            } else {
+                const int pl = (j - 4) >> 1, h = (j - 4) & 1;
+                const int cbytes = live ? chunk * KC * 2 + pl * plane_bytes : OOB;
+                x3_bufds16(rsb, (int)((unsigned)bvo[h] + (unsigned)cbytes), base + (unsigned)(A_BYTES + pl * BP_BYTES + (wave * 2 + h) * 1024));
+            }
+        };
+        auto issue = [&](int st, int chunk) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < PER; ++j) dma_one(st, chunk, j);
+        };
+
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        // ---- fragments.  quarter q of a chunk = (k16 step q >> 1, row block q & 1): 12 MFMAs (2 column blocks x 6 terms) ----
+        float4 araw[2];
+        Frag a3[2][3], b3[2][2][3];                             // a3[set][piece] ; b3[k16 parity][j][piece]
+        const int sw_a = (lr >> 1) & 7, sw_b = (lr >> 2) & 3;
+        auto ldA = [&](int st, int q) __attribute__((always_inline)) {
+            if (p.dbg & 2) return;
+            const int ks = q >> 1, i = q & 1;
+            const unsigned char* As = smem + st * STAGE_BYTES + (wm * WM + i * 32 + lr) * (KC * 4);
+            const int kv = ks * 4 + lk * 2;
+            araw[0] = *reinterpret_cast<const float4*>(As + ((kv ^ sw_a) << 4));
+            araw[1] = *reinterpret_cast<const float4*>(As + (((kv + 1) ^ sw_a) << 4));
+        };
+        // half h of the split: the four values of araw[h] -> 32-bit words 2h, 2h+1 of the three pieces (22 VALU instructions:
+        // one half goes between two groups of three MFMAs, whose 96 matrix-core cycles cover it)
+        unsigned u1[4], u2[4], u3[4];
+        auto splitA_half = [&](int h) __attribute__((always_inline)) {
+            x3_split_pair(araw[h].x, araw[h].y, u1[2 * h], u2[2 * h], u3[2 * h]);
+            x3_split_pair(araw[h].z, araw[h].w, u1[2 * h + 1], u2[2 * h + 1], u3[2 * h + 1]);
+        };
+        auto packA = [&](int set) __attribute__((always_inline)) {
+            const x3_u4 w1 = {u1[0], u1[1], u1[2], u1[3]}, w2 = {u2[0], u2[1], u2[2], u2[3]}, w3 = {u3[0], u3[1], u3[2], u3[3]};
+            a3[set][0] = __builtin_bit_cast(Frag, w1); a3[set][1] = __builtin_bit_cast(Frag, w2); a3[set][2] = __builtin_bit_cast(Frag, w3);
+        };
+        auto ldB = [&](int st, int ks) __attribute__((always_inline)) {
+            if (p.dbg & 2) return;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    const unsigned char* Bs = smem + st * STAGE_BYTES + A_BYTES + pl * BP_BYTES + (wn * WN + j * 32 + lr) * (KC * 2);
+                    b3[ks & 1][j][pl] = *reinterpret_cast<const Frag*>(Bs + (((ks * 2 + lk) ^ sw_b) << 4));
+                }
+        };
+        // three of the twelve MFMAs of a quarter: terms ordered small to large, the two column blocks alternating
+        auto mma3 = [&](int q, int set, int part) __attribute__((always_inline)) {
+            const int ks = q >> 1, i = q & 1;
+            constexpr int TA[6] = {0, 1, 2, 0, 1, 0}, TB[6] = {2, 1, 0, 1, 0, 0};
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int idx = part * 3 + u;                  // 0..11 : term idx >> 1, column block idx & 1
+                const int t = idx >> 1, j = idx & 1;
+                acc[i][j] = MF::mma(a3[set][TA[t]], b3[ks & 1][j][TB[t]], acc[i][j]);
+            }
+        };
+#define X3_SB() __builtin_amdgcn_sched_barrier(0)
+        if (p.dbg & 2) {
+            araw[0] = float4{0.f, 0.f, 0.f, 0.f}; araw[1] = araw[0];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) b3[a][b][c] = Frag{};
+        }
+
+        // ---- K loop: ring of three stages, two chunks ahead.  The 10 DMA instructions of chunk c+2 sit in the quarters of
+        //      chunk c (3 + 3 + 2 before the boundary wait, 2 after it); the boundary (chunk c+1 landed, stage of chunk c
+        //      released) comes before the LAST quarter, whose operands are already in registers.
+        issue(0, cb); issue(1, cb + 1);
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        ldA(0, 0); ldB(0, 0);
+        splitA_half(0); splitA_half(1); packA(0);
+        int st = 0, st_issue = 2;
+        for (int c = 0; c < n; ++c) {
+            int stn = st + 1; if (stn == NST) stn = 0;
+            const int cn = cb + c + 2;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int set = q & 1;
+                if (q == 3 && c + 1 < n) {
+                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+                const bool more = q < 3 || c + 1 < n;             // another quarter follows: its operands are fetched and split under this one's MFMAs
+                X3_SB(); mma3(q, set, 0); X3_SB();
+                if (q < 3) { ldA(st, q + 1); if (q == 0) ldB(st, 1); }
+                else if (c + 1 < n) { ldA(stn, 0); ldB(stn, 0); }
+                dma_one(st_issue, cn, q == 0 ? 0 : q == 1 ? 3 : q == 2 ? 6 : 8);
+                X3_SB(); mma3(q, set, 1); X3_SB();
+                if (more) splitA_half(0);
+                dma_one(st_issue, cn, q == 0 ? 1 : q == 1 ? 4 : q == 2 ? 7 : 9);
+                X3_SB(); mma3(q, set, 2); X3_SB();
+                if (more) { splitA_half(1); packA(set ^ 1); }
+                if (q < 2) dma_one(st_issue, cn, q == 0 ? 2 : 5);
+                X3_SB(); mma3(q, set, 3); X3_SB();
+            }
+            if (++st_issue == NST) st_issue = 0;
+            st = stn;
+        }
+#undef X3_SB
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+
+        // ---- partial tile: publish or collect (gemm_sk.hip) ----------------------------------------------------------------
+        const int slot_lane = (wave * 16) * 64 + lane;
+        if (p.dbg & 4) { it += n; continue; }
+        if (cb > 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        x3_u4 v;
+                        v.x = __float_as_uint(acc[i][j][4 * q]); v.y = __float_as_uint(acc[i][j][4 * q + 1]);
+                        v.z = __float_as_uint(acc[i][j][4 * q + 2]); v.w = __float_as_uint(acc[i][j][4 * q + 3]);
+                        const int unit = slot_lane + ((i * 2 + j) * 4 + q) * 64;
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rsw, ((slot0 + l) * (BM * BN / 4) + unit) * 16, 0, 16);
+                    }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(flags + slot0 + l, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (ce < nch) {
+                int cov = ce;
+                for (int q_l = l + 1; cov < nch; ++q_l) {
+                    const long q0 = (long)q_l * I / R, q1 = (long)(q_l + 1) * I / R;
+                    if (q1 == q0) continue;
+                    if (tid == 0) {
+                        while (__hip_atomic_load(flags + slot0 + q_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(2);
+                    }
+                    __syncthreads();
+                    x3_u4 v[TM * TN * 4];
+#pragma unroll
+                    for (int u = 0; u < TM * TN * 4; ++u)
+                        v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsw, ((slot0 + q_l) * (BM * BN / 4) + slot_lane + u * 64) * 16, 0, 16);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const x3_u4 w = v[(i * 2 + j) * 4 + q];
+                                acc[i][j][4 * q] += __uint_as_float(w.x); acc[i][j][4 * q + 1] += __uint_as_float(w.y);
+                                acc[i][j][4 * q + 2] += __uint_as_float(w.z); acc[i][j][4 * q + 3] += __uint_as_float(w.w);
+                            }
+                    __syncthreads();
+                    if (tid == 0) __hip_atomic_store(flags + slot0 + q_l, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    cov += (int)((q1 - q0) < (long)(nch - cov) ? (q1 - q0) : (long)(nch - cov));
+                }
+            }
+            if constexpr (LEPI) {
+                float* stage = reinterpret_cast<float*>(smem) + wave * (2 * 32 * WN);
+                if (p.epi == EPI_QKV_ROPE) gemm_epilogue_qkv_lds<TO>(acc, p, m0, n0, 0, wm, wn, lr, lk, stage);
+                else gemm_epilogue_lds<TO, TM, TN, WM, WN>(acc, p, m0, n0, 0, 0, wm, wn, lr, lk, stage);
+            } else {
+                gemm_epilogue<TO, TM, TN, WM, WN>(acc, p, m0, n0, 0, 0, wm, wn, lr, lk);
+            }
+            __syncthreads();
+        }
+        it += n;
+    }
+#endif
+}
+
+void launch_linear_x3(const ConvGemmDev& e, hipStream_t s) {
+    int dev = 0, cus = 256;
+    MI_HIP(hipGetDevice(&dev));
+    {
+        static int cu_count[16] = {0};
+        if (!cu_count[dev & 15]) { hipDeviceProp_t pr; MI_HIP(hipGetDeviceProperties(&pr, dev)); cu_count[dev & 15] = pr.multiProcessorCount; }
+        cus = cu_count[dev & 15];
+    }
+    const int P = std::min(cus, e.sk_slots) & ~7;
+    const dim3 grid(P);
+    if (e.lds_epi) {
+        prof_set_kernel("linear_x3_kernel<float, true>", "", "");
+        hipLaunchKernelGGL((linear_x3_kernel<float, true>), grid, dim3(256), 0, s, e);
+    } else {
+        prof_set_kernel("linear_x3_kernel<float, false>", "", "");
+        hipLaunchKernelGGL((linear_x3_kernel<float, false>), grid, dim3(256), 0, s, e);
+    }
+    MI_HIP(hipGetLastError());
+}
+
+}  // namespace mi
