@@ -660,6 +660,12 @@ int mi_bench_conv_gemm(int dtype, int B, int T, int Cin, int N, int taps, int di
         SkWorkspace skw;
         skw.ensure(1024, s);
         skw.attach(p);
+        DevBuf w3;
+        if (dtype == MI_F32 && taps == 1 && gemm_x3_enabled() && nsets <= 1) {      // the bf16x3 kernel needs the weight planes
+            w3.ensure((size_t)3 * nw * 2);
+            split3_planes((const float*)w.p, w3.p, (long)nw, s);
+            p.w3 = w3.p;
+        }
         for (int i = 0; i < 3; ++i) launch_conv_gemm(p, s);
         hipEvent_t e0, e1;
         MI_HIP(hipEventCreate(&e0)); MI_HIP(hipEventCreate(&e1));

@@ -627,6 +627,8 @@ bool gemm_set_option(const char* key, long v) {
     else if (k == "gemm_sk_hybrid") g_sk_hybrid = v;
     else if (k == "gemm_sk_producer") sk_set_producer(v);
     else if (k == "gemm_f32_x3") g_x3 = v;
+    else if (k == "gemm_x3_wide") x3_set_wide(v);
+    else if (k == "gemm_x3_stages") x3_set_stages(v);
     else if (k == "gemm_ph8") g_ph8 = v;
     else if (k == "gemm_ph8_min_tiles") g_ph8_min_tiles = v;
     else if (k == "gemm_ph8_order") g_ph8_order = v;
@@ -698,6 +700,8 @@ void launch_conv_gemm(const ConvGemm& p_in, hipStream_t s) {
             if (const char* n = std::getenv("MI355TTS_SK_HYBRID")) g_sk_hybrid = std::atol(n);
             if (const char* n = std::getenv("MI355TTS_SK_PRODUCER")) sk_set_producer(std::atol(n));
             if (const char* n = std::getenv("MI355TTS_F32_X3")) g_x3 = std::atol(n);
+            if (const char* n = std::getenv("MI355TTS_X3_WIDE")) x3_set_wide(std::atol(n));
+            if (const char* n = std::getenv("MI355TTS_X3_STAGES")) x3_set_stages(std::atol(n));
             if (const char* n = std::getenv("MI355TTS_SK_QKV32")) g_sk_qkv32 = std::atol(n);
             if (const char* n = std::getenv("MI355TTS_PH8")) g_ph8 = std::atol(n);
             if (const char* n = std::getenv("MI355TTS_PH8_MIN")) g_ph8_min_tiles = std::atol(n);

@@ -67,12 +67,17 @@ void split3_planes(const float* w, void* planes, long n, hipStream_t s) {
     MI_HIP(hipGetLastError());
 }
 
-template <typename TO, bool LEPI>
+// WIDE: wave tile 32 x 128 (one row block, four column blocks) instead of 64 x 64 — the split of an x fragment then feeds
+// 24 MFMAs instead of 12 (half the VALU work per MFMA); plain epilogues only (the QKV epilogue wants 64 x 64 per wave).
+template <typename TO, bool LEPI, bool WIDE, int NST>
 __global__ __launch_bounds__(256, 1) void linear_x3_kernel(const ConvGemmDev p) {
     using MF = Mfma<bf16>;
     using Frag = typename MF::Frag;
     constexpr int KC = 32;                                      // K chunk: 32 floats = 128 bytes of an x row
-    constexpr int BM = 128, BN = 128, WM = 64, WN = 64, TM = 2, TN = 2, NST = 3;
+    constexpr int BM = 128, BN = 128, WM = WIDE ? 32 : 64, WN = WIDE ? 128 : 64, TM = WIDE ? 1 : 2, TN = WIDE ? 4 : 2;
+    constexpr int AHEAD = NST - 1;                              // chunks in flight beyond the one being computed (2 or 3)
+    static_assert(NST == 3 || NST == 4, "ring depth");
+    constexpr int STEPS = 2 * TM, GRP = 2 * TN;                 // steps (k16 step, row block) per chunk ; groups of three MFMAs per step
     constexpr int A_BYTES = BM * KC * 4, BP_BYTES = BN * KC * 2, STAGE_BYTES = A_BYTES + 3 * BP_BYTES;     // 16 KB + 3 x 8 KB
     constexpr int PER = 10;                                     // DMA instructions per wave per chunk: 4 (x rows) + 6 (weight planes)
     __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE_BYTES];
@@ -80,7 +85,7 @@ __global__ __launch_bounds__(256, 1) void linear_x3_kernel(const ConvGemmDev p) 
 #if defined(__HIP_DEVICE_COMPILE__)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lk = lane >> 5;
+    const int wm = WIDE ? wave : wave >> 1, wn = WIDE ? 0 : wave & 1, lr = lane & 31, lk = lane >> 5;
     // ranges: see gemm_sk.hip (XCD groups of whole tiles; range r of a group on workgroup (R-1-r)*8 + xg)
     const int P = (int)gridDim.x, R = P >> 3;
     const int xg = (int)blockIdx.x & 7;
@@ -159,22 +164,24 @@ __global__ __launch_bounds__(256, 1) void linear_x3_kernel(const ConvGemmDev p) 
 
         // ---- fragments.  quarter q of a chunk = (k16 step q >> 1, row block q & 1): 12 MFMAs (2 column blocks x 6 terms) ----
         float4 araw[2];
-        Frag a3[2][3], b3[2][2][3];                             // a3[set][piece] ; b3[k16 parity][j][piece]
+        Frag a3[2][3], b3[2][TN][3];                            // a3[set][piece] ; b3[k16 parity][j][piece]
         const int sw_a = (lr >> 1) & 7, sw_b = (lr >> 2) & 3;
         auto ldA = [&](int st, int q) __attribute__((always_inline)) {
             if (p.dbg & 2) return;
-            const int ks = q >> 1, i = q & 1;
+            const int ks = q / TM, i = q % TM;
             const unsigned char* As = smem + st * STAGE_BYTES + (wm * WM + i * 32 + lr) * (KC * 4);
             const int kv = ks * 4 + lk * 2;
             araw[0] = *reinterpret_cast<const float4*>(As + ((kv ^ sw_a) << 4));
             araw[1] = *reinterpret_cast<const float4*>(As + (((kv + 1) ^ sw_a) << 4));
         };
-        // half h of the split: the four values of araw[h] -> 32-bit words 2h, 2h+1 of the three pieces (22 VALU instructions:
-        // one half goes between two groups of three MFMAs, whose 96 matrix-core cycles cover it)
+        // pair pr (0..3) of the split: two of the eight values -> one 32-bit word of each of the three pieces (11 VALU
+        // instructions: placed behind ONE MFMA, whose 32 matrix-core cycles cover most of it — a wave alone on its SIMD only
+        // overlaps what sits in the shadow of an MFMA it has just issued)
         unsigned u1[4], u2[4], u3[4];
-        auto splitA_half = [&](int h) __attribute__((always_inline)) {
-            x3_split_pair(araw[h].x, araw[h].y, u1[2 * h], u2[2 * h], u3[2 * h]);
-            x3_split_pair(araw[h].z, araw[h].w, u1[2 * h + 1], u2[2 * h + 1], u3[2 * h + 1]);
+        auto splitA_pair = [&](int pr) __attribute__((always_inline)) {
+            const float4 v = araw[pr >> 1];
+            if (pr & 1) x3_split_pair(v.z, v.w, u1[pr], u2[pr], u3[pr]);
+            else x3_split_pair(v.x, v.y, u1[pr], u2[pr], u3[pr]);
         };
         auto packA = [&](int set) __attribute__((always_inline)) {
             const x3_u4 w1 = {u1[0], u1[1], u1[2], u1[3]}, w2 = {u2[0], u2[1], u2[2], u2[3]}, w3 = {u3[0], u3[1], u3[2], u3[3]};
@@ -190,16 +197,12 @@ __global__ __launch_bounds__(256, 1) void linear_x3_kernel(const ConvGemmDev p) 
                     b3[ks & 1][j][pl] = *reinterpret_cast<const Frag*>(Bs + (((ks * 2 + lk) ^ sw_b) << 4));
                 }
         };
-        // three of the twelve MFMAs of a quarter: terms ordered small to large, the two column blocks alternating
-        auto mma3 = [&](int q, int set, int part) __attribute__((always_inline)) {
-            const int ks = q >> 1, i = q & 1;
+        // MFMA k of step q: terms ordered small to large, the column blocks alternating
+        auto mma1 = [&](int q, int set, int k) __attribute__((always_inline)) {
+            const int ks = q / TM, i = q % TM;
             constexpr int TA[6] = {0, 1, 2, 0, 1, 0}, TB[6] = {2, 1, 0, 1, 0, 0};
-#pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                const int idx = part * 3 + u;                  // 0..11 : term idx >> 1, column block idx & 1
-                const int t = idx >> 1, j = idx & 1;
-                acc[i][j] = MF::mma(a3[set][TA[t]], b3[ks & 1][j][TB[t]], acc[i][j]);
-            }
+            const int t = k / TN, j = k % TN;
+            acc[i][j] = MF::mma(a3[set][TA[t]], b3[ks & 1][j][TB[t]], acc[i][j]);
         };
 #define X3_SB() __builtin_amdgcn_sched_barrier(0)
         if (p.dbg & 2) {
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(256, 1) void linear_x3_kernel(const ConvGemmDev p) 
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int b = 0; b < 2; ++b)
+                for (int b = 0; b < TN; ++b)
 #pragma unroll
                     for (int c = 0; c < 3; ++c) b3[a][b][c] = Frag{};
         }
@@ -215,35 +218,54 @@ __global__ __launch_bounds__(256, 1) void linear_x3_kernel(const ConvGemmDev p) 
         // ---- K loop: ring of three stages, two chunks ahead.  The 10 DMA instructions of chunk c+2 sit in the quarters of
         //      chunk c (3 + 3 + 2 before the boundary wait, 2 after it); the boundary (chunk c+1 landed, stage of chunk c
         //      released) comes before the LAST quarter, whose operands are already in registers.
-        issue(0, cb); issue(1, cb + 1);
-        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+#pragma unroll
+        for (int a = 0; a < AHEAD; ++a) issue(a, cb + a);
+        if constexpr (AHEAD == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         ldA(0, 0); ldB(0, 0);
-        splitA_half(0); splitA_half(1); packA(0);
-        int st = 0, st_issue = 2;
+        splitA_pair(0); splitA_pair(1); splitA_pair(2); splitA_pair(3); packA(0);
+        int st = 0, st_issue = AHEAD % NST;
         for (int c = 0; c < n; ++c) {
             int stn = st + 1; if (stn == NST) stn = 0;
-            const int cn = cb + c + 2;
+            const int cn = cb + c + AHEAD;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < STEPS; ++q) {
                 const int set = q & 1;
-                if (q == 3 && c + 1 < n) {
-                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                if (q == STEPS - 1 && c + 1 < n) {
+                    if constexpr (AHEAD == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // the 8 pieces of the newest chunk issued so far
+                    else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");                           // ... plus the whole chunk before it
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
                 }
-                const bool more = q < 3 || c + 1 < n;             // another quarter follows: its operands are fetched and split under this one's MFMAs
-                X3_SB(); mma3(q, set, 0); X3_SB();
-                if (q < 3) { ldA(st, q + 1); if (q == 0) ldB(st, 1); }
-                else if (c + 1 < n) { ldA(stn, 0); ldB(stn, 0); }
-                dma_one(st_issue, cn, q == 0 ? 0 : q == 1 ? 3 : q == 2 ? 6 : 8);
-                X3_SB(); mma3(q, set, 1); X3_SB();
-                if (more) splitA_half(0);
-                dma_one(st_issue, cn, q == 0 ? 1 : q == 1 ? 4 : q == 2 ? 7 : 9);
-                X3_SB(); mma3(q, set, 2); X3_SB();
-                if (more) { splitA_half(1); packA(set ^ 1); }
-                if (q < 2) dma_one(st_issue, cn, q == 0 ? 2 : 5);
-                X3_SB(); mma3(q, set, 3); X3_SB();
+                const bool more = q < STEPS - 1 || c + 1 < n;     // another step follows: its operands are fetched and split under this one's MFMAs
+                constexpr int NM = 6 * TN, SP = NM / 6;          // MFMAs per step ; spacing of the four split pairs
+#pragma unroll
+                for (int k = 0; k < NM; ++k) {
+                    X3_SB(); mma1(q, set, k); X3_SB();
+                    const int f = q * NM + k;                    // 0..47 inside the chunk
+                    if (k == 0) {
+                        if (q < STEPS - 1) {
+                            ldA(st, q + 1);
+                            if (q == 0) ldB(st, 1);              // weight fragments of the second k16 step
+                        } else if (c + 1 < n) { ldA(stn, 0); ldB(stn, 0); }
+                    }
+                    if (more && k >= SP && k % SP == 0 && k / SP <= 4) {
+                        splitA_pair(k / SP - 1);
+                        if (k / SP == 4) packA(set ^ 1);
+                    }
+                    // the ten DMA instructions of chunk c+2: eight before the boundary step, two after it
+                    if constexpr (!WIDE) {
+                        if (f == 1) dma_one(st_issue, cn, 0); else if (f == 5) dma_one(st_issue, cn, 1);
+                        else if (f == 9) dma_one(st_issue, cn, 2); else if (f == 13) dma_one(st_issue, cn, 3);
+                        else if (f == 17) dma_one(st_issue, cn, 4); else if (f == 21) dma_one(st_issue, cn, 5);
+                        else if (f == 25) dma_one(st_issue, cn, 6); else if (f == 29) dma_one(st_issue, cn, 7);
+                        else if (f == 37) dma_one(st_issue, cn, 8); else if (f == 41) dma_one(st_issue, cn, 9);
+                    } else {
+                        if (f < 24 && (f % 3) == 1) dma_one(st_issue, cn, f / 3);             // f = 1, 4, ..., 22: eight
+                        else if (f == 25) dma_one(st_issue, cn, 8); else if (f == 29) dma_one(st_issue, cn, 9);
+                    }
+                }
             }
             if (++st_issue == NST) st_issue = 0;
             st = stn;
@@ -266,7 +288,7 @@ __global__ __launch_bounds__(256, 1) void linear_x3_kernel(const ConvGemmDev p) 
                         x3_u4 v;
                         v.x = __float_as_uint(acc[i][j][4 * q]); v.y = __float_as_uint(acc[i][j][4 * q + 1]);
                         v.z = __float_as_uint(acc[i][j][4 * q + 2]); v.w = __float_as_uint(acc[i][j][4 * q + 3]);
-                        const int unit = slot_lane + ((i * 2 + j) * 4 + q) * 64;
+                        const int unit = slot_lane + ((i * TN + j) * 4 + q) * 64;
                         __builtin_amdgcn_raw_buffer_store_b128(v, rsw, ((slot0 + l) * (BM * BN / 4) + unit) * 16, 0, 16);
                     }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -292,7 +314,7 @@ __global__ __launch_bounds__(256, 1) void linear_x3_kernel(const ConvGemmDev p) 
                         for (int j = 0; j < TN; ++j)
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
-                                const x3_u4 w = v[(i * 2 + j) * 4 + q];
+                                const x3_u4 w = v[(i * TN + j) * 4 + q];
                                 acc[i][j][4 * q] += __uint_as_float(w.x); acc[i][j][4 * q + 1] += __uint_as_float(w.y);
                                 acc[i][j][4 * q + 2] += __uint_as_float(w.z); acc[i][j][4 * q + 3] += __uint_as_float(w.w);
                             }
@@ -302,9 +324,12 @@ __global__ __launch_bounds__(256, 1) void linear_x3_kernel(const ConvGemmDev p) 
                 }
             }
             if constexpr (LEPI) {
-                float* stage = reinterpret_cast<float*>(smem) + wave * (2 * 32 * WN);
-                if (p.epi == EPI_QKV_ROPE) gemm_epilogue_qkv_lds<TO>(acc, p, m0, n0, 0, wm, wn, lr, lk, stage);
-                else gemm_epilogue_lds<TO, TM, TN, WM, WN>(acc, p, m0, n0, 0, 0, wm, wn, lr, lk, stage);
+                float* stage = reinterpret_cast<float*>(smem) + wave * (4096);      // 16 KB per wave: 2 x 32 x 64 or 1 x 32 x 128 floats
+                bool done = false;
+                if constexpr (!WIDE) {
+                    if (p.epi == EPI_QKV_ROPE) { gemm_epilogue_qkv_lds<TO>(acc, p, m0, n0, 0, wm, wn, lr, lk, stage); done = true; }
+                }
+                if (!done) gemm_epilogue_lds<TO, TM, TN, WM, WN>(acc, p, m0, n0, 0, 0, wm, wn, lr, lk, stage);
             } else {
                 gemm_epilogue<TO, TM, TN, WM, WN>(acc, p, m0, n0, 0, 0, wm, wn, lr, lk);
             }
@@ -314,6 +339,10 @@ __global__ __launch_bounds__(256, 1) void linear_x3_kernel(const ConvGemmDev p) 
     }
 #endif
 }
+
+static long g_x3_wide = 1, g_x3_stages = 4;
+void x3_set_wide(long v) { g_x3_wide = v; }
+void x3_set_stages(long v) { g_x3_stages = v == 3 ? 3 : 4; }
 
 void launch_linear_x3(const ConvGemmDev& e, hipStream_t s) {
     int dev = 0, cus = 256;
@@ -325,13 +354,18 @@ void launch_linear_x3(const ConvGemmDev& e, hipStream_t s) {
     }
     const int P = std::min(cus, e.sk_slots) & ~7;
     const dim3 grid(P);
-    if (e.lds_epi) {
-        prof_set_kernel("linear_x3_kernel<float, true>", "", "");
-        hipLaunchKernelGGL((linear_x3_kernel<float, true>), grid, dim3(256), 0, s, e);
+    // 32 x 128 per wave for everything but the QKV epilogue (64 x 64 head slices)
+    const bool wide = g_x3_wide && e.epi != EPI_QKV_ROPE;
+#define X3_LAUNCH(LE, WD, NS, NAME)                                                                                    \
+    do { prof_set_kernel(NAME, "", ""); hipLaunchKernelGGL((linear_x3_kernel<float, LE, WD, NS>), grid, dim3(256), 0, s, e); } while (0)
+    if (g_x3_stages == 4) {
+        if (e.lds_epi) { if (wide) X3_LAUNCH(true, true, 4, "linear_x3_kernel<float, true, wide, 4>"); else X3_LAUNCH(true, false, 4, "linear_x3_kernel<float, true, 64x64, 4>"); }
+        else { if (wide) X3_LAUNCH(false, true, 4, "linear_x3_kernel<float, false, wide, 4>"); else X3_LAUNCH(false, false, 4, "linear_x3_kernel<float, false, 64x64, 4>"); }
     } else {
-        prof_set_kernel("linear_x3_kernel<float, false>", "", "");
-        hipLaunchKernelGGL((linear_x3_kernel<float, false>), grid, dim3(256), 0, s, e);
+        if (e.lds_epi) { if (wide) X3_LAUNCH(true, true, 3, "linear_x3_kernel<float, true, wide, 3>"); else X3_LAUNCH(true, false, 3, "linear_x3_kernel<float, true, 64x64, 3>"); }
+        else { if (wide) X3_LAUNCH(false, true, 3, "linear_x3_kernel<float, false, wide, 3>"); else X3_LAUNCH(false, false, 3, "linear_x3_kernel<float, false, 64x64, 3>"); }
     }
+#undef X3_LAUNCH
     MI_HIP(hipGetLastError());
 }
 
