@@ -69,23 +69,29 @@ void split3_planes(const float* w, void* planes, long n, hipStream_t s) {
 
 // WIDE: wave tile 32 x 128 (one row block, four column blocks) instead of 64 x 64 — the split of an x fragment then feeds
 // 24 MFMAs instead of 12 (half the VALU work per MFMA); plain epilogues only (the QKV epilogue wants 64 x 64 per wave).
-template <typename TO, bool LEPI, bool WIDE, int NST>
-__global__ __launch_bounds__(256, 1) void linear_x3_kernel(const ConvGemmDev p) {
+// SHAPE 2: eight waves, 32 x 64 each — two waves per SIMD, so that one wave's DMA issue / waits / barriers leave the other
+// one feeding the matrix core (each DMA instruction costs its wave ~100 cycles of issue; with one wave per SIMD the ten per
+// chunk were a quarter of the kernel: 79.6 -> 58.6 us for FF1 with the DMA switched off)
+template <typename TO, bool LEPI, int SHAPE, int NST>
+__global__ __launch_bounds__(SHAPE == 2 ? 512 : 256, 1) void linear_x3_kernel(const ConvGemmDev p) {
+    constexpr bool WIDE = SHAPE == 1, W8 = SHAPE == 2;
+    constexpr int NW = W8 ? 8 : 4;
     using MF = Mfma<bf16>;
     using Frag = typename MF::Frag;
     constexpr int KC = 32;                                      // K chunk: 32 floats = 128 bytes of an x row
-    constexpr int BM = 128, BN = 128, WM = WIDE ? 32 : 64, WN = WIDE ? 128 : 64, TM = WIDE ? 1 : 2, TN = WIDE ? 4 : 2;
+    constexpr int BM = 128, BN = 128, WM = (WIDE || W8) ? 32 : 64, WN = WIDE ? 128 : 64, TM = (WIDE || W8) ? 1 : 2, TN = WIDE ? 4 : 2;
     constexpr int AHEAD = NST - 1;                              // chunks in flight beyond the one being computed (2 or 3)
     static_assert(NST == 3 || NST == 4, "ring depth");
     constexpr int STEPS = 2 * TM, GRP = 2 * TN;                 // steps (k16 step, row block) per chunk ; groups of three MFMAs per step
     constexpr int A_BYTES = BM * KC * 4, BP_BYTES = BN * KC * 2, STAGE_BYTES = A_BYTES + 3 * BP_BYTES;     // 16 KB + 3 x 8 KB
-    constexpr int PER = 10;                                     // DMA instructions per wave per chunk: 4 (x rows) + 6 (weight planes)
+    constexpr int DA = 16 / NW, DB = 8 / NW;                    // DMA instructions per wave per chunk: DA x-row groups + 3 x DB weight-plane groups
+    constexpr int PER = DA + 3 * DB;                            // 10 (four waves) or 5 (eight waves)
     __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE_BYTES];
     (void)smem;
 #if defined(__HIP_DEVICE_COMPILE__)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = WIDE ? wave : wave >> 1, wn = WIDE ? 0 : wave & 1, lr = lane & 31, lk = lane >> 5;
+    const int wm = WIDE ? wave : wave >> 1, wn = WIDE ? 0 : wave & 1, lr = lane & 31, lk = lane >> 5;     // W8: wm 0..3, wn 0..1
     // ranges: see gemm_sk.hip (XCD groups of whole tiles; range r of a group on workgroup (R-1-r)*8 + xg)
     const int P = (int)gridDim.x, R = P >> 3;
     const int xg = (int)blockIdx.x & 7;
@@ -123,30 +129,30 @@ __global__ __launch_bounds__(256, 1) void linear_x3_kernel(const ConvGemmDev p) 
         if (p.RC == 0) { nt = tile / p.Tm; mt = tile - nt * p.Tm; }
         else { mt = tile / p.Tn; nt = tile - mt * p.Tn; }
         const int m0 = mt * BM, n0 = nt * BN;
-        int avo[4], bvo[2];
+        int avo[DA], bvo[DB];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int R0 = (wave * 4 + j) * 8;
+        for (int j = 0; j < DA; ++j) {
+            const int R0 = (wave * DA + j) * 8;
             avo[j] = (int)(((long)(m0 + R0 + lrow) * p.x_rstride + ((j & 1) ? kvl1 : kvl0) * 4) * 4L);
         }
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const long nn = n0 + (wave * 2 + h) * 16 + brow;
+        for (int h = 0; h < DB; ++h) {
+            const long nn = n0 + (wave * DB + h) * 16 + brow;
             bvo[h] = nn < p.N ? (int)((nn * p.K + kvb * 8) * 2L) : OOB;
         }
         const int plane_bytes = (int)((long)p.N * p.K * 2L);
-        // j < 4: x row groups ; 4 <= j < 10: plane (j-4)/2, 16-row group (j-4)%2 of this wave
+        // j < DA: x row groups ; DA <= j < PER: plane (j-DA)/DB, 16-row group (j-DA)%DB of this wave
         auto dma_one = [&](int st, int chunk, int j) __attribute__((always_inline)) {
             if (p.dbg & 1) return;
             const unsigned base = __builtin_amdgcn_readfirstlane(smem_lds + (unsigned)(st * STAGE_BYTES));
             const bool live = chunk < ce;
-            if (j < 4) {
+            if (j < DA) {
                 const int cbytes = live ? chunk * KC * 4 : OOB;
-                x3_bufds16(rsa, (int)((unsigned)avo[j] + (unsigned)cbytes), base + (unsigned)((wave * 4 + j) * 8 * KC * 4));
+                x3_bufds16(rsa, (int)((unsigned)avo[j] + (unsigned)cbytes), base + (unsigned)((wave * DA + j) * 8 * KC * 4));
             } else {
-                const int pl = (j - 4) >> 1, h = (j - 4) & 1;
+                const int pl = (j - DA) / DB, h = (j - DA) % DB;
                 const int cbytes = live ? chunk * KC * 2 + pl * plane_bytes : OOB;
-                x3_bufds16(rsb, (int)((unsigned)bvo[h] + (unsigned)cbytes), base + (unsigned)(A_BYTES + pl * BP_BYTES + (wave * 2 + h) * 1024));
+                x3_bufds16(rsb, (int)((unsigned)bvo[h] + (unsigned)cbytes), base + (unsigned)(A_BYTES + pl * BP_BYTES + (wave * DB + h) * 1024));
             }
         };
         auto issue = [&](int st, int chunk) __attribute__((always_inline)) {
@@ -220,8 +226,11 @@ __global__ __launch_bounds__(256, 1) void linear_x3_kernel(const ConvGemmDev p) 
         //      released) comes before the LAST quarter, whose operands are already in registers.
 #pragma unroll
         for (int a = 0; a < AHEAD; ++a) issue(a, cb + a);
-        if constexpr (AHEAD == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+        // chunk cb has landed: the AHEAD-1 younger chunks (PER instructions each) may stay in flight
+        if constexpr ((AHEAD - 1) * PER == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if constexpr ((AHEAD - 1) * PER == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        static_assert((AHEAD - 1) * PER == 10 || (AHEAD - 1) * PER == 20 || (AHEAD - 1) * PER == 5, "counted prologue wait");
         __builtin_amdgcn_s_barrier();
         ldA(0, 0); ldB(0, 0);
         splitA_pair(0); splitA_pair(1); splitA_pair(2); splitA_pair(3); packA(0);
@@ -233,8 +242,14 @@ __global__ __launch_bounds__(256, 1) void linear_x3_kernel(const ConvGemmDev p) 
             for (int q = 0; q < STEPS; ++q) {
                 const int set = q & 1;
                 if (q == STEPS - 1 && c + 1 < n) {
-                    if constexpr (AHEAD == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // the 8 pieces of the newest chunk issued so far
-                    else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");                           // ... plus the whole chunk before it
+                    // in flight: the pieces of the newest chunk issued so far (PER - 2 with four waves, PER - 1 with eight) plus
+                    // the AHEAD - 2 whole chunks before it
+                    constexpr int INFL = (AHEAD - 2) * PER + (W8 ? PER - 1 : PER - 2);
+                    if constexpr (INFL == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    else if constexpr (INFL == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+                    else if constexpr (INFL == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+                    static_assert(INFL == 8 || INFL == 18 || INFL == 4 || INFL == 9, "counted boundary wait");
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
                 }
@@ -255,15 +270,19 @@ __global__ __launch_bounds__(256, 1) void linear_x3_kernel(const ConvGemmDev p) 
                         if (k / SP == 4) packA(set ^ 1);
                     }
                     // the ten DMA instructions of chunk c+2: eight before the boundary step, two after it
-                    if constexpr (!WIDE) {
+                    if constexpr (SHAPE == 0) {
                         if (f == 1) dma_one(st_issue, cn, 0); else if (f == 5) dma_one(st_issue, cn, 1);
                         else if (f == 9) dma_one(st_issue, cn, 2); else if (f == 13) dma_one(st_issue, cn, 3);
                         else if (f == 17) dma_one(st_issue, cn, 4); else if (f == 21) dma_one(st_issue, cn, 5);
                         else if (f == 25) dma_one(st_issue, cn, 6); else if (f == 29) dma_one(st_issue, cn, 7);
                         else if (f == 37) dma_one(st_issue, cn, 8); else if (f == 41) dma_one(st_issue, cn, 9);
-                    } else {
+                    } else if constexpr (WIDE) {
                         if (f < 24 && (f % 3) == 1) dma_one(st_issue, cn, f / 3);             // f = 1, 4, ..., 22: eight
                         else if (f == 25) dma_one(st_issue, cn, 8); else if (f == 29) dma_one(st_issue, cn, 9);
+                    } else {                                                                  // eight waves: 24 MFMAs per chunk, 4 + 1 pieces
+                        if (f == 1) dma_one(st_issue, cn, 0); else if (f == 4) dma_one(st_issue, cn, 1);
+                        else if (f == 7) dma_one(st_issue, cn, 2); else if (f == 10) dma_one(st_issue, cn, 3);
+                        else if (f == 14) dma_one(st_issue, cn, 4);
                     }
                 }
             }
@@ -276,7 +295,7 @@ __global__ __launch_bounds__(256, 1) void linear_x3_kernel(const ConvGemmDev p) 
         __builtin_amdgcn_s_barrier();
 
         // ---- partial tile: publish or collect (gemm_sk.hip) ----------------------------------------------------------------
-        const int slot_lane = (wave * 16) * 64 + lane;
+        const int slot_lane = (wave * (TM * TN * 4)) * 64 + lane;
         if (p.dbg & 4) { it += n; continue; }
         if (cb > 0) {
 #pragma unroll
@@ -324,9 +343,9 @@ __global__ __launch_bounds__(256, 1) void linear_x3_kernel(const ConvGemmDev p) 
                 }
             }
             if constexpr (LEPI) {
-                float* stage = reinterpret_cast<float*>(smem) + wave * (4096);      // 16 KB per wave: 2 x 32 x 64 or 1 x 32 x 128 floats
+                float* stage = reinterpret_cast<float*>(smem) + wave * (W8 ? 2048 : 4096);      // 16 KB per wave (2 x 32 x 64 or 1 x 32 x 128 floats), 8 KB with eight waves
                 bool done = false;
-                if constexpr (!WIDE) {
+                if constexpr (SHAPE == 0) {
                     if (p.epi == EPI_QKV_ROPE) { gemm_epilogue_qkv_lds<TO>(acc, p, m0, n0, 0, wm, wn, lr, lk, stage); done = true; }
                 }
                 if (!done) gemm_epilogue_lds<TO, TM, TN, WM, WN>(acc, p, m0, n0, 0, 0, wm, wn, lr, lk, stage);
@@ -340,7 +359,7 @@ __global__ __launch_bounds__(256, 1) void linear_x3_kernel(const ConvGemmDev p) 
 #endif
 }
 
-static long g_x3_wide = 1, g_x3_stages = 4;
+static long g_x3_wide = 2, g_x3_stages = 4;      // wave layout of the plain-epilogue launches: 0 / 1 / 2, see the kernel
 void x3_set_wide(long v) { g_x3_wide = v; }
 void x3_set_stages(long v) { g_x3_stages = v == 3 ? 3 : 4; }
 
@@ -354,16 +373,15 @@ void launch_linear_x3(const ConvGemmDev& e, hipStream_t s) {
     }
     const int P = std::min(cus, e.sk_slots) & ~7;
     const dim3 grid(P);
-    // 32 x 128 per wave for everything but the QKV epilogue (64 x 64 head slices)
-    const bool wide = g_x3_wide && e.epi != EPI_QKV_ROPE;
-#define X3_LAUNCH(LE, WD, NS, NAME)                                                                                    \
-    do { prof_set_kernel(NAME, "", ""); hipLaunchKernelGGL((linear_x3_kernel<float, LE, WD, NS>), grid, dim3(256), 0, s, e); } while (0)
+#define X3_LAUNCH(LE, SH, NS, NAME)                                                                                    \
+    do { prof_set_kernel(NAME, "", ""); hipLaunchKernelGGL((linear_x3_kernel<float, LE, SH, NS>), grid, dim3(SH == 2 ? 512 : 256), 0, s, e); } while (0)
+    const int shape = e.epi == EPI_QKV_ROPE ? 0 : (int)g_x3_wide;             // 0: 64x64 x 4 waves ; 1: 32x128 x 4 ; 2: 32x64 x 8
     if (g_x3_stages == 4) {
-        if (e.lds_epi) { if (wide) X3_LAUNCH(true, true, 4, "linear_x3_kernel<float, true, wide, 4>"); else X3_LAUNCH(true, false, 4, "linear_x3_kernel<float, true, 64x64, 4>"); }
-        else { if (wide) X3_LAUNCH(false, true, 4, "linear_x3_kernel<float, false, wide, 4>"); else X3_LAUNCH(false, false, 4, "linear_x3_kernel<float, false, 64x64, 4>"); }
+        if (e.lds_epi) { if (shape == 2) X3_LAUNCH(true, 2, 4, "linear_x3_kernel<float, true, 8 waves, 4>"); else if (shape == 1) X3_LAUNCH(true, 1, 4, "linear_x3_kernel<float, true, wide, 4>"); else X3_LAUNCH(true, 0, 4, "linear_x3_kernel<float, true, 64x64, 4>"); }
+        else { if (shape == 2) X3_LAUNCH(false, 2, 4, "linear_x3_kernel<float, false, 8 waves, 4>"); else if (shape == 1) X3_LAUNCH(false, 1, 4, "linear_x3_kernel<float, false, wide, 4>"); else X3_LAUNCH(false, 0, 4, "linear_x3_kernel<float, false, 64x64, 4>"); }
     } else {
-        if (e.lds_epi) { if (wide) X3_LAUNCH(true, true, 3, "linear_x3_kernel<float, true, wide, 3>"); else X3_LAUNCH(true, false, 3, "linear_x3_kernel<float, true, 64x64, 3>"); }
-        else { if (wide) X3_LAUNCH(false, true, 3, "linear_x3_kernel<float, false, wide, 3>"); else X3_LAUNCH(false, false, 3, "linear_x3_kernel<float, false, 64x64, 3>"); }
+        if (e.lds_epi) { if (shape == 2) X3_LAUNCH(true, 2, 3, "linear_x3_kernel<float, true, 8 waves, 3>"); else if (shape == 1) X3_LAUNCH(true, 1, 3, "linear_x3_kernel<float, true, wide, 3>"); else X3_LAUNCH(true, 0, 3, "linear_x3_kernel<float, true, 64x64, 3>"); }
+        else { if (shape == 2) X3_LAUNCH(false, 2, 3, "linear_x3_kernel<float, false, 8 waves, 3>"); else if (shape == 1) X3_LAUNCH(false, 1, 3, "linear_x3_kernel<float, false, wide, 3>"); else X3_LAUNCH(false, 0, 3, "linear_x3_kernel<float, false, 64x64, 3>"); }
     }
 #undef X3_LAUNCH
     MI_HIP(hipGetLastError());
