@@ -629,6 +629,7 @@ bool gemm_set_option(const char* key, long v) {
     else if (k == "gemm_f32_x3") g_x3 = v;
     else if (k == "gemm_x3_wide") x3_set_wide(v);
     else if (k == "gemm_x3_stages") x3_set_stages(v);
+    else if (k == "gemm_x3_hybrid") x3_set_hybrid(v);
     else if (k == "gemm_ph8") g_ph8 = v;
     else if (k == "gemm_ph8_min_tiles") g_ph8_min_tiles = v;
     else if (k == "gemm_ph8_order") g_ph8_order = v;
@@ -702,6 +703,7 @@ void launch_conv_gemm(const ConvGemm& p_in, hipStream_t s) {
             if (const char* n = std::getenv("MI355TTS_F32_X3")) g_x3 = std::atol(n);
             if (const char* n = std::getenv("MI355TTS_X3_WIDE")) x3_set_wide(std::atol(n));
             if (const char* n = std::getenv("MI355TTS_X3_STAGES")) x3_set_stages(std::atol(n));
+            if (const char* n = std::getenv("MI355TTS_X3_HYBRID")) x3_set_hybrid(std::atol(n));
             if (const char* n = std::getenv("MI355TTS_SK_QKV32")) g_sk_qkv32 = std::atol(n);
             if (const char* n = std::getenv("MI355TTS_PH8")) g_ph8 = std::atol(n);
             if (const char* n = std::getenv("MI355TTS_PH8_MIN")) g_ph8_min_tiles = std::atol(n);

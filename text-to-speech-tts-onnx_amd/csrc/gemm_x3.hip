@@ -98,11 +98,18 @@ __global__ __launch_bounds__(SHAPE == 2 ? 512 : 256, 1) void linear_x3_kernel(co
     const int l = R - 1 - ((int)blockIdx.x >> 3);
     const int nch = p.K / KC;
     const int T_all = p.Tm * p.Tn;
-    const int tile_lo = (int)((long)xg * T_all / 8), tile_hi = (int)((long)(xg + 1) * T_all / 8);
+    const int tile_lo_g = (int)((long)xg * T_all / 8), tile_hi = (int)((long)(xg + 1) * T_all / 8);
+    // hybrid (p.tail_tiles != 0): `full` whole tiles per workgroup first, all starting at chunk 0 together, so that the 32
+    // workgroups of an XCD walk K in step and share their panels in L2; only the group's remaining tiles are stream-K'd.
+    // (This kernel is bound by the fabric-side fill — PMC: 313 MB per launch against 40 MB algorithmic with pure stream-K
+    // ranges, which start at unrelated chunks — where the native fp32 kernel, MFMA-bound, lost 4 % to the same change.)
+    const int full = p.tail_tiles ? (tile_hi - tile_lo_g) / R : 0;
+    const int tile_lo = tile_lo_g + full * R;
     const long I = (long)(tile_hi - tile_lo) * nch;
     long it = (long)l * I / R;
     const long it1 = (long)(l + 1) * I / R;
     const int slot0 = xg * R;
+    int dp_done = 0;
 
     const float* xb = (const float*)p.x;
     __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, (int)((((long)p.T_in - 1) * p.x_rstride + p.Cin) * 4L), 0x00020000);
@@ -119,11 +126,12 @@ __global__ __launch_bounds__(SHAPE == 2 ? 512 : 256, 1) void linear_x3_kernel(co
     const int kvb = (lane & 3) ^ ((lane >> 4) & 3);
     const int brow = lane >> 2;
 
-    while (it < it1) {
-        const int tile_g = (int)(it / nch);
-        const int cb = (int)(it - (long)tile_g * nch);
-        const int tile = tile_lo + tile_g;
-        const int n = (int)((it1 - it) < (long)(nch - cb) ? (it1 - it) : (long)(nch - cb));
+    while (dp_done < full || it < it1) {
+        const bool dp = p.tail_tiles == 2 ? !(it < it1) : dp_done < full;     // whole tile (mode 1: before the stream-K'd pieces, mode 2: after)
+        const int tile_g = dp ? 0 : (int)(it / nch);
+        const int cb = dp ? 0 : (int)(it - (long)tile_g * nch);
+        const int tile = dp ? tile_lo_g + dp_done * R + l : tile_lo + tile_g;
+        const int n = dp ? nch : (int)((it1 - it) < (long)(nch - cb) ? (it1 - it) : (long)(nch - cb));
         const int ce = cb + n;
         int nt, mt;
         if (p.RC == 0) { nt = tile / p.Tm; mt = tile - nt * p.Tm; }
@@ -296,7 +304,7 @@ __global__ __launch_bounds__(SHAPE == 2 ? 512 : 256, 1) void linear_x3_kernel(co
 
         // ---- partial tile: publish or collect (gemm_sk.hip) ----------------------------------------------------------------
         const int slot_lane = (wave * (TM * TN * 4)) * 64 + lane;
-        if (p.dbg & 4) { it += n; continue; }
+        if (p.dbg & 4) { if (dp) ++dp_done; else it += n; continue; }
         if (cb > 0) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -354,16 +362,22 @@ __global__ __launch_bounds__(SHAPE == 2 ? 512 : 256, 1) void linear_x3_kernel(co
             }
             __syncthreads();
         }
-        it += n;
+        if (dp) ++dp_done; else it += n;
     }
 #endif
 }
 
+// measured slower here as well (whole tiles first 67.4, pieces first 66.0 vs 63.3 us): the eight-piece fix-ups of the remainder
+// cost more than the better L2 hit rate gains
+static long g_x3_hybrid = 0;
+void x3_set_hybrid(long v) { g_x3_hybrid = v; }
 static long g_x3_wide = 2, g_x3_stages = 4;      // wave layout of the plain-epilogue launches: 0 / 1 / 2, see the kernel
 void x3_set_wide(long v) { g_x3_wide = v; }
 void x3_set_stages(long v) { g_x3_stages = v == 3 ? 3 : 4; }
 
-void launch_linear_x3(const ConvGemmDev& e, hipStream_t s) {
+void launch_linear_x3(const ConvGemmDev& e_in, hipStream_t s) {
+    ConvGemmDev e = e_in;
+    e.tail_tiles = (int)g_x3_hybrid;
     int dev = 0, cus = 256;
     MI_HIP(hipGetDevice(&dev));
     {
