@@ -148,6 +148,34 @@ def test_attention_against_oracle_ragged_lengths(small):
     eng.close()
 
 
+def test_fp32_attention_split_products_match_native():
+    """attn_f32_x3: q.k as exact three-way bf16 splits on the bf16 pipes vs the native fp32 MFMA — both inside the DiT gate
+    against the oracle and within 5e-5 of each other (N = 67 .. 700: 128-query and 64-query workgroups, key slices)."""
+    from mi355tts import _lib
+    cfg = F5Config(dim=256, depth=1, heads=4, dim_head=64, text_dim=64, text_num_embeds=40, conv_layers=1,
+                   pos_conv_groups=4, vocos_dim=64, vocos_intermediate=128, vocos_layers=1, nfe_step=4)
+    raw = W.synth_state(W.f5_spec(cfg), 7)
+    st = W.fold_f5(cfg, raw)
+    eng = F5Engine(cfg, raw, dtype="f32")
+    tables = O.time_tables(cfg, st)
+    try:
+        for N in (67, 257, 700):
+            noise = W.synth_normal(3, f"n{N}", (N, cfg.mel_dim))
+            cmt = W.synth_normal(4, f"c{N}", (N, cfg.mel_dim + cfg.text_dim), std=0.7)
+            cmtd = W.synth_normal(5, f"d{N}", (N, cfg.mel_dim + cfg.text_dim), std=0.7)
+            cos, sin = O.rope_tables(N, 64)
+            ref = O.dit_forward(cfg, st, noise, cmt, cmtd, tables[2][1], cos, sin)
+            got = {}
+            for x3 in (1, 0):
+                _lib.set_option("attn_f32_x3", x3)
+                got[x3] = eng.dit_eval(noise[None], cmt[None], cmtd[None], 1)
+                np.testing.assert_allclose(got[x3], ref, atol=3e-4)
+            assert np.abs(got[1] - got[0]).max() < 5e-5
+    finally:
+        _lib.set_option("attn_f32_x3", 1)
+        eng.close()
+
+
 @pytest.mark.parametrize("dtype,tol", [("f32", 3e-4), ("f16", 1.5e-2)])
 def test_attention_key_slices_agree(dtype, tol):
     """Key-sliced attention (gridDim.z slices of the 64-key stages, last-arriver merge in slice order): every slice count,

@@ -20,6 +20,7 @@
 #include "common.h"
 #include "mfma.h"
 #include "f5_kernels.h"
+#include "x3_split.h"
 #include <cstdlib>
 #include <string>
 #include <algorithm>
@@ -31,7 +32,11 @@ namespace mi {
 //                 every 64-key stage, then wave 2g+1 hands its (max, sum, O) to wave 2g through LDS.  Twice as many, half
 //                 as long workgroups: the fp32 kernel is MFMA-bound, and one utterance is 9 x 32 = 288 workgroups on 256
 //                 CUs, so the CUs that got two workgroups set the makespan (2 units); 576 half-size ones finish in 1.5.
-template <typename T, bool SPLIT2 = false>
+// X3S (fp32 only): the S^T = K Q^T products as exact three-way bf16 splits on the bf16 pipes (gemm_x3.hip has the
+//                 arithmetic): 24 v_mfma_f32_32x32x16_bf16 (768 cycles) instead of 32 v_mfma_f32_32x32x2_f32 (2048) per 32x32
+//                 tile; Q is split once per workgroup, the K fragments on their way from LDS (176 VALU instructions per
+//                 tile, overlapped by the co-resident waves).  P V stays on the native fp32 MFMA (it wants V transposed).
+template <typename T, bool SPLIT2 = false, bool X3S = false>
 __global__ __launch_bounds__(256, 3) void attn_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                    const T* __restrict__ v, T* __restrict__ o, int H, int N,
                                                    float* __restrict__ ws, int* __restrict__ cnt) {
@@ -40,7 +45,8 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const T* __restrict__ q, c
     constexpr int D = 64, KT = 64;
     constexpr int VEC = 16 / (int)sizeof(T);
     constexpr int KS = D / (2 * KP);                       // MFMA k-steps over head_dim for S^T
-    constexpr int LDK = D + (sizeof(T) == 4 ? 1 : 8);
+    static_assert(!X3S || sizeof(T) == 4, "the split form is the fp32 kernel");
+    constexpr int LDK = D + (sizeof(T) == 4 ? (X3S ? 4 : 1) : 8);         // X3S: 16-byte aligned rows (float4 fragment reads)
     constexpr int LDV = sizeof(T) == 4 ? D : KT + 4;       // fp32: Vs[key][d] ; 16-bit: Vt[d][key]
     constexpr int NV = KT * D / VEC / 256;                 // 16-byte vectors per thread per tile
     __shared__ __attribute__((aligned(16))) T smem[KT * LDK + (sizeof(T) == 4 ? KT * D : D * LDV)];
@@ -56,8 +62,29 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const T* __restrict__ q, c
     const T* vb = v + (sizeof(T) == 4 ? (long)bh * N * D : (long)bh * D * vld);
 
     // ---- Q fragments (B operand of S^T): Q[q = q0+lr][d = ks*2KP + hi*KP ..] ------------------
-    typename MF::Frag qf[KS];
-    {
+    typename MF::Frag qf[X3S ? 1 : KS];
+    bf16x8 qf3[X3S ? 4 : 1][3];                            // X3S: Q[q][16 ks + 8 hi .. +8] as three bf16 pieces, pre-scaled by log2(e)
+    if constexpr (X3S) {
+        const int qr = q0 + lr;
+        const bool ok = qr < N;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            float4 a = float4{0.f, 0.f, 0.f, 0.f}, b = a;
+            if (ok) {
+                a = *reinterpret_cast<const float4*>(qb + (long)qr * D + ks * 16 + hi * 8);
+                b = *reinterpret_cast<const float4*>(qb + (long)qr * D + ks * 16 + hi * 8 + 4);
+            }
+            constexpr float L2E = 1.4426950408889634f;
+            unsigned u1[4], u2[4], u3[4];
+            x3_split_pair(a.x * L2E, a.y * L2E, u1[0], u2[0], u3[0]);
+            x3_split_pair(a.z * L2E, a.w * L2E, u1[1], u2[1], u3[1]);
+            x3_split_pair(b.x * L2E, b.y * L2E, u1[2], u2[2], u3[2]);
+            x3_split_pair(b.z * L2E, b.w * L2E, u1[3], u2[3], u3[3]);
+            qf3[ks][0] = __builtin_bit_cast(bf16x8, x3_u4{u1[0], u1[1], u1[2], u1[3]});
+            qf3[ks][1] = __builtin_bit_cast(bf16x8, x3_u4{u2[0], u2[1], u2[2], u2[3]});
+            qf3[ks][2] = __builtin_bit_cast(bf16x8, x3_u4{u3[0], u3[1], u3[2], u3[3]});
+        }
+    } else {
         const int qr = q0 + lr;
         const bool ok = qr < N;
 #pragma unroll
@@ -136,11 +163,34 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const T* __restrict__ q, c
             f32x16 sacc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+            if constexpr (X3S) {
+                const float* krow = reinterpret_cast<const float*>(Ks) + (kt * 32 + lr) * LDK + hi * 8;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const typename MF::Frag a =
-                    *reinterpret_cast<const typename MF::Frag*>(Ks + (kt * 32 + lr) * LDK + ks * 2 * KP + hi * KP);
-                sacc = MF::mma(a, qf[ks], sacc);
+                for (int ks = 0; ks < 4; ++ks) {
+                    const float4 a = *reinterpret_cast<const float4*>(krow + ks * 16), b = *reinterpret_cast<const float4*>(krow + ks * 16 + 4);
+                    unsigned u1[4], u2[4], u3[4];
+                    x3_split_pair(a.x, a.y, u1[0], u2[0], u3[0]);
+                    x3_split_pair(a.z, a.w, u1[1], u2[1], u3[1]);
+                    x3_split_pair(b.x, b.y, u1[2], u2[2], u3[2]);
+                    x3_split_pair(b.z, b.w, u1[3], u2[3], u3[3]);
+                    const bf16x8 k1 = __builtin_bit_cast(bf16x8, x3_u4{u1[0], u1[1], u1[2], u1[3]});
+                    const bf16x8 k2 = __builtin_bit_cast(bf16x8, x3_u4{u2[0], u2[1], u2[2], u2[3]});
+                    const bf16x8 k3 = __builtin_bit_cast(bf16x8, x3_u4{u3[0], u3[1], u3[2], u3[3]});
+                    // six partial products, small terms first
+                    sacc = Mfma<bf16>::mma(k1, qf3[ks][2], sacc);
+                    sacc = Mfma<bf16>::mma(k2, qf3[ks][1], sacc);
+                    sacc = Mfma<bf16>::mma(k3, qf3[ks][0], sacc);
+                    sacc = Mfma<bf16>::mma(k1, qf3[ks][1], sacc);
+                    sacc = Mfma<bf16>::mma(k2, qf3[ks][0], sacc);
+                    sacc = Mfma<bf16>::mma(k1, qf3[ks][0], sacc);
+                }
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const typename MF::Frag a =
+                        *reinterpret_cast<const typename MF::Frag*>(Ks + (kt * 32 + lr) * LDK + ks * 2 * KP + hi * KP);
+                    sacc = MF::mma(a, qf[ks], sacc);
+                }
             }
             // ---- online softmax (per lane = per query) -----------------------------------------
             // only the tile that straddles N needs the key >= N select (2 VALU issues per score, a third of the
@@ -354,11 +404,13 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const T* __restrict__ q, c
 }
 
 // key slices of the SPLIT2 form: at most g_attn_zmax for fp32, g_attn_z16 for 16-bit operands (1 = off: no gain measured)
+static int g_attn_x3 = 1;                                // fp32: S^T as exact bf16 splits (X3S)
 static int g_attn_zmax = 4, g_attn_z16 = 1, g_attn_zforce = 0;      // zforce (tests): exactly that many slices, even empty ones
 bool attn_set_option(const char* key, long v) {
     const std::string k(key);
     if (k == "attn_z_max") g_attn_zmax = (int)std::max(1L, std::min(4L, v));
     else if (k == "attn_z16_max") g_attn_z16 = (int)std::max(1L, std::min(4L, v));
+    else if (k == "attn_f32_x3") g_attn_x3 = v != 0;
     else if (k == "attn_z_force") g_attn_zforce = (int)std::max(0L, std::min(4L, v));
     else return false;
     return true;
@@ -378,6 +430,7 @@ void launch_attention(const void* q, const void* k, const void* v, void* o, int 
     if (split < 0) {
         const char* e = std::getenv("MI355TTS_ATTN_NO_SPLIT"); split = (e && e[0] == '1') ? 0 : 1;
         if (const char* z = std::getenv("MI355TTS_ATTN_Z")) g_attn_zmax = std::max(1, std::min(4, std::atoi(z)));
+        if (const char* z = std::getenv("MI355TTS_ATTN_X3")) g_attn_x3 = std::atoi(z) != 0;
         if (const char* z = std::getenv("MI355TTS_ATTN_Z16")) g_attn_z16 = std::max(1, std::min(4, std::atoi(z)));
     }
     const int zmax = g_attn_zmax;
@@ -412,7 +465,14 @@ void launch_attention(const void* q, const void* k, const void* v, void* o, int 
         if (split && (long)((N + 127) / 128) * BH < 1024 && N >= 64) {
             // ... and cut the key range into Z slices when that evens out the workgroups per CU
             const int Z = pick_z(1);
-            ATTN_LAUNCH(float, true, dim3((N + 63) / 64, BH, Z), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt);
+            if (g_attn_x3) {
+                prof_set_kernel("attn_kernel<float, true, x3>", "", "");
+                hipLaunchKernelGGL((attn_kernel<float, true, true>), dim3((N + 63) / 64, BH, Z), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt);
+            } else
+                ATTN_LAUNCH(float, true, dim3((N + 63) / 64, BH, Z), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt);
+        } else if (g_attn_x3) {
+            prof_set_kernel("attn_kernel<float, false, x3>", "", "");
+            hipLaunchKernelGGL((attn_kernel<float, false, true>), dim3((N + 127) / 128, BH), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt);
         } else
             ATTN_LAUNCH(float, false, dim3((N + 127) / 128, BH), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt);
     } else {

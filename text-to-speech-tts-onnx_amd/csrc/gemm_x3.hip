@@ -22,12 +22,9 @@
 #include "common.h"
 #include "mfma.h"
 #include "gemm_epilogue.h"
+#include "x3_split.h"
 
 namespace mi {
-
-typedef unsigned int x3_u4 __attribute__((ext_vector_type(4)));
-typedef float x3_f2 __attribute__((ext_vector_type(2)));
-typedef __bf16 x3_b2 __attribute__((ext_vector_type(2)));
 
 template <typename RSRC>
 __device__ __forceinline__ void x3_bufds16(RSRC rsrc, int voff, unsigned lds_dst) {
@@ -36,18 +33,6 @@ __device__ __forceinline__ void x3_bufds16(RSRC rsrc, int voff, unsigned lds_dst
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst) : "memory");
 #endif
-}
-
-// two fp32 values -> three packed bf16 pairs (low half = x, high half = y)
-__device__ __forceinline__ void x3_split_pair(float x, float y, unsigned& p1, unsigned& p2, unsigned& p3) {
-    const x3_b2 b1 = __builtin_convertvector(x3_f2{x, y}, x3_b2);
-    p1 = __builtin_bit_cast(unsigned, b1);
-    const float rx = x - __uint_as_float(p1 << 16), ry = y - __uint_as_float(p1 & 0xffff0000u);
-    const x3_b2 b2 = __builtin_convertvector(x3_f2{rx, ry}, x3_b2);
-    p2 = __builtin_bit_cast(unsigned, b2);
-    const float sx = rx - __uint_as_float(p2 << 16), sy = ry - __uint_as_float(p2 & 0xffff0000u);
-    const x3_b2 b3 = __builtin_convertvector(x3_f2{sx, sy}, x3_b2);
-    p3 = __builtin_bit_cast(unsigned, b3);
 }
 
 // weights: fp32 [rows][K] -> planes [3][rows][K] bf16
