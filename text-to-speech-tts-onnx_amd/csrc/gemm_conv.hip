@@ -483,7 +483,7 @@ static void dispatch_tiles(const ConvGemmDev& d, int B, hipStream_t s) {
             if (d.w3 && B == 1 && tiles >= 64) {                // d.w3 is only kept when x3_eligible() said yes (launch_conv_gemm)
                 ConvGemmDev e = d;
                 e.Tm = (d.M + 127) / 128; e.Tn = (d.N + 127) / 128; e.RT = e.Tm;
-                e.RC = d.M <= d.N ? 0 : 1;
+                e.RC = 0;       // row tiles fastest: neighbouring ranges share the weight planes, the heavier operand here (24 of the 40 KB per chunk): 62.9 -> 61.0 us
                 if (g_sk_order >= 0) e.RC = (int)g_sk_order;
                 launch_linear_x3(e, s);
                 return;
