@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvGemmDev
 static bool g_use_dma = true, g_xcd_order = false, g_use_dma3 = true, g_big_tiles = true;
 static long g_big_min = 160, g_n192_min = 160, g_mid_min = 160, g_k_min = 2048;
 static bool g_n192 = true, g_f32_dma = true, g_ring4 = true, g_f32_small = true;
-static long g_f32_small_max = 1024, g_small16_max = 256;
+static long g_f32_small_max = 1024, g_small16_max = 256, g_f32_n64_dma = 1, g_n64_dma16 = 0;      // 16-bit: neutral (455 vs 457 ms at 8 utterances), off
 static long g_ring4_max = 256;
 // stream-K (gemm_sk.hip): 0 off ; 1 fp32 linear layers ; 2 also 16-bit ; g_sk_stages: ring depth override (0 = automatic) ;
 // g_sk_max_tiles: only launches with at most this many 128x128 tiles (beyond that one tile per workgroup balances by itself)
@@ -463,6 +463,22 @@ static void dispatch_tiles(const ConvGemmDev& d, int B, hipStream_t s) {
         dim3 grid((d.M + 255) / 256, (d.N + 31) / 32, B * d.G);
         MI_LAUNCH((conv_gemm_kernel<T, TO, 256, 32, 4, 1, KC>), T, TO, grid, blk, 0, s, d);
     } else if (d.N <= 64) {
+        {
+            // N = 64 per group (the DiT position convolution: k = 31, 16 groups of 64 channels): 64x64 tiles of the LDS-DMA kernel
+            // instead of the register-staged 128x64 one (fp32: 186 -> 120 us per launch)
+            constexpr int VEC_ = 16 / (int)sizeof(T);
+            const long lim = sizeof(T) == 4 ? g_f32_n64_dma : g_n64_dma16;
+            if (lim && d.N == 64 && g_use_dma && (sizeof(T) != 4 || g_f32_dma) && d.Cin % VEC_ == 0 && d.K % d.Cin == 0) {
+                ConvGemmDev e = d;
+                e.Tm = (d.M + 63) / 64; e.Tn = 1; e.RT = B * e.Tm; e.RC = 0;
+                e.use_buf = buf_ok(d, (int)sizeof(T));
+                dim3 g2(e.RT * e.Tn, d.G);
+                if (e.lds_epi) MI_LAUNCH((conv_gemm_dma_kernel<T, TO, true, 2, 64>), T, TO, g2, blk, 0, s, e);
+                else MI_LAUNCH((conv_gemm_dma_kernel<T, TO, false, 2, 64>), T, TO, g2, blk, 0, s, e);
+                MI_HIP(hipGetLastError());
+                return;
+            }
+        }
         dim3 grid((d.M + 127) / 128, (d.N + 63) / 64, B * d.G);
         MI_LAUNCH((conv_gemm_kernel<T, TO, 128, 64, 2, 2, KC>), T, TO, grid, blk, 0, s, d);
     } else {
@@ -618,6 +634,8 @@ bool gemm_set_option(const char* key, long v) {
     else if (k == "gemm_buf") g_buf = v != 0;
     else if (k == "gemm_f32_small") g_f32_small = v != 0;
     else if (k == "gemm_f32_small_max") g_f32_small_max = v;
+    else if (k == "gemm_f32_n64_dma") g_f32_n64_dma = v;
+    else if (k == "gemm_n64_dma16") g_n64_dma16 = v;
     else if (k == "gemm_small16_max") g_small16_max = v;
     else if (k == "gemm_ring4_max") g_ring4_max = v;
     else if (k == "gemm_sk") g_sk = v;
@@ -693,6 +711,8 @@ void launch_conv_gemm(const ConvGemm& p_in, hipStream_t s) {
             if (const char* n = std::getenv("MI355TTS_NO_BUF")) g_buf = !(n[0] == '1');
             if (const char* n = std::getenv("MI355TTS_NO_F32_SMALL")) g_f32_small = !(n[0] == '1');
             if (const char* n = std::getenv("MI355TTS_F32_SMALL_MAX")) g_f32_small_max = std::atol(n);
+            if (const char* n = std::getenv("MI355TTS_F32_N64_DMA")) g_f32_n64_dma = std::atol(n);
+            if (const char* n = std::getenv("MI355TTS_N64_DMA16")) g_n64_dma16 = std::atol(n);
             if (const char* n = std::getenv("MI355TTS_SMALL16_MAX")) g_small16_max = std::atol(n);
             if (const char* n = std::getenv("MI355TTS_RING4_MAX")) g_ring4_max = std::atol(n);
             if (const char* n = std::getenv("MI355TTS_SK")) g_sk = std::atol(n);
