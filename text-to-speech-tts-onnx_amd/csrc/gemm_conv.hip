@@ -430,6 +430,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvGemmDev
 static bool g_use_dma = true, g_xcd_order = false, g_use_dma3 = true, g_big_tiles = true;
 static long g_big_min = 160, g_n192_min = 160, g_mid_min = 160, g_k_min = 2048;
 static bool g_n192 = true, g_f32_dma = true, g_ring4 = true, g_f32_small = true;
+static long g_dma3_order = 0;      // 256-row conv kernels: 0 = row tiles fastest, 2 = XCD-aware with the N tiles of a row tile adjacent
 static long g_f32_small_max = 1024, g_small16_max = 256, g_f32_n64_dma = 1, g_n64_dma16 = 0;      // 16-bit: neutral (455 vs 457 ms at 8 utterances), off
 static long g_ring4_max = 256;
 // stream-K (gemm_sk.hip): 0 off ; 1 fp32 linear layers ; 2 also 16-bit ; g_sk_stages: ring depth override (0 = automatic) ;
@@ -533,14 +534,14 @@ static void dispatch_tiles(const ConvGemmDev& d, int B, hipStream_t s) {
                 // N = 192 / 384 (BigVGAN stages 2 and 1): a 192-wide tile has no padded columns (128-wide tiles waste 25 %
                 // of the MFMAs and DMA bytes at N = 192) and the fewest DMA bytes per useful flop after 256x256
                 ConvGemmDev e = d;
-                e.RC = 0; e.Tm = (d.M + 255) / 256; e.Tn = d.N / 192; e.RT = B * e.Tm;
+                e.RC = (int)g_dma3_order; e.Tm = (d.M + 255) / 256; e.Tn = d.N / 192; e.RT = B * e.Tm;
                 launch_conv_gemm_dma3<T, TO>(e, 192, s);
                 MI_HIP(hipGetLastError());
                 return;
             }
             if (g_use_dma3 && d.Cin % 8 == 0 && d.K % d.Cin == 0 && d.M > 128 && d.K > g_k_min) {
                 ConvGemmDev e = d;
-                e.RC = 0;
+                e.RC = (int)g_dma3_order;
                 const long blocks_128 = (long)B * ((d.M + 127) / 128) * ((d.N + 127) / 128);
                 const long blocks_256x128 = (long)B * ((d.M + 255) / 256) * ((d.N + 127) / 128);
                 const long blocks_256x256 = (long)B * ((d.M + 255) / 256) * ((d.N + 255) / 256);
@@ -635,6 +636,7 @@ bool gemm_set_option(const char* key, long v) {
     else if (k == "gemm_f32_small") g_f32_small = v != 0;
     else if (k == "gemm_f32_small_max") g_f32_small_max = v;
     else if (k == "gemm_f32_n64_dma") g_f32_n64_dma = v;
+    else if (k == "gemm_dma3_order") g_dma3_order = v;
     else if (k == "gemm_n64_dma16") g_n64_dma16 = v;
     else if (k == "gemm_small16_max") g_small16_max = v;
     else if (k == "gemm_ring4_max") g_ring4_max = v;
@@ -712,6 +714,7 @@ void launch_conv_gemm(const ConvGemm& p_in, hipStream_t s) {
             if (const char* n = std::getenv("MI355TTS_NO_F32_SMALL")) g_f32_small = !(n[0] == '1');
             if (const char* n = std::getenv("MI355TTS_F32_SMALL_MAX")) g_f32_small_max = std::atol(n);
             if (const char* n = std::getenv("MI355TTS_F32_N64_DMA")) g_f32_n64_dma = std::atol(n);
+            if (const char* n = std::getenv("MI355TTS_DMA3_ORDER")) g_dma3_order = std::atol(n);
             if (const char* n = std::getenv("MI355TTS_N64_DMA16")) g_n64_dma16 = std::atol(n);
             if (const char* n = std::getenv("MI355TTS_SMALL16_MAX")) g_small16_max = std::atol(n);
             if (const char* n = std::getenv("MI355TTS_RING4_MAX")) g_ring4_max = std::atol(n);

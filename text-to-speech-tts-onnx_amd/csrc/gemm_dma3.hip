@@ -36,7 +36,18 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void conv_gemm_dma3_ker
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WGN, wn = wave % WGN, lr = lane & 31, lk = lane >> 5;
     const int L = blockIdx.x;
-    const int nt = L / p.RT, rowt = L - nt * p.RT;        // row tiles fastest: neighbours share the weight panel
+    int nt, rowt;
+    if (p.RC == 2) {
+        // XCD-aware, N tiles fastest: workgroup L lands on XCD L % 8; each XCD walks a contiguous range of the (row tile, N tile)
+        // list with the N tiles of one row tile next to each other, so the second .. Tn-th reading of an x row panel hits the
+        // XCD's own L2 instead of the fabric (row tiles fastest re-reads every panel one block round later: PMC 2.1x over-fetch)
+        const int total = p.RT * p.Tn, per = (total + 7) >> 3;
+        const int t = (L & 7) * per + (L >> 3);
+        if ((L >> 3) >= per || t >= total) return;
+        rowt = t / p.Tn; nt = t - rowt * p.Tn;
+    } else {
+        nt = L / p.RT; rowt = L - nt * p.RT;               // row tiles fastest: neighbours share the weight panel
+    }
     const int b = rowt / p.Tm, mt = rowt - b * p.Tm;
     const int m0 = mt * BM, n0 = nt * BN;
     const int g = blockIdx.y;
@@ -243,7 +254,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void conv_gemm_dma3_ker
 // DMA: the dispatcher only selects them for whole 64-deep chunks) ; bn = 128: 256x128 / 64x64 / 3-stage ring (flat addresses)
 template <typename T, typename TO>
 void launch_conv_gemm_dma3(const ConvGemmDev& e, int bn, hipStream_t s) {
-    const dim3 grid(e.RT * e.Tn, e.G);
+    const dim3 grid(e.RC == 2 ? 8 * ((e.RT * e.Tn + 7) / 8) : e.RT * e.Tn, e.G);
     if (bn == 192) MI_LAUNCH((conv_gemm_dma3_kernel<T, TO, 256, 192, 64, 96, 2, true>), T, TO, grid, dim3(512), 0, s, e);
     else if (bn == 256) MI_LAUNCH((conv_gemm_dma3_kernel<T, TO, 256, 256, 128, 64, 2, true>), T, TO, grid, dim3(512), 0, s, e);
     else MI_LAUNCH((conv_gemm_dma3_kernel<T, TO, 256, 128, 64, 64, 3>), T, TO, grid, dim3(512), 0, s, e);
