@@ -288,15 +288,16 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x16 (&acc)[TM][TN], const C
 // applied on the 8-column chunk a lane holds.  V (transposed for the attention kernel, [b*H + h][d][key]): the tile is
 // read back column-wise with lane = key, so every store instruction writes 32 consecutive keys of one d (64 contiguous
 // bytes) instead of 64 two-byte writes to 64 different rows.
-template <typename TO>
-__device__ __forceinline__ void gemm_epilogue_qkv_lds(f32x16 (&acc)[2][2], const ConvGemmDev& p, int m0, int n0, int b,
+// TMQ: 32-row blocks of the wave tile (2: 64 x 64 per wave ; 1: 32 x 64, the eight-wave layout of gemm_x3.hip)
+template <typename TO, int TMQ = 2>
+__device__ __forceinline__ void gemm_epilogue_qkv_lds(f32x16 (&acc)[TMQ][2], const ConvGemmDev& p, int m0, int n0, int b,
                                                       int wm, int wn, int lr, int lk, float* stage) {
     const int lane = lk * 32 + lr;
     const int dm = p.heads * 64;
     const int nbase = n0 + wn * 64;
     const int which = nbase / dm, hh = (nbase - which * dm) >> 6;           // wave-uniform
     const int Mb = p.Mb > 0 ? p.Mb : p.M;
-    const int mbase = m0 + wm * 64;
+    const int mbase = m0 + wm * (32 * TMQ);
     const int bi0 = mbase / Mb, mloc0 = mbase - bi0 * Mb;
     const bool vt = which == 2 && p.v_ld > 0;
     TO* base = (TO*)(which == 0 ? p.out : which == 1 ? p.out2 : p.out3);
@@ -306,7 +307,7 @@ __device__ __forceinline__ void gemm_epilogue_qkv_lds(f32x16 (&acc)[2][2], const
         for (int j = 0; j < 2; ++j) {
             const float bv = p.bias ? p.bias[nbase + j * 32 + lr] : 0.f;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TMQ; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     stage[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * 64 + j * 32 + lr] = acc[i][j][r] + bv;
@@ -319,7 +320,7 @@ __device__ __forceinline__ void gemm_epilogue_qkv_lds(f32x16 (&acc)[2][2], const
         struct alignas(16) H8 { f16 v[8]; };
         constexpr int GRP = 4;
 #pragma unroll
-        for (int it0 = 0; it0 < 8; it0 += GRP) {
+        for (int it0 = 0; it0 < 4 * TMQ; it0 += GRP) {
             int mv[GRP], biv[GRP];
             bool okv[GRP];
             H8 cs[GRP];
@@ -381,7 +382,7 @@ __device__ __forceinline__ void gemm_epilogue_qkv_lds(f32x16 (&acc)[2][2], const
     } else {
         const int row = lane & 31, dh = lane >> 5;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < TMQ; ++i) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const float bv = p.bias ? p.bias[nbase + j * 32 + lr] : 0.f;
@@ -420,6 +421,7 @@ void launch_linear_x3(const ConvGemmDev& e, hipStream_t s);
 void x3_set_wide(long v);
 void x3_set_stages(long v);
 void x3_set_hybrid(long v);
+void x3_set_qkv8(long v);
 // gemm_ph8.hip: 256x256 eight-phase kernel for 16-bit linear layers with many row tiles
 template <typename T, typename TO> void launch_linear_ph8(const ConvGemmDev& e, hipStream_t s);
 void ph8_set_split_max(long v);

@@ -340,6 +340,8 @@ __global__ __launch_bounds__(SHAPE == 2 ? 512 : 256, 1) void linear_x3_kernel(co
                 bool done = false;
                 if constexpr (SHAPE == 0) {
                     if (p.epi == EPI_QKV_ROPE) { gemm_epilogue_qkv_lds<TO>(acc, p, m0, n0, 0, wm, wn, lr, lk, stage); done = true; }
+                } else if constexpr (SHAPE == 2) {
+                    if (p.epi == EPI_QKV_ROPE) { gemm_epilogue_qkv_lds<TO, 1>(acc, p, m0, n0, 0, wm, wn, lr, lk, stage); done = true; }
                 }
                 if (!done) gemm_epilogue_lds<TO, TM, TN, WM, WN>(acc, p, m0, n0, 0, 0, wm, wn, lr, lk, stage);
             } else {
@@ -356,6 +358,8 @@ __global__ __launch_bounds__(SHAPE == 2 ? 512 : 256, 1) void linear_x3_kernel(co
 // cost more than the better L2 hit rate gains
 static long g_x3_hybrid = 0;
 void x3_set_hybrid(long v) { g_x3_hybrid = v; }
+static long g_x3_qkv8 = 1;
+void x3_set_qkv8(long v) { g_x3_qkv8 = v; }
 static long g_x3_wide = 2, g_x3_stages = 4;      // wave layout of the plain-epilogue launches: 0 / 1 / 2, see the kernel
 void x3_set_wide(long v) { g_x3_wide = v; }
 void x3_set_stages(long v) { g_x3_stages = v == 3 ? 3 : 4; }
@@ -374,7 +378,8 @@ void launch_linear_x3(const ConvGemmDev& e_in, hipStream_t s) {
     const dim3 grid(P);
 #define X3_LAUNCH(LE, SH, NS, NAME)                                                                                    \
     do { prof_set_kernel(NAME, "", ""); hipLaunchKernelGGL((linear_x3_kernel<float, LE, SH, NS>), grid, dim3(SH == 2 ? 512 : 256), 0, s, e); } while (0)
-    const int shape = e.epi == EPI_QKV_ROPE ? 0 : (int)g_x3_wide;             // 0: 64x64 x 4 waves ; 1: 32x128 x 4 ; 2: 32x64 x 8
+    // 0: 64x64 x 4 waves ; 1: 32x128 x 4 ; 2: 32x64 x 8 ; the QKV epilogue wants 64-column head slices: layouts 0 and 2
+    const int shape = e.epi == EPI_QKV_ROPE ? (g_x3_qkv8 && e.lds_epi ? 2 : 0) : (int)g_x3_wide;
     if (g_x3_stages == 4) {
         if (e.lds_epi) { if (shape == 2) X3_LAUNCH(true, 2, 4, "linear_x3_kernel<float, true, 8 waves, 4>"); else if (shape == 1) X3_LAUNCH(true, 1, 4, "linear_x3_kernel<float, true, wide, 4>"); else X3_LAUNCH(true, 0, 4, "linear_x3_kernel<float, true, 64x64, 4>"); }
         else { if (shape == 2) X3_LAUNCH(false, 2, 4, "linear_x3_kernel<float, false, 8 waves, 4>"); else if (shape == 1) X3_LAUNCH(false, 1, 4, "linear_x3_kernel<float, false, wide, 4>"); else X3_LAUNCH(false, 0, 4, "linear_x3_kernel<float, false, 64x64, 4>"); }
