@@ -285,7 +285,7 @@ def run_f5(args, world, rank, local, dev, dist, torch):
                 r3, _ = fb.measure("f32", args.batch, 2, 2)
             finally:
                 _lib.set_option("gemm_f32_x3", 1)
-                _lib.set_option("attn_f32_x3", 1)
+                _lib.set_option("attn_f32_x3", 2)
             r3["workload"] = f5_workload_name("f32", args.batch, N) + " — linear layers and attention on the native fp32 MFMA (gemm_f32_x3 = 0, attn_f32_x3 = 0)"
             secondary["f5_f32_native_mfma"] = r3
     del fb.blob_t
@@ -301,7 +301,7 @@ def run_f5(args, world, rank, local, dev, dist, torch):
                    "utterances_per_gpu": args.batch, "frames": N,
                    "audio_seconds_per_step_per_gpu": res["audio_seconds_per_step_per_gpu"], "rtf": res["rtf"],
                    "weights": "synthetic seeded (337 M DiT + 13.5 M Vocos params)", "weight_bcast_ms": fb.bcast_ms,
-                   "arithmetic": ("fp32 values, fp32 accumulation; the DiT linear layers and the q.k products of attention form each fp32 "
+                   "arithmetic": ("fp32 values, fp32 accumulation; the DiT linear layers and both products of attention form each fp32 "
                                   "product as six exact bf16 x bf16 partial products (3-way operand split, gemm_x3.hip) — same fp32 parity "
                                   "gates as the native fp32 MFMA path, which is timed in secondary.f5_f32_native_mfma") if args.dtype == "f32" else "16-bit operands, fp32 accumulation, fp32 residual stream",
                    "end_to_end_TFLOP_per_step": res["end_to_end_TFLOP_per_step"],

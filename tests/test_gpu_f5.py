@@ -149,8 +149,9 @@ def test_attention_against_oracle_ragged_lengths(small):
 
 
 def test_fp32_attention_split_products_match_native():
-    """attn_f32_x3: q.k as exact three-way bf16 splits on the bf16 pipes vs the native fp32 MFMA — both inside the DiT gate
-    against the oracle and within 5e-5 of each other (N = 67 .. 700: 128-query and 64-query workgroups, key slices)."""
+    """attn_f32_x3 = 1: q.k as exact three-way bf16 splits on the bf16 pipes; = 2: p.v as well (K / V^T split once per stage
+    into bf16 planes in LDS, V transposed by the QKV epilogue); = 0: native fp32 MFMA.  All inside the DiT gate against the
+    oracle and within 5e-5 of each other (N = 67 .. 700: 128-query and 64-query workgroups, key slices)."""
     from mi355tts import _lib
     cfg = F5Config(dim=256, depth=1, heads=4, dim_head=64, text_dim=64, text_num_embeds=40, conv_layers=1,
                    pos_conv_groups=4, vocos_dim=64, vocos_intermediate=128, vocos_layers=1, nfe_step=4)
@@ -166,13 +167,14 @@ def test_fp32_attention_split_products_match_native():
             cos, sin = O.rope_tables(N, 64)
             ref = O.dit_forward(cfg, st, noise, cmt, cmtd, tables[2][1], cos, sin)
             got = {}
-            for x3 in (1, 0):
+            for x3 in (2, 1, 0):
                 _lib.set_option("attn_f32_x3", x3)
                 got[x3] = eng.dit_eval(noise[None], cmt[None], cmtd[None], 1)
                 np.testing.assert_allclose(got[x3], ref, atol=3e-4)
-            assert np.abs(got[1] - got[0]).max() < 5e-5
+                assert np.array_equal(got[x3], eng.dit_eval(noise[None], cmt[None], cmtd[None], 1))
+            assert np.abs(got[1] - got[0]).max() < 5e-5 and np.abs(got[2] - got[0]).max() < 5e-5
     finally:
-        _lib.set_option("attn_f32_x3", 1)
+        _lib.set_option("attn_f32_x3", 2)
         eng.close()
 
 

@@ -403,14 +403,337 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const T* __restrict__ q, c
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// attn_x3f_kernel — fp32 attention with BOTH products as exact three-way bf16 splits (the arithmetic of gemm_x3.hip).
+// Layout and tiling of the 16-bit kernel above (V arrives transposed, [bh][64][v_ld]; K planes [key][64 + 8], V planes
+// [d][64 + 4] in LDS), with fp32 in HBM: K and V^T are split ONCE per 64-key stage on their way into LDS (three bf16 planes
+// each, shared by the four waves — 22 VALU instructions per float4 instead of a split per wave and tile), Q once per
+// workgroup, the probabilities per tile.  Per 32x32 tile: 24 + 24 v_mfma_f32_32x32x16_bf16 (1536 matrix-core cycles)
+// against 32 + 32 v_mfma_f32_32x32x2_f32 (4096).  SPLIT2 / key slices / merge: as attn_kernel.
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool SPLIT2>
+__global__ __launch_bounds__(256, 2) void attn_x3f_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                       const float* __restrict__ v, float* __restrict__ o, int H, int N,
+                                                       float* __restrict__ ws, int* __restrict__ cnt) {
+    using MF = Mfma<bf16>;
+    using Frag = bf16x8;
+    constexpr int D = 64, KT = 64;
+    constexpr int LDK = D + 8, LDV = KT + 4;                // bf16 elements per plane row
+    constexpr int KPL = KT * LDK, VPL = D * LDV;            // elements per plane
+    __shared__ __attribute__((aligned(16))) bf16 smem[3 * KPL + 3 * VPL];
+    static_assert(sizeof(smem) >= (2 * 32 * 64 + 2 * 64 * 2 + 4) * sizeof(float), "merge buffer fits the stage");
+    bf16* Ks = smem;
+    bf16* Vs = smem + 3 * KPL;
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, hi = lane >> 5;
+    const int bh = blockIdx.y;
+    const int q0 = SPLIT2 ? blockIdx.x * 64 + (wave >> 1) * 32 : blockIdx.x * 128 + wave * 32;
+    const float* qb = q + (long)bh * N * D;
+    const float* kb = k + (long)bh * N * D;
+    const long vld = (long)((N + 7) / 8 * 8);
+    const float* vb = v + (long)bh * D * vld;
+
+    auto split4 = [&](const float4 a, uint2& w1, uint2& w2, uint2& w3) __attribute__((always_inline)) {
+        x3_split_pair(a.x, a.y, w1.x, w2.x, w3.x);
+        x3_split_pair(a.z, a.w, w1.y, w2.y, w3.y);
+    };
+    auto split8 = [&](const float4 a, const float4 b, Frag& f1, Frag& f2, Frag& f3) __attribute__((always_inline)) {
+        uint2 a1, a2, a3, b1, b2, b3;
+        split4(a, a1, a2, a3); split4(b, b1, b2, b3);
+        f1 = __builtin_bit_cast(Frag, x3_u4{a1.x, a1.y, b1.x, b1.y});
+        f2 = __builtin_bit_cast(Frag, x3_u4{a2.x, a2.y, b2.x, b2.y});
+        f3 = __builtin_bit_cast(Frag, x3_u4{a3.x, a3.y, b3.x, b3.y});
+    };
+
+    // ---- Q: three bf16 pieces of log2(e) * Q[q0 + lr][16 ks + 8 hi .. +8] ------------------------------------------------
+    Frag qf3[4][3];
+    {
+        const int qr = q0 + lr;
+        const bool ok = qr < N;
+        constexpr float L2E = 1.4426950408889634f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            float4 a = float4{0.f, 0.f, 0.f, 0.f}, b = a;
+            if (ok) {
+                a = *reinterpret_cast<const float4*>(qb + (long)qr * D + ks * 16 + hi * 8);
+                b = *reinterpret_cast<const float4*>(qb + (long)qr * D + ks * 16 + hi * 8 + 4);
+            }
+            a.x *= L2E; a.y *= L2E; a.z *= L2E; a.w *= L2E; b.x *= L2E; b.y *= L2E; b.z *= L2E; b.w *= L2E;
+            split8(a, b, qf3[ks][0], qf3[ks][1], qf3[ks][2]);
+        }
+    }
+
+    // ---- stage loads: 64 keys x 64 d of K (rows = keys) and of V^T (rows = d), four float4 per thread each ----------------
+    float4 kreg[4], vreg[4];
+    auto load_regs = [&](int key0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int vi = tid + i * 256;
+            const int key = vi >> 4, dv = vi & 15;              // K: row key, floats 4 dv .. 4 dv + 3
+            const int d = vi >> 4, kv = vi & 15;                // V^T: row d, keys key0 + 4 kv .. + 3
+            float4 a = float4{0.f, 0.f, 0.f, 0.f}, b = a;
+            if (key0 + key < N) a = *reinterpret_cast<const float4*>(kb + (long)(key0 + key) * D + dv * 4);
+            if (key0 + kv * 4 < N) b = *reinterpret_cast<const float4*>(vb + (long)d * vld + key0 + kv * 4);
+            kreg[i] = a; vreg[i] = b;
+        }
+    };
+    auto store_lds = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int vi = tid + i * 256;
+            const int r = vi >> 4, c = vi & 15;
+            uint2 w1, w2, w3;
+            split4(kreg[i], w1, w2, w3);
+            *reinterpret_cast<uint2*>(Ks + r * LDK + c * 4) = w1;
+            *reinterpret_cast<uint2*>(Ks + KPL + r * LDK + c * 4) = w2;
+            *reinterpret_cast<uint2*>(Ks + 2 * KPL + r * LDK + c * 4) = w3;
+            split4(vreg[i], w1, w2, w3);
+            *reinterpret_cast<uint2*>(Vs + r * LDV + c * 4) = w1;
+            *reinterpret_cast<uint2*>(Vs + VPL + r * LDV + c * 4) = w2;
+            *reinterpret_cast<uint2*>(Vs + 2 * VPL + r * LDV + c * 4) = w3;
+        }
+    };
+
+    f32x16 oacc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.f; oacc[1][r] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int nstage_all = (N + KT - 1) / KT;
+    const int st0 = SPLIT2 ? (int)((long)blockIdx.z * nstage_all / gridDim.z) : 0;
+    const int nstage = SPLIT2 ? (int)((long)(blockIdx.z + 1) * nstage_all / gridDim.z) : nstage_all;
+    if (st0 < nstage) {
+        load_regs(st0 * KT);
+        store_lds();
+        __syncthreads();
+    }
+    constexpr int TA[6] = {0, 1, 2, 0, 1, 0}, TB[6] = {2, 1, 0, 1, 0, 0};      // piece pairs, small terms first
+    for (int st = st0; st < nstage; ++st) {
+        if (st + 1 < nstage) load_regs((st + 1) * KT);
+        auto tile = [&](int kt) {
+            const int key0 = st * KT + kt * 32;
+            // ---- S^T tile: 32 keys x 32 queries, six partial products per k16 step ---------------------------------------
+            f32x16 sacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                Frag kf[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    kf[pl] = *reinterpret_cast<const Frag*>(Ks + pl * KPL + (kt * 32 + lr) * LDK + ks * 16 + hi * 8);
+#pragma unroll
+                for (int t = 0; t < 6; ++t) sacc = MF::mma(kf[TA[t]], qf3[ks][TB[t]], sacc);
+            }
+            if (key0 + 32 > N) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (key >= N) sacc[r] = -INFINITY;
+                }
+            }
+            float mloc = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, sacc[r]);
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+            float alpha = 1.f;
+            if (!__all(mloc - m_run <= 8.0f)) {
+                const float m_new = fmaxf(m_run, mloc);
+                alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                m_run = m_new;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
+            }
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            float p[16];
+            f2 ls2 = f2{0.f, 0.f};
+            const f2 m2 = f2{m_run, m_run};
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const f2 dd = f2{sacc[r], sacc[r + 1]} - m2;
+                const f2 e = f2{__builtin_amdgcn_exp2f(dd.x), __builtin_amdgcn_exp2f(dd.y)};
+                p[r] = e.x; p[r + 1] = e.y;
+                ls2 += e;
+            }
+            float lsum = ls2.x + ls2.y;
+            lsum += __shfl_xor(lsum, 32);
+            l_run = l_run * alpha + lsum;
+            // ---- O^T += V^T P^T: the probabilities a lane holds are the B operand (keys in accumulator-row order) ------------
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                Frag pf[3];
+                split8(float4{p[8 * s2], p[8 * s2 + 1], p[8 * s2 + 2], p[8 * s2 + 3]},
+                       float4{p[8 * s2 + 4], p[8 * s2 + 5], p[8 * s2 + 6], p[8 * s2 + 7]}, pf[0], pf[1], pf[2]);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    Frag vf[3];
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+                        const bf16* row = Vs + pl * VPL + (dt * 32 + lr) * LDV + kt * 32 + 16 * s2 + 4 * hi;
+                        uint2 a2[2];
+                        a2[0] = *reinterpret_cast<const uint2*>(row);
+                        a2[1] = *reinterpret_cast<const uint2*>(row + 8);
+                        vf[pl] = __builtin_bit_cast(Frag, x3_u4{a2[0].x, a2[0].y, a2[1].x, a2[1].y});
+                    }
+#pragma unroll
+                    for (int t = 0; t < 6; ++t) oacc[dt] = MF::mma(vf[TA[t]], pf[TB[t]], oacc[dt]);
+                }
+            }
+        };
+        if constexpr (SPLIT2) {
+            if (st * KT + (wave & 1) * 32 < N) tile(wave & 1);
+        } else {
+#pragma unroll
+            for (int kt = 0; kt < KT / 32; ++kt) {
+                const int key0 = st * KT + kt * 32;
+                if (key0 < N) tile(kt);
+            }
+        }
+        __syncthreads();
+        if (st + 1 < nstage) {
+            store_lds();
+            __syncthreads();
+        }
+    }
+    bool owner = true;                                              // this wave holds a finished 32-query result
+    if constexpr (SPLIT2) {
+        // ---- merge the two key halves: m = max(m0, m1) ; l = l0 2^(m0-m) + l1 2^(m1-m) ; O likewise ----------------------
+        __syncthreads();                                            // every wave is done with the K / V stage
+        float* comb = reinterpret_cast<float*>(smem);               // [2 groups][32 accumulator registers][64 lanes]
+        float* stats = comb + 2 * 32 * 64;                          // [2 groups][64 lanes][m, l]
+        static_assert(sizeof(smem) >= (2 * 32 * 64 + 2 * 64 * 2 + 4) * sizeof(float), "merge buffer fits the stage");
+        const int grp = wave >> 1;
+        owner = !(wave & 1);
+        if (!owner) {
+            stats[(grp * 64 + lane) * 2] = m_run; stats[(grp * 64 + lane) * 2 + 1] = l_run;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) comb[((grp * 2 + dt) * 16 + r) * 64 + lane] = oacc[dt][r];
+        }
+        __syncthreads();
+        if (owner) {
+            const float m1 = stats[(grp * 64 + lane) * 2], l1 = stats[(grp * 64 + lane) * 2 + 1];
+            const float m = fmaxf(m_run, m1);
+            const float s0 = m_run == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m_run - m);
+            const float s1 = m1 == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m1 - m);
+            l_run = l_run * s0 + l1 * s1;
+            m_run = m;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[dt][r] = oacc[dt][r] * s0 + comb[((grp * 2 + dt) * 16 + r) * 64 + lane] * s1;
+        }
+        // ---- key slices (gridDim.z > 1).  One utterance in fp32 is 18 x 32 = 576 of these workgroups on 768 slots (three per
+        // CU): 2.25 per CU, so the CUs that got three set the makespan and a quarter of the chip idles.  With Z slices the
+        // work comes in pieces of 1 / Z (Z = 4: exactly 9 per CU).  Every slice publishes (m, l, O) of its keys with
+        // write-through stores, drains them, and takes a ticket (relaxed agent-scope fetch-add: the gemm_sk.hip hand-off);
+        // the workgroup that draws the last ticket adds the slices IN SLICE ORDER (its own from registers), so the result
+        // does not depend on which one that is, resets the ticket counter (hipGraph replays find it at zero) and stores.
+        // Nobody waits for anybody: there is no residency requirement. ---------------------------------------------------
+        const int Z = (int)gridDim.z;
+        if (Z > 1) {
+            const int z = (int)blockIdx.z;
+            const int unit = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+            constexpr int SLOT = 2 * 32 * 64 + 2 * 64 * 2;           // floats per (unit, slice)
+            // write-through (sc1) stores / sc1 loads through a buffer descriptor, as in gemm_sk.hip: no L2-wide write-back fence
+            typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+            typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+            __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)(ws + (long)unit * Z * SLOT), 0, Z * SLOT * 4, 0x00020000);
+            if (owner) {
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        u4 val;
+                        val.x = __float_as_uint(oacc[dt][4 * g4]); val.y = __float_as_uint(oacc[dt][4 * g4 + 1]);
+                        val.z = __float_as_uint(oacc[dt][4 * g4 + 2]); val.w = __float_as_uint(oacc[dt][4 * g4 + 3]);
+                        __builtin_amdgcn_raw_buffer_store_b128(val, rsw, (z * SLOT + (((grp * 2 + dt) * 4 + g4) * 64 + lane) * 4) * 4, 0, 16);
+                    }
+                u2 st2; st2.x = __float_as_uint(m_run); st2.y = __float_as_uint(l_run);
+                __builtin_amdgcn_raw_buffer_store_b64(st2, rsw, (z * SLOT + 2 * 32 * 64 + (grp * 64 + lane) * 2) * 4, 0, 16);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            int* ticket = reinterpret_cast<int*>(stats + 2 * 64 * 2);
+            if (tid == 0) *ticket = __hip_atomic_fetch_add(cnt + unit, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if (*ticket != Z - 1) return;                            // not the last slice of this query tile
+            if (tid == 0) __hip_atomic_store(cnt + unit, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!owner) return;
+            float mz[4], lz[4], M = -INFINITY;
+#pragma unroll
+            for (int zz = 0; zz < 4; ++zz) {
+                mz[zz] = -INFINITY; lz[zz] = 0.f;
+                if (zz < Z) {
+                    if (zz == z) { mz[zz] = m_run; lz[zz] = l_run; }
+                    else {
+                        const u2 st2 = __builtin_amdgcn_raw_buffer_load_b64(rsw, (zz * SLOT + 2 * 32 * 64 + (grp * 64 + lane) * 2) * 4, 0, 16);
+                        mz[zz] = __uint_as_float(st2.x); lz[zz] = __uint_as_float(st2.y);
+                    }
+                    M = fmaxf(M, mz[zz]);
+                }
+            }
+            f32x16 osum[2];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { osum[0][r] = 0.f; osum[1][r] = 0.f; }
+            float lsum = 0.f;
+#pragma unroll
+            for (int zz = 0; zz < 4; ++zz) {
+                if (zz >= Z) break;
+                const float sc = mz[zz] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mz[zz] - M);
+                lsum += lz[zz] * sc;
+                if (zz == z) {
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) osum[dt][r] += oacc[dt][r] * sc;
+                } else {
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            const u4 val = __builtin_amdgcn_raw_buffer_load_b128(rsw, (zz * SLOT + (((grp * 2 + dt) * 4 + g4) * 64 + lane) * 4) * 4, 0, 16);
+                            osum[dt][4 * g4] += __uint_as_float(val.x) * sc; osum[dt][4 * g4 + 1] += __uint_as_float(val.y) * sc;
+                            osum[dt][4 * g4 + 2] += __uint_as_float(val.z) * sc; osum[dt][4 * g4 + 3] += __uint_as_float(val.w) * sc;
+                        }
+                }
+            }
+            oacc[0] = osum[0]; oacc[1] = osum[1];
+            l_run = lsum;
+        }
+    }
+    if (!owner) return;
+    // ---- normalise + store o[b][n][h*64 + d] ---------------------------------------------------------
+    const int qr = q0 + lr;
+    if (qr < N) {
+        const float inv = 1.0f / l_run;
+        const int b = bh / H, h = bh - b * H;
+        float* ob = o + ((long)b * N + qr) * H * D + h * D;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float vals[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) vals[e] = (oacc[dt][g * 4 + e] * inv);
+                float* dst = ob + dt * 32 + 8 * g + 4 * hi;
+                *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(vals);
+            }
+    }
+}
+
 // key slices of the SPLIT2 form: at most g_attn_zmax for fp32, g_attn_z16 for 16-bit operands (1 = off: no gain measured)
-static int g_attn_x3 = 1;                                // fp32: S^T as exact bf16 splits (X3S)
+// fp32 attention: 0 = native fp32 MFMA ; 1 = q.k as exact bf16 splits (attn_kernel X3S) ; 2 = both products (attn_x3f_kernel;
+// V then arrives transposed like in the 16-bit engines: attention_v_ld() tells the QKV epilogue)
+static int g_attn_x3 = 2;
+long attention_v_ld(int N, int dtype) { return (dtype == MI_F32 && g_attn_x3 != 2) ? 0 : (long)((N + 7) / 8 * 8); }
 static int g_attn_zmax = 4, g_attn_z16 = 1, g_attn_zforce = 0;      // zforce (tests): exactly that many slices, even empty ones
 bool attn_set_option(const char* key, long v) {
     const std::string k(key);
     if (k == "attn_z_max") g_attn_zmax = (int)std::max(1L, std::min(4L, v));
     else if (k == "attn_z16_max") g_attn_z16 = (int)std::max(1L, std::min(4L, v));
-    else if (k == "attn_f32_x3") g_attn_x3 = v != 0;
+    else if (k == "attn_f32_x3") g_attn_x3 = (int)std::max(0L, std::min(2L, v));
     else if (k == "attn_z_force") g_attn_zforce = (int)std::max(0L, std::min(4L, v));
     else return false;
     return true;
@@ -430,7 +753,7 @@ void launch_attention(const void* q, const void* k, const void* v, void* o, int 
     if (split < 0) {
         const char* e = std::getenv("MI355TTS_ATTN_NO_SPLIT"); split = (e && e[0] == '1') ? 0 : 1;
         if (const char* z = std::getenv("MI355TTS_ATTN_Z")) g_attn_zmax = std::max(1, std::min(4, std::atoi(z)));
-        if (const char* z = std::getenv("MI355TTS_ATTN_X3")) g_attn_x3 = std::atoi(z) != 0;
+        if (const char* z = std::getenv("MI355TTS_ATTN_X3")) g_attn_x3 = std::max(0, std::min(2, std::atoi(z)));
         if (const char* z = std::getenv("MI355TTS_ATTN_Z16")) g_attn_z16 = std::max(1, std::min(4, std::atoi(z)));
     }
     const int zmax = g_attn_zmax;
@@ -465,12 +788,18 @@ void launch_attention(const void* q, const void* k, const void* v, void* o, int 
         if (split && (long)((N + 127) / 128) * BH < 1024 && N >= 64) {
             // ... and cut the key range into Z slices when that evens out the workgroups per CU
             const int Z = pick_z(1);
-            if (g_attn_x3) {
+            if (g_attn_x3 == 2) {
+                prof_set_kernel("attn_x3f_kernel<true>", "", "");
+                hipLaunchKernelGGL((attn_x3f_kernel<true>), dim3((N + 63) / 64, BH, Z), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt);
+            } else if (g_attn_x3 == 1) {
                 prof_set_kernel("attn_kernel<float, true, x3>", "", "");
                 hipLaunchKernelGGL((attn_kernel<float, true, true>), dim3((N + 63) / 64, BH, Z), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt);
             } else
                 ATTN_LAUNCH(float, true, dim3((N + 63) / 64, BH, Z), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt);
-        } else if (g_attn_x3) {
+        } else if (g_attn_x3 == 2) {
+            prof_set_kernel("attn_x3f_kernel<false>", "", "");
+            hipLaunchKernelGGL((attn_x3f_kernel<false>), dim3((N + 127) / 128, BH), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt);
+        } else if (g_attn_x3 == 1) {
             prof_set_kernel("attn_kernel<float, false, x3>", "", "");
             hipLaunchKernelGGL((attn_kernel<float, false, true>), dim3((N + 127) / 128, BH), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt);
         } else

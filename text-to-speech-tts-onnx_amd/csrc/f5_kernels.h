@@ -25,12 +25,15 @@ void launch_cat_noise(const float* noise, void* cat, int U, int N, int M, int ld
 void launch_cfg_update(float* noise, const float* pred, int U, int N, int M, float cfg, const float* dt, int k, hipStream_t s);
 
 // attention.hip: softmax_fp32(q k^T) v, no mask, no scale (q/k are pre-scaled): modules.py:467
-//   q,k [BH][N][64], v [BH][N][64] (fp32) or transposed [BH][64][v_ld] (16-bit, v_ld = attention_v_ld(N))
+//   q,k [BH][N][64], v [BH][N][64] (fp32, native / q.k-split kernels) or transposed [BH][64][v_ld] (16-bit, and the fp32
+//   kernel with both products split; v_ld = attention_v_ld(N, dtype))
 //   -> o [B][N][H*64] (dtype), B = BH / H
 // ws / cnt: optional workspace of the key-sliced fp32 kernel ((2*32*64 + 256) floats per 64-query tile and slice; one zeroed
 // counter per tile); without them every query tile is one workgroup
 void launch_attention(const void* q, const void* k, const void* v, void* o, int BH, int H, int N, int dtype, hipStream_t s,
                       float* ws = nullptr, long ws_floats = 0, int* cnt = nullptr, long cnt_n = 0);
-inline long attention_v_ld(int N, int dtype) { return dtype == MI_F32 ? 0 : (long)((N + 7) / 8 * 8); }
+// row length of the transposed V the attention kernel in use expects (0: V untransposed, [BH][N][64]) — ask per launch: the
+// fp32 answer follows the attn_f32_x3 option
+long attention_v_ld(int N, int dtype);
 
 }  // namespace mi

@@ -665,7 +665,7 @@ static bool x3_eligible(const ConvGemm& p) {
     if (!g_x3 || !p.w3 || p.dtype != MI_F32 || (p.out_dtype >= 0 && p.out_dtype != MI_F32)) return false;
     if (!p.sk_ws || !p.sk_flags || p.sk_slots < 256 || p.B != 1 || p.G != 1 || p.taps != 1 || p.pad != 0 || p.Cin % 32 != 0 || p.M <= 128) return false;
     if (p.epi != EPI_PLAIN && p.epi != EPI_QKV_ROPE) return false;
-    if (p.epi == EPI_QKV_ROPE && !(p.head_dim == 64 && p.rope_pack && p.v_ld == 0 && (p.rows_per_item == 0 ? p.M : p.rows_per_item) >= 64 &&
+    if (p.epi == EPI_QKV_ROPE && !(p.head_dim == 64 && p.rope_pack && (p.rows_per_item == 0 ? p.M : p.rows_per_item) >= 64 &&
                                    ((uintptr_t)p.out % 16) == 0 && ((uintptr_t)p.out2 % 16) == 0 && ((uintptr_t)p.out3 % 16) == 0)) return false;
     const long tiles = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
     if (tiles < 64 || tiles > g_sk_max_tiles) return false;
@@ -756,7 +756,7 @@ void launch_conv_gemm(const ConvGemm& p_in, hipStream_t s) {
         const int ch = 16 / (int)dtype_size(odt);
         // measured: +8-14 % on the K = 1024 DiT linears in the 2-blocks-per-CU 128x128 kernel, a loss on the conv shapes
         // (N <= 768) and in the one-block-per-CU 8-wave kernels, so it is used for wide linear layers only
-        // (fp32 outputs: only the bf16x3 kernel has the staged QKV epilogue; rows leave as 32-byte stores, V untransposed)
+        // (fp32 outputs: only the bf16x3 kernel has the staged QKV epilogue; rows leave as 32-byte stores, V either way)
         const bool qkv_x3 = use_x3;
         const bool qkv_lds = p.epi == EPI_QKV_ROPE && p.head_dim == 64 && (dtype_size(odt) == 2 || qkv_x3) && p.G == 1 &&
                              (p.rows_per_item == 0 ? p.M : p.rows_per_item) >= 64 && ((uintptr_t)p.out % 16) == 0 &&

@@ -336,7 +336,7 @@ __global__ __launch_bounds__(SHAPE == 2 ? 512 : 256, 1) void linear_x3_kernel(co
                 }
             }
             if constexpr (LEPI) {
-                float* stage = reinterpret_cast<float*>(smem) + wave * (W8 ? 2048 : 4096);      // 16 KB per wave (2 x 32 x 64 or 1 x 32 x 128 floats), 8 KB with eight waves
+                float* stage = reinterpret_cast<float*>(smem) + wave * (W8 ? 2176 : 4096);      // 16 KB per wave (2 x 32 x 64 or 1 x 32 x 128 floats); eight waves: 32 x 64, or 32 x 65 for the transposed-V path of the QKV epilogue
                 bool done = false;
                 if constexpr (SHAPE == 0) {
                     if (p.epi == EPI_QKV_ROPE) { gemm_epilogue_qkv_lds<TO>(acc, p, m0, n0, 0, wm, wn, lr, lk, stage); done = true; }
