@@ -203,7 +203,17 @@ int         mi_bench_conv_gemm(int dtype, int B, int T, int Cin, int N, int taps
  * "gemm_mid_tile_min", "gemm_dma3_k_min", "gemm_use_dma3", "gemm_use_dma", "gemm_big_tiles", "gemm_n192", "gemm_f32_dma", "gemm_ring4", "gemm_ring4_max", "gemm_buf", "gemm_f32_small", "gemm_f32_small_max", "gemm_small16_max", "gemm_sk" (stream-K linear layers: 0 off, 1 fp32, 2 also 16-bit), "gemm_sk_stages", "gemm_sk_max_tiles"), and
  * "gpt_mfma_min" (sentences from which mi_gpt_generate_batch runs its linears on MFMA; default 9), and
  * "aa_conv_deterministic" (1: one workgroup per CU in the fused AA+conv kernel, which makes the 16-bit BigVGAN output
- * bit-identical from run to run at +19 % forward time; default 0: a few of 10^7 samples may differ by one 16-bit ulp).   */
+ * bit-identical from run to run at +19 % forward time; default 0: a few of 10^7 samples may differ by one 16-bit ulp).
+ * Arithmetic of fp32 engines (all keep fp32 values and fp32 accumulation, and pass the same parity gates):
+ *   "gemm_f32_x3" (default 1): the big linear layers form every fp32 product as six exact bf16 x bf16 partial products on the
+ *       bf16 matrix cores (three-way operand split, gemm_x3.hip); 0: native v_mfma_f32_32x32x2_f32.
+ *   "attn_f32_x3" (default 2): attention with both products formed that way (V is then kept transposed, like in the 16-bit
+ *       engines); 1: q.k only; 0: native fp32 MFMA.
+ * Further tuning keys (defaults are the measured best): "gemm_ph8", "gemm_ph8_min_tiles", "gemm_ph8_order",
+ * "gemm_ph8_split_max", "gemm_ph8_split_min_nk" (256x256 16-bit kernel); "gemm_sk_hybrid", "gemm_sk_producer",
+ * "gemm_sk_qkv32"; "gemm_x3_wide" (wave layout 0 / 1 / 2), "gemm_x3_stages" (3 / 4), "gemm_x3_hybrid", "gemm_x3_qkv8";
+ * "gemm_f32_n64_dma", "gemm_n64_dma16", "gemm_dma3_order"; "attn_z_max", "attn_z16_max", "attn_z_force" (key slices).
+ * Changing an option invalidates the hipGraphs captured by existing handles.   */
 int         mi_set_option(const char* key, int64_t value);
 
 /* ---- profiling hooks (bench.py roofline leg) -------------------------------------------------
