@@ -167,14 +167,17 @@ def test_fp32_attention_split_products_match_native():
             cos, sin = O.rope_tables(N, 64)
             ref = O.dit_forward(cfg, st, noise, cmt, cmtd, tables[2][1], cos, sin)
             got = {}
-            for x3 in (2, 1, 0):
-                _lib.set_option("attn_f32_x3", x3)
-                got[x3] = eng.dit_eval(noise[None], cmt[None], cmtd[None], 1)
-                np.testing.assert_allclose(got[x3], ref, atol=3e-4)
-                assert np.array_equal(got[x3], eng.dit_eval(noise[None], cmt[None], cmtd[None], 1))
-            assert np.abs(got[1] - got[0]).max() < 5e-5 and np.abs(got[2] - got[0]).max() < 5e-5
+            for split in (1, 0):                               # 64-query key-split workgroups / the 128-query form of large batches
+                _lib.set_option("attn_split", split)
+                for x3 in (2, 1, 0):
+                    _lib.set_option("attn_f32_x3", x3)
+                    got[x3] = eng.dit_eval(noise[None], cmt[None], cmtd[None], 1)
+                    np.testing.assert_allclose(got[x3], ref, atol=3e-4)
+                    assert np.array_equal(got[x3], eng.dit_eval(noise[None], cmt[None], cmtd[None], 1))
+                assert np.abs(got[1] - got[0]).max() < 5e-5 and np.abs(got[2] - got[0]).max() < 5e-5
     finally:
         _lib.set_option("attn_f32_x3", 2)
+        _lib.set_option("attn_split", 1)
         eng.close()
 
 

@@ -728,12 +728,14 @@ __global__ __launch_bounds__(256, 2) void attn_x3f_kernel(const float* __restric
 // V then arrives transposed like in the 16-bit engines: attention_v_ld() tells the QKV epilogue)
 static int g_attn_x3 = 2;
 long attention_v_ld(int N, int dtype) { return (dtype == MI_F32 && g_attn_x3 != 2) ? 0 : (long)((N + 7) / 8 * 8); }
+static int g_attn_split = 1;                             // 64-query workgroups with the keys split between wave pairs when the grid is small
 static int g_attn_zmax = 4, g_attn_z16 = 1, g_attn_zforce = 0;      // zforce (tests): exactly that many slices, even empty ones
 bool attn_set_option(const char* key, long v) {
     const std::string k(key);
     if (k == "attn_z_max") g_attn_zmax = (int)std::max(1L, std::min(4L, v));
     else if (k == "attn_z16_max") g_attn_z16 = (int)std::max(1L, std::min(4L, v));
     else if (k == "attn_f32_x3") g_attn_x3 = (int)std::max(0L, std::min(2L, v));
+    else if (k == "attn_split") g_attn_split = v != 0;
     else if (k == "attn_z_force") g_attn_zforce = (int)std::max(0L, std::min(4L, v));
     else return false;
     return true;
@@ -749,9 +751,10 @@ void launch_attention(const void* q, const void* k, const void* v, void* o, int 
         prof_set_kernel("attn_kernel<T, " #SP ">", type_label<TT>());           \
         hipLaunchKernelGGL((attn_kernel<TT, SP>), __VA_ARGS__);                 \
     } while (0)
-    static int split = -1;
-    if (split < 0) {
-        const char* e = std::getenv("MI355TTS_ATTN_NO_SPLIT"); split = (e && e[0] == '1') ? 0 : 1;
+    static int env_read = -1;
+    if (env_read < 0) {
+        env_read = 1;
+        const char* e = std::getenv("MI355TTS_ATTN_NO_SPLIT"); if (e && e[0] == '1') g_attn_split = 0;
         if (const char* z = std::getenv("MI355TTS_ATTN_Z")) g_attn_zmax = std::max(1, std::min(4, std::atoi(z)));
         if (const char* z = std::getenv("MI355TTS_ATTN_X3")) g_attn_x3 = std::max(0, std::min(2, std::atoi(z)));
         if (const char* z = std::getenv("MI355TTS_ATTN_Z16")) g_attn_z16 = std::max(1, std::min(4, std::atoi(z)));
@@ -785,7 +788,7 @@ void launch_attention(const void* q, const void* k, const void* v, void* o, int 
     const int z16 = g_attn_z16;
     if (dtype == MI_F32) {
         // few 128-query workgroups (one or two utterances): halve them along the keys, see attn_kernel
-        if (split && (long)((N + 127) / 128) * BH < 1024 && N >= 64) {
+        if (g_attn_split && (long)((N + 127) / 128) * BH < 1024 && N >= 64) {
             // ... and cut the key range into Z slices when that evens out the workgroups per CU
             const int Z = pick_z(1);
             if (g_attn_x3 == 2) {
@@ -807,7 +810,7 @@ void launch_attention(const void* q, const void* k, const void* v, void* o, int 
     } else {
         // 16-bit: the same split below 512 workgroups (one utterance: attention 24.3 -> 21.1 ms per step; at two utterances,
         // 576 workgroups, the 128-query form is already balanced and shares each K / V stage among more waves)
-        const bool sp = split && (long)((N + 127) / 128) * BH < 512 && N >= 64;
+        const bool sp = g_attn_split && (long)((N + 127) / 128) * BH < 512 && N >= 64;
         const dim3 grid(sp ? (N + 63) / 64 : (N + 127) / 128, BH, sp ? pick_z(z16) : 1);
         if (dtype == MI_F16) {
             if (sp) ATTN_LAUNCH(f16, true, grid, dim3(256), 0, s, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)o, H, N, ws, cnt);
