@@ -316,7 +316,7 @@ def test_bad_inputs_raise(small_voc):
 # only when the launch fills the chip) and compared with the oracle
 # ---------------------------------------------------------------------------------------------
 _DEFAULTS = {"gemm_big_tile_min": 160, "gemm_n192_min": 160, "gemm_mid_tile_min": 160, "gemm_dma3_k_min": 2048,
-             "gemm_use_dma3": 1, "gemm_use_dma": 1, "gemm_big_tiles": 1, "gemm_n192": 1, "gemm_f32_dma": 1, "gemm_ring4": 1, "gemm_ring4_max": 256, "gemm_buf": 1, "gemm_f32_small": 1, "gemm_f32_small_max": 1024, "gemm_small16_max": 256, "gemm_sk": 1, "gemm_sk_stages": 0, "gemm_ph8": 1, "gemm_ph8_min_tiles": 200, "gemm_ph8_order": 1, "gemm_ph8_split_max": 2, "gemm_ph8_split_min_nk": 24, "gemm_sk_hybrid": 0, "gemm_sk_producer": 0, "gemm_f32_x3": 1, "gemm_x3_wide": 2, "gemm_x3_stages": 4}
+             "gemm_use_dma3": 1, "gemm_use_dma": 1, "gemm_big_tiles": 1, "gemm_n192": 1, "gemm_f32_dma": 1, "gemm_ring4": 1, "gemm_ring4_max": 256, "gemm_buf": 1, "gemm_f32_small": 1, "gemm_f32_small_max": 1024, "gemm_small16_max": 256, "gemm_sk": 1, "gemm_sk_stages": 0, "gemm_ph8": 1, "gemm_ph8_min_tiles": 200, "gemm_ph8_order": 1, "gemm_ph8_split_max": 2, "gemm_ph8_split_min_nk": 24, "gemm_sk_hybrid": 0, "gemm_sk_producer": 0, "gemm_f32_x3": 1, "gemm_x3_wide": 2, "gemm_x3_stages": 4, "gemm_x3_big": 0}
 
 
 @pytest.fixture
@@ -459,6 +459,13 @@ def test_f32_linear_as_exact_bf16_splits_vs_oracle(gemm_options, shape, stages, 
     y0 = BV.conv1d(x, w, b, dtype="f32")                    # v_mfma_f32_32x32x2_f32
     np.testing.assert_allclose(y0, ref, atol=3e-5, rtol=1e-5)
     assert np.abs(y - y0).max() < 1e-5
+    if shape == 2 and stages == 4:
+        gemm_options("gemm_f32_x3", 1)
+        gemm_options("gemm_x3_big", 1)                      # 256x128 tiles, two stages (slower in the model: opt-in; kept correct)
+        yb = BV.conv1d(x, w, b, dtype="f32")
+        np.testing.assert_allclose(yb, ref, atol=3e-5, rtol=1e-5)
+        assert np.abs(yb - y0).max() < 1e-5
+        gemm_options("gemm_x3_big", 0)
     # the split loses nothing against native fp32: both sit at the same distance from a float64 evaluation
     ref64 = np.einsum("oc,bct->bot", w[:, :, 0].astype(np.float64), x.astype(np.float64)) + b.astype(np.float64)[None, :, None]
     e_x3, e_native = rms(y - ref64), rms(y0 - ref64)

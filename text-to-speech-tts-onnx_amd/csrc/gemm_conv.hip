@@ -651,6 +651,7 @@ bool gemm_set_option(const char* key, long v) {
     else if (k == "gemm_x3_stages") x3_set_stages(v);
     else if (k == "gemm_x3_hybrid") x3_set_hybrid(v);
     else if (k == "gemm_x3_qkv8") x3_set_qkv8(v);
+    else if (k == "gemm_x3_big") x3_set_big(v);
     else if (k == "gemm_ph8") g_ph8 = v;
     else if (k == "gemm_ph8_min_tiles") g_ph8_min_tiles = v;
     else if (k == "gemm_ph8_order") g_ph8_order = v;
@@ -729,6 +730,7 @@ void launch_conv_gemm(const ConvGemm& p_in, hipStream_t s) {
             if (const char* n = std::getenv("MI355TTS_X3_STAGES")) x3_set_stages(std::atol(n));
             if (const char* n = std::getenv("MI355TTS_X3_HYBRID")) x3_set_hybrid(std::atol(n));
             if (const char* n = std::getenv("MI355TTS_X3_QKV8")) x3_set_qkv8(std::atol(n));
+            if (const char* n = std::getenv("MI355TTS_X3_BIG")) x3_set_big(std::atol(n));
             if (const char* n = std::getenv("MI355TTS_SK_QKV32")) g_sk_qkv32 = std::atol(n);
             if (const char* n = std::getenv("MI355TTS_PH8")) g_ph8 = std::atol(n);
             if (const char* n = std::getenv("MI355TTS_PH8_MIN")) g_ph8_min_tiles = std::atol(n);

@@ -422,6 +422,7 @@ void x3_set_wide(long v);
 void x3_set_stages(long v);
 void x3_set_hybrid(long v);
 void x3_set_qkv8(long v);
+void x3_set_big(long v);
 // gemm_ph8.hip: 256x256 eight-phase kernel for 16-bit linear layers with many row tiles
 template <typename T, typename TO> void launch_linear_ph8(const ConvGemmDev& e, hipStream_t s);
 void ph8_set_split_max(long v);

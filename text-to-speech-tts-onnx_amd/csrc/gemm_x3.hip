@@ -58,25 +58,28 @@ void split3_planes(const float* w, void* planes, long n, hipStream_t s) {
 // one feeding the matrix core (each DMA instruction costs its wave ~100 cycles of issue; with one wave per SIMD the ten per
 // chunk were a quarter of the kernel: 79.6 -> 58.6 us for FF1 with the DMA switched off)
 template <typename TO, bool LEPI, int SHAPE, int NST>
-__global__ __launch_bounds__(SHAPE == 2 ? 512 : 256, 1) void linear_x3_kernel(const ConvGemmDev p) {
-    constexpr bool WIDE = SHAPE == 1, W8 = SHAPE == 2;
-    constexpr int NW = W8 ? 8 : 4;
+__global__ __launch_bounds__(SHAPE >= 2 ? 512 : 256, 1) void linear_x3_kernel(const ConvGemmDev p) {
+    // SHAPE 3: 256 x 128 tile, eight waves of 64 x 64, TWO stages (56 KB each): 28 KB of operands per 128x128x32 block of work
+    // instead of 40 — this kernel is bound by the fabric-side fill
+    constexpr bool WIDE = SHAPE == 1, W8 = SHAPE == 2, BIG = SHAPE == 3;
+    constexpr int NW = (W8 || BIG) ? 8 : 4;
     using MF = Mfma<bf16>;
     using Frag = typename MF::Frag;
     constexpr int KC = 32;                                      // K chunk: 32 floats = 128 bytes of an x row
-    constexpr int BM = 128, BN = 128, WM = (WIDE || W8) ? 32 : 64, WN = WIDE ? 128 : 64, TM = (WIDE || W8) ? 1 : 2, TN = WIDE ? 4 : 2;
+    constexpr int BM = BIG ? 256 : 128, BN = 128, WM = (WIDE || W8) ? 32 : 64, WN = WIDE ? 128 : 64, TM = (WIDE || W8) ? 1 : 2, TN = WIDE ? 4 : 2;
     constexpr int AHEAD = NST - 1;                              // chunks in flight beyond the one being computed (2 or 3)
-    static_assert(NST == 3 || NST == 4, "ring depth");
+    static_assert((BIG && NST == 2) || (!BIG && (NST == 3 || NST == 4)), "ring depth");
     constexpr int STEPS = 2 * TM, GRP = 2 * TN;                 // steps (k16 step, row block) per chunk ; groups of three MFMAs per step
     constexpr int A_BYTES = BM * KC * 4, BP_BYTES = BN * KC * 2, STAGE_BYTES = A_BYTES + 3 * BP_BYTES;     // 16 KB + 3 x 8 KB
-    constexpr int DA = 16 / NW, DB = 8 / NW;                    // DMA instructions per wave per chunk: DA x-row groups + 3 x DB weight-plane groups
+    constexpr int DA = BM / 8 / NW, DB = 8 / NW;                    // DMA instructions per wave per chunk: DA x-row groups + 3 x DB weight-plane groups
     constexpr int PER = DA + 3 * DB;                            // 10 (four waves) or 5 (eight waves)
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE_BYTES];
+    constexpr int EPI_BYTES = NW * 16384 + 8 * 512;              // LDS-staged epilogues: 16 KB per wave (+ the 32 x 65 slack of the transposed-V path)
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE_BYTES > EPI_BYTES || !BIG ? NST * STAGE_BYTES : EPI_BYTES];
     (void)smem;
 #if defined(__HIP_DEVICE_COMPILE__)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = WIDE ? wave : wave >> 1, wn = WIDE ? 0 : wave & 1, lr = lane & 31, lk = lane >> 5;     // W8: wm 0..3, wn 0..1
+    const int wm = WIDE ? wave : wave >> 1, wn = WIDE ? 0 : wave & 1, lr = lane & 31, lk = lane >> 5;     // W8 / BIG: wm 0..3, wn 0..1
     // ranges: see gemm_sk.hip (XCD groups of whole tiles; range r of a group on workgroup (R-1-r)*8 + xg)
     const int P = (int)gridDim.x, R = P >> 3;
     const int xg = (int)blockIdx.x & 7;
@@ -220,10 +223,11 @@ __global__ __launch_bounds__(SHAPE == 2 ? 512 : 256, 1) void linear_x3_kernel(co
 #pragma unroll
         for (int a = 0; a < AHEAD; ++a) issue(a, cb + a);
         // chunk cb has landed: the AHEAD-1 younger chunks (PER instructions each) may stay in flight
-        if constexpr ((AHEAD - 1) * PER == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        if constexpr (AHEAD == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if constexpr ((AHEAD - 1) * PER == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
         else if constexpr ((AHEAD - 1) * PER == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        static_assert((AHEAD - 1) * PER == 10 || (AHEAD - 1) * PER == 20 || (AHEAD - 1) * PER == 5, "counted prologue wait");
+        static_assert(AHEAD == 1 || (AHEAD - 1) * PER == 10 || (AHEAD - 1) * PER == 20 || (AHEAD - 1) * PER == 5, "counted prologue wait");
         __builtin_amdgcn_s_barrier();
         ldA(0, 0); ldB(0, 0);
         splitA_pair(0); splitA_pair(1); splitA_pair(2); splitA_pair(3); packA(0);
@@ -237,12 +241,13 @@ __global__ __launch_bounds__(SHAPE == 2 ? 512 : 256, 1) void linear_x3_kernel(co
                 if (q == STEPS - 1 && c + 1 < n) {
                     // in flight: the pieces of the newest chunk issued so far (PER - 2 with four waves, PER - 1 with eight) plus
                     // the AHEAD - 2 whole chunks before it
-                    constexpr int INFL = (AHEAD - 2) * PER + (W8 ? PER - 1 : PER - 2);
-                    if constexpr (INFL == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    constexpr int INFL = AHEAD == 1 ? 0 : (AHEAD - 2) * PER + (W8 ? PER - 1 : PER - 2);      // two stages: everything has landed
+                    if constexpr (INFL == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    else if constexpr (INFL == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                     else if constexpr (INFL == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
                     else if constexpr (INFL == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-                    static_assert(INFL == 8 || INFL == 18 || INFL == 4 || INFL == 9, "counted boundary wait");
+                    static_assert(INFL == 0 || INFL == 8 || INFL == 18 || INFL == 4 || INFL == 9, "counted boundary wait");
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
                 }
@@ -272,6 +277,8 @@ __global__ __launch_bounds__(SHAPE == 2 ? 512 : 256, 1) void linear_x3_kernel(co
                     } else if constexpr (WIDE) {
                         if (f < 24 && (f % 3) == 1) dma_one(st_issue, cn, f / 3);             // f = 1, 4, ..., 22: eight
                         else if (f == 25) dma_one(st_issue, cn, 8); else if (f == 29) dma_one(st_issue, cn, 9);
+                    } else if constexpr (BIG) {                                               // 48 MFMAs per chunk, all 7 pieces before the boundary
+                        if (f < 28 && (f & 3) == 1) dma_one(st_issue, cn, f >> 2);             // f = 1, 5, ..., 25
                     } else {                                                                  // eight waves: 24 MFMAs per chunk, 4 + 1 pieces
                         if (f == 1) dma_one(st_issue, cn, 0); else if (f == 4) dma_one(st_issue, cn, 1);
                         else if (f == 7) dma_one(st_issue, cn, 2); else if (f == 10) dma_one(st_issue, cn, 3);
@@ -338,7 +345,7 @@ __global__ __launch_bounds__(SHAPE == 2 ? 512 : 256, 1) void linear_x3_kernel(co
             if constexpr (LEPI) {
                 float* stage = reinterpret_cast<float*>(smem) + wave * (W8 ? 2176 : 4096);      // 16 KB per wave (2 x 32 x 64 or 1 x 32 x 128 floats); eight waves: 32 x 64, or 32 x 65 for the transposed-V path of the QKV epilogue
                 bool done = false;
-                if constexpr (SHAPE == 0) {
+                if constexpr (SHAPE == 0 || SHAPE == 3) {
                     if (p.epi == EPI_QKV_ROPE) { gemm_epilogue_qkv_lds<TO>(acc, p, m0, n0, 0, wm, wn, lr, lk, stage); done = true; }
                 } else if constexpr (SHAPE == 2) {
                     if (p.epi == EPI_QKV_ROPE) { gemm_epilogue_qkv_lds<TO, 1>(acc, p, m0, n0, 0, wm, wn, lr, lk, stage); done = true; }
@@ -358,6 +365,8 @@ __global__ __launch_bounds__(SHAPE == 2 ? 512 : 256, 1) void linear_x3_kernel(co
 // cost more than the better L2 hit rate gains
 static long g_x3_hybrid = 0;
 void x3_set_hybrid(long v) { g_x3_hybrid = v; }
+static long g_x3_big = 0;        // > 0: 256x128 tiles (layout 3) for launches with at least that many of them
+void x3_set_big(long v) { g_x3_big = v; }
 static long g_x3_qkv8 = 1;
 void x3_set_qkv8(long v) { g_x3_qkv8 = v; }
 static long g_x3_wide = 2, g_x3_stages = 4;      // wave layout of the plain-epilogue launches: 0 / 1 / 2, see the kernel
@@ -374,12 +383,20 @@ void launch_linear_x3(const ConvGemmDev& e_in, hipStream_t s) {
         if (!cu_count[dev & 15]) { hipDeviceProp_t pr; MI_HIP(hipGetDeviceProperties(&pr, dev)); cu_count[dev & 15] = pr.multiProcessorCount; }
         cus = cu_count[dev & 15];
     }
-    const int P = std::min(cus, e.sk_slots) & ~7;
+    // 0: 64x64 x 4 waves ; 1: 32x128 x 4 ; 2: 32x64 x 8 ; 3: 256x128 tile, 64x64 x 8 ; the QKV epilogue wants 64-column head
+    // slices: layouts 0, 2, 3
+    int shape = e.epi == EPI_QKV_ROPE ? (g_x3_qkv8 && e.lds_epi ? 2 : 0) : (int)g_x3_wide;
+    if (g_x3_big && e.lds_epi && (long)((e.M + 255) / 256) * ((e.N + 127) / 128) >= g_x3_big) shape = 3;
+    if (shape == 3) { e.Tm = (e.M + 255) / 256; e.RT = e.Tm; }
+    const int P = std::min(cus, shape == 3 ? e.sk_slots / 2 : e.sk_slots) & ~7;
     const dim3 grid(P);
 #define X3_LAUNCH(LE, SH, NS, NAME)                                                                                    \
-    do { prof_set_kernel(NAME, "", ""); hipLaunchKernelGGL((linear_x3_kernel<float, LE, SH, NS>), grid, dim3(SH == 2 ? 512 : 256), 0, s, e); } while (0)
-    // 0: 64x64 x 4 waves ; 1: 32x128 x 4 ; 2: 32x64 x 8 ; the QKV epilogue wants 64-column head slices: layouts 0 and 2
-    const int shape = e.epi == EPI_QKV_ROPE ? (g_x3_qkv8 && e.lds_epi ? 2 : 0) : (int)g_x3_wide;
+    do { prof_set_kernel(NAME, "", ""); hipLaunchKernelGGL((linear_x3_kernel<float, LE, SH, NS>), grid, dim3(SH >= 2 ? 512 : 256), 0, s, e); } while (0)
+    if (shape == 3) {
+        X3_LAUNCH(true, 3, 2, "linear_x3_kernel<float, true, 256x128, 2>");
+        MI_HIP(hipGetLastError());
+        return;
+    }
     if (g_x3_stages == 4) {
         if (e.lds_epi) { if (shape == 2) X3_LAUNCH(true, 2, 4, "linear_x3_kernel<float, true, 8 waves, 4>"); else if (shape == 1) X3_LAUNCH(true, 1, 4, "linear_x3_kernel<float, true, wide, 4>"); else X3_LAUNCH(true, 0, 4, "linear_x3_kernel<float, true, 64x64, 4>"); }
         else { if (shape == 2) X3_LAUNCH(false, 2, 4, "linear_x3_kernel<float, false, 8 waves, 4>"); else if (shape == 1) X3_LAUNCH(false, 1, 4, "linear_x3_kernel<float, false, wide, 4>"); else X3_LAUNCH(false, 0, 4, "linear_x3_kernel<float, false, 64x64, 4>"); }
