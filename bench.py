@@ -69,7 +69,7 @@ def cpu_baseline_bigvgan(cfg, state, frames: int):
         cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
     except Exception:
         cores = os.cpu_count() or 1
-    return {"value": secs / dt, "unit": "audio_seconds_per_second", "cores": int(cores), "kind": "port",
+    return {"value": secs / dt, "unit": "audio-s/s", "cores": int(cores), "kind": "port",
             "sample": f"numpy oracle, BigVGAN-v2 fp32, mel (1,{cfg.num_mels},{frames}) = {secs:.2f} s audio in {dt:.1f} s"}
 
 
@@ -108,7 +108,7 @@ def cpu_baseline_f5(cfg, raw_state, audio, ids, N, noise):
         cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
     except Exception:
         cores = os.cpu_count() or 1
-    return {"value": secs / total, "unit": "audio_seconds_per_second", "cores": int(cores), "kind": "port",
+    return {"value": secs / total, "unit": "audio-s/s", "cores": int(cores), "kind": "port",
             "sample": f"numpy oracle fp32: preprocess {t1 - t0:.1f} s + 1 of {cfg.nfe_step - 1} DiT evaluations "
                       f"{t2 - t1:.1f} s (x{cfg.nfe_step - 1} extrapolated) + decode {t3 - t2:.1f} s for one {secs:.2f} s utterance"}
 
