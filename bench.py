@@ -89,28 +89,37 @@ def f5_synthetic_inputs(cfg, U: int, rank: int):
 
 def cpu_baseline_f5(cfg, raw_state, audio, ids, N, noise):
     """numpy oracle (kind 'port'): preprocess + ONE of the 31 DiT evaluations + decode, extrapolated to the
-    full 31-evaluation utterance (every evaluation costs the same)."""
+    full 31-evaluation utterance (every evaluation costs the same).  Threads: min(nproc, 32) for BLAS and for the oracle's
+    own row / head parallelism (oracle/f5_np.py set_threads); the reference driver's own setting is MAX_THREADS = 8
+    (F5-TTS-ONNX-Inference.py:36) — on an 8-core host the two coincide."""
     from oracle import f5_np as O
     from mi355tts import weights as W
     st = W.fold_f5(cfg, raw_state)
-    t0 = time.perf_counter()
-    pre = O.preprocess(cfg, st, audio, ids, N, noise)
-    tables = O.time_tables(cfg, st)
-    t1 = time.perf_counter()
-    x = O.transformer_step(cfg, st, tables, pre["noise"], pre, 0)
-    t2 = time.perf_counter()
-    w = O.decode(cfg, st, x, pre["ref_signal_len"])
-    t3 = time.perf_counter()
+    nproc = os.cpu_count() or 1
+    T = int(os.environ.get("MI355TTS_CPU_THREADS", min(nproc, 32)))
+    O.set_threads(T)
+    try:
+        from threadpoolctl import threadpool_limits
+        lim = threadpool_limits(limits=T, user_api="blas")
+    except Exception:
+        import contextlib
+        lim = contextlib.nullcontext()
+    with lim:
+        t0 = time.perf_counter()
+        pre = O.preprocess(cfg, st, audio, ids, N, noise)
+        tables = O.time_tables(cfg, st)
+        t1 = time.perf_counter()
+        x = O.transformer_step(cfg, st, tables, pre["noise"], pre, 0)
+        t2 = time.perf_counter()
+        w = O.decode(cfg, st, x, pre["ref_signal_len"])
+        t3 = time.perf_counter()
+    O.set_threads(1)
     total = (t1 - t0) + (t2 - t1) * (cfg.nfe_step - 1) + (t3 - t2)
     secs = w.shape[-1] / cfg.sample_rate
-    try:
-        from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
-    except Exception:
-        cores = os.cpu_count() or 1
-    return {"value": secs / total, "unit": "audio-s/s", "cores": int(cores), "kind": "port",
-            "sample": f"numpy oracle fp32: preprocess {t1 - t0:.1f} s + 1 of {cfg.nfe_step - 1} DiT evaluations "
-                      f"{t2 - t1:.1f} s (x{cfg.nfe_step - 1} extrapolated) + decode {t3 - t2:.1f} s for one {secs:.2f} s utterance"}
+    return {"value": secs / total, "unit": "audio-s/s", "cores": T, "kind": "port", "host_nproc": nproc,
+            "sample": f"numpy oracle fp32 on {T} threads of a {nproc}-core host: preprocess {t1 - t0:.1f} s + 1 of {cfg.nfe_step - 1} DiT "
+                      f"evaluations {t2 - t1:.1f} s (x{cfg.nfe_step - 1} extrapolated) + decode {t3 - t2:.1f} s for one {secs:.2f} s utterance "
+                      f"(the reference's own torch modules ran one evaluation in 3.0-3.4 s on 8 threads of the build container)"}
 
 
 def _cores() -> int:
@@ -145,6 +154,62 @@ def dominant_kernel_roofline(kernels, steps: int, peak: float, bound: str, note:
                          "avg_launch_us": x["ms"] / x["launches"] * 1e3,
                          "tflops": x["flops"] / (x["ms"] * 1e-3) / 1e12 if x["ms"] > 0 else 0.0,
                          "alg_GBps": x["bytes"] / (x["ms"] * 1e-3) / 1e9 if x["ms"] > 0 else 0.0} for x in ks[:8]]}
+
+
+def pmc_traffic(kernel_label: str, dtype: str, U: int):
+    """`roofline.traffic` of the dominant kernel: fabric-side bytes per launch from rocprofv3 PMC counters, collected as
+    MI355X_MICROARCH.md (HBM section) prescribes — FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes (they do not fit one
+    pass), FETCH_SIZE doubled (gfx950 tallies 128-byte requests at 64 B), WRITE_SIZE as reported (uncalibrated), both in KB.
+    The passes run a SHORT child command (tools/pmc_f5_eval.py: one DiT evaluation of the same utterance shape on the same
+    engine, ~260 dispatches — a PMC pass costs ~40 ms per dispatch) and the counters of the launches of that kernel are
+    averaged.  Returns (bytes_per_launch, detail) or (None, reason)."""
+    import csv
+    import glob
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None, "bench.py is itself running under a profiler: nested PMC passes skipped"
+    base = kernel_label.split("<")[0].strip()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["TMPDIR"] = "/tmp"
+    sums, counts, names = {}, {}, {}
+    with tempfile.TemporaryDirectory(prefix="mi355tts_pmc_", dir="/tmp") as td:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(td, ctr)
+            cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", out, "--", sys.executable,
+                   os.path.join(ROOT, "tools", "pmc_f5_eval.py"), dtype, str(U), "1"]
+            try:
+                r = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=600)
+            except subprocess.TimeoutExpired:
+                return None, f"rocprofv3 --pmc {ctr} timed out"
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {ctr} failed: {r.stderr[-300:]}"
+            per = {}
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name") != ctr:
+                        continue
+                    nm = re.sub(r"\(.*\)$", "", re.sub(r"^void ", "", row["Kernel_Name"])).replace("mi::", "")
+                    if not nm.startswith(base):
+                        continue
+                    e = per.setdefault(nm, [0.0, 0])
+                    e[0] += float(row["Counter_Value"]); e[1] += 1
+            if not per:
+                return None, f"no {base} dispatch in the {ctr} pass"
+            nm = max(per, key=lambda k: per[k][1])              # the instantiation with the most launches
+            sums[ctr], counts[ctr], names[ctr] = per[nm][0], per[nm][1], nm
+    fetch = 2.0 * sums["FETCH_SIZE"] * 1024.0 / counts["FETCH_SIZE"]
+    write = sums["WRITE_SIZE"] * 1024.0 / counts["WRITE_SIZE"]
+    return fetch + write, {"kernel": names["FETCH_SIZE"], "launches_sampled": counts["FETCH_SIZE"],
+                           "fetch_bytes_per_launch_x2_corrected": fetch, "write_bytes_per_launch": write,
+                           "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes over tools/pmc_f5_eval.py "
+                                     "(one DiT evaluation, same shapes); FETCH_SIZE x2 per the gfx950 note of MI355X_MICROARCH.md; "
+                                     "fabric-side bytes (Infinity-Cache hits are counted)"}
 
 
 def bcast_device_blob(torch, dist, blob_t):
@@ -232,6 +297,16 @@ class F5Bench:
         _lib.prof_enable(())
         kernels = _lib.prof_kernels()
         dt = max_over_ranks(torch, self.dist, self.world, dt, dev)
+        # the reference's own bracket (F5-TTS-ONNX-Inference.py:246-312: host int16 audio + ids in, int16 waveform on the host):
+        # the same steps through the host-pointer form of the C-ABI (H2D of audio / ids / noise, D2H of the waveform inside).
+        # Reported next to `value`, never as `value` (bench contract: inputs resident in HBM).
+        host_ms = None
+        if self.world == 1:
+            eng.synthesize(audio, ids, N, noise=noise)
+            th = time.perf_counter()
+            for _ in range(steps):
+                eng.synthesize(audio, ids, N, noise=noise)
+            host_ms = (time.perf_counter() - th) / steps * 1e3
         if self.dump_dir:
             np.save(os.path.join(self.dump_dir, f"f5_{dtype}_u{U}_rank{self.rank}.npy"), out.cpu().numpy())
         eng.close()
@@ -251,7 +326,8 @@ class F5Bench:
         res = {"value": self.world * audio_s * steps / dt, "ms_per_step": dt / steps * 1e3, "dtype": dtype,
                "rtf": dt / steps / audio_s, "utterances_per_gpu": U, "frames": N, "audio_seconds_per_step_per_gpu": audio_s,
                "end_to_end_TFLOP_per_step": alg_flops / 1e12, "end_to_end_TFLOP_per_s": alg_flops / (dt / steps) / 1e12,
-               "event_timed_kernel_ms_in_eager_pass": ev_ms, "roofline": roof}
+               "event_timed_kernel_ms_in_eager_pass": ev_ms, "roofline": roof,
+               "host_io_ms_per_step": host_ms, "host_io_value": (audio_s / (host_ms * 1e-3)) if host_ms else None}
         return res, (audio, ids, N, noise)
 
 
@@ -301,17 +377,24 @@ def run_f5(args, world, rank, local, dev, dist, torch):
                    "utterances_per_gpu": args.batch, "frames": N,
                    "audio_seconds_per_step_per_gpu": res["audio_seconds_per_step_per_gpu"], "rtf": res["rtf"],
                    "weights": "synthetic seeded (337 M DiT + 13.5 M Vocos params)", "weight_bcast_ms": fb.bcast_ms,
+                   "collective_backend": dist.get_backend() if world > 1 else None,
                    "arithmetic": ("fp32 values, fp32 accumulation; the DiT linear layers and both products of attention form each fp32 "
                                   "product as six exact bf16 x bf16 partial products (3-way operand split, gemm_x3.hip) — same fp32 parity "
                                   "gates as the native fp32 MFMA path, which is timed in secondary.f5_f32_native_mfma") if args.dtype == "f32" else "16-bit operands, fp32 accumulation, fp32 residual stream",
                    "end_to_end_TFLOP_per_step": res["end_to_end_TFLOP_per_step"],
                    "end_to_end_TFLOP_per_s": res["end_to_end_TFLOP_per_s"],
                    "inputs": "audio / text ids / injected noise resident in HBM, int16 waveform left in HBM",
+                   "host_io_ms_per_step": res["host_io_ms_per_step"], "host_io_audio_s_per_s": res["host_io_value"],
+                   "host_io_note": "the reference's bracket (host int16 audio + ids in, int16 waveform back on the host, H2D / D2H inside the call) timed over the same steps; reported beside value, not as value",
                    "reference_published": "README.md:29-30: 180 s (i7-1165G7, ORT CPU) / 62 s (MX150) per utterance"},
         "roofline": res["roofline"],
     }
     if secondary:
         line["secondary"] = secondary
+    if world == 1 and not args.no_pmc and not fb.small and line["roofline"]:
+        tb, detail = pmc_traffic(line["roofline"]["kernel"], args.dtype, args.batch)
+        line["roofline"]["traffic"] = tb
+        line["roofline"]["traffic_detail"] = detail
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline_f5(fb.cfg, fb.raw, audio[0], ids[0], N, noise[0])
     print(json.dumps(line), flush=True)
@@ -538,6 +621,22 @@ def measure_bigvgan(torch, dist, world, rank, local, dev, dtype, B, F, steps, wa
     return res, (cfg, state)
 
 
+def spawn_ranks(n: int) -> int:
+    """Re-run this command line under torch.distributed.run with n ranks on this node; returns its exit code.  stdout
+    (rank 0's one JSON line) and stderr pass straight through."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tokens", type=int, default=256, help="indextts: mel codes decoded per sentence")
@@ -553,10 +652,16 @@ def main():
     ap.add_argument("--dtype", default=None, help="f5: f32 on one GPU (configs[2]), bf16 with --gpus > 1 (configs[3]) | f16 ; "
                                                   "bigvgan: f16 (default) | f32 | bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="f5 on one GPU: skip the two rocprofv3 --pmc passes that fill roofline.traffic")
     ap.add_argument("--no-secondary", action="store_true", help="f5 on one GPU: skip the configs[1] / configs[3]-shard blocks")
     ap.add_argument("--cpu-frames", type=int, default=128)
     ap.add_argument("--dump-dir", default=None, help="f5: every rank saves its int16 waveforms there (tests)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, rendezvous on
+        # 127.0.0.1) and hand over; under `python -m torch.distributed.run ... bench.py --gpus N` the env is already there
+        raise SystemExit(spawn_ranks(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -564,6 +669,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit(f"bench.py needs an MI355X (no CPU fallback) [rank {rank} of {world}]")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -571,9 +680,9 @@ def main():
         dist.init_process_group(os.environ.get("MI355TTS_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
     if os.environ.get("MI355TTS_BENCH_ONE_GPU") == "1":
         local = 0
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    if os.environ.get("MI355TTS_BENCH_ONE_GPU") != "1" and torch.cuda.device_count() < world and world > 1:
+        raise SystemExit(f"bench.py: --gpus {world} but only {torch.cuda.device_count()} device(s) visible "
+                         "(MI355TTS_BENCH_ONE_GPU=1 MI355TTS_BENCH_BACKEND=gloo maps every rank to device 0 for plumbing tests)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 

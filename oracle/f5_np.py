@@ -30,6 +30,56 @@ from scipy.special import erf as _erf
 
 F32 = np.float32
 
+# ------------------------------------------------------------------------------------------------
+# threads (bench.py's cpu_baseline leg): numpy runs its element-wise passes and the per-head attention loop on ONE core,
+# which made the timed baseline 5x slower than the reference's own torch modules on the same 8 cores.  With
+# set_threads(n > 1) the independent pieces — rows of an element-wise pass, (branch, head) pairs of attention — are spread
+# over n Python threads (numpy releases the GIL inside ufuncs and BLAS); BLAS itself is limited to one thread inside
+# the head loop and to n threads elsewhere.  Each piece is the single-threaded arithmetic; only OpenBLAS's own
+# blocking changes with its thread count, so results for different n agree to fp32 rounding, not bit for bit
+# (tests/test_oracle_f5.py checks both settings against the reference fixture).
+# ------------------------------------------------------------------------------------------------
+_THREADS = 1
+_POOL = None
+
+
+def set_threads(n: int) -> int:
+    """Number of worker threads for the row-parallel passes and the attention head loop (1 = plain numpy)."""
+    global _THREADS, _POOL
+    n = max(1, int(n))
+    if _POOL is not None:
+        _POOL.shutdown(wait=True)
+        _POOL = None
+    _THREADS = n
+    if n > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL = ThreadPoolExecutor(max_workers=n)
+    return n
+
+
+def get_threads() -> int:
+    return _THREADS
+
+
+def _blas_limit(n):
+    try:
+        from threadpoolctl import threadpool_limits
+        return threadpool_limits(limits=n, user_api="blas")
+    except Exception:                                  # threadpoolctl missing: BLAS keeps its own setting
+        import contextlib
+        return contextlib.nullcontext()
+
+
+def _rows(fn, x):
+    """fn applied to row blocks of x (all leading axes flattened) on the worker threads; fn must act row by row."""
+    if _POOL is None or x.ndim < 2 or x.shape[0] * int(np.prod(x.shape[1:-1], dtype=np.int64)) < 4 * _THREADS:
+        return fn(x)
+    flat = x.reshape(-1, x.shape[-1])
+    n = flat.shape[0]
+    step = -(-n // (_THREADS * 2))
+    parts = list(_POOL.map(lambda i: fn(flat[i:i + step]), range(0, n, step)))
+    return np.concatenate(parts, axis=0).reshape(x.shape[:-1] + parts[0].shape[-1:])
+
 
 # ------------------------------------------------------------------------------------------------
 # small math
@@ -38,9 +88,13 @@ def gelu_erf(x):
     return (F32(0.5) * x * (F32(1.0) + _erf(x * F32(0.7071067811865476)).astype(F32))).astype(F32)
 
 
-def gelu_tanh(x):
+def _gelu_tanh1(x):
     k0, k1 = F32(0.7978845608028654), F32(0.044715)
     return (F32(0.5) * x * (F32(1.0) + np.tanh(k0 * (x + k1 * x * x * x)))).astype(F32)
+
+
+def gelu_tanh(x):
+    return _rows(_gelu_tanh1, x)
 
 
 def silu(x):
@@ -52,18 +106,22 @@ def mish(x):
     return (x * np.tanh(sp)).astype(F32)
 
 
-def layer_norm(x, eps=1e-6):
-    """LayerNorm over the last axis, no affine, biased variance."""
+def _layer_norm1(x, eps=1e-6):
     mu = x.mean(axis=-1, keepdims=True, dtype=np.float64)
     var = ((x - mu) ** 2).mean(axis=-1, keepdims=True, dtype=np.float64)
     return ((x - mu) / np.sqrt(var + eps)).astype(F32)
 
 
+def layer_norm(x, eps=1e-6):
+    """LayerNorm over the last axis, no affine, biased variance."""
+    return _rows(lambda r: _layer_norm1(r, eps), x)
+
+
 def linear(x, w, b=None):
     y = x @ w.T
     if b is not None:
-        y = y + b
-    return y.astype(F32)
+        y += b
+    return y if y.dtype == F32 else y.astype(F32)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -301,16 +359,23 @@ def attention(cfg, st, p, u, cos, sin):
     q = linear(u, st[p + "to_q.weight"], st[p + "to_q.bias"]).reshape(B, N, H, D).transpose(0, 2, 1, 3)
     k = linear(u, st[p + "to_k.weight"], st[p + "to_k.bias"]).reshape(B, N, H, D).transpose(0, 2, 1, 3)
     v = linear(u, st[p + "to_v.weight"], st[p + "to_v.bias"]).reshape(B, N, H, D).transpose(0, 2, 1, 3)
-    q = rope_apply(q, cos, sin)
-    k = rope_apply(k, cos, sin)
     o = np.empty((B, N, H, D), dtype=F32)
-    for bi in range(B):
-        for h in range(H):
-            s = q[bi, h] @ k[bi, h].T                                   # (N, N) fp32
-            s -= s.max(axis=-1, keepdims=True)
-            np.exp(s, out=s)
-            s /= s.sum(axis=-1, keepdims=True)
-            o[bi, :, h, :] = s @ np.ascontiguousarray(v[bi, h])
+
+    def head(j):
+        bi, h = divmod(j, H)
+        qh, kh = rope_apply(q[bi, h], cos, sin), rope_apply(k[bi, h], cos, sin)
+        s = qh @ kh.T                                                   # (N, N) fp32
+        s -= s.max(axis=-1, keepdims=True)
+        np.exp(s, out=s)
+        s /= s.sum(axis=-1, keepdims=True)
+        o[bi, :, h, :] = s @ np.ascontiguousarray(v[bi, h])
+
+    if _POOL is None:
+        for j in range(B * H):
+            head(j)
+    else:
+        with _blas_limit(1):
+            list(_POOL.map(head, range(B * H)))
     return linear(o.reshape(B, N, H * D), st[p + "to_out.0.weight"], st[p + "to_out.0.bias"])
 
 

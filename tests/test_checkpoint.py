@@ -82,3 +82,36 @@ def test_bigvgan_generator_checkpoint(tmp_path, flavour):
         np.testing.assert_allclose(got, want, rtol=2e-6, atol=1e-7)
     torch.save(sd, tmp_path / "bare.pt")                                             # a bare state dict is accepted too
     np.testing.assert_allclose(CK.pack_bigvgan_from_file(cfg, str(tmp_path / "bare.pt")), want, rtol=2e-6, atol=1e-7)
+
+
+def test_safetensors_reader_rejects_malformed_files(tmp_path):
+    """the header is untrusted input — oversize header length, offsets outside the file, size / shape mismatch,
+    truncation and unsupported dtypes all raise a ValueError naming the problem (no huge allocation, no opaque reshape)."""
+    import json
+    import struct
+    from mi355tts import checkpoint as C
+
+    def write(name, header, data=b"", hlen=None):
+        h = json.dumps(header).encode()
+        p = tmp_path / name
+        p.write_bytes(struct.pack("<Q", len(h) if hlen is None else hlen) + h + data)
+        return str(p)
+
+    good = {"a": {"dtype": "F32", "shape": [2, 2], "data_offsets": [0, 16]}}
+    assert C.read_safetensors(write("ok.safetensors", good, b"\0" * 16))["a"].shape == (2, 2)
+    with pytest.raises(ValueError, match="header length"):
+        C.read_safetensors(write("hlen.safetensors", good, b"\0" * 16, hlen=1 << 40))
+    with pytest.raises(ValueError, match="tensor a.*outside"):
+        C.read_safetensors(write("trunc.safetensors", good, b"\0" * 8))
+    bad = {"a": {"dtype": "F32", "shape": [3, 2], "data_offsets": [0, 16]}}
+    with pytest.raises(ValueError, match="tensor a.*needs 24"):
+        C.read_safetensors(write("shape.safetensors", bad, b"\0" * 16))
+    bad = {"ok": good["a"], "z": {"dtype": "F8_E4M3", "shape": [4], "data_offsets": [16, 20]}}
+    with pytest.raises(ValueError, match="tensor z.*unsupported dtype"):
+        C.read_safetensors(write("dtype.safetensors", bad, b"\0" * 20))
+    bad = {"a": {"dtype": "F32", "shape": [2, 2], "data_offsets": [8, 4]}}
+    with pytest.raises(ValueError, match="tensor a"):
+        C.read_safetensors(write("order.safetensors", bad, b"\0" * 16))
+    (tmp_path / "short.safetensors").write_bytes(b"\x01\x02")
+    with pytest.raises(ValueError, match="shorter"):
+        C.read_safetensors(str(tmp_path / "short.safetensors"))

@@ -153,3 +153,22 @@ def test_two_rank_f5_utterance_list_buckets_and_gather():
     assert len(waves) == 5
     for u, w in enumerate(waves):
         assert np.array_equal(np.asarray(w), _f5_run(cfg, st, utts[u])), u
+
+
+def test_bench_spawns_its_ranks_when_no_launcher_is_present():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset (the driver's form) must start two ranks itself.
+    There is no GPU here, so each rank stops at the loud no-fallback check — which names its rank and the world size, and
+    that is what this test looks for (the old behaviour was an assertion `--gpus 2 but WORLD_SIZE=1` in a single process)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    out = r.stdout + r.stderr
+    import torch
+    if torch.cuda.is_available():
+        return
+    assert r.returncode != 0
+    assert "WORLD_SIZE=1" not in out
+    assert "[rank 0 of 2]" in out and "[rank 1 of 2]" in out, out[-3000:]

@@ -279,23 +279,17 @@ def test_full_size_reference_fixture(full_state, golden_dir):
     assert w8.shape == (8, 1, 131102)
     err16 = rms((w8[0, 0] - ref) / 32767.0)
     assert err16 < 2e-2, err16
-    # batch position does not change an item's result: bit-identical with the reproducible tile policy (one workgroup per
-    # CU in the fused AA+conv kernel); the default policy (two per CU, 19 % faster) may flip a few of 10^7 intermediate
-    # values by one fp16 ulp (tools/ubench/aa_race.hip), i.e. a handful of output samples by a few LSB
-    from mi355tts import _lib
-    wt = v.run(np.repeat(mel8[:1], 8, axis=0))
+    # batch position does not change an item's result, and neither does running it again: bit-identical in the DEFAULT
+    # policy (two workgroups of the fused AA+conv kernel per CU).  Round 2 tolerated <= 64 LSB here; the cause was one
+    # sample per channel read through `v_pk_fma_f32 ... op_sel:[0,1,0]` next to another workgroup's MFMAs (aa_math.h,
+    # profiles/r3/aa_conv_opsel_*.txt) and is gone with the channel-pair form of the AA math.
+    tiled = np.repeat(mel8[:1], 8, axis=0)
+    wt = v.run(tiled)
     for b in range(8):
-        d = np.abs(wt[b, 0].astype(np.int32) - wt[0, 0].astype(np.int32))
-        assert d.max() <= 64 and (d > 0).mean() < 1e-2, (b, d.max(), (d > 0).mean())
-    _lib.set_option("aa_conv_deterministic", 1)
-    try:
-        wd = v.run(np.repeat(mel8[:1], 8, axis=0))
-        for b in range(8):
-            assert np.array_equal(wd[b], wd[0])
-        assert np.array_equal(wd, v.run(np.repeat(mel8[:1], 8, axis=0)))
-        assert rms((wd[0, 0] - ref) / 32767.0) < 2e-2
-    finally:
-        _lib.set_option("aa_conv_deterministic", 0)
+        assert np.array_equal(wt[b], wt[0]), (b, np.abs(wt[b, 0].astype(np.int32) - wt[0, 0].astype(np.int32)).max())
+    for _ in range(3):
+        assert np.array_equal(wt, v.run(tiled))
+    assert np.array_equal(wt[0], w8[0])
     v.close()
     print(f"BigVGAN full size vs reference: fp32 rms {err32:.2e} (max |d| {d.max()} LSB), fp16 B=8 rms {err16:.2e}")
 

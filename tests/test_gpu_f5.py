@@ -310,8 +310,21 @@ def gfull(golden_dir):
     return np.load(os.path.join(golden_dir, "f5_full.npz"))
 
 
-def test_full_size_fp32_against_reference_fixture(full, gfull):
-    """configs[2]: fp32, one utterance, NFE grid 32 — the north-star gate (waveform <= 1e-3 RMS) on the north-star config."""
+@pytest.mark.parametrize("native", [False, True], ids=["bf16x3-splits", "native-fp32-mfma"])
+def test_full_size_fp32_against_reference_fixture(full, gfull, native):
+    """configs[2]: fp32, one utterance, NFE grid 32 — the north-star gate (waveform <= 1e-3 RMS) on the north-star config.
+    Both fp32 forms of the engine: the default (linear layers and attention as exact bf16 splits) and the native fp32 MFMA
+    (gemm_f32_x3 = 0, attn_f32_x3 = 0: what bench.py times as secondary.f5_f32_native_mfma)."""
+    from mi355tts import _lib
+    if native:
+        _lib.set_option("gemm_f32_x3", 0); _lib.set_option("attn_f32_x3", 0)
+    try:
+        _full_size_fp32_body(full, gfull, native)
+    finally:
+        _lib.set_option("gemm_f32_x3", 1); _lib.set_option("attn_f32_x3", 2)
+
+
+def _full_size_fp32_body(full, gfull, native):
     cfg, raw, audio, ids, N, noise = full
     assert int(gfull["N"]) == N
     eng = F5Engine(cfg, raw, dtype="f32")
@@ -335,7 +348,8 @@ def test_full_size_fp32_against_reference_fixture(full, gfull):
     assert err < 1e-3, err                                               # THE north-star gate
     assert rms(gfull["e2e_i16"]) > 500
     eng.close()
-    print(f"F5 full size fp32 vs reference: DiT eval rel {e_pred:.2e}, 31-step state rel {e_loop:.2e}, waveform rms {err:.2e}")
+    print(f"F5 full size fp32 ({'native fp32 MFMA' if native else 'bf16x3 splits'}) vs reference: DiT eval rel {e_pred:.2e}, "
+          f"31-step state rel {e_loop:.2e}, waveform rms {err:.2e}")
 
 
 @pytest.mark.parametrize("dtype,gate", [("bf16", 3e-2), ("f16", 1e-2)])

@@ -59,6 +59,40 @@ def test_bench_two_ranks_on_one_gpu_equals_single_process(tmp_path):
     eng.close()
 
 
+@pytest.mark.timeout(900)
+def test_bench_launches_its_own_ranks_without_torchrun(tmp_path):
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE (the driver's form): bench.py re-executes itself under
+    torch.distributed.run, rank 0 prints the one JSON line.  Both ranks share the box's one GPU (gloo)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(MI355TTS_BENCH_BACKEND="gloo", MI355TTS_BENCH_ONE_GPU="1", MI355TTS_BENCH_SMALL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "2",
+           "--dtype", "bf16", "--dump-dir", str(tmp_path)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=800, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["weight_bcast_ms"] > 0
+    assert (tmp_path / "f5_bf16_u2_rank0.npy").exists() and (tmp_path / "f5_bf16_u2_rank1.npy").exists()
+
+
+@pytest.mark.timeout(1800)
+def test_bench_two_gpus_rccl():
+    """The real thing, when the box has two devices: one rank per GPU, backend nccl (= RCCL over xGMI), the weight blob
+    broadcast device to device, configs[3] shard per rank."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=1700, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert line["n_gpus"] == 2 and line["dtype"] == "bf16" and "configs[3] shard" in line["config"]["workload"]
+    assert line["config"]["weight_bcast_ms"] > 0 and line["config"]["collective_backend"] == "nccl"
+
+
 def test_engine_from_device_blob_equals_engine_from_host_blob():
     """mi_f5_create_mem(MI_DEVICE) (device-to-device conversion of the DiT / Vocos matrices, bf16 rounding done by a kernel)
     builds the same engine as the host-blob path, for every engine dtype."""

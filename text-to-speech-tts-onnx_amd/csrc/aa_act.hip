@@ -100,19 +100,31 @@ __global__ __launch_bounds__(256) void aa_act_kernel(const T* __restrict__ x, T*
     const AATaps tp = aa_make_taps(c_h);
     const int lo = -ext, hi = 2 * Tlen + ext;
     const bool edge = (2 * (mp0 - 3) - 1 < lo) || (2 * (mp0 + TT + 3) >= hi);      // block-uniform
-    const int nitems = CT * (TT / R);
+    // two adjacent channels per work item (CT is even): one LDS access moves a channel pair, and the packed FMAs of
+    // aa_math.h carry the pair in their two halves
+    struct alignas(2 * sizeof(T)) Pair { T a, b; };
+    const int CP = CT >> 1;
+    const int nitems = CP * (TT / R);
     for (int it = tid; it < nitems; it += 256) {
-        const int run = it / CT, c = it - run * CT;
+        const int run = it / CP, c = 2 * (it - run * CP);
         const int ml = run * R;               // local output row
-        const float al = FAST ? alpha[c0 + c] * 0.15915494309189535f : alpha[c0 + c];
-        const float ib = inv_beta[c0 + c];
-        float xv[R + 10], acc[R];
+        const float s0 = FAST ? 0.15915494309189535f : 1.f;
+        const aa_f2 al = aa_f2{alpha[c0 + c] * s0, alpha[c0 + c + 1] * s0};
+        const aa_f2 ib = aa_f2{inv_beta[c0 + c], inv_beta[c0 + c + 1]};
+        aa_f2 xv[R + 10], acc[R];
 #pragma unroll
-        for (int j = 0; j < R + 10; ++j) xv[j] = to_f32(xs[(ml + j) * CT + c]);
+        for (int j = 0; j < R + 10; ++j) {
+            const Pair pr = *reinterpret_cast<const Pair*>(xs + (ml + j) * CT + c);
+            xv[j] = aa_f2{to_f32(pr.a), to_f32(pr.b)};
+        }
         if (edge) aa_run<R, FAST, true>(xv, acc, tp, al, ib, mp0 + ml, lo, hi);
         else aa_run<R, FAST, false>(xv, acc, tp, al, ib, mp0 + ml, lo, hi);
 #pragma unroll
-        for (int r = 0; r < R; ++r) ys[(ml + r) * CT + c] = from_f32<T>(acc[r]);
+        for (int r = 0; r < R; ++r) {
+            Pair pr;
+            pr.a = from_f32<T>(acc[r].x); pr.b = from_f32<T>(acc[r].y);
+            *reinterpret_cast<Pair*>(ys + (ml + r) * CT + c) = pr;
+        }
     }
     __syncthreads();
 

@@ -18,6 +18,7 @@
 //   f16/bf16 : v_mfma_f32_32x32x16 — V is staged transposed ([d][key]) so that the 8 keys a lane feeds
 //                 per instruction are two contiguous 8-byte LDS reads.
 #include "common.h"
+#include <mutex>
 #include "mfma.h"
 #include "f5_kernels.h"
 #include "x3_split.h"
@@ -727,10 +728,27 @@ __global__ __launch_bounds__(256, 2) void attn_x3f_kernel(const float* __restric
 // fp32 attention: 0 = native fp32 MFMA ; 1 = q.k as exact bf16 splits (attn_kernel X3S) ; 2 = both products (attn_x3f_kernel;
 // V then arrives transposed like in the 16-bit engines: attention_v_ld() tells the QKV epilogue)
 static int g_attn_x3 = 2;
-long attention_v_ld(int N, int dtype) { return (dtype == MI_F32 && g_attn_x3 != 2) ? 0 : (long)((N + 7) / 8 * 8); }
 static int g_attn_split = 1;                             // 64-query workgroups with the keys split between wave pairs when the grid is small
 static int g_attn_zmax = 4, g_attn_z16 = 1, g_attn_zforce = 0;      // zforce (tests): exactly that many slices, even empty ones
+// The MI355TTS_ATTN_* environment overrides are read ONCE, before the first use of any of the globals above by ANY of the
+// three entry points: F5::dit_eval asks attention_v_ld() for the V layout of the QKV epilogue before the first
+// launch_attention() of the process, and a lazy read inside launch_attention() made that first block write V transposed
+// for a kernel that then read it untransposed.  mi_set_option() applied later overrides the environment.
+static void attn_env_once() {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* e = std::getenv("MI355TTS_ATTN_NO_SPLIT"); if (e && e[0] == '1') g_attn_split = 0;
+        if (const char* z = std::getenv("MI355TTS_ATTN_Z")) g_attn_zmax = std::max(1, std::min(4, std::atoi(z)));
+        if (const char* z = std::getenv("MI355TTS_ATTN_X3")) g_attn_x3 = std::max(0, std::min(2, std::atoi(z)));
+        if (const char* z = std::getenv("MI355TTS_ATTN_Z16")) g_attn_z16 = std::max(1, std::min(4, std::atoi(z)));
+    });
+}
+long attention_v_ld(int N, int dtype) {
+    attn_env_once();
+    return (dtype == MI_F32 && g_attn_x3 != 2) ? 0 : (long)((N + 7) / 8 * 8);
+}
 bool attn_set_option(const char* key, long v) {
+    attn_env_once();
     const std::string k(key);
     if (k == "attn_z_max") g_attn_zmax = (int)std::max(1L, std::min(4L, v));
     else if (k == "attn_z16_max") g_attn_z16 = (int)std::max(1L, std::min(4L, v));
@@ -751,14 +769,7 @@ void launch_attention(const void* q, const void* k, const void* v, void* o, int 
         prof_set_kernel("attn_kernel<T, " #SP ">", type_label<TT>());           \
         hipLaunchKernelGGL((attn_kernel<TT, SP>), __VA_ARGS__);                 \
     } while (0)
-    static int env_read = -1;
-    if (env_read < 0) {
-        env_read = 1;
-        const char* e = std::getenv("MI355TTS_ATTN_NO_SPLIT"); if (e && e[0] == '1') g_attn_split = 0;
-        if (const char* z = std::getenv("MI355TTS_ATTN_Z")) g_attn_zmax = std::max(1, std::min(4, std::atoi(z)));
-        if (const char* z = std::getenv("MI355TTS_ATTN_X3")) g_attn_x3 = std::max(0, std::min(2, std::atoi(z)));
-        if (const char* z = std::getenv("MI355TTS_ATTN_Z16")) g_attn_z16 = std::max(1, std::min(4, std::atoi(z)));
-    }
+    attn_env_once();
     const int zmax = g_attn_zmax;
     // key slices for the SPLIT2 form (see attn_kernel): makespan(Z) = ceil(units * Z / CUs) / Z in units of one unsliced
     // workgroup, + 6 % per extra slice for the prologue and the merge (measured, fp32, one utterance = 576 units:

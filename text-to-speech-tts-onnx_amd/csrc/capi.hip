@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <algorithm>
 #include <mutex>
+#include <exception>
 
 using namespace mi;
 
@@ -208,9 +209,16 @@ void mi_f5_destroy(mi_f5* h) {
     delete h;
 }
 
+// runs F5::recover() when the call leaves by an exception (while the handle lock is still held)
+struct F5Recover {
+    F5* e; int n;
+    explicit F5Recover(F5* e_) : e(e_), n(std::uncaught_exceptions()) {}
+    ~F5Recover() { if (std::uncaught_exceptions() > n) e->recover(); }
+};
 #define F5_CHECK(h, mem, name)                                                     \
     MI_REQUIRE((h) && (h)->impl, name ": null handle");                            \
     std::lock_guard<std::mutex> lk_((h)->mu);                                      \
+    F5Recover rec_((h)->impl);                                                     \
     MI_REQUIRE((mem) == MI_HOST || (mem) == MI_DEVICE, name ": bad mem kind")
 
 static void copy_out(void* dst, const void* src, size_t bytes, int mem, hipStream_t s) {

@@ -52,6 +52,7 @@ struct F5 {
     bool use_graph = true;          // MI355TTS_NO_GRAPH=1 disables
     long graph_epoch = 0;           // option_epoch() the cached graphs were captured under
     void drop_graphs();
+    void recover();          // after an error on this handle: drain the stream, drop graphs, re-zero the hand-off flags / tickets
     void steps_eager(int U, int N, int k0, int nsteps);
 
     // ---- workspace ----

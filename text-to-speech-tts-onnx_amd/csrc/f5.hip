@@ -331,10 +331,12 @@ void F5::ensure_workspace(int U, int N) {
     const size_t rows = (size_t)2 * Um * Nm;
     sk.ensure(1024, stream);     // 64 MB: stream-K slots (64 KB) and the split-tail slabs of gemm_ph8.hip (256 KB)
     {
-        // key-sliced attention (attention.hip): used while there are fewer than 1024 (fp32) / 512 (16-bit) 128-query workgroups, i.e. up to
-        // ~3 utterances; 4 slices x (8192 + 256) floats per 64-query tile
-        const long tiles = (long)((Nm + 63) / 64) * 2 * Um * c.heads;
-        if ((long)((Nm + 127) / 128) * 2 * Um * c.heads < 1024 && tiles > attn_cnt_n) {
+        // key-sliced attention (attention.hip): used while a launch has fewer than 1024 (fp32) / 512 (16-bit) 128-query
+        // workgroups, i.e. fewer than 2048 64-query tiles — whatever the LARGEST batch this handle has seen (the running
+        // maxima Um, Nm only size the activations: a handle that first ran 8 utterances must still slice a later single
+        // one).  Reserved once: 2048 tiles x 4 slices x (8192 + 256) floats = 277 MB of the 288 GB.
+        const long tiles = 2048;
+        if (tiles > attn_cnt_n) {
             attn_ws_floats = tiles * 4 * (2 * 32 * 64 + 2 * 64 * 2);
             attn_ws.ensure((size_t)attn_ws_floats * 4);
             attn_cnt.ensure((size_t)tiles * 4);
@@ -580,6 +582,22 @@ void F5::drop_graphs() {
     for (auto& kv : graphs)
         if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
     graphs.clear();
+}
+
+// Called by the C-ABI when a call on this handle threw (capi.hip F5_CHECK).  The inter-workgroup hand-offs of the GEMM and
+// attention kernels keep persistent flags / ticket counters in the workspace that every COMPLETED launch leaves at zero;
+// after a faulted or aborted launch (or a capture that failed half way) they may be set, and the next launch would consume
+// stale slabs or spin.  Nothing here throws.
+void F5::recover() {
+    (void)hipSetDevice(device);
+    (void)hipStreamSynchronize(stream);
+    (void)hipGetLastError();
+    drop_graphs();
+    sk.reset(stream);
+    if (attn_cnt.p && attn_cnt_n > 0) {
+        (void)hipMemsetAsync(attn_cnt.p, 0, (size_t)attn_cnt_n * 4, stream);
+        (void)hipStreamSynchronize(stream);
+    }
 }
 
 // The reference drives 31 host round trips (F5-TTS-ONNX-Inference.py:291-304).  Here the whole loop is ~5000 kernel

@@ -803,4 +803,14 @@ void SkWorkspace::ensure(int n_slots, hipStream_t s) {
     slots = n_slots;
 }
 
+// The stream-K / split-tail hand-offs (gemm_sk.hip, gemm_x3.hip, gemm_ph8.hip) leave every flag at zero when a launch
+// completes; a launch that faulted or was aborted (or a failed graph capture) may not have.  Consumers spin on these
+// flags, so whoever observes an error on the stream re-zeroes them before the next launch.  Errors are swallowed: this
+// runs on the error path.
+void SkWorkspace::reset(hipStream_t s) {
+    if (!flags.p || slots <= 0) return;
+    (void)hipMemsetAsync(flags.p, 0, (size_t)slots * 4, s);
+    (void)hipStreamSynchronize(s);
+}
+
 }  // namespace mi

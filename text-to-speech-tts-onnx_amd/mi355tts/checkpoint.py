@@ -31,25 +31,61 @@ _ST_DTYPES = {"F32": np.float32, "F16": np.float16, "F64": np.float64, "I64": np
 
 
 def read_safetensors(path: str) -> Dict[str, np.ndarray]:
-    """All tensors of a .safetensors file as numpy arrays (BF16 widened to float32)."""
+    """All tensors of a .safetensors file as numpy arrays (BF16 widened to float32).  The header is validated before
+    anything is allocated from it: a truncated or malformed file raises a ValueError that names the tensor."""
+    import os
     out = {}
+    fsize = os.path.getsize(path)
     with open(path, "rb") as f:
-        (hlen,) = struct.unpack("<Q", f.read(8))
-        header = json.loads(f.read(hlen).decode("utf-8"))
+        h8 = f.read(8)
+        if len(h8) != 8:
+            raise ValueError(f"{path}: not a safetensors file (shorter than its 8-byte header length)")
+        (hlen,) = struct.unpack("<Q", h8)
+        if hlen > fsize - 8:
+            raise ValueError(f"{path}: header length {hlen} exceeds the file ({fsize} bytes)")
+        hraw = f.read(hlen)
+        if len(hraw) != hlen:
+            raise ValueError(f"{path}: short read of the header")
+        try:
+            header = json.loads(hraw.decode("utf-8"))
+        except (UnicodeDecodeError, json.JSONDecodeError) as e:
+            raise ValueError(f"{path}: header is not JSON ({e})") from None
+        if not isinstance(header, dict):
+            raise ValueError(f"{path}: header is not a JSON object")
         base = 8 + hlen
-        for name, meta in header.items():
+        dsize = fsize - base
+        plan = []
+        for name, meta in header.items():          # validate every entry first: no partial work on a bad file
             if name == "__metadata__":
                 continue
-            lo, hi = meta["data_offsets"]
-            f.seek(base + lo)
-            raw = f.read(hi - lo)
-            dt, shape = meta["dtype"], tuple(meta["shape"])
+            try:
+                dt, shape = meta["dtype"], tuple(int(d) for d in meta["shape"])
+                lo, hi = (int(v) for v in meta["data_offsets"])
+            except (KeyError, TypeError, ValueError):
+                raise ValueError(f"{path}: tensor {name}: malformed header entry {meta!r}") from None
             if dt == "BF16":
-                a = (np.frombuffer(raw, dtype="<u2").astype(np.uint32) << 16).view(np.float32)
+                isz = 2
             elif dt in _ST_DTYPES:
-                a = np.frombuffer(raw, dtype=np.dtype(_ST_DTYPES[dt]).newbyteorder("<"))
+                isz = np.dtype(_ST_DTYPES[dt]).itemsize
             else:
                 raise ValueError(f"{path}: tensor {name} has unsupported dtype {dt}")
+            if any(d < 0 for d in shape):
+                raise ValueError(f"{path}: tensor {name}: negative dimension in shape {shape}")
+            if not (0 <= lo <= hi <= dsize):
+                raise ValueError(f"{path}: tensor {name}: data_offsets [{lo}, {hi}) outside the {dsize}-byte data section")
+            want = int(np.prod(shape, dtype=np.int64)) * isz if shape else isz
+            if hi - lo != want:
+                raise ValueError(f"{path}: tensor {name}: {hi - lo} bytes stored, shape {shape} x {dt} needs {want}")
+            plan.append((name, dt, shape, lo, hi))
+        for name, dt, shape, lo, hi in plan:
+            f.seek(base + lo)
+            raw = f.read(hi - lo)
+            if len(raw) != hi - lo:
+                raise ValueError(f"{path}: tensor {name}: short read ({len(raw)} of {hi - lo} bytes)")
+            if dt == "BF16":
+                a = (np.frombuffer(raw, dtype="<u2").astype(np.uint32) << 16).view(np.float32)
+            else:
+                a = np.frombuffer(raw, dtype=np.dtype(_ST_DTYPES[dt]).newbyteorder("<"))
             out[name] = np.array(a, copy=True).reshape(shape)
     return out
 

@@ -1,3 +1,4 @@
+// ROUND-2 FORM, kept for the determinism A/B of tools/ubench/aa_race.sh only (the product uses csrc/aa_conv.hip).
 // aa_conv.hip — fused [anti-aliased SnakeBeta -> Conv1d(k, dilation) -> +bias (+residual) (*alpha) (+=)]
 // for the HBM-bound low-channel BigVGAN stages (C = 96 / 48 / 24 at T = 32k..131k), gfx950.
 //
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(256) void aa_conv_kernel(const AAConvDev p) {
         }
     }
     __syncthreads();
-    // ---- 2. AA (aa_math.h): runs of R outputs per (channel pair, run), packed-fp32 FIRs -------------------
+    // ---- 2. AA (aa_math.h): runs of R outputs per (channel, run), packed-fp32 FIRs ------------------------
     {
         constexpr bool FAST = sizeof(T) == 2;
         const AATaps tp = aa_make_taps(c_h_fused);
@@ -86,22 +87,24 @@ __global__ __launch_bounds__(256) void aa_conv_kernel(const AAConvDev p) {
             const int c = 2 * cp;
             const int ml = run * R;
             const float s0 = FAST ? 0.15915494309189535f : 1.f;
-            const aa_f2 al = aa_f2{p.alpha_s[c] * s0, p.alpha_s[c + 1] * s0};
-            const aa_f2 ib = aa_f2{p.inv_beta[c], p.inv_beta[c + 1]};
-            aa_f2 xv[R + 10], o[R];
+            const float al0 = p.alpha_s[c] * s0, al1 = p.alpha_s[c + 1] * s0;
+            const float ib0 = p.inv_beta[c], ib1 = p.inv_beta[c + 1];
+            float xv0[R + 10], xv1[R + 10], o0[R], o1[R];
 #pragma unroll
             for (int j = 0; j < R + 10; ++j) {
                 const Pair pr = *reinterpret_cast<const Pair*>(XS + (ml + j) * C + c);
-                xv[j] = aa_f2{to_f32(pr.a), to_f32(pr.b)};
+                xv0[j] = to_f32(pr.a); xv1[j] = to_f32(pr.b);
             }
             const int mp = t_act0 + ml;
             if (p.dbg & 1) {
 #pragma unroll
-                for (int r = 0; r < R; ++r) o[r] = xv[r + 5];
+                for (int r = 0; r < R; ++r) { o0[r] = xv0[r + 5]; o1[r] = xv1[r + 5]; }
             } else if (edge) {
-                aa_run<R, FAST, true>(xv, o, tp, al, ib, mp, 0, hi2);
+                aa_run<R, FAST, true>(xv0, o0, tp, al0, ib0, mp, 0, hi2);
+                aa_run<R, FAST, true>(xv1, o1, tp, al1, ib1, mp, 0, hi2);
             } else {
-                aa_run<R, FAST, false>(xv, o, tp, al, ib, mp, 0, hi2);
+                aa_run<R, FAST, false>(xv0, o0, tp, al0, ib0, mp, 0, hi2);
+                aa_run<R, FAST, false>(xv1, o1, tp, al1, ib1, mp, 0, hi2);
             }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(256) void aa_conv_kernel(const AAConvDev p) {
                     const int t = mp + r;
                     const bool in = t >= 0 && t < p.T;
                     Pair pr;
-                    pr.a = from_f32<T>(in ? o[r].x : 0.f); pr.b = from_f32<T>(in ? o[r].y : 0.f);
+                    pr.a = from_f32<T>(in ? o0[r] : 0.f); pr.b = from_f32<T>(in ? o1[r] : 0.f);
                     *reinterpret_cast<Pair*>(AS + row * S + c) = pr;
                 }
             }
