@@ -50,7 +50,13 @@ def _compile(src: str, force: bool, hdig: str) -> str:
     return obj
 
 
-def build(force: bool = False, jobs: int = 4) -> str:
+def build(force: bool = False, jobs: int = 4, variant: str = "") -> str:
+    """variant: a second build beside the product one (objects in build_<variant>/, library libmi355tts_<variant>.so —
+    load it with MI355TTS_LIB=...): A/B measurements of kernel variants without touching the in-tree product library."""
+    global OBJ, LIB
+    if variant:
+        OBJ = os.path.join(HERE, "build_" + variant)
+        LIB = os.path.join(HERE, "mi355tts", f"libmi355tts_{variant}.so")
     os.makedirs(OBJ, exist_ok=True)
     hdig = _headers_digest()
     srcs = _sources()
@@ -69,4 +75,5 @@ if __name__ == "__main__":
     j = 4
     if "-j" in sys.argv:
         j = int(sys.argv[sys.argv.index("-j") + 1])
-    print(build(force="--force" in sys.argv, jobs=j))
+    v = sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else ""
+    print(build(force="--force" in sys.argv, jobs=j, variant=v))

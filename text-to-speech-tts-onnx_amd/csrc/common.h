@@ -164,8 +164,13 @@ struct ConvGemm {
     float* sk_ws = nullptr; int* sk_flags = nullptr; int sk_slots = 0;
     // fp32 linear layers through the bf16 pipes (gemm_x3.hip): the weights split into three bf16 planes [3][N][K] (split3_planes)
     const void* w3 = nullptr;
+    // gemm_x3p.hip (round 3): both operands as pre-split, pre-tiled "panel planes" (x3p_split_rows): xp replaces x, w3p replaces w3
+    const void* xp = nullptr; const void* w3p = nullptr;
 };
 void launch_conv_gemm(const ConvGemm& p, hipStream_t s);
+long x3p_bytes(long rows, long K);                                                    // gemm_x3p.hip: bytes of the panel planes of a [rows][K] matrix
+void x3p_split_rows(const float* x, long ld, void* planes, int rows, int K, hipStream_t s);
+bool gemm_x3p_enabled();
 // owner of a stream-K workspace (one per engine handle / stream)
 struct SkWorkspace {
     DevBuf ws, flags; int slots = 0;

@@ -17,7 +17,7 @@ struct F5Cfg {
 F5Cfg parse_f5_cfg(const int32_t* ci, int ni, const float* cf, int nf);
 int64_t f5_param_count(const F5Cfg& c);
 
-struct Lin { DevBuf w, b, w3; int n = 0, k = 0; };      // w3: fp32 engines, the three bf16 planes of w (gemm_x3.hip)
+struct Lin { DevBuf w, b, w3, w3p; int n = 0, k = 0; };      // fp32 engines: w3 = the three bf16 planes of w (gemm_x3.hip), w3p = the same as panel planes (gemm_x3p.hip)
 
 struct F5 {
     F5Cfg cfg;
@@ -60,6 +60,7 @@ struct F5 {
     DevBuf attn_ws, attn_cnt; // key-sliced fp32 attention: partial (m, l, O) per 64-query tile and slice, ticket counters
     long attn_ws_floats = 0, attn_cnt_n = 0;
     int ws_U = 0, ws_N = 0;
+    DevBuf Ap;               // fp32 engines: the A operand of the big linear layers as panel planes (gemm_x3p.hip)
     DevBuf d_noise, d_cmt, d_cmtd, cat, h32, hT, c1, X, Ub, qb, kb, vb, Ob, Hff, pred;
     DevBuf p_audio, p_pad, p_spec, p_mag, p_mel, p_ids, p_tid, p_err, p_tx, p_ty, p_ty2, p_ss;
     std::vector<float> h_noise;

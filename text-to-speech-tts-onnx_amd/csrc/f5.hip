@@ -199,6 +199,10 @@ F5::F5(const F5Cfg& c, const float* w, int64_t nw, int dt, int dev, int mem) : c
             for (Lin* L : {&bk.qkv, &bk.o, &bk.ff1, &bk.ff2}) {
                 L->w3.ensure((size_t)3 * L->n * L->k * 2);
                 split3_planes(L->w.as<float>(), L->w3.p, (long)L->n * L->k, s);
+                if (L->n % 128 == 0 && L->k % 32 == 0) {
+                    L->w3p.ensure((size_t)x3p_bytes(L->n, L->k));
+                    x3p_split_rows(L->w.as<float>(), L->k, L->w3p.p, L->n, L->k, s);
+                }
             }
         }
     }
@@ -357,6 +361,7 @@ void F5::ensure_workspace(int U, int N) {
         if (vbytes > vb.bytes) { vb.ensure(vbytes); MI_HIP(hipMemsetAsync(vb.p, 0, vbytes, stream)); }
     }
     Hff.ensure(rows * c.ff() * es);
+    if (dtype == MI_F32) Ap.ensure((size_t)x3p_bytes((long)rows, std::max(c.dim, c.ff())));
     pred.ensure(rows * c.mel * 4);
     // preprocess temporaries
     const int ti = c.text_dim * c.conv_mult;
@@ -381,6 +386,12 @@ void F5::gemm(int dt, const void* x, long xb, long xr, int K, const Lin& L, void
     sk.attach(g);
     if (B > 1 && xb == (long)M * xr && ob == (long)M * orr) {      // rows of all batch items are contiguous: one M axis
         g.B = 1; g.T_in = B * M; g.M = B * M;                      // (no per-item tile padding: 2252 rows -> 9 tiles, not 10)
+    }
+    if (dt == MI_F32 && L.w3p.p && g.B == 1 && Ap.p && gemm_x3p_enabled()) {
+        // fp32 big linear layer: the rows once more as panel planes (stage A of round 3: a separate pass; the producers
+        // of these rows write the planes themselves where that is fused)
+        x3p_split_rows((const float*)x, xr, Ap.p, g.M, K, stream);
+        g.xp = Ap.p; g.w3p = L.w3p.p;
     }
     launch_conv_gemm(g, stream);
 }
@@ -557,6 +568,10 @@ void F5::dit_eval(int U, int N, int k) {
             g.epi = EPI_QKV_ROPE; g.rope_cos = rope_cos.as<float>(); g.rope_sin = rope_sin.as<float>(); g.rope_pack = rope_pack.p; g.heads = H; g.head_dim = D;
             g.v_ld = attention_v_ld(N, dtype);
             sk.attach(g);
+            if (dtype == MI_F32 && bk.qkv.w3p.p && Ap.p && gemm_x3p_enabled()) {
+                x3p_split_rows(Ub.as<float>(), d, Ap.p, B * N, d, s);
+                g.xp = Ap.p; g.w3p = bk.qkv.w3p.p;
+            }
             launch_conv_gemm(g, s);
         }
         launch_attention(qb.p, kb.p, vb.p, Ob.p, B * H, H, N, dtype, s, attn_ws.as<float>(), attn_ws_floats, attn_cnt.as<int>(), attn_cnt_n);

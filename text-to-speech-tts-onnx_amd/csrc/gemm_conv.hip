@@ -442,6 +442,9 @@ static long g_sk_hybrid = 0;
 // fp32 linear layers as six exact bf16 x bf16 partial products (gemm_x3.hip) when the caller supplies the weight planes
 static long g_x3 = 1;
 bool gemm_x3_enabled() { return g_x3 != 0; }
+// ... with both operands as panel planes (gemm_x3p.hip, round 3) when the caller supplies them
+static long g_x3p = 1;
+bool gemm_x3p_enabled() { return g_x3 != 0 && g_x3p != 0; }
 // fp32 QKV + RoPE: its scatter epilogue is slow and in a persistent launch every workgroup runs it at the same time at the
 // end (in-model 184 us against 138 us for the 64x64 tiles, whose epilogues overlap other workgroups' main loops): off
 static long g_sk_qkv32 = 0;
@@ -497,6 +500,12 @@ static void dispatch_tiles(const ConvGemmDev& d, int B, hipStream_t s) {
         }
         if constexpr (sizeof(T) == 4) {
             const long tiles = (long)((d.M + 127) / 128) * ((d.N + 127) / 128);
+            if (d.xp && d.w3p && B == 1) {                      // both kept only when x3p_eligible() said yes (launch_conv_gemm)
+                ConvGemmDev e = d;
+                e.x = d.xp; e.w3 = d.w3p;
+                launch_linear_x3p(e, s);
+                return;
+            }
             if (d.w3 && B == 1 && tiles >= 64) {                // d.w3 is only kept when x3_eligible() said yes (launch_conv_gemm)
                 ConvGemmDev e = d;
                 e.Tm = (d.M + 127) / 128; e.Tn = (d.N + 127) / 128; e.RT = e.Tm;
@@ -647,6 +656,9 @@ bool gemm_set_option(const char* key, long v) {
     else if (k == "gemm_sk_hybrid") g_sk_hybrid = v;
     else if (k == "gemm_sk_producer") sk_set_producer(v);
     else if (k == "gemm_f32_x3") g_x3 = v;
+    else if (k == "gemm_f32_x3p") g_x3p = v;
+    else if (k == "gemm_x3p_noalign") x3p_set_option(0, v);
+    else if (k == "gemm_x3p_grid") x3p_set_option(1, v);
     else if (k == "gemm_x3_wide") x3_set_wide(v);
     else if (k == "gemm_x3_stages") x3_set_stages(v);
     else if (k == "gemm_x3_hybrid") x3_set_hybrid(v);
@@ -674,6 +686,16 @@ static bool x3_eligible(const ConvGemm& p) {
     return g_buf && a_bytes + (long)512 * p.x_rstride * 4 < 0x7fff0000L && b_bytes < 0x7fff0000L;
 }
 
+// ... and the panel-plane form of it (gemm_x3p.hip): whole 128-column weight panels, whole 32-deep chunks
+static bool x3p_eligible(const ConvGemm& p) {
+    if (!g_x3p || !p.xp || !p.w3p) return false;
+    ConvGemm q = p;
+    q.w3 = p.w3p;                                     // same conditions as the round-2 kernel (q.w3 only has to be non-null)
+    if (!x3_eligible(q)) return false;
+    const long nch = p.Cin / 32;
+    return p.N % 128 == 0 && ((long)(p.M + 127) / 128) * nch * 24576 < 0x7fff0000L && ((long)p.N / 128) * nch * 24576 < 0x7fff0000L;
+}
+
 void launch_conv_gemm(const ConvGemm& p_in, hipStream_t s) {
     ConvGemm p = p_in;
     if (p.B > 1 && p.taps == 1 && p.G == 1 && p.pad == 0 && p.epi == EPI_PLAIN && p.M == p.T_in && p.gate_bstride == 0 &&
@@ -698,8 +720,10 @@ void launch_conv_gemm(const ConvGemm& p_in, hipStream_t s) {
     d.rope_cos = p.rope_cos; d.rope_sin = p.rope_sin; d.rope_pack = p.rope_pack; d.heads = p.heads; d.head_dim = p.head_dim;
     d.out2 = p.out2; d.out3 = p.out3; d.v_ld = p.v_ld; d.Mb = p.rows_per_item;
     d.sk_ws = p.sk_ws; d.sk_flags = p.sk_flags; d.sk_slots = p.sk_slots;
-    const bool use_x3 = x3_eligible(p);
+    const bool use_x3p = x3p_eligible(p);
+    const bool use_x3 = use_x3p || x3_eligible(p);
     d.w3 = use_x3 ? p.w3 : nullptr;
+    d.xp = use_x3p ? p.xp : nullptr; d.w3p = use_x3p ? p.w3p : nullptr;
     d.tail_tiles = 0; d.tail_split = 1;
     d.use_buf = 0;
     {
@@ -726,6 +750,9 @@ void launch_conv_gemm(const ConvGemm& p_in, hipStream_t s) {
             if (const char* n = std::getenv("MI355TTS_SK_HYBRID")) g_sk_hybrid = std::atol(n);
             if (const char* n = std::getenv("MI355TTS_SK_PRODUCER")) sk_set_producer(std::atol(n));
             if (const char* n = std::getenv("MI355TTS_F32_X3")) g_x3 = std::atol(n);
+            if (const char* n = std::getenv("MI355TTS_F32_X3P")) g_x3p = std::atol(n);
+            if (const char* n = std::getenv("MI355TTS_X3P_NOALIGN")) x3p_set_option(0, std::atol(n));
+            if (const char* n = std::getenv("MI355TTS_X3P_GRID")) x3p_set_option(1, std::atol(n));
             if (const char* n = std::getenv("MI355TTS_X3_WIDE")) x3_set_wide(std::atol(n));
             if (const char* n = std::getenv("MI355TTS_X3_STAGES")) x3_set_stages(std::atol(n));
             if (const char* n = std::getenv("MI355TTS_X3_HYBRID")) x3_set_hybrid(std::atol(n));

@@ -38,6 +38,7 @@ struct ConvGemmDev {
     int Tm, Tn, RT, RC;    // XCD-aware tile order (DMA kernel): M-tiles per batch item, N-tiles, row tiles (B*Tm), rows per XCD
     float* sk_ws; int* sk_flags; int sk_slots;   // stream-K (gemm_sk.hip): 64 KB partial-tile slot + flag per persistent workgroup
     const void* w3;                              // gemm_x3.hip: weight planes [3][N][K] bf16 (null: not available)
+    const void* xp; const void* w3p;             // gemm_x3p.hip: A and B as panel planes (null: not available)
     int tail_tiles, tail_split;                  // gemm_ph8.hip: the last tail_tiles tiles are cut into tail_split K slices (0 / 1: none)
 };
 
@@ -425,6 +426,8 @@ void x3_set_qkv8(long v);
 void x3_set_big(long v);
 // gemm_ph8.hip: 256x256 eight-phase kernel for 16-bit linear layers with many row tiles
 template <typename T, typename TO> void launch_linear_ph8(const ConvGemmDev& e, hipStream_t s);
+void launch_linear_x3p(const ConvGemmDev& e, hipStream_t s);
+void x3p_set_option(int which, long v);
 void ph8_set_split_max(long v);
 void ph8_set_split_min_nk(long v);
 

@@ -1,0 +1,388 @@
+// gemm_x3p.hip — round 3: the fp32 DiT linear layers (QKV, O, FF1, FF2) as exact three-way bf16 splits with BOTH operands
+// pre-split and pre-tiled ("panel planes"), so that the main loop is nothing but LDS-DMA, ds_read_b128 and MFMA.
+//
+// Arithmetic: that of gemm_x3.hip (a = a1 + a2 + a3, b = b1 + b2 + b3 in bf16, six partial products per block, fp32
+// accumulate, small terms first) — fp32 products carried by the bf16 matrix cores, 2500 / 6 = 416.7 TFLOP/s ceiling.
+//
+// What round 2's kernel (gemm_x3.hip) paid for, measured (profiles/r2): it staged the activations as
+// fp32 and split them in registers in front of the MFMAs (11 VALU per pair, repeated by each of the 8-24 column tiles that
+// read the same rows), fetched the weight planes as 64-byte row pieces (the per-CU L2->LDS fill rate is bound per cache
+// line touched: 64-byte pieces run at half the rate of whole lines), and its stream-K ranges walked K out of step, so an
+// XCD's workgroups did not share panels in L2 (TCC hit 38 %, 214 MB of fabric traffic per launch against ~38 MB).
+//
+// Here:
+//  * Panel-plane layout, for the weights (once at load) AND for the activations (written by the producer of the rows:
+//    x3p_split_rows, or the fused epilogues of rownorm / attention / FF1):
+//        [panel = row / 128][chunk = k / 32][plane 0..2][row % 128][32 bf16]      = 24 KB per (panel, chunk)
+//    with the 16-byte k-slots of a 64-byte row XOR-swizzled by (row >> 2) & 3 IN MEMORY.  One K chunk of a tile operand
+//    is 24 KB contiguous: every LDS-DMA instruction moves 1 KB of consecutive bytes (the best fill pattern, fillrate.hip),
+//    needs no per-lane address arithmetic, and lands in LDS already in the conflict-free fragment layout.
+//  * 128x128 tile, eight waves = two groups of four: group g multiplies k16 step g of every chunk on 64x64 per wave
+//    (24 MFMAs per wave per chunk from 12 ds_read_b128: 62 B/clk of LDS reads at full MFMA rate, against 85-94 for the
+//    32x64 wave tiles of round 2); the two groups' accumulators meet once per tile in LDS.  Two waves per SIMD.
+//  * Three LDS stages of 48 KB; the fragments of chunk c+1 are read into a second register set under the MFMAs of chunk
+//    c, so the ring holds chunks c+1 .. c+3: a chunk is requested two full chunk times (~3000 clk) before its barrier.
+//    One barrier per chunk, placed in front of the last six MFMAs; every wait is a counted vmcnt(6).
+//  * Stream-K frame of gemm_sk.hip (range-ordered fix-up, flags) with two changes for L2: the 8 XCD groups own 2-D blocks
+//    of tiles (GR x GC bands: A is fetched by GC XCDs and B by GR, instead of A by all 8), and every tile walks K
+//    CYCLICALLY from a per-tile start chunk chosen so that all workgroups of the launch are at the same physical chunk at
+//    the same time (ranges still differ by (range length mod chunks-per-tile) for their tail pieces): the workgroups of an
+//    XCD that share a row or weight panel request the same 24 KB within a few chunk times of each other.
+#include "common.h"
+#include "mfma.h"
+#include "gemm_epilogue.h"
+#include "x3_split.h"
+#include <type_traits>
+
+namespace mi {
+
+constexpr int X3P_PLANE = 128 * 32 * 2;          // one plane of one (panel, chunk): 128 rows x 64 bytes
+constexpr int X3P_CHUNK = 3 * X3P_PLANE;         // 24 KB
+
+long x3p_bytes(long rows, long K) { return ((rows + 127) / 128) * (K / 32) * (long)X3P_CHUNK; }
+
+// fp32 rows [rows][ld] (K columns used) -> panel planes.  One thread = one 16-byte k-slot (8 values) of one row; rows in
+// [rows, rows_pad) are written as zeros (the last row panel is always whole).
+__global__ __launch_bounds__(256) void x3p_split_rows_kernel(const float* __restrict__ x, long ld, unsigned char* __restrict__ out,
+                                                             int rows, int K, long total) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int s8n = K >> 3;
+    const int row = (int)(idx / s8n), s8 = (int)(idx - (long)row * s8n);
+    float4 v0 = float4{0.f, 0.f, 0.f, 0.f}, v1 = v0;
+    if (row < rows) {
+        const float4* src = reinterpret_cast<const float4*>(x + (long)row * ld + s8 * 8);
+        v0 = src[0]; v1 = src[1];
+    }
+    unsigned a[4], b[4], c[4];
+    x3_split_pair(v0.x, v0.y, a[0], b[0], c[0]); x3_split_pair(v0.z, v0.w, a[1], b[1], c[1]);
+    x3_split_pair(v1.x, v1.y, a[2], b[2], c[2]); x3_split_pair(v1.z, v1.w, a[3], b[3], c[3]);
+    const int nch = K >> 5, r = row & 127, ch = s8 >> 2, slot = s8 & 3;
+    unsigned char* dst = out + ((long)(row >> 7) * nch + ch) * X3P_CHUNK + r * 64 + ((slot ^ ((r >> 2) & 3)) << 4);
+    *reinterpret_cast<x3_u4*>(dst) = x3_u4{a[0], a[1], a[2], a[3]};
+    *reinterpret_cast<x3_u4*>(dst + X3P_PLANE) = x3_u4{b[0], b[1], b[2], b[3]};
+    *reinterpret_cast<x3_u4*>(dst + 2 * X3P_PLANE) = x3_u4{c[0], c[1], c[2], c[3]};
+}
+
+void x3p_split_rows(const float* x, long ld, void* planes, int rows, int K, hipStream_t s) {
+    MI_REQUIRE(K % 32 == 0 && ld % 4 == 0 && ((uintptr_t)x % 16) == 0, "x3p_split_rows: K must be whole 32-deep chunks, rows 16-byte aligned");
+    const int rows_pad = (rows + 127) / 128 * 128;
+    const long total = (long)rows_pad * (K / 8);
+    prof_set_kernel("x3p_split_rows_kernel", "", "");
+    hipLaunchKernelGGL(x3p_split_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, ld, (unsigned char*)planes, rows, K, total);
+    MI_HIP(hipGetLastError());
+}
+
+template <typename RSRC>
+__device__ __forceinline__ void x3p_dma16(RSRC rsrc, int voff, unsigned lds_dst) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst) : "memory");
+#endif
+}
+
+// p.x  = A panel planes (x3p layout, Tm panels x nch chunks) ; p.w3 = B panel planes (Tn panels x nch chunks)
+// p.Tm, p.Tn tiles ; p.RT = GR, p.RC = GC (XCD bands) ; p.tail_tiles bit0 = no cyclic K alignment (A/B switch)
+template <typename TO, bool LEPI>
+__global__ __launch_bounds__(512, 1) void linear_x3p_kernel(const ConvGemmDev p) {
+    using MF = Mfma<bf16>;
+    using Frag = typename MF::Frag;
+    constexpr int BM = 128, BN = 128, WM = 64, WN = 64, TM = 2, TN = 2, NST = 3;
+    constexpr int STAGE = 2 * X3P_CHUNK;                        // 48 KB: A chunk then B chunk
+    constexpr int PER = 6;                                      // DMA instructions per wave per chunk (48 x 1 KB over 8 waves)
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE];
+    (void)smem;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kg = wave >> 2, w4 = wave & 3;                    // k16 half of every chunk ; 64x64 sub-tile
+    const int wm = w4 >> 1, wn = w4 & 1, lr = lane & 31, lk = lane >> 5;
+    const int P = (int)gridDim.x, R = P >> 3;
+    const int xg = (int)blockIdx.x & 7;
+    const int l = R - 1 - ((int)blockIdx.x >> 3);               // range index inside the XCD group (gemm_sk.hip: pieces are awaited from lower workgroup ids)
+    const int nch = p.K >> 5;
+    // XCD group -> band of row tiles x band of column tiles
+    const int GR = p.RT, GC = p.RC;
+    const int gr = xg / GC, gc = xg - gr * GC;
+    const int r0 = (int)((long)gr * p.Tm / GR), r1 = (int)((long)(gr + 1) * p.Tm / GR);
+    const int c0 = (int)((long)gc * p.Tn / GC), c1 = (int)((long)(gc + 1) * p.Tn / GC);
+    const int bh = r1 - r0;
+    const long I = (long)bh * (c1 - c0) * nch;
+    long it = (long)l * I / R;
+    const long it1 = (long)(l + 1) * I / R;
+    const int slot0 = xg * R;
+
+    __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.sk_ws, 0, (int)((long)P * BM * BN * 4), 0x00020000);
+    const bool opA = wave < 4;                                  // waves 0-3 stage the A chunk, waves 4-7 the B chunk
+    constexpr int OOB = 0x7fffff00;
+    const unsigned smem_lds = (unsigned)(unsigned long)(const __attribute__((address_space(3))) void*)smem;
+    int* flags = p.sk_flags;
+    const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)(opA ? p.x : p.w3), 0, (int)((long)(opA ? p.Tm : p.Tn) * nch * X3P_CHUNK), 0x00020000);
+    const int lane16 = lane * 16;
+    const unsigned lds_part = (unsigned)((opA ? 0 : X3P_CHUNK) + w4 * PER * 1024);
+    // fragment addresses inside a stage: row (wm*64 + i*32 + lr) of plane pl, k-slot 2*kg + lk, swizzled
+    const int sw = (lr >> 2) & 3;
+    const unsigned fa_off = (unsigned)((wm * WM + lr) * 64 + (((2 * kg + lk) ^ sw) << 4));
+    const unsigned fb_off = (unsigned)(X3P_CHUNK + (wn * WN + lr) * 64 + (((2 * kg + lk) ^ sw) << 4));
+
+    while (it < it1) {
+        const int tile_g = (int)(it / nch);
+        const int cb = (int)(it - (long)tile_g * nch);
+        const int n = (int)((it1 - it) < (long)(nch - cb) ? (it1 - it) : (long)(nch - cb));
+        const int ce = cb + n;
+        const int nt = c0 + tile_g / bh, mt = r0 + tile_g - (tile_g / bh) * bh;     // row tiles fastest inside the band
+        const int m0 = mt * BM, n0 = nt * BN;
+        // cyclic K walk: local chunk u of this tile is physical chunk (u + shift) mod nch, shift = distance of the tile's
+        // first iteration from the start of the range that owns it (so that owner is at physical chunk (its own elapsed
+        // chunks) mod nch, like every other workgroup)
+        int shift = 0;
+        if (!(p.tail_tiles & 1)) {
+            const long s_t = (long)tile_g * nch;
+            const long lh = ((s_t + 1) * R - 1) / I;
+            shift = (int)((s_t - lh * I / R) % nch);
+        }
+        const int a_base = (int)((long)mt * nch * X3P_CHUNK) + lane16 + w4 * PER * 1024;
+        const int b_base = (int)((long)nt * nch * X3P_CHUNK) + lane16 + w4 * PER * 1024;
+        const int d_base = opA ? a_base : b_base;
+        auto issue = [&](int st, int local) __attribute__((always_inline)) {
+            if (p.dbg & 1) return;
+            int ph = local + shift; if (ph >= nch) ph -= nch;
+            const int coff = local < ce ? ph * X3P_CHUNK : OOB;             // past the piece: out of range -> zeros, nothing fetched (uniform vmcnt)
+            const unsigned base = __builtin_amdgcn_readfirstlane(smem_lds + (unsigned)(st * STAGE) + lds_part);
+#pragma unroll
+            for (int j = 0; j < PER; ++j) x3p_dma16(rsd, (int)((unsigned)d_base + (unsigned)coff + (unsigned)(j * 1024)), base + (unsigned)(j * 1024));
+        };
+        auto issue_one = [&](int st, int local, int j) __attribute__((always_inline)) {
+            if (p.dbg & 1) return;
+            int ph = local + shift; if (ph >= nch) ph -= nch;
+            const int coff = local < ce ? ph * X3P_CHUNK : OOB;
+            const unsigned base = __builtin_amdgcn_readfirstlane(smem_lds + (unsigned)(st * STAGE) + lds_part);
+            x3p_dma16(rsd, (int)((unsigned)d_base + (unsigned)coff + (unsigned)(j * 1024)), base + (unsigned)(j * 1024));
+        };
+
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        Frag fa[2][TM][3], fb[2][TN][3];                        // [register set][block][plane]
+        if (p.dbg & 2) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { fa[a][b][c] = Frag{}; fb[a][b][c] = Frag{}; }
+        }
+        // one of the 12 fragment reads of a chunk: q < 6: A (block q / 3, plane q % 3) ; else B
+        auto ldfrag1 = [&](int st, auto SET, int q) __attribute__((always_inline)) {
+            if (p.dbg & 2) return;
+            constexpr int set = decltype(SET)::value;
+            const unsigned char* sb = smem + st * STAGE;
+            if (q < 6) fa[set][q / 3][q % 3] = *reinterpret_cast<const Frag*>(sb + fa_off + (q / 3) * (32 * 64) + (q % 3) * X3P_PLANE);
+            else { const int qq = q - 6; fb[set][qq / 3][qq % 3] = *reinterpret_cast<const Frag*>(sb + fb_off + (qq / 3) * (32 * 64) + (qq % 3) * X3P_PLANE); }
+        };
+        // MFMA k of a chunk (0..23): term t = k / 4 (small to large), block k % 4
+        auto mma1 = [&](auto SET, int k) __attribute__((always_inline)) {
+            constexpr int set = decltype(SET)::value;
+            constexpr int TA[6] = {0, 1, 2, 0, 1, 0}, TB[6] = {2, 1, 0, 1, 0, 0};
+            const int t = k >> 2, i = (k >> 1) & 1, j = k & 1;
+            acc[i][j] = MF::mma(fa[set][i][TA[t]], fb[set][j][TB[t]], acc[i][j]);
+        };
+#define X3P_SB() __builtin_amdgcn_sched_barrier(0)
+        // ---- prologue: chunks cb, cb+1, cb+2 requested; chunk cb's fragments into set 0 ----
+        issue(0, cb); issue(1, cb + 1); issue(2, cb + 2);
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int q = 0; q < 12; ++q) ldfrag1(0, std::integral_constant<int, 0>{}, q);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                           // chunk cb+1 landed, stage 0 free
+        int st_next = 1, st_free = 0;                           // stage of chunk c+1 ; stage chunk c+3 goes to (= stage of chunk c)
+        auto body = [&](int c, auto SET) __attribute__((always_inline)) {
+            constexpr int set = decltype(SET)::value;
+            using NSET = std::integral_constant<int, set ^ 1>;
+            const bool more = c + 1 < n;
+#pragma unroll
+            for (int k = 0; k < 24; ++k) {
+                if (k == 18 && more) {
+                    // boundary: chunk c+2 has landed (this wave's six pieces of chunk c+3 may stay in flight), the fragments
+                    // of chunk c+1 are in registers (its stage is free); the last six MFMAs run behind the barrier
+                    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+                X3P_SB(); mma1(SET{}, k); X3P_SB();
+                if (k < 12) { if (more) ldfrag1(st_next, NSET{}, k); }
+                else if (k < 18) issue_one(st_free, cb + c + 3, k - 12);
+            }
+        };
+        for (int c = 0; c < n; c += 2) {
+            body(c, std::integral_constant<int, 0>{});
+            { const int t = st_free; st_free = st_next; st_next = st_next + 1 == NST ? 0 : st_next + 1; (void)t; }
+            if (c + 1 < n) {
+                body(c + 1, std::integral_constant<int, 1>{});
+                st_free = st_next; st_next = st_next + 1 == NST ? 0 : st_next + 1;
+            }
+        }
+#undef X3P_SB
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+
+        // ---- the two k16 groups meet: waves 4-7 park their 64x64 accumulators in LDS, waves 0-3 add them (fixed order) ----
+        {
+            x3_u4* red = reinterpret_cast<x3_u4*>(smem);
+            if (kg == 1) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            x3_u4 v;
+                            v.x = __float_as_uint(acc[i][j][4 * q]); v.y = __float_as_uint(acc[i][j][4 * q + 1]);
+                            v.z = __float_as_uint(acc[i][j][4 * q + 2]); v.w = __float_as_uint(acc[i][j][4 * q + 3]);
+                            red[(w4 * 16 + (i * TN + j) * 4 + q) * 64 + lane] = v;
+                        }
+            }
+            __syncthreads();
+            if (kg == 0) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const x3_u4 v = red[(w4 * 16 + (i * TN + j) * 4 + q) * 64 + lane];
+                            acc[i][j][4 * q] += __uint_as_float(v.x); acc[i][j][4 * q + 1] += __uint_as_float(v.y);
+                            acc[i][j][4 * q + 2] += __uint_as_float(v.z); acc[i][j][4 * q + 3] += __uint_as_float(v.w);
+                        }
+            }
+            __syncthreads();
+        }
+
+        // ---- partial tile: publish or collect (gemm_sk.hip); waves 4-7 only keep the barriers company ------------------------
+        const bool worker = kg == 0;
+        const int slot_lane = (w4 * (TM * TN * 4)) * 64 + lane;
+        if (p.dbg & 4) { it += n; continue; }
+        if (cb > 0) {
+            if (worker) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            x3_u4 v;
+                            v.x = __float_as_uint(acc[i][j][4 * q]); v.y = __float_as_uint(acc[i][j][4 * q + 1]);
+                            v.z = __float_as_uint(acc[i][j][4 * q + 2]); v.w = __float_as_uint(acc[i][j][4 * q + 3]);
+                            const int unit = slot_lane + ((i * TN + j) * 4 + q) * 64;
+                            __builtin_amdgcn_raw_buffer_store_b128(v, rsw, ((slot0 + l) * (BM * BN / 4) + unit) * 16, 0, 16);
+                        }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(flags + slot0 + l, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (ce < nch) {
+                int cov = ce;
+                for (int q_l = l + 1; cov < nch; ++q_l) {
+                    const long q0 = (long)q_l * I / R, q1 = (long)(q_l + 1) * I / R;
+                    if (q1 == q0) continue;
+                    if (tid == 0) {
+                        // bounded spin (in-order workgroup dispatch makes the producer a lower workgroup id that is already
+                        // resident; the bound only turns a broken invariant into wrong numbers + an error word instead of a hang)
+                        long spins = 0;
+                        while (__hip_atomic_load(flags + slot0 + q_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                            __builtin_amdgcn_s_sleep(2);
+                            if (++spins > (1L << 26)) { __hip_atomic_store(flags + P, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                        }
+                    }
+                    __syncthreads();
+                    if (worker) {
+                        x3_u4 v[TM * TN * 4];
+#pragma unroll
+                        for (int u = 0; u < TM * TN * 4; ++u)
+                            v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsw, ((slot0 + q_l) * (BM * BN / 4) + slot_lane + u * 64) * 16, 0, 16);
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    const x3_u4 w = v[(i * TN + j) * 4 + q];
+                                    acc[i][j][4 * q] += __uint_as_float(w.x); acc[i][j][4 * q + 1] += __uint_as_float(w.y);
+                                    acc[i][j][4 * q + 2] += __uint_as_float(w.z); acc[i][j][4 * q + 3] += __uint_as_float(w.w);
+                                }
+                    }
+                    __syncthreads();
+                    if (tid == 0) __hip_atomic_store(flags + slot0 + q_l, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    cov += (int)((q1 - q0) < (long)(nch - cov) ? (q1 - q0) : (long)(nch - cov));
+                }
+            }
+            if (worker) {
+                if constexpr (LEPI) {
+                    float* stage = reinterpret_cast<float*>(smem) + w4 * 4096;       // 16 KB per wave
+                    if (p.epi == EPI_QKV_ROPE) gemm_epilogue_qkv_lds<TO>(acc, p, m0, n0, 0, wm, wn, lr, lk, stage);
+                    else gemm_epilogue_lds<TO, TM, TN, WM, WN>(acc, p, m0, n0, 0, 0, wm, wn, lr, lk, stage);
+                } else {
+                    gemm_epilogue<TO, TM, TN, WM, WN>(acc, p, m0, n0, 0, 0, wm, wn, lr, lk);
+                }
+            }
+            __syncthreads();
+        }
+        it += n;
+    }
+#endif
+}
+
+static long g_x3p_noalign = 0, g_x3p_grid = 0;       // A/B switches: 1 = no cyclic K alignment ; grid: 0 = automatic, else GR (1, 2, 4, 8)
+void x3p_set_option(int which, long v) { if (which == 0) g_x3p_noalign = v; else g_x3p_grid = v; }
+
+void launch_linear_x3p(const ConvGemmDev& e_in, hipStream_t s) {
+    ConvGemmDev e = e_in;
+    int dev = 0, cus = 256;
+    MI_HIP(hipGetDevice(&dev));
+    {
+        static int cu_count[16] = {0};
+        if (!cu_count[dev & 15]) { hipDeviceProp_t pr; MI_HIP(hipGetDeviceProperties(&pr, dev)); cu_count[dev & 15] = pr.multiProcessorCount; }
+        cus = cu_count[dev & 15];
+    }
+    e.Tm = (e.M + 127) / 128; e.Tn = (e.N + 127) / 128;
+    // XCD bands: GR x GC = 8.  Fabric-side bytes ~ GC * |A| + GR * |B|; the bands must also balance the tile counts
+    // (ranges are cut per group).  Pick the split with the smallest worst-case group, then the smallest traffic.
+    int best = 1; double best_cost = 1e300;
+    for (int gr = 1; gr <= 8; gr *= 2) {
+        const int gc = 8 / gr;
+        if (g_x3p_grid && gr != g_x3p_grid) continue;
+        long worst = 0, least = 1L << 60;
+        for (int a = 0; a < gr; ++a)
+            for (int b = 0; b < gc; ++b) {
+                const long t = ((long)(a + 1) * e.Tm / gr - (long)a * e.Tm / gr) * ((long)(b + 1) * e.Tn / gc - (long)b * e.Tn / gc);
+                worst = std::max(worst, t); least = std::min(least, t);
+            }
+        if (least == 0 && !g_x3p_grid) continue;
+        const double traffic = (double)gc * e.M + (double)gr * e.N;       // x K x 6 bytes, common factor dropped
+        const double cost = (double)worst * 1e9 + traffic;
+        if (cost < best_cost) { best_cost = cost; best = gr; }
+    }
+    e.RT = best; e.RC = 8 / best;
+    e.tail_tiles = (int)g_x3p_noalign;
+    const int P = std::min(cus, e.sk_slots - 8) & ~7;          // flags[P] is the watchdog's error word
+    const dim3 grid(P);
+    if (e.lds_epi) {
+        prof_set_kernel("linear_x3p_kernel<float, true>", "", "");
+        hipLaunchKernelGGL((linear_x3p_kernel<float, true>), grid, dim3(512), 0, s, e);
+    } else {
+        prof_set_kernel("linear_x3p_kernel<float, false>", "", "");
+        hipLaunchKernelGGL((linear_x3p_kernel<float, false>), grid, dim3(512), 0, s, e);
+    }
+    MI_HIP(hipGetLastError());
+}
+
+}  // namespace mi
