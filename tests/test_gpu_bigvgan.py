@@ -310,7 +310,8 @@ def test_bad_inputs_raise(small_voc):
 # only when the launch fills the chip) and compared with the oracle
 # ---------------------------------------------------------------------------------------------
 _DEFAULTS = {"gemm_big_tile_min": 160, "gemm_n192_min": 160, "gemm_mid_tile_min": 160, "gemm_dma3_k_min": 2048,
-             "gemm_use_dma3": 1, "gemm_use_dma": 1, "gemm_big_tiles": 1, "gemm_n192": 1, "gemm_f32_dma": 1, "gemm_ring4": 1, "gemm_ring4_max": 256, "gemm_buf": 1, "gemm_f32_small": 1, "gemm_f32_small_max": 1024, "gemm_small16_max": 256, "gemm_sk": 1, "gemm_sk_stages": 0, "gemm_ph8": 1, "gemm_ph8_min_tiles": 200, "gemm_ph8_order": 1, "gemm_ph8_split_max": 2, "gemm_ph8_split_min_nk": 24, "gemm_sk_hybrid": 0, "gemm_sk_producer": 0, "gemm_f32_x3": 1, "gemm_x3_wide": 2, "gemm_x3_stages": 4, "gemm_x3_big": 0}
+             "gemm_use_dma3": 1, "gemm_use_dma": 1, "gemm_big_tiles": 1, "gemm_n192": 1, "gemm_f32_dma": 1, "gemm_ring4": 1, "gemm_ring4_max": 256, "gemm_buf": 1, "gemm_f32_small": 1, "gemm_f32_small_max": 1024, "gemm_small16_max": 256, "gemm_sk": 1, "gemm_sk_stages": 0, "gemm_ph8": 1, "gemm_ph8_min_tiles": 200, "gemm_ph8_order": 1, "gemm_ph8_split_max": 2, "gemm_ph8_split_min_nk": 24, "gemm_sk_hybrid": 0, "gemm_sk_producer": 0, "gemm_f32_x3": 1, "gemm_x3_wide": 2, "gemm_x3_stages": 4, "gemm_x3_big": 0,
+             "gemm_f32_x3p": 1, "gemm_x3p_grid": 0, "gemm_x3p_noalign": 0}
 
 
 @pytest.fixture
@@ -440,6 +441,7 @@ def test_f32_linear_as_exact_bf16_splits_vs_oracle(gemm_options, shape, stages, 
     far inside that gate, an error against a float64 evaluation no larger than the native kernel's, every wave layout (64x64 / 32x128 per wave with four waves, 32x64 with
     eight) and ring depth, ragged M / N tails, tiles split between workgroups, run-to-run identity."""
     gemm_options("gemm_f32_x3", 1)
+    gemm_options("gemm_f32_x3p", 0)                        # the round-2 kernel itself (panel-plane form: next test)
     gemm_options("gemm_x3_wide", shape)
     gemm_options("gemm_x3_stages", stages)
     x = W.synth_normal(1, f"x3x{Ci}{T}", (B, Ci, T))
@@ -461,6 +463,38 @@ def test_f32_linear_as_exact_bf16_splits_vs_oracle(gemm_options, shape, stages, 
         assert np.abs(yb - y0).max() < 1e-5
         gemm_options("gemm_x3_big", 0)
     # the split loses nothing against native fp32: both sit at the same distance from a float64 evaluation
+    ref64 = np.einsum("oc,bct->bot", w[:, :, 0].astype(np.float64), x.astype(np.float64)) + b.astype(np.float64)[None, :, None]
+    e_x3, e_native = rms(y - ref64), rms(y0 - ref64)
+    assert e_x3 < 1.5 * e_native + 1e-9, (e_x3, e_native)
+
+
+@pytest.mark.parametrize("grid", [0, 1, 2, 4, 8])
+@pytest.mark.parametrize("noalign", [0, 1])
+@pytest.mark.parametrize("Ci,Co,T,B", [(1024, 1024, 1126, 2), (1024, 3072, 1126, 2), (2048, 1024, 1126, 2), (1024, 2048, 2252, 1),
+                                        (256, 1024, 1500, 1), (1024, 1024, 1126, 6), (64, 1280, 700, 2)])
+def test_f32_linear_panel_planes_vs_oracle(gemm_options, grid, noalign, Ci, Co, T, B):
+    """gemm_x3p.hip (round 3): the same exact bf16 splits with BOTH operands pre-split into panel planes, eight waves as
+    two k16 groups, 2-D XCD bands (gemm_x3p_grid = GR, 0 = automatic) and the cyclic K walk (gemm_x3p_noalign = 1 switches
+    it off).  Same gates as the round-2 kernel: atol 3e-5 against the oracle, < 1e-5 from the native fp32 MFMA, error
+    against float64 no larger than native, run-to-run identity; the DiT shapes at one utterance (M = 2252) and three
+    (M = 6756: several tiles per workgroup), K = 64 ... 2048, a ragged last row panel."""
+    gemm_options("gemm_f32_x3", 1)
+    gemm_options("gemm_f32_x3p", 1)
+    gemm_options("gemm_x3p_grid", grid)
+    gemm_options("gemm_x3p_noalign", noalign)
+    x = W.synth_normal(1, f"x3x{Ci}{T}", (B, Ci, T))
+    w = W.synth_normal(2, f"x3w{Ci}{Co}", (Co, Ci, 1), std=1.0 / np.sqrt(Ci))
+    b = W.synth_normal(3, "x3b", (Co,), std=0.1)
+    ref = O.conv1d(x, w, b)
+    y = BV.conv1d(x, w, b, dtype="f32")
+    np.testing.assert_allclose(y, ref, atol=3e-5, rtol=1e-5)
+    assert np.array_equal(y, BV.conv1d(x, w, b, dtype="f32"))
+    gemm_options("gemm_f32_x3p", 0)
+    y2 = BV.conv1d(x, w, b, dtype="f32")                    # round-2 kernel: same arithmetic, other summation order
+    assert np.abs(y - y2).max() < 1e-5 and not np.array_equal(y, y2)
+    gemm_options("gemm_f32_x3", 0)
+    y0 = BV.conv1d(x, w, b, dtype="f32")                    # v_mfma_f32_32x32x2_f32
+    assert np.abs(y - y0).max() < 1e-5
     ref64 = np.einsum("oc,bct->bot", w[:, :, 0].astype(np.float64), x.astype(np.float64)) + b.astype(np.float64)[None, :, None]
     e_x3, e_native = rms(y - ref64), rms(y0 - ref64)
     assert e_x3 < 1.5 * e_native + 1e-9, (e_x3, e_native)

@@ -142,23 +142,24 @@ __global__ __launch_bounds__(512, 1) void linear_x3p_kernel(const ConvGemmDev p)
             const long lh = ((s_t + 1) * R - 1) / I;
             shift = (int)((s_t - lh * I / R) % nch);
         }
-        const int a_base = (int)((long)mt * nch * X3P_CHUNK) + lane16 + w4 * PER * 1024;
-        const int b_base = (int)((long)nt * nch * X3P_CHUNK) + lane16 + w4 * PER * 1024;
-        const int d_base = opA ? a_base : b_base;
-        auto issue = [&](int st, int local) __attribute__((always_inline)) {
-            if (p.dbg & 1) return;
+        // per-lane byte offsets of this wave's six 1 KB pieces of a chunk (A chunk for waves 0-3, B chunk for waves 4-7)
+        int vb[PER];
+        {
+            const int d_base = (int)((long)(opA ? mt : nt) * nch * X3P_CHUNK) + lane16 + w4 * PER * 1024;
+#pragma unroll
+            for (int j = 0; j < PER; ++j) vb[j] = d_base + j * 1024;
+        }
+        // byte offset of local chunk `local` inside its panel (wave-uniform); past the piece: out of range -> the range check
+        // writes zeros, nothing is fetched (keeps the vmcnt arithmetic uniform)
+        auto chunk_off = [&](int local) __attribute__((always_inline)) -> int {
             int ph = local + shift; if (ph >= nch) ph -= nch;
-            const int coff = local < ce ? ph * X3P_CHUNK : OOB;             // past the piece: out of range -> zeros, nothing fetched (uniform vmcnt)
+            return __builtin_amdgcn_readfirstlane(local < ce ? ph * X3P_CHUNK : OOB);
+        };
+        auto issue = [&](int st, int local) __attribute__((always_inline)) {
+            const int coff = chunk_off(local);
             const unsigned base = __builtin_amdgcn_readfirstlane(smem_lds + (unsigned)(st * STAGE) + lds_part);
 #pragma unroll
-            for (int j = 0; j < PER; ++j) x3p_dma16(rsd, (int)((unsigned)d_base + (unsigned)coff + (unsigned)(j * 1024)), base + (unsigned)(j * 1024));
-        };
-        auto issue_one = [&](int st, int local, int j) __attribute__((always_inline)) {
-            if (p.dbg & 1) return;
-            int ph = local + shift; if (ph >= nch) ph -= nch;
-            const int coff = local < ce ? ph * X3P_CHUNK : OOB;
-            const unsigned base = __builtin_amdgcn_readfirstlane(smem_lds + (unsigned)(st * STAGE) + lds_part);
-            x3p_dma16(rsd, (int)((unsigned)d_base + (unsigned)coff + (unsigned)(j * 1024)), base + (unsigned)(j * 1024));
+            for (int j = 0; j < PER; ++j) x3p_dma16(rsd, (int)((unsigned)vb[j] + (unsigned)coff), base + (unsigned)(j * 1024));
         };
 
         f32x16 acc[TM][TN];
@@ -169,21 +170,11 @@ __global__ __launch_bounds__(512, 1) void linear_x3p_kernel(const ConvGemmDev p)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         Frag fa[2][TM][3], fb[2][TN][3];                        // [register set][block][plane]
-        if (p.dbg & 2) {
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b)
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) { fa[a][b][c] = Frag{}; fb[a][b][c] = Frag{}; }
-        }
         // one of the 12 fragment reads of a chunk: q < 6: A (block q / 3, plane q % 3) ; else B
-        auto ldfrag1 = [&](int st, auto SET, int q) __attribute__((always_inline)) {
-            if (p.dbg & 2) return;
+        auto ldfrag1 = [&](const unsigned char* sa, const unsigned char* sb, auto SET, int q) __attribute__((always_inline)) {
             constexpr int set = decltype(SET)::value;
-            const unsigned char* sb = smem + st * STAGE;
-            if (q < 6) fa[set][q / 3][q % 3] = *reinterpret_cast<const Frag*>(sb + fa_off + (q / 3) * (32 * 64) + (q % 3) * X3P_PLANE);
-            else { const int qq = q - 6; fb[set][qq / 3][qq % 3] = *reinterpret_cast<const Frag*>(sb + fb_off + (qq / 3) * (32 * 64) + (qq % 3) * X3P_PLANE); }
+            if (q < 6) fa[set][q / 3][q % 3] = *reinterpret_cast<const Frag*>(sa + (q / 3) * (32 * 64) + (q % 3) * X3P_PLANE);
+            else { const int qq = q - 6; fb[set][qq / 3][qq % 3] = *reinterpret_cast<const Frag*>(sb + (qq / 3) * (32 * 64) + (qq % 3) * X3P_PLANE); }
         };
         // MFMA k of a chunk (0..23): term t = k / 4 (small to large), block k % 4
         auto mma1 = [&](auto SET, int k) __attribute__((always_inline)) {
@@ -198,15 +189,22 @@ __global__ __launch_bounds__(512, 1) void linear_x3p_kernel(const ConvGemmDev p)
         asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
         __builtin_amdgcn_s_barrier();
 #pragma unroll
-        for (int q = 0; q < 12; ++q) ldfrag1(0, std::integral_constant<int, 0>{}, q);
+        for (int q = 0; q < 12; ++q) ldfrag1(smem + fa_off, smem + fb_off, std::integral_constant<int, 0>{}, q);
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                           // chunk cb+1 landed, stage 0 free
         int st_next = 1, st_free = 0;                           // stage of chunk c+1 ; stage chunk c+3 goes to (= stage of chunk c)
+        // One chunk: 24 MFMAs on the fragments of chunk c (register set SET); under the first twelve, the fragments of chunk
+        // c+1 are read into the other set (past the piece they are stale LDS, never used); under the next six, this wave's six
+        // pieces of chunk c+3 are requested; then the boundary, then the last six MFMAs.
         auto body = [&](int c, auto SET) __attribute__((always_inline)) {
             constexpr int set = decltype(SET)::value;
             using NSET = std::integral_constant<int, set ^ 1>;
             const bool more = c + 1 < n;
+            const unsigned char* sa = smem + st_next * STAGE + fa_off;
+            const unsigned char* sb = smem + st_next * STAGE + fb_off;
+            const int coff = chunk_off(cb + c + 3);
+            const unsigned ldsd = __builtin_amdgcn_readfirstlane(smem_lds + (unsigned)(st_free * STAGE) + lds_part);
 #pragma unroll
             for (int k = 0; k < 24; ++k) {
                 if (k == 18 && more) {
@@ -216,14 +214,14 @@ __global__ __launch_bounds__(512, 1) void linear_x3p_kernel(const ConvGemmDev p)
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
                 }
-                X3P_SB(); mma1(SET{}, k); X3P_SB();
-                if (k < 12) { if (more) ldfrag1(st_next, NSET{}, k); }
-                else if (k < 18) issue_one(st_free, cb + c + 3, k - 12);
+                X3P_SB(); mma1(SET, k); X3P_SB();
+                if (k < 12) ldfrag1(sa, sb, NSET{}, k);
+                else if (k < 18) x3p_dma16(rsd, (int)((unsigned)vb[k - 12] + (unsigned)coff), ldsd + (unsigned)((k - 12) * 1024));
             }
         };
         for (int c = 0; c < n; c += 2) {
             body(c, std::integral_constant<int, 0>{});
-            { const int t = st_free; st_free = st_next; st_next = st_next + 1 == NST ? 0 : st_next + 1; (void)t; }
+            st_free = st_next; st_next = st_next + 1 == NST ? 0 : st_next + 1;
             if (c + 1 < n) {
                 body(c + 1, std::integral_constant<int, 1>{});
                 st_free = st_next; st_next = st_next + 1 == NST ? 0 : st_next + 1;
@@ -269,7 +267,7 @@ __global__ __launch_bounds__(512, 1) void linear_x3p_kernel(const ConvGemmDev p)
         // ---- partial tile: publish or collect (gemm_sk.hip); waves 4-7 only keep the barriers company ------------------------
         const bool worker = kg == 0;
         const int slot_lane = (w4 * (TM * TN * 4)) * 64 + lane;
-        if (p.dbg & 4) { it += n; continue; }
+        if (p.dbg & 4) { it += n; continue; }                  // tuning: no fix-up, no epilogue
         if (cb > 0) {
             if (worker) {
 #pragma unroll
@@ -305,20 +303,21 @@ __global__ __launch_bounds__(512, 1) void linear_x3p_kernel(const ConvGemmDev p)
                     }
                     __syncthreads();
                     if (worker) {
-                        x3_u4 v[TM * TN * 4];
 #pragma unroll
-                        for (int u = 0; u < TM * TN * 4; ++u)
-                            v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsw, ((slot0 + q_l) * (BM * BN / 4) + slot_lane + u * 64) * 16, 0, 16);
+                        for (int i = 0; i < TM; ++i) {          // eight 16-byte units at a time (32 registers in flight)
+                            x3_u4 v[TN * 4];
 #pragma unroll
-                        for (int i = 0; i < TM; ++i)
+                            for (int u = 0; u < TN * 4; ++u)
+                                v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsw, ((slot0 + q_l) * (BM * BN / 4) + slot_lane + (i * TN * 4 + u) * 64) * 16, 0, 16);
 #pragma unroll
                             for (int j = 0; j < TN; ++j)
 #pragma unroll
                                 for (int q = 0; q < 4; ++q) {
-                                    const x3_u4 w = v[(i * TN + j) * 4 + q];
+                                    const x3_u4 w = v[j * 4 + q];
                                     acc[i][j][4 * q] += __uint_as_float(w.x); acc[i][j][4 * q + 1] += __uint_as_float(w.y);
                                     acc[i][j][4 * q + 2] += __uint_as_float(w.z); acc[i][j][4 * q + 3] += __uint_as_float(w.w);
                                 }
+                        }
                     }
                     __syncthreads();
                     if (tid == 0) __hip_atomic_store(flags + slot0 + q_l, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
