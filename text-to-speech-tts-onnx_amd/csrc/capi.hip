@@ -674,6 +674,13 @@ int mi_bench_conv_gemm(int dtype, int B, int T, int Cin, int N, int taps, int di
             split3_planes((const float*)w.p, w3.p, (long)nw, s);
             p.w3 = w3.p;
         }
+        DevBuf xp, w3p;
+        if (p.w3 && gemm_x3p_enabled() && N % 128 == 0 && Cin % 32 == 0 && p.pad == 0) {       // ... and the panel-plane form (gemm_x3p.hip)
+            xp.ensure((size_t)x3p_bytes((long)B * T, Cin)); w3p.ensure((size_t)x3p_bytes(N, Cin));
+            x3p_split_rows((const float*)x.p, Cin, xp.p, B * T, Cin, s);
+            x3p_split_rows((const float*)w.p, Cin, w3p.p, N, Cin, s);
+            p.xp = xp.p; p.w3p = w3p.p;
+        }
         for (int i = 0; i < 3; ++i) launch_conv_gemm(p, s);
         hipEvent_t e0, e1;
         MI_HIP(hipEventCreate(&e0)); MI_HIP(hipEventCreate(&e1));

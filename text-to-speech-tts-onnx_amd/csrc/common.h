@@ -168,9 +168,19 @@ struct ConvGemm {
     const void* xp = nullptr; const void* w3p = nullptr;
 };
 void launch_conv_gemm(const ConvGemm& p, hipStream_t s);
-long x3p_bytes(long rows, long K);                                                    // gemm_x3p.hip: bytes of the panel planes of a [rows][K] matrix
+// gemm_x3p.hip panel planes: [panel = row / 128][chunk = k / 32][plane 0..2][row % 128][32 bf16], the four 16-byte k-slots of a
+// 64-byte row XOR-swizzled by (row >> 2) & 3
+constexpr int X3P_PLANE = 128 * 32 * 2;          // one plane of one (panel, chunk): 128 rows x 64 bytes
+constexpr int X3P_CHUNK = 3 * X3P_PLANE;         // 24 KB
+// byte offset of the 16-byte slot holding k = 8 * s8 .. 8 * s8 + 7 of `row` in plane 0 (planes 1, 2: + X3P_PLANE each)
+__host__ __device__ inline long x3p_slot_offset(long row, int s8, int nch) {
+    const int r = (int)(row & 127);
+    return ((row >> 7) * nch + (s8 >> 2)) * (long)X3P_CHUNK + r * 64 + (((s8 & 3) ^ ((r >> 2) & 3)) << 4);
+}
+long x3p_bytes(long rows, long K);                                                    // bytes of the panel planes of a [rows][K] matrix
 void x3p_split_rows(const float* x, long ld, void* planes, int rows, int K, hipStream_t s);
 bool gemm_x3p_enabled();
+bool gemm_x3p_would_run(const ConvGemm& p);        // p.xp / p.w3p set: will launch_conv_gemm(p) take the panel-plane kernel?
 // owner of a stream-K workspace (one per engine handle / stream)
 struct SkWorkspace {
     DevBuf ws, flags; int slots = 0;

@@ -70,7 +70,7 @@ struct F5 {
     ~F5();
     void ensure_workspace(int U, int N);
     void gemm(int dt, const void* x, long xb, long xr, int K, const Lin& L, void* out, int odt, long ob, long orr,
-              int B, int M, int act = ACT_NONE, const void* res = nullptr, const float* gate = nullptr);
+              int B, int M, int act = ACT_NONE, const void* res = nullptr, const float* gate = nullptr, bool planes_ready = false);
     // fills d_noise, d_cmt, d_cmtd for U utterances (asynchronous on `stream`); returns ref_signal_len
     int preprocess(int U, const int16_t* audio, long L, const int32_t* text_ids, int T, int N,
                    const float* noise_in, uint64_t seed, int mem);

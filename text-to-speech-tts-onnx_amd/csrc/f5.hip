@@ -376,8 +376,10 @@ void F5::ensure_workspace(int U, int N) {
     ws_U = Um; ws_N = Nm;
 }
 
+// planes_ready: Ap already holds the rows as panel planes (written by their producer) and the caller has checked
+// gemm_x3p_would_run(): x is not read
 void F5::gemm(int dt, const void* x, long xb, long xr, int K, const Lin& L, void* out, int odt, long ob, long orr, int B,
-              int M, int act, const void* res, const float* gate) {
+              int M, int act, const void* res, const float* gate, bool planes_ready) {
     ConvGemm g;
     g.dtype = dt; g.out_dtype = odt; g.x = x; g.w = L.w.p; g.w3 = L.w3.p; g.bias = L.b.p ? L.b.as<float>() : nullptr; g.out = out;
     g.res = res; g.gate = gate; g.gate_bstride = 0;
@@ -388,10 +390,14 @@ void F5::gemm(int dt, const void* x, long xb, long xr, int K, const Lin& L, void
         g.B = 1; g.T_in = B * M; g.M = B * M;                      // (no per-item tile padding: 2252 rows -> 9 tiles, not 10)
     }
     if (dt == MI_F32 && L.w3p.p && g.B == 1 && Ap.p && gemm_x3p_enabled()) {
-        // fp32 big linear layer: the rows once more as panel planes (stage A of round 3: a separate pass; the producers
-        // of these rows write the planes themselves where that is fused)
-        x3p_split_rows((const float*)x, xr, Ap.p, g.M, K, stream);
+        // fp32 big linear layer: the rows as panel planes — written by their producer (planes_ready) or by a separate pass here
         g.xp = Ap.p; g.w3p = L.w3p.p;
+        if (!planes_ready) {
+            if (gemm_x3p_would_run(g)) x3p_split_rows((const float*)x, xr, Ap.p, g.M, K, stream);
+            else { g.xp = nullptr; g.w3p = nullptr; }
+        }
+    } else {
+        MI_REQUIRE(!planes_ready, "f5: planes_ready without the panel-plane path");
     }
     launch_conv_gemm(g, stream);
 }
@@ -558,7 +564,6 @@ void F5::dit_eval(int U, int N, int k) {
     for (int i = 0; i < c.depth; ++i) {
         const Block& bk = blocks[i];
         const float* m = modk + (size_t)i * 6 * d;       // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
-        launch_rownorm(NORM_LN_MOD, X.as<float>(), Ub.p, dtype, m + d, m, rows, d, 1e-6f, s);
         {
             ConvGemm g;
             g.dtype = dtype; g.x = Ub.p; g.w = bk.qkv.w.p; g.w3 = bk.qkv.w3.p; g.bias = bk.qkv.b.as<float>();
@@ -568,16 +573,33 @@ void F5::dit_eval(int U, int N, int k) {
             g.epi = EPI_QKV_ROPE; g.rope_cos = rope_cos.as<float>(); g.rope_sin = rope_sin.as<float>(); g.rope_pack = rope_pack.p; g.heads = H; g.head_dim = D;
             g.v_ld = attention_v_ld(N, dtype);
             sk.attach(g);
+            bool fused = false;
             if (dtype == MI_F32 && bk.qkv.w3p.p && Ap.p && gemm_x3p_enabled()) {
-                x3p_split_rows(Ub.as<float>(), d, Ap.p, B * N, d, s);
                 g.xp = Ap.p; g.w3p = bk.qkv.w3p.p;
+                fused = gemm_x3p_would_run(g);
+                if (!fused) { g.xp = nullptr; g.w3p = nullptr; }
             }
+            // AdaLN: LN(x) * (1 + scale) + shift — straight into the panel planes the QKV GEMM reads, or as rows
+            if (fused) launch_rownorm_x3p(X.as<float>(), Ap.p, m + d, m, rows, d, 1e-6f, s);
+            else launch_rownorm(NORM_LN_MOD, X.as<float>(), Ub.p, dtype, m + d, m, rows, d, 1e-6f, s);
             launch_conv_gemm(g, s);
         }
         launch_attention(qb.p, kb.p, vb.p, Ob.p, B * H, H, N, dtype, s, attn_ws.as<float>(), attn_ws_floats, attn_cnt.as<int>(), attn_cnt_n);
         gemm(dtype, Ob.p, (long)N * d, d, d, bk.o, X.p, MI_F32, (long)N * d, d, B, N, ACT_NONE, X.p, m + 2 * d);
-        launch_rownorm(NORM_LN_MOD, X.as<float>(), Ub.p, dtype, m + 4 * d, m + 3 * d, rows, d, 1e-6f, s);
-        gemm(dtype, Ub.p, (long)N * d, d, d, bk.ff1, Hff.p, dtype, (long)N * ff, ff, B, N, ACT_GELU_TANH);
+        {
+            bool fused = false;
+            if (dtype == MI_F32 && bk.ff1.w3p.p && Ap.p && gemm_x3p_enabled()) {
+                ConvGemm g;      // the FF1 launch as F5::gemm will build it, to ask whether the panel-plane kernel takes it
+                g.dtype = dtype; g.out_dtype = dtype; g.x = Ub.p; g.w = bk.ff1.w.p; g.w3 = bk.ff1.w3.p; g.xp = Ap.p; g.w3p = bk.ff1.w3p.p;
+                g.bias = bk.ff1.b.as<float>(); g.out = Hff.p; g.B = 1; g.T_in = B * N; g.M = B * N; g.N = ff; g.Cin = d; g.taps = 1;
+                g.x_bstride = (long)N * d; g.x_rstride = d; g.out_bstride = (long)N * ff; g.out_rstride = ff; g.act = ACT_GELU_TANH;
+                sk.attach(g);
+                fused = gemm_x3p_would_run(g);
+            }
+            if (fused) launch_rownorm_x3p(X.as<float>(), Ap.p, m + 4 * d, m + 3 * d, rows, d, 1e-6f, s);
+            else launch_rownorm(NORM_LN_MOD, X.as<float>(), Ub.p, dtype, m + 4 * d, m + 3 * d, rows, d, 1e-6f, s);
+            gemm(dtype, Ub.p, (long)N * d, d, d, bk.ff1, Hff.p, dtype, (long)N * ff, ff, B, N, ACT_GELU_TANH, nullptr, nullptr, fused);
+        }
         gemm(dtype, Hff.p, (long)N * ff, ff, ff, bk.ff2, X.p, MI_F32, (long)N * d, d, B, N, ACT_NONE, X.p, m + 5 * d);
     }
     // ---- AdaLN-final (scale, shift order: modules.py:323) + proj_out ------------------------------------------

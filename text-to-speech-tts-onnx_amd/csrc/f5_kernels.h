@@ -8,6 +8,8 @@ enum { NORM_LN_MOD = 0, NORM_LN_AFFINE = 1, NORM_L2 = 2 };
 // x fp32 [rows][D] -> y (out_dtype) ; LN_MOD: LN(x)*(1+a)+b ; LN_AFFINE: LN(x)*a+b ; L2: a*x/||x||+b
 void launch_rownorm(int mode, const float* x, void* y, int out_dtype, const float* a, const float* b, long rows, int D,
                     float eps, hipStream_t s);
+// LN_MOD with the result as gemm_x3p.hip panel planes (three-way bf16 split of the fp32 value) instead of fp32 rows
+void launch_rownorm_x3p(const float* x, void* planes, const float* a, const float* b, long rows, int D, float eps, hipStream_t s);
 void launch_dwconv7(const float* x, float* y, const float* w, const float* bias, int B, int T, int C, hipStream_t s);
 void launch_grn(float* y, float* ss_scratch, const float* gamma, const float* beta, int B, int T, int C, hipStream_t s);
 // ids [U][N]; out slabs 2u (text) / 2u+1 (drop)

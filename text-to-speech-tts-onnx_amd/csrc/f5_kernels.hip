@@ -11,6 +11,7 @@
 //   CFG/Euler        x += (p + (p - p1)*cfg) * dt[k]              Export_F5.py:179-180
 #include "common.h"
 #include "f5_kernels.h"
+#include "x3_split.h"
 
 namespace mi {
 
@@ -80,6 +81,75 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ 
             }
         }
     }
+}
+
+// LayerNorm + AdaLN modulation with the result written as gemm_x3p.hip panel planes (three-way bf16 split of the fp32
+// value, x3_split.h) instead of fp32 rows: the A operand of the QKV / FF1 GEMMs needs no separate split pass.  One wave
+// per row, a lane holds 8 consecutive columns per pass (one 16-byte k-slot of each plane).
+template <int MAXP>
+__global__ __launch_bounds__(256) void rownorm_x3p_kernel(const float* __restrict__ x, unsigned char* __restrict__ planes,
+                                                          const float* __restrict__ a, const float* __restrict__ b,
+                                                          long rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * D;
+    float4 v[MAXP][2];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        const bool in = c < D;
+        v[i][0] = in ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0, 0, 0, 0);
+        v[i][1] = in ? *reinterpret_cast<const float4*>(xr + c + 4) : make_float4(0, 0, 0, 0);
+        s += ((v[i][0].x + v[i][0].y) + (v[i][0].z + v[i][0].w)) + ((v[i][1].x + v[i][1].y) + (v[i][1].z + v[i][1].w));
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        if (c < D) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float d0 = v[i][h].x - mean, d1 = v[i][h].y - mean, d2 = v[i][h].z - mean, d3 = v[i][h].w - mean;
+                q += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+            }
+        }
+    }
+    const float inv = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);   // biased variance
+    const int nch = D >> 5;
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+        const int s8 = i * 64 + lane, c = s8 * 8;
+        if (c < D) {
+            float o[8] = {v[i][0].x, v[i][0].y, v[i][0].z, v[i][0].w, v[i][1].x, v[i][1].y, v[i][1].z, v[i][1].w};
+            const float4 a0 = *reinterpret_cast<const float4*>(a + c), a1 = *reinterpret_cast<const float4*>(a + c + 4);
+            const float4 b0 = *reinterpret_cast<const float4*>(b + c), b1 = *reinterpret_cast<const float4*>(b + c + 4);
+            const float aa[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = (o[k] - mean) * inv * (1.f + aa[k]) + bb[k];
+            unsigned p1[4], p2[4], p3[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) x3_split_pair(o[2 * k], o[2 * k + 1], p1[k], p2[k], p3[k]);
+            unsigned char* dst = planes + x3p_slot_offset(row, s8, nch);
+            *reinterpret_cast<x3_u4*>(dst) = x3_u4{p1[0], p1[1], p1[2], p1[3]};
+            *reinterpret_cast<x3_u4*>(dst + X3P_PLANE) = x3_u4{p2[0], p2[1], p2[2], p2[3]};
+            *reinterpret_cast<x3_u4*>(dst + 2 * X3P_PLANE) = x3_u4{p3[0], p3[1], p3[2], p3[3]};
+        }
+    }
+}
+
+void launch_rownorm_x3p(const float* x, void* planes, const float* a, const float* b, long rows, int D, float eps, hipStream_t s) {
+    MI_REQUIRE(D % 32 == 0 && D <= 2048, "rownorm_x3p: D must be whole 32-deep chunks and <= 2048");
+    dim3 grid((unsigned)((rows + 3) / 4));
+    ProfScope ps(FAM_NORM, s, (double)rows * D * (4.0 + 6.0), 8.0 * rows * D);
+    prof_set_kernel("rownorm_x3p_kernel", "", "");
+    const int mp = (D + 511) / 512;
+    if (mp == 1) hipLaunchKernelGGL((rownorm_x3p_kernel<1>), grid, dim3(256), 0, s, x, (unsigned char*)planes, a, b, rows, D, eps);
+    else if (mp == 2) hipLaunchKernelGGL((rownorm_x3p_kernel<2>), grid, dim3(256), 0, s, x, (unsigned char*)planes, a, b, rows, D, eps);
+    else hipLaunchKernelGGL((rownorm_x3p_kernel<4>), grid, dim3(256), 0, s, x, (unsigned char*)planes, a, b, rows, D, eps);
+    MI_HIP(hipGetLastError());
 }
 
 void launch_rownorm(int mode, const float* x, void* y, int out_dtype, const float* a, const float* b, long rows, int D,

@@ -696,6 +696,8 @@ static bool x3p_eligible(const ConvGemm& p) {
     return p.N % 128 == 0 && ((long)(p.M + 127) / 128) * nch * 24576 < 0x7fff0000L && ((long)p.N / 128) * nch * 24576 < 0x7fff0000L;
 }
 
+bool gemm_x3p_would_run(const ConvGemm& p) { return x3p_eligible(p) && p.B == 1 && p.G == 1; }
+
 void launch_conv_gemm(const ConvGemm& p_in, hipStream_t s) {
     ConvGemm p = p_in;
     if (p.B > 1 && p.taps == 1 && p.G == 1 && p.pad == 0 && p.epi == EPI_PLAIN && p.M == p.T_in && p.gate_bstride == 0 &&

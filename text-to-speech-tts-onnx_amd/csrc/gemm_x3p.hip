@@ -36,9 +36,6 @@
 
 namespace mi {
 
-constexpr int X3P_PLANE = 128 * 32 * 2;          // one plane of one (panel, chunk): 128 rows x 64 bytes
-constexpr int X3P_CHUNK = 3 * X3P_PLANE;         // 24 KB
-
 long x3p_bytes(long rows, long K) { return ((rows + 127) / 128) * (K / 32) * (long)X3P_CHUNK; }
 
 // fp32 rows [rows][ld] (K columns used) -> panel planes.  One thread = one 16-byte k-slot (8 values) of one row; rows in
@@ -57,8 +54,7 @@ __global__ __launch_bounds__(256) void x3p_split_rows_kernel(const float* __rest
     unsigned a[4], b[4], c[4];
     x3_split_pair(v0.x, v0.y, a[0], b[0], c[0]); x3_split_pair(v0.z, v0.w, a[1], b[1], c[1]);
     x3_split_pair(v1.x, v1.y, a[2], b[2], c[2]); x3_split_pair(v1.z, v1.w, a[3], b[3], c[3]);
-    const int nch = K >> 5, r = row & 127, ch = s8 >> 2, slot = s8 & 3;
-    unsigned char* dst = out + ((long)(row >> 7) * nch + ch) * X3P_CHUNK + r * 64 + ((slot ^ ((r >> 2) & 3)) << 4);
+    unsigned char* dst = out + x3p_slot_offset(row, s8, K >> 5);
     *reinterpret_cast<x3_u4*>(dst) = x3_u4{a[0], a[1], a[2], a[3]};
     *reinterpret_cast<x3_u4*>(dst + X3P_PLANE) = x3_u4{b[0], b[1], b[2], b[3]};
     *reinterpret_cast<x3_u4*>(dst + 2 * X3P_PLANE) = x3_u4{c[0], c[1], c[2], c[3]};
@@ -84,7 +80,9 @@ __device__ __forceinline__ void x3p_dma16(RSRC rsrc, int voff, unsigned lds_dst)
 
 // p.x  = A panel planes (x3p layout, Tm panels x nch chunks) ; p.w3 = B panel planes (Tn panels x nch chunks)
 // p.Tm, p.Tn tiles ; p.RT = GR, p.RC = GC (XCD bands) ; p.tail_tiles bit0 = no cyclic K alignment (A/B switch)
-template <typename TO, bool LEPI>
+// DBG (tuning builds of the same kernel, MI355TTS_GEMM_DBG): bit 0 no LDS-DMA, bit 1 no fragment reads, bit 3 no MFMA; p.dbg bit 2
+// (run time): no fix-up / epilogue
+template <typename TO, bool LEPI, int DBG = 0>
 __global__ __launch_bounds__(512, 1) void linear_x3p_kernel(const ConvGemmDev p) {
     using MF = Mfma<bf16>;
     using Frag = typename MF::Frag;
@@ -158,6 +156,7 @@ __global__ __launch_bounds__(512, 1) void linear_x3p_kernel(const ConvGemmDev p)
         auto issue = [&](int st, int local) __attribute__((always_inline)) {
             const int coff = chunk_off(local);
             const unsigned base = __builtin_amdgcn_readfirstlane(smem_lds + (unsigned)(st * STAGE) + lds_part);
+            if constexpr (DBG & 1) return;
 #pragma unroll
             for (int j = 0; j < PER; ++j) x3p_dma16(rsd, (int)((unsigned)vb[j] + (unsigned)coff), base + (unsigned)(j * 1024));
         };
@@ -170,9 +169,18 @@ __global__ __launch_bounds__(512, 1) void linear_x3p_kernel(const ConvGemmDev p)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         Frag fa[2][TM][3], fb[2][TN][3];                        // [register set][block][plane]
+        if constexpr (DBG & 2) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { fa[a][b][c] = Frag{}; fb[a][b][c] = Frag{}; }
+        }
         // one of the 12 fragment reads of a chunk: q < 6: A (block q / 3, plane q % 3) ; else B
         auto ldfrag1 = [&](const unsigned char* sa, const unsigned char* sb, auto SET, int q) __attribute__((always_inline)) {
             constexpr int set = decltype(SET)::value;
+            if constexpr (DBG & 2) return;
             if (q < 6) fa[set][q / 3][q % 3] = *reinterpret_cast<const Frag*>(sa + (q / 3) * (32 * 64) + (q % 3) * X3P_PLANE);
             else { const int qq = q - 6; fb[set][qq / 3][qq % 3] = *reinterpret_cast<const Frag*>(sb + (qq / 3) * (32 * 64) + (qq % 3) * X3P_PLANE); }
         };
@@ -181,6 +189,7 @@ __global__ __launch_bounds__(512, 1) void linear_x3p_kernel(const ConvGemmDev p)
             constexpr int set = decltype(SET)::value;
             constexpr int TA[6] = {0, 1, 2, 0, 1, 0}, TB[6] = {2, 1, 0, 1, 0, 0};
             const int t = k >> 2, i = (k >> 1) & 1, j = k & 1;
+            if constexpr (DBG & 8) return;
             acc[i][j] = MF::mma(fa[set][i][TA[t]], fb[set][j][TB[t]], acc[i][j]);
         };
 #define X3P_SB() __builtin_amdgcn_sched_barrier(0)
@@ -216,7 +225,7 @@ __global__ __launch_bounds__(512, 1) void linear_x3p_kernel(const ConvGemmDev p)
                 }
                 X3P_SB(); mma1(SET, k); X3P_SB();
                 if (k < 12) ldfrag1(sa, sb, NSET{}, k);
-                else if (k < 18) x3p_dma16(rsd, (int)((unsigned)vb[k - 12] + (unsigned)coff), ldsd + (unsigned)((k - 12) * 1024));
+                else if (k < 18) { if constexpr (!(DBG & 1)) x3p_dma16(rsd, (int)((unsigned)vb[k - 12] + (unsigned)coff), ldsd + (unsigned)((k - 12) * 1024)); }
             }
         };
         for (int c = 0; c < n; c += 2) {
@@ -375,8 +384,13 @@ void launch_linear_x3p(const ConvGemmDev& e_in, hipStream_t s) {
     const int P = std::min(cus, e.sk_slots - 8) & ~7;          // flags[P] is the watchdog's error word
     const dim3 grid(P);
     if (e.lds_epi) {
-        prof_set_kernel("linear_x3p_kernel<float, true>", "", "");
-        hipLaunchKernelGGL((linear_x3p_kernel<float, true>), grid, dim3(512), 0, s, e);
+        switch (e.dbg & 11) {       // tuning instantiations (MI355TTS_GEMM_DBG)
+            case 1: prof_set_kernel("linear_x3p_kernel<float, true, noDMA>", "", ""); hipLaunchKernelGGL((linear_x3p_kernel<float, true, 1>), grid, dim3(512), 0, s, e); break;
+            case 2: prof_set_kernel("linear_x3p_kernel<float, true, noLDSread>", "", ""); hipLaunchKernelGGL((linear_x3p_kernel<float, true, 2>), grid, dim3(512), 0, s, e); break;
+            case 3: prof_set_kernel("linear_x3p_kernel<float, true, noDMA noLDSread>", "", ""); hipLaunchKernelGGL((linear_x3p_kernel<float, true, 3>), grid, dim3(512), 0, s, e); break;
+            case 8: prof_set_kernel("linear_x3p_kernel<float, true, noMFMA>", "", ""); hipLaunchKernelGGL((linear_x3p_kernel<float, true, 8>), grid, dim3(512), 0, s, e); break;
+            default: prof_set_kernel("linear_x3p_kernel<float, true>", "", ""); hipLaunchKernelGGL((linear_x3p_kernel<float, true>), grid, dim3(512), 0, s, e); break;
+        }
     } else {
         prof_set_kernel("linear_x3p_kernel<float, false>", "", "");
         hipLaunchKernelGGL((linear_x3p_kernel<float, false>), grid, dim3(512), 0, s, e);
