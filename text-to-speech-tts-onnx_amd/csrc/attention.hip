@@ -415,7 +415,10 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const T* __restrict__ q, c
 template <bool SPLIT2>
 __global__ __launch_bounds__(256, 2) void attn_x3f_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                        const float* __restrict__ v, float* __restrict__ o, int H, int N,
-                                                       float* __restrict__ ws, int* __restrict__ cnt) {
+                                                       float* __restrict__ ws, int* __restrict__ cnt,
+                                                       unsigned char* __restrict__ o_planes) {
+    // o_planes != null: the output leaves as gemm_x3p.hip panel planes of the [B * N][H * 64] matrix (the A operand of the O
+    // projection), three-way split here, instead of fp32 rows in o
     using MF = Mfma<bf16>;
     using Frag = bf16x8;
     constexpr int D = 64, KT = 64;
@@ -711,6 +714,7 @@ __global__ __launch_bounds__(256, 2) void attn_x3f_kernel(const float* __restric
         const float inv = 1.0f / l_run;
         const int b = bh / H, h = bh - b * H;
         float* ob = o + ((long)b * N + qr) * H * D + h * D;
+        const long row = (long)b * N + qr;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -718,8 +722,19 @@ __global__ __launch_bounds__(256, 2) void attn_x3f_kernel(const float* __restric
                 float vals[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) vals[e] = (oacc[dt][g * 4 + e] * inv);
-                float* dst = ob + dt * 32 + 8 * g + 4 * hi;
-                *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(vals);
+                if (o_planes) {
+                    // columns h*64 + dt*32 + 8g + 4hi .. +3: half (8 bytes) of the k-slot s8 = h*8 + dt*4 + g of every plane
+                    uint2 w1, w2, w3;
+                    x3_split_pair(vals[0], vals[1], w1.x, w2.x, w3.x);
+                    x3_split_pair(vals[2], vals[3], w1.y, w2.y, w3.y);
+                    unsigned char* dst = o_planes + x3p_slot_offset(row, h * 8 + dt * 4 + g, (H * D) >> 5) + 8 * hi;
+                    *reinterpret_cast<uint2*>(dst) = w1;
+                    *reinterpret_cast<uint2*>(dst + X3P_PLANE) = w2;
+                    *reinterpret_cast<uint2*>(dst + 2 * X3P_PLANE) = w3;
+                } else {
+                    float* dst = ob + dt * 32 + 8 * g + 4 * hi;
+                    *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(vals);
+                }
             }
     }
 }
@@ -759,8 +774,15 @@ bool attn_set_option(const char* key, long v) {
     return true;
 }
 
+bool attention_can_write_planes(int N, int BH, int dtype) {
+    attn_env_once();
+    (void)N; (void)BH;
+    return dtype == MI_F32 && g_attn_x3 == 2;
+}
+
 void launch_attention(const void* q, const void* k, const void* v, void* o, int BH, int H, int N, int dtype, hipStream_t s,
-                      float* ws, long ws_floats, int* cnt, long cnt_n) {
+                      float* ws, long ws_floats, int* cnt, long cnt_n, void* o_planes) {
+    MI_REQUIRE(!o_planes || attention_can_write_planes(N, BH, dtype), "attention: panel-plane output needs the fp32 split kernel");
     MI_REQUIRE(BH % H == 0 && N > 0, "attention: bad shape");
     const double esz = (double)dtype_size(dtype);
     ProfScope ps(FAM_ATTN, s, 4.0 * BH * N * 64.0 * esz, 4.0 * BH * (double)N * N * 64.0);
@@ -804,7 +826,7 @@ void launch_attention(const void* q, const void* k, const void* v, void* o, int 
             const int Z = pick_z(1);
             if (g_attn_x3 == 2) {
                 prof_set_kernel("attn_x3f_kernel<true>", "", "");
-                hipLaunchKernelGGL((attn_x3f_kernel<true>), dim3((N + 63) / 64, BH, Z), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt);
+                hipLaunchKernelGGL((attn_x3f_kernel<true>), dim3((N + 63) / 64, BH, Z), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt, (unsigned char*)o_planes);
             } else if (g_attn_x3 == 1) {
                 prof_set_kernel("attn_kernel<float, true, x3>", "", "");
                 hipLaunchKernelGGL((attn_kernel<float, true, true>), dim3((N + 63) / 64, BH, Z), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt);
@@ -812,7 +834,7 @@ void launch_attention(const void* q, const void* k, const void* v, void* o, int 
                 ATTN_LAUNCH(float, true, dim3((N + 63) / 64, BH, Z), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt);
         } else if (g_attn_x3 == 2) {
             prof_set_kernel("attn_x3f_kernel<false>", "", "");
-            hipLaunchKernelGGL((attn_x3f_kernel<false>), dim3((N + 127) / 128, BH), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt);
+            hipLaunchKernelGGL((attn_x3f_kernel<false>), dim3((N + 127) / 128, BH), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt, (unsigned char*)o_planes);
         } else if (g_attn_x3 == 1) {
             prof_set_kernel("attn_kernel<float, false, x3>", "", "");
             hipLaunchKernelGGL((attn_kernel<float, false, true>), dim3((N + 127) / 128, BH), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt);

@@ -166,6 +166,9 @@ struct ConvGemm {
     const void* w3 = nullptr;
     // gemm_x3p.hip (round 3): both operands as pre-split, pre-tiled "panel planes" (x3p_split_rows): xp replaces x, w3p replaces w3
     const void* xp = nullptr; const void* w3p = nullptr;
+    // ... and its output as panel planes too (the A operand of the NEXT linear layer: FF1 -> FF2), instead of rows in `out`;
+    // plain epilogue only: bias + activation, no residual / gate / accumulate
+    void* out_planes = nullptr;
 };
 void launch_conv_gemm(const ConvGemm& p, hipStream_t s);
 // gemm_x3p.hip panel planes: [panel = row / 128][chunk = k / 32][plane 0..2][row % 128][32 bf16], the four 16-byte k-slots of a

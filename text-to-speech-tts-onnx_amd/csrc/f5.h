@@ -60,7 +60,7 @@ struct F5 {
     DevBuf attn_ws, attn_cnt; // key-sliced fp32 attention: partial (m, l, O) per 64-query tile and slice, ticket counters
     long attn_ws_floats = 0, attn_cnt_n = 0;
     int ws_U = 0, ws_N = 0;
-    DevBuf Ap;               // fp32 engines: the A operand of the big linear layers as panel planes (gemm_x3p.hip)
+    DevBuf Ap, Ap2;          // fp32 engines: the A operand of the big linear layers as panel planes (gemm_x3p.hip): dim / ff columns
     DevBuf d_noise, d_cmt, d_cmtd, cat, h32, hT, c1, X, Ub, qb, kb, vb, Ob, Hff, pred;
     DevBuf p_audio, p_pad, p_spec, p_mag, p_mel, p_ids, p_tid, p_err, p_tx, p_ty, p_ty2, p_ss;
     std::vector<float> h_noise;
@@ -70,7 +70,8 @@ struct F5 {
     ~F5();
     void ensure_workspace(int U, int N);
     void gemm(int dt, const void* x, long xb, long xr, int K, const Lin& L, void* out, int odt, long ob, long orr,
-              int B, int M, int act = ACT_NONE, const void* res = nullptr, const float* gate = nullptr, bool planes_ready = false);
+              int B, int M, int act = ACT_NONE, const void* res = nullptr, const float* gate = nullptr, bool planes_ready = false,
+              const void* in_planes = nullptr, void* out_planes = nullptr);
     // fills d_noise, d_cmt, d_cmtd for U utterances (asynchronous on `stream`); returns ref_signal_len
     int preprocess(int U, const int16_t* audio, long L, const int32_t* text_ids, int T, int N,
                    const float* noise_in, uint64_t seed, int mem);

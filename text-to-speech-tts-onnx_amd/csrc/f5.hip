@@ -361,7 +361,7 @@ void F5::ensure_workspace(int U, int N) {
         if (vbytes > vb.bytes) { vb.ensure(vbytes); MI_HIP(hipMemsetAsync(vb.p, 0, vbytes, stream)); }
     }
     Hff.ensure(rows * c.ff() * es);
-    if (dtype == MI_F32) Ap.ensure((size_t)x3p_bytes((long)rows, std::max(c.dim, c.ff())));
+    if (dtype == MI_F32) { Ap.ensure((size_t)x3p_bytes((long)rows, c.dim)); Ap2.ensure((size_t)x3p_bytes((long)rows, c.ff())); }
     pred.ensure(rows * c.mel * 4);
     // preprocess temporaries
     const int ti = c.text_dim * c.conv_mult;
@@ -379,7 +379,7 @@ void F5::ensure_workspace(int U, int N) {
 // planes_ready: Ap already holds the rows as panel planes (written by their producer) and the caller has checked
 // gemm_x3p_would_run(): x is not read
 void F5::gemm(int dt, const void* x, long xb, long xr, int K, const Lin& L, void* out, int odt, long ob, long orr, int B,
-              int M, int act, const void* res, const float* gate, bool planes_ready) {
+              int M, int act, const void* res, const float* gate, bool planes_ready, const void* in_planes, void* out_planes) {
     ConvGemm g;
     g.dtype = dt; g.out_dtype = odt; g.x = x; g.w = L.w.p; g.w3 = L.w3.p; g.bias = L.b.p ? L.b.as<float>() : nullptr; g.out = out;
     g.res = res; g.gate = gate; g.gate_bstride = 0;
@@ -391,13 +391,15 @@ void F5::gemm(int dt, const void* x, long xb, long xr, int K, const Lin& L, void
     }
     if (dt == MI_F32 && L.w3p.p && g.B == 1 && Ap.p && gemm_x3p_enabled()) {
         // fp32 big linear layer: the rows as panel planes — written by their producer (planes_ready) or by a separate pass here
-        g.xp = Ap.p; g.w3p = L.w3p.p;
+        void* planes = in_planes ? const_cast<void*>(in_planes) : (K <= cfg.dim ? Ap.p : Ap2.p);
+        g.xp = planes; g.w3p = L.w3p.p; g.out_planes = out_planes;
         if (!planes_ready) {
-            if (gemm_x3p_would_run(g)) x3p_split_rows((const float*)x, xr, Ap.p, g.M, K, stream);
+            MI_REQUIRE(!out_planes, "f5: out_planes is only requested after gemm_x3p_would_run()");
+            if (gemm_x3p_would_run(g)) x3p_split_rows((const float*)x, xr, planes, g.M, K, stream);
             else { g.xp = nullptr; g.w3p = nullptr; }
         }
     } else {
-        MI_REQUIRE(!planes_ready, "f5: planes_ready without the panel-plane path");
+        MI_REQUIRE(!planes_ready && !out_planes, "f5: planes_ready / out_planes without the panel-plane path");
     }
     launch_conv_gemm(g, stream);
 }
@@ -584,8 +586,21 @@ void F5::dit_eval(int U, int N, int k) {
             else launch_rownorm(NORM_LN_MOD, X.as<float>(), Ub.p, dtype, m + d, m, rows, d, 1e-6f, s);
             launch_conv_gemm(g, s);
         }
-        launch_attention(qb.p, kb.p, vb.p, Ob.p, B * H, H, N, dtype, s, attn_ws.as<float>(), attn_ws_floats, attn_cnt.as<int>(), attn_cnt_n);
-        gemm(dtype, Ob.p, (long)N * d, d, d, bk.o, X.p, MI_F32, (long)N * d, d, B, N, ACT_NONE, X.p, m + 2 * d);
+        {
+            // attention output: straight into the panel planes the O projection reads, when that GEMM takes the panel-plane kernel
+            bool fused = false;
+            if (dtype == MI_F32 && bk.o.w3p.p && Ap.p && gemm_x3p_enabled() && attention_can_write_planes(N, B * H, dtype)) {
+                ConvGemm g;
+                g.dtype = dtype; g.out_dtype = MI_F32; g.x = Ob.p; g.w = bk.o.w.p; g.w3 = bk.o.w3.p; g.xp = Ap.p; g.w3p = bk.o.w3p.p;
+                g.bias = bk.o.b.as<float>(); g.out = X.p; g.res = X.p; g.gate = m + 2 * d; g.B = 1; g.T_in = B * N; g.M = B * N; g.N = d; g.Cin = d;
+                g.x_bstride = (long)N * d; g.x_rstride = d; g.out_bstride = (long)N * d; g.out_rstride = d;
+                sk.attach(g);
+                fused = gemm_x3p_would_run(g);
+            }
+            launch_attention(qb.p, kb.p, vb.p, Ob.p, B * H, H, N, dtype, s, attn_ws.as<float>(), attn_ws_floats, attn_cnt.as<int>(), attn_cnt_n,
+                             fused ? Ap.p : nullptr);
+            gemm(dtype, Ob.p, (long)N * d, d, d, bk.o, X.p, MI_F32, (long)N * d, d, B, N, ACT_NONE, X.p, m + 2 * d, fused, Ap.p);
+        }
         {
             bool fused = false;
             if (dtype == MI_F32 && bk.ff1.w3p.p && Ap.p && gemm_x3p_enabled()) {
@@ -598,9 +613,20 @@ void F5::dit_eval(int U, int N, int k) {
             }
             if (fused) launch_rownorm_x3p(X.as<float>(), Ap.p, m + 4 * d, m + 3 * d, rows, d, 1e-6f, s);
             else launch_rownorm(NORM_LN_MOD, X.as<float>(), Ub.p, dtype, m + 4 * d, m + 3 * d, rows, d, 1e-6f, s);
-            gemm(dtype, Ub.p, (long)N * d, d, d, bk.ff1, Hff.p, dtype, (long)N * ff, ff, B, N, ACT_GELU_TANH, nullptr, nullptr, fused);
+            // FF1's GELU output: as the panel planes FF2 reads (Ap2), when both GEMMs take the panel-plane kernel
+            bool fused2 = false;
+            if (fused && bk.ff2.w3p.p && Ap2.p) {
+                ConvGemm g;
+                g.dtype = dtype; g.out_dtype = MI_F32; g.x = Hff.p; g.w = bk.ff2.w.p; g.w3 = bk.ff2.w3.p; g.xp = Ap2.p; g.w3p = bk.ff2.w3p.p;
+                g.bias = bk.ff2.b.as<float>(); g.out = X.p; g.res = X.p; g.gate = m + 5 * d; g.B = 1; g.T_in = B * N; g.M = B * N; g.N = d; g.Cin = ff;
+                g.x_bstride = (long)N * ff; g.x_rstride = ff; g.out_bstride = (long)N * d; g.out_rstride = d;
+                sk.attach(g);
+                fused2 = gemm_x3p_would_run(g);
+            }
+            gemm(dtype, Ub.p, (long)N * d, d, d, bk.ff1, Hff.p, dtype, (long)N * ff, ff, B, N, ACT_GELU_TANH, nullptr, nullptr, fused, Ap.p,
+                 fused2 ? Ap2.p : nullptr);
+            gemm(dtype, Hff.p, (long)N * ff, ff, ff, bk.ff2, X.p, MI_F32, (long)N * d, d, B, N, ACT_NONE, X.p, m + 5 * d, fused2, Ap2.p);
         }
-        gemm(dtype, Hff.p, (long)N * ff, ff, ff, bk.ff2, X.p, MI_F32, (long)N * d, d, B, N, ACT_NONE, X.p, m + 5 * d);
     }
     // ---- AdaLN-final (scale, shift order: modules.py:323) + proj_out ------------------------------------------
     const float* mf = modk + (size_t)c.depth * 6 * d;

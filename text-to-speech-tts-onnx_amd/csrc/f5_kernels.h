@@ -33,7 +33,10 @@ void launch_cfg_update(float* noise, const float* pred, int U, int N, int M, flo
 // ws / cnt: optional workspace of the key-sliced fp32 kernel ((2*32*64 + 256) floats per 64-query tile and slice; one zeroed
 // counter per tile); without them every query tile is one workgroup
 void launch_attention(const void* q, const void* k, const void* v, void* o, int BH, int H, int N, int dtype, hipStream_t s,
-                      float* ws = nullptr, long ws_floats = 0, int* cnt = nullptr, long cnt_n = 0);
+                      float* ws = nullptr, long ws_floats = 0, int* cnt = nullptr, long cnt_n = 0, void* o_planes = nullptr);
+// o_planes (fp32 engines, both products split): the output as gemm_x3p.hip panel planes of the [B * N][H * 64] matrix instead
+// of rows in o — ask attention_can_write_planes() first
+bool attention_can_write_planes(int N, int BH, int dtype);
 // row length of the transposed V the attention kernel in use expects (0: V untransposed, [BH][N][64]) — ask per launch: the
 // fp32 answer follows the attn_f32_x3 option
 long attention_v_ld(int N, int dtype);

@@ -726,6 +726,12 @@ void launch_conv_gemm(const ConvGemm& p_in, hipStream_t s) {
     const bool use_x3 = use_x3p || x3_eligible(p);
     d.w3 = use_x3 ? p.w3 : nullptr;
     d.xp = use_x3p ? p.xp : nullptr; d.w3p = use_x3p ? p.w3p : nullptr;
+    d.out_planes = nullptr;
+    if (p.out_planes) {
+        MI_REQUIRE(use_x3p && p.epi == EPI_PLAIN && !p.res && !p.gate && !p.accumulate && p.alpha == 1.f && p.N % 32 == 0,
+                   "conv_gemm: out_planes needs the panel-plane kernel and a plain bias + activation epilogue");
+        d.out_planes = p.out_planes;
+    }
     d.tail_tiles = 0; d.tail_split = 1;
     d.use_buf = 0;
     {

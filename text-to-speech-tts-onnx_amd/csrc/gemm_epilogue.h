@@ -39,6 +39,7 @@ struct ConvGemmDev {
     float* sk_ws; int* sk_flags; int sk_slots;   // stream-K (gemm_sk.hip): 64 KB partial-tile slot + flag per persistent workgroup
     const void* w3;                              // gemm_x3.hip: weight planes [3][N][K] bf16 (null: not available)
     const void* xp; const void* w3p;             // gemm_x3p.hip: A and B as panel planes (null: not available)
+    void* out_planes;                            // gemm_x3p.hip: output as panel planes of an [M][N] matrix (null: rows in `out`)
     int tail_tiles, tail_split;                  // gemm_ph8.hip: the last tail_tiles tiles are cut into tail_split K slices (0 / 1: none)
 };
 
