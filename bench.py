@@ -331,6 +331,50 @@ class F5Bench:
         return res, (audio, ids, N, noise)
 
 
+def measure_f5_plus_bigvgan(torch, fb, f5_dtype: str, voc_dtype: str, U: int, steps: int, warmup: int):
+    """The pipeline BASELINE.json's metric names — F5-TTS NFE=32 + BigVGAN-v2 24 kHz: preprocess -> 31 DiT evaluations with
+    CFG -> the generated mel frames handed to the BigVGAN engine (mi_f5_synthesize_mel -> mi_bigvgan_forward) -> int16, all
+    on the device.  (The reference's exported F5 graphs decode with Vocos — that is the headline line; this block is the
+    same sampler with the BigVGAN vocoder of configs[0]/[1] behind it.)"""
+    from mi355tts.config import BigVGANConfig
+    from mi355tts.f5 import F5Engine
+    from mi355tts.bigvgan import BigVGANVocoder
+    cfg, dev, W = fb.cfg, fb.dev, fb.W
+    vcfg = BigVGANConfig()
+    eng = F5Engine(cfg, blob_device=fb.blob_t, dtype=f5_dtype, device=fb.local)
+    voc = BigVGANVocoder(vcfg, blob=W.pack_bigvgan(vcfg, W.synth_state(W.bigvgan_spec(vcfg), 9527)), dtype=voc_dtype, device=fb.local)
+    audio, ids, N, noise = W.f5_synthetic_inputs(cfg, U, fb.rank, L=fb.L)
+    R = audio.shape[1] // cfg.hop_length + 1
+    F = N - R
+    t_audio, t_ids, t_noise = torch.from_numpy(audio).to(dev), torch.from_numpy(ids).to(dev), torch.from_numpy(noise).to(dev)
+    mel = torch.empty((U, cfg.mel_dim, F), dtype=torch.float32, device=dev)
+    out = torch.empty((U, 1, voc.out_len(F)), dtype=torch.int16, device=dev)
+
+    def step():
+        eng.synthesize_mel_torch(t_audio, t_ids, N, noise=t_noise, out=mel)
+        voc.run_torch(mel, out)
+
+    for _ in range(max(warmup, 2)):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    tv = time.perf_counter()
+    for _ in range(steps):
+        voc.run_torch(mel, out)
+    torch.cuda.synchronize()
+    voc_ms = (time.perf_counter() - tv) / steps * 1e3
+    audio_s = U * out.shape[-1] / vcfg.sampling_rate
+    eng.close(); voc.close()
+    return {"value": audio_s / dt, "unit": "audio-s/s", "ms_per_step": dt * 1e3, "rtf": dt / audio_s, "dtype": f"{f5_dtype} DiT + {voc_dtype} vocoder",
+            "vocoder_ms_per_step": voc_ms, "mel_frames": F, "utterances_per_gpu": U,
+            "workload": f"F5-TTS {f5_dtype} NFE=32 (N={N}) -> generated mel ({U},100,{F}) -> BigVGAN-v2 24khz_100band_256x {voc_dtype} -> int16, "
+                        f"one device-resident pipeline (mi_f5_synthesize_mel + mi_bigvgan_forward)"}
+
+
 def f5_workload_name(dtype, U, N, small=False):
     if small:
         return f"PLUMBING TEST ONLY (MI355TTS_BENCH_SMALL=1): reduced F5 model, {dtype}, {U} utterance(s) per GPU, N={N}"
@@ -364,6 +408,8 @@ def run_f5(args, world, rank, local, dev, dist, torch):
                 _lib.set_option("attn_f32_x3", 2)
             r3["workload"] = f5_workload_name("f32", args.batch, N) + " — linear layers and attention on the native fp32 MFMA (gemm_f32_x3 = 0, attn_f32_x3 = 0)"
             secondary["f5_f32_native_mfma"] = r3
+    if world == 1 and not args.no_secondary and not fb.small:
+        secondary["f5_plus_bigvgan"] = measure_f5_plus_bigvgan(torch, fb, args.dtype, "f16", args.batch, 3, 2)
     del fb.blob_t
     if rank != 0:
         return

@@ -144,6 +144,14 @@ int         mi_f5_synthesize(mi_f5* h, int U, const int16_t* audio, int64_t L, c
                              int64_t max_duration, const float* noise_in, uint64_t seed, int16_t* out,
                              int64_t* out_len, int mem);
 
+/* A -> loop, with the generated frames handed on as a vocoder mel instead of going through Vocos: mel_out (U, 100, N - R)
+ * fp32, channels first = the `mel_features` layout of mi_bigvgan_forward (BigVGAN-v2 24khz_100band_256x has F5's 100 bands,
+ * hop 256, 24 kHz).  The "F5-TTS + BigVGAN" pipeline of BASELINE.json's metric; the reference's bigvgan-type mel front end is
+ * F5_TTS/modeling_modified/F5/modules.py:30-72 (its exported graphs use the Vocos pair).  *n_frames receives N - R.     */
+int         mi_f5_synthesize_mel(mi_f5* h, int U, const int16_t* audio, int64_t L, const int32_t* text_ids, int64_t T,
+                                 int64_t max_duration, const float* noise_in, uint64_t seed, float* mel_out,
+                                 int64_t* n_frames, int mem);
+
 /* ---- IndexTTS acoustic GPT-2 (graphs B, C, E + the greedy decode loop) ------------------------------------------
  * Replaces ort_session_B / _C / _E of IndexTTS/Inference_IndexTTS_ONNX.py:619-675 and the loop at :745-783
  * (graph definitions: IndexTTS/Export_IndexTTS.py:203-289).  The KV cache lives in the handle (the reference

@@ -98,6 +98,36 @@ def test_batched_utterances_equal_single(g, small):
     assert np.array_equal(a[0], b0[0]) and np.array_equal(a[1], b1[0])
 
 
+def test_f5_mel_handoff_to_bigvgan(g, small):
+    """The "F5-TTS + BigVGAN" pipeline of the metric: mi_f5_synthesize_mel hands the generated frames on as (U, 100, N - R)
+    channels-first fp32 = BigVGAN's mel_features.  It must be the sampler's own final state (== the reference sampler's
+    fixture inside the loop tolerance), and a BigVGAN engine run on it must match the vocoder oracle run on the REFERENCE
+    sampler's frames (fp32 engines: waveform <= 1e-3 RMS, the north-star gate)."""
+    import dataclasses
+    from mi355tts.config import BigVGANConfig
+    from mi355tts.bigvgan import BigVGANVocoder
+    from oracle import bigvgan_np as OB
+    cfg, st, eng = small
+    N, R = int(g["pre_N"]), int(g["pre_ref_signal_len"])
+    audio, ids = g["pre_audio"].reshape(1, -1), g["pre_text_ids"].reshape(1, -1)
+    noise = g["dit_noise"].reshape(1, N, cfg.mel_dim)
+    mel = eng.synthesize_mel(audio, ids, N, noise=noise)
+    assert mel.shape == (1, cfg.mel_dim, N - R) and mel.dtype == np.float32
+    o = eng.preprocess(audio.reshape(1, 1, -1), ids, np.array([N]), noise=noise[0])
+    xs = eng.sample(noise, o["cat_mel_text"], o["cat_mel_text_drop"])
+    assert np.array_equal(mel[0], xs[0, R:].T)
+    ref_mel = g["loop_final"][R:].T[None].astype(np.float32)
+    np.testing.assert_allclose(mel, ref_mel, atol=5e-4)                             # the reference's own sampler state
+    vcfg = dataclasses.replace(BigVGANConfig.small(), num_mels=cfg.mel_dim)
+    vst = W.synth_state(W.bigvgan_spec(vcfg), 9527)
+    voc = BigVGANVocoder(vcfg, vst, dtype="f32")
+    wav = voc.run(mel)
+    ref = OB.bigvgan_int16(vcfg, vst, ref_mel)
+    assert wav.shape == ref.shape and rms(ref) > 100
+    assert rms((wav.astype(np.float64) - ref.astype(np.float64)) / 32767.0) < 1e-3
+    voc.close()
+
+
 def test_decode_golden(g, small):
     cfg, st, eng = small
     R = int(g["pre_ref_signal_len"])

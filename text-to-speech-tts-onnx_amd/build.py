@@ -76,4 +76,6 @@ if __name__ == "__main__":
     if "-j" in sys.argv:
         j = int(sys.argv[sys.argv.index("-j") + 1])
     v = sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else ""
+    if "--tuning" in sys.argv:          # the ablation instantiations of the kernels (MI355TTS_GEMM_DBG): tools/r3/*.sh use a `tune` variant
+        FLAGS.append("-DMI355TTS_TUNING")
     print(build(force="--force" in sys.argv, jobs=j, variant=v))

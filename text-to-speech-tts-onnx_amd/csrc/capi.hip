@@ -335,6 +335,32 @@ int mi_f5_synthesize(mi_f5* h, int U, const int16_t* audio, int64_t L, const int
     });
 }
 
+// A -> loop, and the generated frames handed on as a mel for a vocoder engine: (U, 100, N - R) fp32, channels first — the
+// `mel_features` layout of mi_bigvgan_forward (BigVGAN-v2 24khz_100band_256x shares F5's 100 bands / hop 256 / 24 kHz; the
+// reference's bigvgan-type front end is modules.py:30-72).  *n_frames receives N - R.
+int mi_f5_synthesize_mel(mi_f5* h, int U, const int16_t* audio, int64_t L, const int32_t* text_ids, int64_t T,
+                         int64_t max_duration, const float* noise_in, uint64_t seed, float* mel_out, int64_t* n_frames, int mem) {
+    return guard([&] {
+        F5_CHECK(h, mem, "mi_f5_synthesize_mel");
+        MI_REQUIRE(audio && text_ids && mel_out && U >= 1 && max_duration > 0, "mi_f5_synthesize_mel: bad arguments");
+        F5& e = *h->impl;
+        const int N = (int)max_duration;
+        const int R = e.preprocess(U, audio, L, text_ids, (int)T, N, noise_in, seed, mem);
+        const int F = N - R, mel = e.cfg.mel;
+        MI_REQUIRE(F >= 1, "mi_f5_synthesize_mel: max_duration leaves no generated frames");
+        e.build_cat_cond(U, N);
+        e.steps(U, N, 0, e.cfg.nfe - 1);
+        float* dst = mel_out;
+        if (mem == MI_HOST) { e.v_outf.ensure((size_t)U * mel * F * 4); dst = e.v_outf.as<float>(); }
+        for (int u = 0; u < U; ++u)
+            launch_nlc_to_ncl(e.d_noise.as<float>() + ((size_t)u * N + R) * mel, dst + (size_t)u * mel * F, 1, mel, F, MI_F32, e.stream);
+        if (mem == MI_HOST) copy_out(mel_out, dst, (size_t)U * mel * F * 4, mem, e.stream);
+        MI_HIP(hipStreamSynchronize(e.stream));
+        e.check_text_ids();
+        if (n_frames) *n_frames = F;
+    });
+}
+
 int mi_f5_stft(mi_f5* h, const int16_t* audio, int64_t L, float* spec, int mem) {
     return guard([&] {
         F5_CHECK(h, mem, "mi_f5_stft");

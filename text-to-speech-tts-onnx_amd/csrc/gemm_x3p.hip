@@ -152,11 +152,7 @@ __device__ __forceinline__ void x3p_set_m0(unsigned v) {
 // p.Tm, p.Tn tiles ; p.RT = GR, p.RC = GC (XCD bands) ; p.tail_tiles bit0 = no cyclic K alignment (A/B switch)
 // DBG (tuning builds of the same kernel, MI355TTS_GEMM_DBG): bit 0 no LDS-DMA, bit 1 no fragment reads, bit 3 no MFMA; p.dbg bit 2
 // (run time): no fix-up / epilogue
-// VAR (placement of the six LDS-DMA pieces and twelve fragment reads among the first 18 MFMAs of a chunk; A/B, MI355TTS_X3P_VAR):
-//   0: reads under MFMAs 0-11, DMA under 12-17, M0 written per piece        1: the same with two M0 writes per chunk (instruction offsets)
-//   2: DMA under 0-5 (right after the boundary, no ds_read in flight), reads under 6-17, two M0 writes
-//   3: DMA spread (MFMAs 1, 4, 7, 10, 13, 16), reads in the other slots, two M0 writes
-template <typename TO, bool LEPI, int DBG = 0, int VAR = 0>
+template <typename TO, bool LEPI, int DBG = 0>
 __global__ __launch_bounds__(512, 1) void linear_x3p_kernel(const ConvGemmDev p) {
     using MF = Mfma<bf16>;
     using Frag = typename MF::Frag;
@@ -273,17 +269,21 @@ __global__ __launch_bounds__(512, 1) void linear_x3p_kernel(const ConvGemmDev p)
         __builtin_amdgcn_s_barrier();
 #pragma unroll
         for (int q = 0; q < 12; ++q) ldfrag1(smem + fa_off, smem + fb_off, std::integral_constant<int, 0>{}, q);
+        if constexpr (DBG & 16) {       // tuning: REAL operand values in both register sets, then a loop of MFMAs only
+#pragma unroll
+            for (int q = 0; q < 12; ++q) ldfrag1(smem + fa_off, smem + fb_off, std::integral_constant<int, 1>{}, q);
+        }
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                           // chunk cb+1 landed, stage 0 free
         int st_next = 1, st_free = 0;                           // stage of chunk c+1 ; stage chunk c+3 goes to (= stage of chunk c)
         // One chunk: 24 MFMAs on the fragments of chunk c (register set SET).  Under twelve of them the fragments of chunk c+1
         // are read into the other set (past the piece they are stale LDS, never used), under six this wave's six pieces of
-        // chunk c+3 are requested (placement: VAR); then the boundary, then the last six MFMAs.  An LDS-DMA instruction
-        // blocks its wave's issue for ~50 cycles among bare MFMAs and ~160 with ds_reads around it (measured here: MFMA-only
-        // 45 us + data-only 36 us gave 75 us together; DMA without reads +7 us, reads without DMA +2 us, both +27 us —
-        // profiles/r3/x3p_ablation_*.txt).  Giving the two waves of a SIMD their DMA slots at OPPOSITE ends of the chunk
-        // was slower still (83 us: the late readers then wait for LDS at the boundary).
+        // chunk c+3 are requested; then the boundary, then the last six MFMAs.  Measured (profiles/r3/x3p_ablation_*.txt,
+        // QKV shape): MFMAs alone on zero operands 45 us, data movement alone 36 us, together 75 us.  WHERE the six DMA
+        // pieces and twelve reads sit among the MFMAs makes no difference (DMA first / last / every third slot, M0 written
+        // per piece or twice per chunk: 74.8 - 76.1 us), and giving the two waves of a SIMD opposite slots is slower (83 us):
+        // the parts do not hide each other because the package is at its power cap — see DESIGN.md section 4.
         auto body = [&](int c, auto SET) __attribute__((always_inline)) {
             constexpr int set = decltype(SET)::value;
             using NSET = std::integral_constant<int, set ^ 1>;
@@ -292,17 +292,6 @@ __global__ __launch_bounds__(512, 1) void linear_x3p_kernel(const ConvGemmDev p)
             const unsigned char* sb = smem + st_next * STAGE + fb_off;
             const int coff = chunk_off(cb + c + 3);
             const unsigned ldsd = __builtin_amdgcn_readfirstlane(smem_lds + (unsigned)(st_free * STAGE) + lds_part);
-            // DMA piece dj / fragment read rq of MFMA slot k (-1: none)
-            auto slot_dma = [](int k) constexpr -> int {
-                if (VAR <= 1) return k >= 12 && k < 18 ? k - 12 : -1;
-                if (VAR == 2) return k < 6 ? k : -1;
-                return (k < 18 && k % 3 == 1) ? k / 3 : -1;
-            };
-            auto slot_read = [](int k) constexpr -> int {
-                if (VAR <= 1) return k < 12 ? k : -1;
-                if (VAR == 2) return k >= 6 && k < 18 ? k - 6 : -1;
-                return (k < 18 && k % 3 != 1) ? k - (k + 2) / 3 : -1;
-            };
 #pragma unroll
             for (int k = 0; k < 24; ++k) {
                 if (k == 18 && more) {
@@ -313,20 +302,19 @@ __global__ __launch_bounds__(512, 1) void linear_x3p_kernel(const ConvGemmDev p)
                     __builtin_amdgcn_s_barrier();
                 }
                 X3P_SB(); mma1(SET, k); X3P_SB();
-                const int dj = slot_dma(k), rq = slot_read(k);
-                if (dj >= 0) {
+                if constexpr (DBG & 16) continue;
+                if (k < 12) ldfrag1(sa, sb, NSET{}, k);
+                else if (k < 18) {
                     if constexpr (!(DBG & 1)) {
-                        if constexpr (VAR == 0) x3p_dma16(rsd, (int)((unsigned)vb[dj] + (unsigned)coff), ldsd + (unsigned)(dj * 1024));
-                        else {
-                            // pieces 0-3 under one M0, pieces 4-5 under the next; vb[] already carries the piece's 1 KB step,
-                            // so the instruction offset is taken off the per-lane offset again
-                            if (dj == 0) x3p_set_m0(ldsd); else if (dj == 4) x3p_set_m0(ldsd + 4096u);
-                            const int v0 = (int)((unsigned)vb[dj & 4] + (unsigned)coff);
-                            if ((dj & 3) == 0) x3p_dma16_off<0>(rsd, v0); else if ((dj & 3) == 1) x3p_dma16_off<1024>(rsd, v0);
-                            else if ((dj & 3) == 2) x3p_dma16_off<2048>(rsd, v0); else x3p_dma16_off<3072>(rsd, v0);
-                        }
+                        // pieces 0-3 under one M0 value, pieces 4-5 under the next (instruction offsets 0 / 1 / 2 / 3 KB move the
+                        // global and the LDS address together)
+                        const int dj = k - 12;
+                        if (dj == 0) x3p_set_m0(ldsd); else if (dj == 4) x3p_set_m0(ldsd + 4096u);
+                        const int v0 = (int)((unsigned)vb[dj & 4] + (unsigned)coff);
+                        if ((dj & 3) == 0) x3p_dma16_off<0>(rsd, v0); else if ((dj & 3) == 1) x3p_dma16_off<1024>(rsd, v0);
+                        else if ((dj & 3) == 2) x3p_dma16_off<2048>(rsd, v0); else x3p_dma16_off<3072>(rsd, v0);
                     }
-                } else if (rq >= 0) ldfrag1(sa, sb, NSET{}, rq);
+                }
             }
         };
         for (int c = 0; c < n; c += 2) {
@@ -480,21 +468,19 @@ void launch_linear_x3p(const ConvGemmDev& e_in, hipStream_t s) {
     e.tail_tiles = (int)g_x3p_noalign;
     const int P = std::min(cus, e.sk_slots - 8) & ~7;          // flags[P] is the watchdog's error word
     const dim3 grid(P);
-    static int var = -1;
-    if (var < 0) { const char* v = std::getenv("MI355TTS_X3P_VAR"); var = v ? std::atoi(v) : 0; }
     if (e.lds_epi) {
-        switch (e.dbg & 11) {       // tuning instantiations (MI355TTS_GEMM_DBG)
-            case 1: prof_set_kernel("linear_x3p_kernel<float, true, noDMA>", "", ""); hipLaunchKernelGGL((linear_x3p_kernel<float, true, 1>), grid, dim3(512), 0, s, e); break;
-            case 2: prof_set_kernel("linear_x3p_kernel<float, true, noLDSread>", "", ""); hipLaunchKernelGGL((linear_x3p_kernel<float, true, 2>), grid, dim3(512), 0, s, e); break;
-            case 3: prof_set_kernel("linear_x3p_kernel<float, true, noDMA noLDSread>", "", ""); hipLaunchKernelGGL((linear_x3p_kernel<float, true, 3>), grid, dim3(512), 0, s, e); break;
-            case 8: prof_set_kernel("linear_x3p_kernel<float, true, noMFMA>", "", ""); hipLaunchKernelGGL((linear_x3p_kernel<float, true, 8>), grid, dim3(512), 0, s, e); break;
-            default:
-                if (var == 1) { prof_set_kernel("linear_x3p_kernel<float, true, var1>", "", ""); hipLaunchKernelGGL((linear_x3p_kernel<float, true, 0, 1>), grid, dim3(512), 0, s, e); }
-                else if (var == 2) { prof_set_kernel("linear_x3p_kernel<float, true, var2>", "", ""); hipLaunchKernelGGL((linear_x3p_kernel<float, true, 0, 2>), grid, dim3(512), 0, s, e); }
-                else if (var == 3) { prof_set_kernel("linear_x3p_kernel<float, true, var3>", "", ""); hipLaunchKernelGGL((linear_x3p_kernel<float, true, 0, 3>), grid, dim3(512), 0, s, e); }
-                else { prof_set_kernel("linear_x3p_kernel<float, true>", "", ""); hipLaunchKernelGGL((linear_x3p_kernel<float, true>), grid, dim3(512), 0, s, e); }
-                break;
+#if defined(MI355TTS_TUNING)
+        switch (e.dbg & 27) {       // tuning instantiations (build.py --tuning, MI355TTS_GEMM_DBG)
+            case 1: prof_set_kernel("linear_x3p_kernel<float, true, noDMA>", "", ""); hipLaunchKernelGGL((linear_x3p_kernel<float, true, 1>), grid, dim3(512), 0, s, e); MI_HIP(hipGetLastError()); return;
+            case 2: prof_set_kernel("linear_x3p_kernel<float, true, noLDSread>", "", ""); hipLaunchKernelGGL((linear_x3p_kernel<float, true, 2>), grid, dim3(512), 0, s, e); MI_HIP(hipGetLastError()); return;
+            case 3: prof_set_kernel("linear_x3p_kernel<float, true, noDMA noLDSread>", "", ""); hipLaunchKernelGGL((linear_x3p_kernel<float, true, 3>), grid, dim3(512), 0, s, e); MI_HIP(hipGetLastError()); return;
+            case 8: prof_set_kernel("linear_x3p_kernel<float, true, noMFMA>", "", ""); hipLaunchKernelGGL((linear_x3p_kernel<float, true, 8>), grid, dim3(512), 0, s, e); MI_HIP(hipGetLastError()); return;
+            case 16: prof_set_kernel("linear_x3p_kernel<float, true, MFMA on real operands only>", "", ""); hipLaunchKernelGGL((linear_x3p_kernel<float, true, 16>), grid, dim3(512), 0, s, e); MI_HIP(hipGetLastError()); return;
+            default: break;
         }
+#endif
+        prof_set_kernel("linear_x3p_kernel<float, true>", "", "");
+        hipLaunchKernelGGL((linear_x3p_kernel<float, true>), grid, dim3(512), 0, s, e);
     } else {
         prof_set_kernel("linear_x3p_kernel<float, false>", "", "");
         hipLaunchKernelGGL((linear_x3p_kernel<float, false>), grid, dim3(512), 0, s, e);

@@ -88,6 +88,9 @@ def load() -> C.CDLL:
     L.mi_f5_synthesize.argtypes = [vp, C.c_int, vp, C.c_int64, vp, C.c_int64, C.c_int64, vp, C.c_uint64, vp, i64p,
                                    C.c_int]
     L.mi_f5_synthesize.restype = C.c_int
+    L.mi_f5_synthesize_mel.argtypes = [vp, C.c_int, vp, C.c_int64, vp, C.c_int64, C.c_int64, vp, C.c_uint64, vp, i64p,
+                                       C.c_int]
+    L.mi_f5_synthesize_mel.restype = C.c_int
     L.mi_gpt_param_count.argtypes = [C.POINTER(C.c_int32), C.c_int]; L.mi_gpt_param_count.restype = C.c_int64
     L.mi_gpt_create.argtypes = [C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_float), C.c_int64, C.c_int, C.c_int]
     L.mi_gpt_create.restype = C.c_void_p

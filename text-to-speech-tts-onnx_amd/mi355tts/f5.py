@@ -206,6 +206,52 @@ class F5Engine:
         assert ln.value == n
         return out
 
+    def synthesize_mel(self, audio, text_ids, max_duration, noise=None, seed: int = 9527):
+        """A -> loop, generated frames as a vocoder mel: float32 (U, 100, N - R), channels first — what
+        ``BigVGANVocoder.run`` takes (the "F5-TTS + BigVGAN" pipeline; see include/mi355tts.h mi_f5_synthesize_mel)."""
+        cfg = self.cfg
+        audio = np.ascontiguousarray(np.atleast_2d(np.asarray(audio)))
+        if audio.dtype != np.int16:
+            raise ValueError("audio must be int16")
+        text_ids = np.ascontiguousarray(np.atleast_2d(np.asarray(text_ids)), dtype=np.int32)
+        U, Ln = audio.shape
+        if text_ids.shape[0] != U:
+            raise ValueError("audio / text_ids batch mismatch")
+        N = int(max_duration)
+        F = N - (Ln // cfg.hop_length + 1)
+        if F < 1:
+            raise ValueError("max_duration leaves no generated frames")
+        if noise is not None:
+            noise = np.ascontiguousarray(noise, dtype=np.float32).reshape(U, N, cfg.mel_dim)
+        mel = np.empty((U, cfg.mel_dim, F), np.float32)
+        nf = C.c_int64(0)
+        _lib.check(_lib.load().mi_f5_synthesize_mel(self._h, U, audio.ctypes.data, Ln, text_ids.ctypes.data, text_ids.shape[1],
+                                                    N, _p(noise), seed, mel.ctypes.data, C.byref(nf), _lib.MI_HOST),
+                   "mi_f5_synthesize_mel")
+        assert nf.value == F
+        return mel
+
+    def synthesize_mel_torch(self, audio, text_ids, max_duration, noise=None, seed: int = 9527, out=None):
+        """Device-resident variant of synthesize_mel: CUDA tensors in, float32 (U, 100, N - R) CUDA tensor out."""
+        import torch
+        cfg = self.cfg
+        U, Ln = audio.shape
+        N = int(max_duration)
+        F = N - (Ln // cfg.hop_length + 1)
+        if out is None:
+            out = torch.empty((U, cfg.mel_dim, F), dtype=torch.float32, device=audio.device)
+        assert audio.is_cuda and audio.dtype == torch.int16 and audio.is_contiguous()
+        assert text_ids.is_cuda and text_ids.dtype == torch.int32 and text_ids.is_contiguous()
+        assert out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == (U, cfg.mel_dim, F)
+        if noise is not None:
+            assert noise.is_cuda and noise.dtype == torch.float32 and noise.is_contiguous()
+        torch.cuda.current_stream(audio.device).synchronize()
+        nf = C.c_int64(0)
+        _lib.check(_lib.load().mi_f5_synthesize_mel(self._h, U, audio.data_ptr(), Ln, text_ids.data_ptr(), text_ids.shape[1], N,
+                                                    None if noise is None else noise.data_ptr(), seed, out.data_ptr(),
+                                                    C.byref(nf), _lib.MI_DEVICE), "mi_f5_synthesize_mel")
+        return out
+
     def synthesize_torch(self, audio, text_ids, max_duration, noise=None, seed: int = 9527, out=None):
         """Device-resident variant: torch int16 (U,L) / int32 (U,T) / float32 (U,N,100) CUDA tensors."""
         import torch
