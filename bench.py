@@ -314,8 +314,8 @@ class F5Bench:
         gemm_like = [k for k in kernels if k["family"] in ("conv_gemm", "attn")]
         note = ("HIP events on the engine's stream around every launch, one separate eager pass after the timed region (the timed "
                 "region replays a hipGraph; events cannot be recorded into it); flops = 2*M*N*K of the launch")
-        if gemm_like and "linear_x3_kernel" in gemm_like[0]["kernel"]:
-            # fp32 products formed as six exact bf16 x bf16 partial products (gemm_x3.hip): the kernel runs on the bf16 pipes,
+        if gemm_like and ("linear_x3_kernel" in gemm_like[0]["kernel"] or "linear_x3p_kernel" in gemm_like[0]["kernel"]):
+            # fp32 products formed as six exact bf16 x bf16 partial products (gemm_x3p.hip / gemm_x3.hip): the kernel runs on the bf16 pipes,
             # so its ceiling is the dense bf16 MFMA peak / 6 in fp32-equivalent flops, not the fp32 MFMA peak
             peak = MFMA_F16_PEAK_TF / 6.0
             note += ("; this kernel computes every fp32 product as 6 bf16 MFMA partial products (3-way exact operand split, fp32 "
@@ -392,7 +392,7 @@ def run_f5(args, world, rank, local, dev, dist, torch):
         args.no_secondary = args.no_cpu_baseline = True
     if world == 1 and not args.no_secondary:
         if not (args.dtype == "bf16" and args.batch == 8):
-            r2, _ = fb.measure("bf16", 8, 2, 2)
+            r2, _ = fb.measure("bf16", 8, 10, 2)
             r2["workload"] = f5_workload_name("bf16", 8, N)
             secondary["f5_bf16_u8"] = r2
         if args.dtype == "f32":
@@ -402,7 +402,7 @@ def run_f5(args, world, rank, local, dev, dist, torch):
             _lib.set_option("gemm_f32_x3", 0)
             _lib.set_option("attn_f32_x3", 0)
             try:
-                r3, _ = fb.measure("f32", args.batch, 2, 2)
+                r3, _ = fb.measure("f32", args.batch, 5, 2)
             finally:
                 _lib.set_option("gemm_f32_x3", 1)
                 _lib.set_option("attn_f32_x3", 2)
@@ -425,7 +425,7 @@ def run_f5(args, world, rank, local, dev, dist, torch):
                    "weights": "synthetic seeded (337 M DiT + 13.5 M Vocos params)", "weight_bcast_ms": fb.bcast_ms,
                    "collective_backend": dist.get_backend() if world > 1 else None,
                    "arithmetic": ("fp32 values, fp32 accumulation; the DiT linear layers and both products of attention form each fp32 "
-                                  "product as six exact bf16 x bf16 partial products (3-way operand split, gemm_x3.hip) — same fp32 parity "
+                                  "product as six exact bf16 x bf16 partial products (3-way operand split, gemm_x3p.hip) — same fp32 parity "
                                   "gates as the native fp32 MFMA path, which is timed in secondary.f5_f32_native_mfma") if args.dtype == "f32" else "16-bit operands, fp32 accumulation, fp32 residual stream",
                    "end_to_end_TFLOP_per_step": res["end_to_end_TFLOP_per_step"],
                    "end_to_end_TFLOP_per_s": res["end_to_end_TFLOP_per_s"],
