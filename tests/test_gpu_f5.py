@@ -382,6 +382,28 @@ def _full_size_fp32_body(full, gfull, native):
           f"31-step state rel {e_loop:.2e}, waveform rms {err:.2e}")
 
 
+def test_full_size_fp32_fused_producers_are_bit_neutral(full):
+    """Round 3 moved the three-way bf16 split of the fp32 operands out of the consumers into their producers (rownorm /
+    attention / FF1 epilogue write the next GEMM's panel planes, the QKV epilogue writes K and V^T as planes for attention).
+    The split is a function of the fp32 value alone, so WHERE it happens must not change a bit: K / V planes on vs off give
+    identical DiT evaluations (one and three utterances: both attention tilings)."""
+    from mi355tts import _lib
+    cfg, raw, audio, ids, N, noise = full
+    eng = F5Engine(cfg, raw, dtype="f32")
+    try:
+        for U in (1, 3):
+            o = [eng.preprocess(audio[u].reshape(1, 1, -1), ids[u].reshape(1, -1), np.array([N]), noise=noise[u]) for u in range(U)]
+            cmt = np.concatenate([x["cat_mel_text"] for x in o]); cmtd = np.concatenate([x["cat_mel_text_drop"] for x in o])
+            a = eng.dit_eval(noise[:U], cmt, cmtd, 5)
+            _lib.set_option("attn_kv_planes", 0)
+            b = eng.dit_eval(noise[:U], cmt, cmtd, 5)
+            _lib.set_option("attn_kv_planes", 1)
+            assert np.array_equal(a, b), (U, np.abs(a - b).max())
+    finally:
+        _lib.set_option("attn_kv_planes", 1)
+        eng.close()
+
+
 @pytest.mark.parametrize("dtype,gate", [("bf16", 3e-2), ("f16", 1e-2)])
 def test_full_size_lowp_u8_against_reference_fixture(full, gfull, dtype, gate):
     """configs[3] shard: 8 utterances per GPU in one batch, 16-bit DiT operands.  Utterance 0 is the reference fixture's

@@ -412,7 +412,12 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const T* __restrict__ q, c
 // workgroup, the probabilities per tile.  Per 32x32 tile: 24 + 24 v_mfma_f32_32x32x16_bf16 (1536 matrix-core cycles)
 // against 32 + 32 v_mfma_f32_32x32x2_f32 (4096).  SPLIT2 / key slices / merge: as attn_kernel.
 // ---------------------------------------------------------------------------------------------------------------------
-template <bool SPLIT2>
+// KVP: K and V^T arrive ALREADY split, as the three bf16 planes the QKV epilogue wrote (k = [bh][3][kld][64] bf16,
+// v = [bh][3][64][vld] bf16, kld = vld = N rounded up to the 64-key stage): a stage is 12 16-byte loads per thread copied to
+// LDS as they are, instead of 8 float4 loads + 176 VALU of splitting per thread and stage — work that every one of the
+// N / 64 query tiles of a head repeated on the same K / V values (with the key-split 64-query workgroups a wave multiplies
+// ONE 32x32 tile per stage: the stage split was as many VALU cycles as the tile's softmax and P split together).
+template <bool SPLIT2, bool KVP = false>
 __global__ __launch_bounds__(256, 2) void attn_x3f_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                        const float* __restrict__ v, float* __restrict__ o, int H, int N,
                                                        float* __restrict__ ws, int* __restrict__ cnt,
@@ -434,8 +439,10 @@ __global__ __launch_bounds__(256, 2) void attn_x3f_kernel(const float* __restric
     const int q0 = SPLIT2 ? blockIdx.x * 64 + (wave >> 1) * 32 : blockIdx.x * 128 + wave * 32;
     const float* qb = q + (long)bh * N * D;
     const float* kb = k + (long)bh * N * D;
-    const long vld = (long)((N + 7) / 8 * 8);
+    const long vld = KVP ? (long)((N + 63) / 64 * 64) : (long)((N + 7) / 8 * 8);
     const float* vb = v + (long)bh * D * vld;
+    const bf16* kpb = reinterpret_cast<const bf16*>(k) + (long)bh * 3 * vld * D;      // KVP: planes [3][kld][64], kld = vld
+    const bf16* vpb = reinterpret_cast<const bf16*>(v) + (long)bh * 3 * D * vld;      // KVP: planes [3][64][vld]
 
     auto split4 = [&](const float4 a, uint2& w1, uint2& w2, uint2& w3) __attribute__((always_inline)) {
         x3_split_pair(a.x, a.y, w1.x, w2.x, w3.x);
@@ -468,8 +475,19 @@ __global__ __launch_bounds__(256, 2) void attn_x3f_kernel(const float* __restric
     }
 
     // ---- stage loads: 64 keys x 64 d of K (rows = keys) and of V^T (rows = d), four float4 per thread each ----------------
-    float4 kreg[4], vreg[4];
+    float4 kreg[KVP ? 1 : 4], vreg[KVP ? 1 : 4];
+    x3_u4 kpl[KVP ? 6 : 1], vpl[KVP ? 6 : 1];
     auto load_regs = [&](int key0) {
+        if constexpr (KVP) {
+            // unit u = tid + 256 i: plane u / 512 ; K: key (u % 512) / 8, 8 d's ; V^T: d (u % 512) / 8, 8 keys.  Rows past N are
+            // inside the padded planes (K: any finite-or-not value, masked below; V: zero since allocation)
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int u = tid + i * 256, pl = u >> 9, r = (u & 511) >> 3, c = u & 7;
+                kpl[i] = *reinterpret_cast<const x3_u4*>(kpb + ((long)pl * vld + key0 + r) * D + c * 8);
+                vpl[i] = *reinterpret_cast<const x3_u4*>(vpb + ((long)pl * D + r) * vld + key0 + c * 8);
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int vi = tid + i * 256;
@@ -480,8 +498,18 @@ __global__ __launch_bounds__(256, 2) void attn_x3f_kernel(const float* __restric
             if (key0 + kv * 4 < N) b = *reinterpret_cast<const float4*>(vb + (long)d * vld + key0 + kv * 4);
             kreg[i] = a; vreg[i] = b;
         }
+        }
     };
     auto store_lds = [&]() {
+        if constexpr (KVP) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int u = tid + i * 256, pl = u >> 9, r = (u & 511) >> 3, c = u & 7;
+                *reinterpret_cast<x3_u4*>(Ks + pl * KPL + r * LDK + c * 8) = kpl[i];                 // 144-byte rows: 16-byte aligned
+                uint2* vd = reinterpret_cast<uint2*>(Vs + pl * VPL + r * LDV + c * 8);                // 136-byte rows: 8-byte aligned
+                vd[0] = uint2{vpl[i].x, vpl[i].y}; vd[1] = uint2{vpl[i].z, vpl[i].w};
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int vi = tid + i * 256;
@@ -495,6 +523,7 @@ __global__ __launch_bounds__(256, 2) void attn_x3f_kernel(const float* __restric
             *reinterpret_cast<uint2*>(Vs + r * LDV + c * 4) = w1;
             *reinterpret_cast<uint2*>(Vs + VPL + r * LDV + c * 4) = w2;
             *reinterpret_cast<uint2*>(Vs + 2 * VPL + r * LDV + c * 4) = w3;
+        }
         }
     };
 
@@ -745,6 +774,7 @@ __global__ __launch_bounds__(256, 2) void attn_x3f_kernel(const float* __restric
 static int g_attn_x3 = 2;
 static int g_attn_split = 1;                             // 64-query workgroups with the keys split between wave pairs when the grid is small
 static int g_attn_zmax = 4, g_attn_z16 = 1, g_attn_zforce = 0;      // zforce (tests): exactly that many slices, even empty ones
+static int g_attn_kvp = 1;                               // fp32, both products split: K / V^T pre-split by the QKV epilogue (A/B: attn_kv_planes)
 // The MI355TTS_ATTN_* environment overrides are read ONCE, before the first use of any of the globals above by ANY of the
 // three entry points: F5::dit_eval asks attention_v_ld() for the V layout of the QKV epilogue before the first
 // launch_attention() of the process, and a lazy read inside launch_attention() made that first block write V transposed
@@ -756,6 +786,7 @@ static void attn_env_once() {
         if (const char* z = std::getenv("MI355TTS_ATTN_Z")) g_attn_zmax = std::max(1, std::min(4, std::atoi(z)));
         if (const char* z = std::getenv("MI355TTS_ATTN_X3")) g_attn_x3 = std::max(0, std::min(2, std::atoi(z)));
         if (const char* z = std::getenv("MI355TTS_ATTN_Z16")) g_attn_z16 = std::max(1, std::min(4, std::atoi(z)));
+        if (const char* z = std::getenv("MI355TTS_ATTN_KVP")) g_attn_kvp = std::atoi(z) != 0;
     });
 }
 long attention_v_ld(int N, int dtype) {
@@ -769,9 +800,16 @@ bool attn_set_option(const char* key, long v) {
     else if (k == "attn_z16_max") g_attn_z16 = (int)std::max(1L, std::min(4L, v));
     else if (k == "attn_f32_x3") g_attn_x3 = (int)std::max(0L, std::min(2L, v));
     else if (k == "attn_split") g_attn_split = v != 0;
+    else if (k == "attn_kv_planes") g_attn_kvp = v != 0;
     else if (k == "attn_z_force") g_attn_zforce = (int)std::max(0L, std::min(4L, v));
     else return false;
     return true;
+}
+
+bool attention_takes_kv_planes(int N, int BH, int dtype) {
+    attn_env_once();
+    (void)N; (void)BH;
+    return dtype == MI_F32 && g_attn_x3 == 2 && g_attn_kvp != 0;
 }
 
 bool attention_can_write_planes(int N, int BH, int dtype) {
@@ -781,8 +819,9 @@ bool attention_can_write_planes(int N, int BH, int dtype) {
 }
 
 void launch_attention(const void* q, const void* k, const void* v, void* o, int BH, int H, int N, int dtype, hipStream_t s,
-                      float* ws, long ws_floats, int* cnt, long cnt_n, void* o_planes) {
+                      float* ws, long ws_floats, int* cnt, long cnt_n, void* o_planes, int kv_planes) {
     MI_REQUIRE(!o_planes || attention_can_write_planes(N, BH, dtype), "attention: panel-plane output needs the fp32 split kernel");
+    MI_REQUIRE(!kv_planes || attention_can_write_planes(N, BH, dtype), "attention: pre-split K / V need the fp32 split kernel");
     MI_REQUIRE(BH % H == 0 && N > 0, "attention: bad shape");
     const double esz = (double)dtype_size(dtype);
     ProfScope ps(FAM_ATTN, s, 4.0 * BH * N * 64.0 * esz, 4.0 * BH * (double)N * N * 64.0);
@@ -825,16 +864,26 @@ void launch_attention(const void* q, const void* k, const void* v, void* o, int 
             // ... and cut the key range into Z slices when that evens out the workgroups per CU
             const int Z = pick_z(1);
             if (g_attn_x3 == 2) {
+                if (kv_planes) {
+                    prof_set_kernel("attn_x3f_kernel<true, pre-split K V>", "", "");
+                    hipLaunchKernelGGL((attn_x3f_kernel<true, true>), dim3((N + 63) / 64, BH, Z), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt, (unsigned char*)o_planes);
+                } else {
                 prof_set_kernel("attn_x3f_kernel<true>", "", "");
                 hipLaunchKernelGGL((attn_x3f_kernel<true>), dim3((N + 63) / 64, BH, Z), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt, (unsigned char*)o_planes);
+                }
             } else if (g_attn_x3 == 1) {
                 prof_set_kernel("attn_kernel<float, true, x3>", "", "");
                 hipLaunchKernelGGL((attn_kernel<float, true, true>), dim3((N + 63) / 64, BH, Z), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt);
             } else
                 ATTN_LAUNCH(float, true, dim3((N + 63) / 64, BH, Z), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt);
         } else if (g_attn_x3 == 2) {
+            if (kv_planes) {
+                prof_set_kernel("attn_x3f_kernel<false, pre-split K V>", "", "");
+                hipLaunchKernelGGL((attn_x3f_kernel<false, true>), dim3((N + 127) / 128, BH), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt, (unsigned char*)o_planes);
+            } else {
             prof_set_kernel("attn_x3f_kernel<false>", "", "");
             hipLaunchKernelGGL((attn_x3f_kernel<false>), dim3((N + 127) / 128, BH), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt, (unsigned char*)o_planes);
+            }
         } else if (g_attn_x3 == 1) {
             prof_set_kernel("attn_kernel<float, false, x3>", "", "");
             hipLaunchKernelGGL((attn_kernel<float, false, true>), dim3((N + 127) / 128, BH), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt);

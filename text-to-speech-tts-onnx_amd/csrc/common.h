@@ -159,6 +159,9 @@ struct ConvGemm {
     void* out2 = nullptr; void* out3 = nullptr;
     int rows_per_item = 0;        // EPI_QKV_ROPE with the batch flattened into M: tokens per batch item (0: M)
     long v_ld = 0;                // > 0: V is written transposed, [b*H + h][head_dim][v_ld] (keys contiguous)
+    // fp32 + LDS-staged QKV epilogue only: K and V^T leave as the three bf16 planes of x3_split.h (the attention kernel then
+    // stages them without splitting): out2 = [b*H + h][3][k_ld][64], out3 = [b*H + h][3][64][v_ld]; q stays fp32
+    int kv_planes = 0; long k_ld = 0;
     // stream-K workspace of the caller (gemm_sk.hip): sk_slots x 64 KB of partial tiles + sk_slots zero-initialised flags;
     // null: plain linear layers run one tile per workgroup
     float* sk_ws = nullptr; int* sk_flags = nullptr; int sk_slots = 0;

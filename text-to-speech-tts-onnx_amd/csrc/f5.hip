@@ -354,10 +354,15 @@ void F5::ensure_workspace(int U, int N) {
     cat.ensure(rows * c.cat_dim() * es);
     h32.ensure(rows * c.dim * 4); hT.ensure(rows * c.dim * es); c1.ensure(rows * c.dim * es);
     X.ensure(rows * c.dim * 4); Ub.ensure(rows * c.dim * es);
-    qb.ensure(rows * c.dim * es); kb.ensure(rows * c.dim * es); Ob.ensure(rows * c.dim * es);
+    qb.ensure(rows * c.dim * es); Ob.ensure(rows * c.dim * es);
     {   // V may be stored transposed with the key axis padded to a multiple of 8; the pad columns are read (and
-        // multiplied by exactly-zero probabilities), so they must hold finite values: zero the buffer once
-        const size_t vbytes = (size_t)2 * Um * (size_t)(Nm + 8) * c.dim * es;
+        // multiplied by exactly-zero probabilities), so they must hold finite values: zero the buffer once.
+        // fp32 engines: K and V^T may be kept as three bf16 planes with the key axis padded to the 64-key stage
+        // (ConvGemm::kv_planes, attention.hip KVP): 6 bytes per element instead of 4
+        const size_t keypad = (size_t)(Nm + 63) / 64 * 64;
+        size_t kbytes = rows * c.dim * es, vbytes = (size_t)2 * Um * (size_t)(Nm + 8) * c.dim * es;
+        if (dtype == MI_F32) { kbytes = std::max(kbytes, (size_t)2 * Um * keypad * c.dim * 6); vbytes = std::max(vbytes, (size_t)2 * Um * keypad * c.dim * 6); }
+        if (kbytes > kb.bytes) { kb.ensure(kbytes); MI_HIP(hipMemsetAsync(kb.p, 0, kbytes, stream)); }
         if (vbytes > vb.bytes) { vb.ensure(vbytes); MI_HIP(hipMemsetAsync(vb.p, 0, vbytes, stream)); }
     }
     Hff.ensure(rows * c.ff() * es);
@@ -566,6 +571,7 @@ void F5::dit_eval(int U, int N, int k) {
     for (int i = 0; i < c.depth; ++i) {
         const Block& bk = blocks[i];
         const float* m = modk + (size_t)i * 6 * d;       // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
+        bool kvp = false;                                // this block's K / V^T leave the QKV epilogue as bf16 planes
         {
             ConvGemm g;
             g.dtype = dtype; g.x = Ub.p; g.w = bk.qkv.w.p; g.w3 = bk.qkv.w3.p; g.bias = bk.qkv.b.as<float>();
@@ -581,6 +587,9 @@ void F5::dit_eval(int U, int N, int k) {
                 fused = gemm_x3p_would_run(g);
                 if (!fused) { g.xp = nullptr; g.w3p = nullptr; }
             }
+            // K and V^T pre-split for the attention kernel (only the LDS-staged fp32 QKV epilogue of the panel-plane GEMM writes them)
+            kvp = fused && attention_takes_kv_planes(N, B * H, dtype);
+            if (kvp) { g.kv_planes = 1; g.k_ld = g.v_ld = (long)((N + 63) / 64 * 64); }
             // AdaLN: LN(x) * (1 + scale) + shift — straight into the panel planes the QKV GEMM reads, or as rows
             if (fused) launch_rownorm_x3p(X.as<float>(), Ap.p, m + d, m, rows, d, 1e-6f, s);
             else launch_rownorm(NORM_LN_MOD, X.as<float>(), Ub.p, dtype, m + d, m, rows, d, 1e-6f, s);
@@ -598,7 +607,7 @@ void F5::dit_eval(int U, int N, int k) {
                 fused = gemm_x3p_would_run(g);
             }
             launch_attention(qb.p, kb.p, vb.p, Ob.p, B * H, H, N, dtype, s, attn_ws.as<float>(), attn_ws_floats, attn_cnt.as<int>(), attn_cnt_n,
-                             fused ? Ap.p : nullptr);
+                             fused ? Ap.p : nullptr, kvp ? 1 : 0);
             gemm(dtype, Ob.p, (long)N * d, d, d, bk.o, X.p, MI_F32, (long)N * d, d, B, N, ACT_NONE, X.p, m + 2 * d, fused, Ap.p);
         }
         {

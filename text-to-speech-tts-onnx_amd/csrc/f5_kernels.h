@@ -33,7 +33,11 @@ void launch_cfg_update(float* noise, const float* pred, int U, int N, int M, flo
 // ws / cnt: optional workspace of the key-sliced fp32 kernel ((2*32*64 + 256) floats per 64-query tile and slice; one zeroed
 // counter per tile); without them every query tile is one workgroup
 void launch_attention(const void* q, const void* k, const void* v, void* o, int BH, int H, int N, int dtype, hipStream_t s,
-                      float* ws = nullptr, long ws_floats = 0, int* cnt = nullptr, long cnt_n = 0, void* o_planes = nullptr);
+                      float* ws = nullptr, long ws_floats = 0, int* cnt = nullptr, long cnt_n = 0, void* o_planes = nullptr,
+                      int kv_planes = 0);
+// kv_planes (fp32 engines, both products split): k and v are the pre-split bf16 planes the QKV epilogue wrote (ConvGemm::kv_planes:
+// k [BH][3][ld][64], v [BH][3][64][ld], ld = N rounded up to 64, pad keys of v zero) — ask attention_takes_kv_planes() first
+bool attention_takes_kv_planes(int N, int BH, int dtype);
 // o_planes (fp32 engines, both products split): the output as gemm_x3p.hip panel planes of the [B * N][H * 64] matrix instead
 // of rows in o — ask attention_can_write_planes() first
 bool attention_can_write_planes(int N, int BH, int dtype);

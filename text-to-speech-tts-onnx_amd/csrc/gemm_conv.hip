@@ -721,6 +721,7 @@ void launch_conv_gemm(const ConvGemm& p_in, hipStream_t s) {
     d.u = p.u; d.Cout = p.Cout; d.padT = p.padT; d.T_out = p.T_out;
     d.rope_cos = p.rope_cos; d.rope_sin = p.rope_sin; d.rope_pack = p.rope_pack; d.heads = p.heads; d.head_dim = p.head_dim;
     d.out2 = p.out2; d.out3 = p.out3; d.v_ld = p.v_ld; d.Mb = p.rows_per_item;
+    d.kv_planes = p.kv_planes; d.k_ld = p.k_ld;
     d.sk_ws = p.sk_ws; d.sk_flags = p.sk_flags; d.sk_slots = p.sk_slots;
     const bool use_x3p = x3p_eligible(p);
     const bool use_x3 = use_x3p || x3_eligible(p);
@@ -804,6 +805,8 @@ void launch_conv_gemm(const ConvGemm& p_in, hipStream_t s) {
                     p.out_bstride % ch == 0 && ((uintptr_t)p.out % 16) == 0 && (!p.res || ((uintptr_t)p.res % 16) == 0) &&
                     (p.epi != EPI_CONVT || p.Cout % ch == 0);
     }
+    if (p.kv_planes) MI_REQUIRE(p.epi == EPI_QKV_ROPE && p.dtype == MI_F32 && d.lds_epi && p.v_ld > 0 && p.k_ld > 0 && p.v_ld % 8 == 0,
+                                "conv_gemm: kv_planes needs the fp32 LDS-staged QKV epilogue with transposed V");
     if (p.epi == EPI_CONVT) MI_REQUIRE(p.Cout > 0 && p.N == p.u * p.Cout, "conv_gemm: convT shape");
     if (p.epi == EPI_QKV_ROPE)
         MI_REQUIRE((p.rows_per_item == 0 || p.rows_per_item >= 32) && p.G == 1 && p.heads > 0 && p.head_dim % 2 == 0 && p.N == 3 * p.heads * p.head_dim && p.N % 32 == 0 &&

@@ -3,6 +3,7 @@
 #pragma once
 #include "common.h"
 #include "mfma.h"
+#include "x3_split.h"
 
 namespace mi {
 
@@ -40,6 +41,7 @@ struct ConvGemmDev {
     const void* w3;                              // gemm_x3.hip: weight planes [3][N][K] bf16 (null: not available)
     const void* xp; const void* w3p;             // gemm_x3p.hip: A and B as panel planes (null: not available)
     void* out_planes;                            // gemm_x3p.hip: output as panel planes of an [M][N] matrix (null: rows in `out`)
+    int kv_planes; long k_ld;                    // EPI_QKV_ROPE, fp32: K and V^T leave as three bf16 planes (attention.hip KVP): out2 = [bh][3][k_ld][64], out3 = [bh][3][64][v_ld]
     int tail_tiles, tail_split;                  // gemm_ph8.hip: the last tail_tiles tiles are cut into tail_split K slices (0 / 1: none)
 };
 
@@ -373,6 +375,20 @@ __device__ __forceinline__ void gemm_epilogue_qkv_lds(f32x16 (&acc)[TMQ][2], con
                         x[q + 1] = o * c[q + 1] + e * sn[q + 1];
                     }
                 }
+                if constexpr (sizeof(TO) == 4) if (p.kv_planes && which == 1) {
+                    // K for the fp32 attention kernel with pre-split operands: the three bf16 pieces of the row's eight values,
+                    // one 16-byte store per plane ([bh][plane][key][64])
+                    unsigned p1[4], p2[4], p3[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) x3_split_pair(x[2 * q], x[2 * q + 1], p1[q], p2[q], p3[q]);
+                    bf16* kp = (bf16*)p.out2 + ((((long)b + biv[gi]) * p.heads + hh) * 3 * p.k_ld + mv[gi]) * 64 + c8;
+                    if (okv[gi]) {
+                        *reinterpret_cast<x3_u4*>(kp) = x3_u4{p1[0], p1[1], p1[2], p1[3]};
+                        *reinterpret_cast<x3_u4*>(kp + p.k_ld * 64) = x3_u4{p2[0], p2[1], p2[2], p2[3]};
+                        *reinterpret_cast<x3_u4*>(kp + 2 * p.k_ld * 64) = x3_u4{p3[0], p3[1], p3[2], p3[3]};
+                    }
+                    continue;
+                }
                 Pk o8;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) o8.v[q] = from_f32<TO>(x[q]);
@@ -399,6 +415,22 @@ __device__ __forceinline__ void gemm_epilogue_qkv_lds(f32x16 (&acc)[TMQ][2], con
             int m = mloc0 + rr, bi = bi0;
             if (m >= Mb) { m -= Mb; ++bi; }
             TO* dst = base + (((long)b + bi) * p.heads + hh) * 64 * p.v_ld + m;
+            if (sizeof(TO) == 4 && p.kv_planes) {   // (fp32 instantiations only reach this with kv_planes set)
+                // V^T as three bf16 planes [bh][plane][d][v_ld]: 2-byte stores, 32 consecutive keys per instruction
+                unsigned short* vp = (unsigned short*)p.out3 + (((long)b + bi) * p.heads + hh) * 3 * 64 * p.v_ld + m;
+                const long pstride = 64 * p.v_ld;
+#pragma unroll 8
+                for (int d = 0; d < 32; ++d) {
+                    const int dd = dh * 32 + d;
+                    unsigned p1, p2, p3;
+                    x3_split_pair(stage[row * 65 + dd], 0.f, p1, p2, p3);
+                    if (ok) {
+                        vp[(long)dd * p.v_ld] = (unsigned short)p1;
+                        vp[pstride + (long)dd * p.v_ld] = (unsigned short)p2;
+                        vp[2 * pstride + (long)dd * p.v_ld] = (unsigned short)p3;
+                    }
+                }
+            } else
 #pragma unroll 8
             for (int d = 0; d < 32; ++d) {
                 const int dd = dh * 32 + d;
