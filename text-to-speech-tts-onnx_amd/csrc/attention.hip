@@ -487,6 +487,20 @@ __global__ __launch_bounds__(256, 2) void attn_x3f_kernel(const float* __restric
                 kpl[i] = *reinterpret_cast<const x3_u4*>(kpb + ((long)pl * vld + key0 + r) * D + c * 8);
                 vpl[i] = *reinterpret_cast<const x3_u4*>(vpb + ((long)pl * D + r) * vld + key0 + c * 8);
             }
+            if (key0 + KT > N) {
+                // last stage: the V^T values of keys >= N meet probabilities that are exactly zero, but 0 x NaN is NaN and
+                // the pad columns hold whatever the buffer held before (another layout, another mode): clear them here
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const int keep = N - (key0 + ((tid + i * 256) & 7) * 8);          // valid keys among this unit's eight
+                    if (keep < 8) {
+                        unsigned w[4] = {vpl[i].x, vpl[i].y, vpl[i].z, vpl[i].w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) w[e] &= (2 * e < keep ? 0x0000ffffu : 0u) | (2 * e + 1 < keep ? 0xffff0000u : 0u);
+                        vpl[i] = x3_u4{w[0], w[1], w[2], w[3]};
+                    }
+                }
+            }
         } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {

@@ -430,12 +430,13 @@ __device__ __forceinline__ void gemm_epilogue_qkv_lds(f32x16 (&acc)[TMQ][2], con
                         vp[2 * pstride + (long)dd * p.v_ld] = (unsigned short)p3;
                     }
                 }
-            } else
+            } else {
 #pragma unroll 8
-            for (int d = 0; d < 32; ++d) {
-                const int dd = dh * 32 + d;
-                const float v = stage[row * 65 + dd];
-                if (ok) dst[(long)dd * p.v_ld] = from_f32<TO>(v);
+                for (int d = 0; d < 32; ++d) {
+                    const int dd = dh * 32 + d;
+                    const float v = stage[row * 65 + dd];
+                    if (ok) dst[(long)dd * p.v_ld] = from_f32<TO>(v);
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();

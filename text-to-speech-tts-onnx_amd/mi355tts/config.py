@@ -194,5 +194,86 @@ class IndexGPTConfig:
                               max_generate_length=40)
 
 
+@dataclass
+class IndexCondConfig:
+    """IndexTTS-1.5 graph A (IndexTTS/Export_IndexTTS.py:74-200): mel front end -> Conformer conditioning encoder -> Perceiver
+    resampler (conds_latent) and ECAPA-TDNN speaker encoder -> BigVGAN conditioning vectors.
+
+    The architecture numbers live in the un-vendored IndexTTS ``config.yaml`` / ``indextts`` package (gpt.condition_module,
+    gpt.model_dim, bigvgan.speaker_embedding_dim ...); the defaults are the published IndexTTS-1.5 values — "parity
+    unpinned" for them, like the other un-vendored configs.  The export fixes n_fft / hop / mels / rate at
+    Export_IndexTTS.py:38-50 and the 0.1 s random ``audio_pad`` at :94."""
+    n_fft: int = 1024
+    hop: int = 256
+    n_mels: int = 100
+    sample_rate: int = 24000
+    audio_pad: int = 2400               # int(sample_rate * 0.1) samples of N(0,1) prepended to the prompt (:94, :133)
+    max_signal_len: int = 4096          # pos_enc.pe rows kept (:87)
+    # Conformer conditioning encoder (wenet-style, input_layer conv2d2, rel_pos attention, no macaron)
+    enc_dim: int = 512
+    enc_heads: int = 8
+    enc_linear: int = 2048
+    enc_blocks: int = 6
+    enc_kernel: int = 15
+    ln_eps: float = 1e-5
+    # Perceiver resampler
+    model_dim: int = 1280
+    latents: int = 32
+    perc_depth: int = 2
+    perc_heads: int = 8
+    perc_dim_head: int = 64
+    perc_mult: int = 2
+    # ECAPA-TDNN speaker encoder (speechbrain-style) inside the vocoder + the conditioning 1x1 convs
+    spk_channels: Tuple[int, ...] = (512, 512, 512, 512, 1536)
+    spk_kernels: Tuple[int, ...] = (5, 3, 3, 3, 1)
+    spk_dilations: Tuple[int, ...] = (1, 2, 3, 4, 1)
+    spk_att: int = 128
+    spk_res2net_scale: int = 8
+    spk_se: int = 128
+    spk_embed: int = 512
+    bn_eps: float = 1e-5
+    voc_initial: int = 1536             # bigvgan.cond_layer out channels (= upsample_initial_channel)
+    voc_channels: Tuple[int, ...] = (768, 384, 192, 96, 48, 24)     # bigvgan.conds[i] out channels
+
+    @property
+    def enc_dk(self) -> int:
+        return self.enc_dim // self.enc_heads
+
+    @property
+    def perc_inner(self) -> int:
+        return self.perc_heads * self.perc_dim_head
+
+    @property
+    def perc_ff(self) -> int:
+        return int(self.model_dim * self.perc_mult * 2 / 3)
+
+    @property
+    def sub_freq(self) -> int:          # mel bins left by the k3 s2 Conv2d
+        return (self.n_mels - 3) // 2 + 1
+
+    def frames(self, audio_len: int) -> int:
+        return (audio_len + self.audio_pad) // self.hop + 1
+
+    def enc_len(self, audio_len: int) -> int:
+        return (self.frames(audio_len) - 3) // 2 + 1
+
+    def to_int_array(self) -> List[int]:
+        a = [self.n_fft, self.hop, self.n_mels, self.sample_rate, self.audio_pad, self.max_signal_len, self.enc_dim, self.enc_heads,
+             self.enc_linear, self.enc_blocks, self.enc_kernel, self.model_dim, self.latents, self.perc_depth, self.perc_heads,
+             self.perc_dim_head, self.perc_mult, self.spk_att, self.spk_res2net_scale, self.spk_se, self.spk_embed, self.voc_initial,
+             len(self.spk_channels)]
+        a += list(self.spk_channels) + list(self.spk_kernels) + list(self.spk_dilations)
+        a += [len(self.voc_channels)] + list(self.voc_channels)
+        return a
+
+    @staticmethod
+    def small() -> "IndexCondConfig":
+        """Reduced model for the golden fixture (head dims stay 64 / 32)."""
+        return IndexCondConfig(audio_pad=300, max_signal_len=256, enc_dim=64, enc_heads=2, enc_linear=96, enc_blocks=2, enc_kernel=15,
+                               model_dim=128, latents=6, perc_depth=2, perc_heads=2, perc_dim_head=32, perc_mult=2,
+                               spk_channels=(32, 32, 32, 32, 96), spk_att=16, spk_res2net_scale=4, spk_se=8, spk_embed=24,
+                               voc_initial=32, voc_channels=(16, 8))
+
+
 def as_dict(cfg) -> dict:
     return asdict(cfg)
