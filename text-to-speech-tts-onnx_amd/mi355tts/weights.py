@@ -21,7 +21,7 @@ from typing import Dict, List, Tuple
 
 import numpy as np
 
-from .config import BigVGANConfig, F5Config, IndexGPTConfig
+from .config import IndexCondConfig, BigVGANConfig, F5Config, IndexGPTConfig
 
 Spec = List[Tuple[str, Tuple[int, ...], str]]   # (name, shape, kind)
 
@@ -138,6 +138,14 @@ def synth_tensor(seed: int, name: str, shape, kind: str, fast: bool = False) -> 
         return synth_normal(seed, name, shape, std=0.1, mean=1.0)
     if kind == "mod":        # AdaLN modulation linears (upstream zero-inits these: dit.py:156-166)
         return synth_normal(seed, name, shape, std=0.5 / math.sqrt(shape[1]))
+    if kind == "conv2d":     # (out, in, kh, kw)
+        return synth_normal(seed, name, shape, std=1.0 / math.sqrt(shape[1] * shape[2] * shape[3]))
+    if kind == "linear_res":  # last linear of a residual branch
+        return synth_normal(seed, name, shape, std=0.5 / math.sqrt(shape[1]))
+    if kind == "bias_big":   # position biases / BatchNorm running means: large enough to matter
+        return synth_normal(seed, name, shape, std=0.3)
+    if kind == "var":        # BatchNorm running variance: positive, around one
+        return (0.5 + np.abs(synth_normal(seed, name, shape, std=0.5))).astype(np.float32)
     if kind == "gamma":      # layer-scale / GRN gamma
         return synth_normal(seed, name, shape, std=0.1, mean=0.5)
     raise ValueError(kind)
@@ -326,6 +334,103 @@ def fold_gpt(cfg: IndexGPTConfig, state: Dict[str, np.ndarray]) -> "OrderedDict[
 def pack_gpt(cfg: IndexGPTConfig, state: Dict[str, np.ndarray]) -> np.ndarray:
     st = fold_gpt(cfg, state)
     return np.ascontiguousarray(np.concatenate([st[name].reshape(-1) for name, _, _ in gpt_spec(cfg)]))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# IndexTTS graph A: conditioning encoder + perceiver (indexTTS.gpt.*) and ECAPA speaker encoder + cond layers (indexTTS.bigvgan.*)
+# ---------------------------------------------------------------------------------------------------------------------
+def cond_spec(cfg: IndexCondConfig) -> Spec:
+    """Upstream-named state the export wrapper IndexTTS_A reads (IndexTTS/Export_IndexTTS.py:74-200): ``gpt.conditioning_encoder``
+    (wenet-style Conformer: Conv2dSubsampling2 + rel-pos blocks with a conv module), ``gpt.perceiver_encoder`` (lucidrains-style
+    PerceiverResampler) and ``bigvgan.speaker_encoder`` (speechbrain-style ECAPA-TDNN: wrapped Conv1d / BatchNorm1d modules,
+    hence the doubled ``conv.conv`` / ``norm.norm`` names) + ``bigvgan.cond_layer`` / ``bigvgan.conds``.  The sub-module
+    definitions are un-vendored (no source in the reference tree): names and shapes follow the published packages."""
+    d, h, lin, k = cfg.enc_dim, cfg.enc_heads, cfg.enc_linear, cfg.enc_kernel
+    s: Spec = [("audio_pad", (cfg.audio_pad,), "embed"),                    # the wrapper's torch.randn(0.1 s) constant (:94)
+               ("gpt.conditioning_encoder.embed.conv.0.weight", (d, 1, 3, 3), "conv2d"),
+               ("gpt.conditioning_encoder.embed.conv.0.bias", (d,), "bias"),
+               ("gpt.conditioning_encoder.embed.out.0.weight", (d, d * cfg.sub_freq), "linear"),
+               ("gpt.conditioning_encoder.embed.out.0.bias", (d,), "bias")]
+    for i in range(cfg.enc_blocks):
+        p = f"gpt.conditioning_encoder.encoders.{i}."
+        for n in ("norm_mha", "norm_conv", "norm_ff", "norm_final", "conv_module.norm"):
+            s += [(p + n + ".weight", (d,), "norm_w"), (p + n + ".bias", (d,), "bias")]
+        for n in ("linear_q", "linear_k", "linear_v", "linear_out"):
+            s += [(p + f"self_attn.{n}.weight", (d, d), "linear_res" if n == "linear_out" else "linear"), (p + f"self_attn.{n}.bias", (d,), "bias")]
+        s += [(p + "self_attn.linear_pos.weight", (d, d), "linear"),
+              (p + "self_attn.pos_bias_u", (h, cfg.enc_dk), "bias_big"), (p + "self_attn.pos_bias_v", (h, cfg.enc_dk), "bias_big"),
+              (p + "conv_module.pointwise_conv1.weight", (2 * d, d, 1), "conv"), (p + "conv_module.pointwise_conv1.bias", (2 * d,), "bias"),
+              (p + "conv_module.depthwise_conv.weight", (d, 1, k), "conv"), (p + "conv_module.depthwise_conv.bias", (d,), "bias"),
+              (p + "conv_module.pointwise_conv2.weight", (d, d, 1), "conv_res"), (p + "conv_module.pointwise_conv2.bias", (d,), "bias"),
+              (p + "feed_forward.w_1.weight", (lin, d), "linear"), (p + "feed_forward.w_1.bias", (lin,), "bias"),
+              (p + "feed_forward.w_2.weight", (d, lin), "linear_res"), (p + "feed_forward.w_2.bias", (d,), "bias")]
+    s += [("gpt.conditioning_encoder.after_norm.weight", (d,), "norm_w"), ("gpt.conditioning_encoder.after_norm.bias", (d,), "bias")]
+    D, inner, ffi = cfg.model_dim, cfg.perc_inner, cfg.perc_ff
+    s += [("gpt.perceiver_encoder.proj_context.weight", (D, d), "linear"), ("gpt.perceiver_encoder.proj_context.bias", (D,), "bias"),
+          ("gpt.perceiver_encoder.latents", (cfg.latents, D), "embed")]
+    for j in range(cfg.perc_depth):
+        p = f"gpt.perceiver_encoder.layers.{j}."
+        s += [(p + "0.to_q.weight", (inner, D), "linear"), (p + "0.to_kv.weight", (2 * inner, D), "linear"),
+              (p + "0.to_out.weight", (D, inner), "linear_res"),
+              (p + "1.0.weight", (2 * ffi, D), "linear"), (p + "1.0.bias", (2 * ffi,), "bias"),
+              (p + "1.2.weight", (D, ffi), "linear_res"), (p + "1.2.bias", (D,), "bias")]
+    s += [("gpt.perceiver_encoder.norm.gamma", (D,), "norm_w")]
+
+    def tdnn(prefix, cin, cout, kk):
+        return [(prefix + "conv.conv.weight", (cout, cin, kk), "conv"), (prefix + "conv.conv.bias", (cout,), "bias"),
+                (prefix + "norm.norm.weight", (cout,), "norm_w"), (prefix + "norm.norm.bias", (cout,), "bias"),
+                (prefix + "norm.norm.running_mean", (cout,), "bias_big"), (prefix + "norm.norm.running_var", (cout,), "var")]
+    ch, ks = cfg.spk_channels, cfg.spk_kernels
+    e = "bigvgan.speaker_encoder."
+    s += tdnn(e + "blocks.0.", cfg.n_mels, ch[0], ks[0])
+    for i in range(1, len(ch) - 1):
+        p = e + f"blocks.{i}."
+        c, sc = ch[i], cfg.spk_res2net_scale
+        s += tdnn(p + "tdnn1.", ch[i - 1], c, 1)
+        for r in range(sc - 1):
+            s += tdnn(p + f"res2net_block.blocks.{r}.", c // sc, c // sc, ks[i])
+        s += tdnn(p + "tdnn2.", c, c, 1)
+        s += [(p + "se_block.conv1.conv.weight", (cfg.spk_se, c, 1), "conv"), (p + "se_block.conv1.conv.bias", (cfg.spk_se,), "bias"),
+              (p + "se_block.conv2.conv.weight", (c, cfg.spk_se, 1), "conv"), (p + "se_block.conv2.conv.bias", (c,), "bias")]
+    cm = ch[-1]
+    s += tdnn(e + "mfa.", cm, cm, ks[-1])
+    s += tdnn(e + "asp.tdnn.", 3 * cm, cfg.spk_att, 1)
+    s += [(e + "asp.conv.conv.weight", (cm, cfg.spk_att, 1), "conv"), (e + "asp.conv.conv.bias", (cm,), "bias"),
+          (e + "asp_bn.norm.weight", (2 * cm,), "norm_w"), (e + "asp_bn.norm.bias", (2 * cm,), "bias"),
+          (e + "asp_bn.norm.running_mean", (2 * cm,), "bias_big"), (e + "asp_bn.norm.running_var", (2 * cm,), "var"),
+          (e + "fc.conv.weight", (cfg.spk_embed, 2 * cm, 1), "conv"), (e + "fc.conv.bias", (cfg.spk_embed,), "bias"),
+          ("bigvgan.cond_layer.weight", (cfg.voc_initial, cfg.spk_embed, 1), "conv"), ("bigvgan.cond_layer.bias", (cfg.voc_initial,), "bias")]
+    for i, c in enumerate(cfg.voc_channels):
+        s += [(f"bigvgan.conds.{i}.weight", (c, cfg.spk_embed, 1), "conv"), (f"bigvgan.conds.{i}.bias", (c,), "bias")]
+    return s
+
+
+def fold_cond(cfg: IndexCondConfig, state: Dict[str, np.ndarray]) -> "OrderedDict[str, np.ndarray]":
+    """Export-time folds of IndexTTS_A.__init__ (Export_IndexTTS.py:88-129) that change VALUES: embed.out weight and bias times
+    xscale = sqrt(enc_dim) (:88-89); per encoder layer linear_q / linear_k (weight, bias), linear_pos (weight) and
+    pos_bias_u / pos_bias_v times d_k**-0.25 (:97-104); perceiver to_q and the K half of to_kv times dim_head**-0.25 (:121-125).
+    The wrapper's per-head weight views (:106-129) only re-index the same numbers and are not applied here: the oracle and
+    the engine contract over the same (head, d) axes of the unsplit matrices."""
+    st = OrderedDict((k, np.array(v, dtype=np.float32, copy=True)) for k, v in state.items())
+    xs = np.float32(math.sqrt(cfg.enc_dim))
+    st["gpt.conditioning_encoder.embed.out.0.weight"] *= xs
+    st["gpt.conditioning_encoder.embed.out.0.bias"] *= xs
+    sc = np.float32(float(cfg.enc_dk) ** -0.25)
+    for i in range(cfg.enc_blocks):
+        p = f"gpt.conditioning_encoder.encoders.{i}.self_attn."
+        for n in ("linear_q.weight", "linear_q.bias", "linear_k.weight", "linear_k.bias", "linear_pos.weight", "pos_bias_u", "pos_bias_v"):
+            st[p + n] *= sc
+    ps = np.float32(float(cfg.perc_dim_head) ** -0.25)
+    for j in range(cfg.perc_depth):
+        p = f"gpt.perceiver_encoder.layers.{j}.0."
+        st[p + "to_q.weight"] *= ps
+        st[p + "to_kv.weight"][: cfg.perc_inner] *= ps
+    return st
+
+
+def pack_cond(cfg: IndexCondConfig, state: Dict[str, np.ndarray]) -> np.ndarray:
+    """cond_spec order, folded values: the blob mi_indextts_cond_create takes."""
+    return pack_state(cond_spec(cfg), fold_cond(cfg, state))
 
 
 def synth_vocab(n: int = 2545) -> Dict[str, int]:
