@@ -161,6 +161,7 @@ int         mi_f5_synthesize_mel(mi_f5* h, int U, const int16_t* audio, int64_t 
  * weights: canonical fp32 blob of mi355tts.weights.pack_gpt (Conv1D weights transposed to (out, in); q and k rows
  * pre-scaled by head_dim^-0.25 like Export_IndexTTS.py:257-258).                                                  */
 typedef struct mi_gpt mi_gpt;
+typedef struct mi_cond mi_cond;
 int64_t     mi_gpt_param_count(const int32_t* cfg, int n_cfg);
 mi_gpt*     mi_gpt_create(const int32_t* cfg, int n_cfg, const float* weights, int64_t n_weights, int dtype, int device);
 mi_gpt*     mi_gpt_create_mem(const int32_t* cfg, int n_cfg, const float* weights, int64_t n_weights, int dtype, int device,
@@ -222,6 +223,20 @@ int         mi_bench_conv_gemm(int dtype, int B, int T, int Cin, int N, int taps
  * "gemm_sk_qkv32"; "gemm_x3_wide" (wave layout 0 / 1 / 2), "gemm_x3_stages" (3 / 4), "gemm_x3_hybrid", "gemm_x3_qkv8";
  * "gemm_f32_n64_dma", "gemm_n64_dma16", "gemm_dma3_order"; "attn_z_max", "attn_z16_max", "attn_z_force" (key slices).
  * Changing an option invalidates the hipGraphs captured by existing handles.   */
+/* ---- IndexTTS graph A: prompt audio -> conditioning (cond.hip) -----------------------------------------------------------
+ * Replaces ort_session_A of IndexTTS/Inference_IndexTTS_ONNX.py:700-712 (graph definition: IndexTTS_A,
+ * IndexTTS/Export_IndexTTS.py:74-200): mel front end (0.1 s constant noise pad + 'constant'-padded STFT + HTK mel + log) ->
+ * Conformer conditioning encoder (rel-pos attention with rel_shift) -> Perceiver resampler => conds_latent (latents, model_dim),
+ * the prompt of the acoustic GPT (graph D's first input); ECAPA-TDNN speaker encoder + the 1x1 conditioning convolutions =>
+ * conds = [bigvgan_cond_layer_speaker_embedding (voc_initial) | save_bigvgan_conds_0 | ... | _n-1], exactly the `conds` vector
+ * mi_bigvgan_forward_latent takes.  fp32 engine.  cfg: mi355tts.config.IndexCondConfig.to_int_array(); weights: the packed
+ * blob of mi355tts.weights.pack_cond (export-time folds applied).  mel (optional, may be NULL): the (frames, n_mels) log-mel. */
+int64_t     mi_indextts_cond_param_count(const int32_t* cfg, int n_cfg);
+mi_cond*    mi_indextts_cond_create(const int32_t* cfg, int n_cfg, const float* weights, int64_t n_weights, int device);
+void        mi_indextts_cond_destroy(mi_cond* h);
+int         mi_indextts_cond_run(mi_cond* h, const int16_t* audio, int64_t L, float* conds, float* conds_latent, float* mel,
+                                 int mem);
+
 int         mi_set_option(const char* key, int64_t value);
 
 /* ---- profiling hooks (bench.py roofline leg) -------------------------------------------------

@@ -3,6 +3,7 @@
 #include "bigvgan.h"
 #include "f5.h"
 #include "gpt.h"
+#include "cond.h"
 #include <cstdlib>
 #include <algorithm>
 #include <mutex>
@@ -14,6 +15,7 @@ using namespace mi;
 struct mi_bigvgan { BigVGAN* impl; std::mutex mu; };
 struct mi_f5 { F5* impl; std::mutex mu; };
 struct mi_gpt { Gpt* impl; std::mutex mu; };
+struct mi_cond { Cond* impl; std::mutex mu; };
 
 template <typename F> static int guard(F&& f) {
     try {
@@ -721,6 +723,40 @@ int mi_bench_conv_gemm(int dtype, int B, int T, int Cin, int N, int taps, int di
         MI_HIP(hipEventElapsedTime(&t, e0, e1));
         *ms = (double)t / iters;
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(s);
+    });
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// IndexTTS graph A (cond.hip)
+// ---------------------------------------------------------------------------------------------------------------
+int64_t mi_indextts_cond_param_count(const int32_t* cfg, int n_cfg) {
+    int64_t n = -1;
+    int rc = guard([&] { n = cond_param_count(parse_cond_cfg(cfg, n_cfg)); });
+    return rc == MI_OK ? n : (int64_t)rc;
+}
+
+mi_cond* mi_indextts_cond_create(const int32_t* cfg, int n_cfg, const float* weights, int64_t n_weights, int device) {
+    mi_cond* h = nullptr;
+    int rc = guard([&] {
+        MI_REQUIRE(weights != nullptr, "mi_indextts_cond_create: null weights");
+        Cond* impl = cond_create(parse_cond_cfg(cfg, n_cfg), weights, n_weights, device);
+        h = new mi_cond; h->impl = impl;
+    });
+    return rc == MI_OK ? h : nullptr;
+}
+
+void mi_indextts_cond_destroy(mi_cond* h) {
+    if (!h) return;
+    cond_destroy(h->impl);
+    delete h;
+}
+
+int mi_indextts_cond_run(mi_cond* h, const int16_t* audio, int64_t L, float* conds, float* conds_latent, float* mel, int mem) {
+    return guard([&] {
+        MI_REQUIRE(h && h->impl, "mi_indextts_cond_run: null handle");
+        std::lock_guard<std::mutex> lk_(h->mu);
+        MI_REQUIRE(mem == MI_HOST || mem == MI_DEVICE, "mi_indextts_cond_run: bad mem kind");
+        cond_run(h->impl, audio, (long)L, conds, conds_latent, mel, mem);
     });
 }
 

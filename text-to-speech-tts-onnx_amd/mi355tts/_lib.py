@@ -91,6 +91,11 @@ def load() -> C.CDLL:
     L.mi_f5_synthesize_mel.argtypes = [vp, C.c_int, vp, C.c_int64, vp, C.c_int64, C.c_int64, vp, C.c_uint64, vp, i64p,
                                        C.c_int]
     L.mi_f5_synthesize_mel.restype = C.c_int
+    L.mi_indextts_cond_param_count.argtypes = [C.POINTER(C.c_int32), C.c_int]; L.mi_indextts_cond_param_count.restype = C.c_int64
+    L.mi_indextts_cond_create.argtypes = [C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_float), C.c_int64, C.c_int]
+    L.mi_indextts_cond_create.restype = vp
+    L.mi_indextts_cond_destroy.argtypes = [vp]; L.mi_indextts_cond_destroy.restype = None
+    L.mi_indextts_cond_run.argtypes = [vp, vp, C.c_int64, vp, vp, vp, C.c_int]; L.mi_indextts_cond_run.restype = C.c_int
     L.mi_gpt_param_count.argtypes = [C.POINTER(C.c_int32), C.c_int]; L.mi_gpt_param_count.restype = C.c_int64
     L.mi_gpt_create.argtypes = [C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_float), C.c_int64, C.c_int, C.c_int]
     L.mi_gpt_create.restype = C.c_void_p

@@ -13,6 +13,7 @@ There is no CPU fallback: without libmi355tts.so and an MI355X every call raises
 """
 from __future__ import annotations
 
+import ctypes as C
 from typing import Optional, Sequence
 
 import numpy as np
@@ -252,3 +253,63 @@ class IndexGPT:
         prompt, concat_len = self.concat(np.asarray(conds_latent, np.float32), text_h, mel_h)
         limit = (c.max_generate_length if max_generate_length is None else int(max_generate_length)) - int(concat_len[0])
         return self.generate_from_prompt(prompt, limit, **kw)
+
+
+class IndexCond:
+    """IndexTTS graph A (ort_session_A of Inference_IndexTTS_ONNX.py:700-712; IndexTTS_A, Export_IndexTTS.py:74-200): int16
+    prompt audio -> (conds_latent, vocoder conditioning).  ``state``: upstream-named tensors of weights.cond_spec (folds applied
+    here), or ``blob``: the packed array of weights.pack_cond."""
+
+    def __init__(self, cfg, state=None, blob=None, device: int = 0):
+        from .config import IndexCondConfig
+        from . import weights as W
+        assert isinstance(cfg, IndexCondConfig)
+        self.cfg = cfg
+        _lib.init(device)
+        if blob is None:
+            if state is None:
+                raise ValueError("IndexCond needs a state dict or a packed blob")
+            blob = W.pack_cond(cfg, state)
+        blob = np.ascontiguousarray(blob, dtype=np.float32)
+        arr = np.asarray(cfg.to_int_array(), dtype=np.int32)
+        L = _lib.load()
+        n = L.mi_indextts_cond_param_count(_lib.i32p(arr), arr.size)
+        if n != blob.size:
+            raise ValueError(f"IndexCond: blob has {blob.size} weights, the config needs {n}")
+        self._h = L.mi_indextts_cond_create(_lib.i32p(arr), arr.size, blob.ctypes.data_as(C.POINTER(C.c_float)), blob.size, device)
+        if not self._h:
+            raise _lib.MiError("mi_indextts_cond_create: " + L.mi_last_error().decode())
+        self.ncond = cfg.voc_initial + sum(cfg.voc_channels)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.load().mi_indextts_cond_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self, audio, return_mel: bool = False):
+        """audio int16 (L,) or (1, 1, L) -> (conds (ncond,) = cond_layer | conds_0 | ..., conds_latent (latents, model_dim)[, mel])."""
+        a = np.ascontiguousarray(np.asarray(audio).reshape(-1))
+        if a.dtype != np.int16:
+            raise ValueError("audio must be int16")
+        cfg = self.cfg
+        conds = np.empty((self.ncond,), np.float32)
+        lat = np.empty((cfg.latents, cfg.model_dim), np.float32)
+        mel = np.empty((cfg.frames(a.size), cfg.n_mels), np.float32) if return_mel else None
+        _lib.check(_lib.load().mi_indextts_cond_run(self._h, a.ctypes.data, a.size, conds.ctypes.data, lat.ctypes.data,
+                                                    None if mel is None else mel.ctypes.data, _lib.MI_HOST), "mi_indextts_cond_run")
+        return (conds, lat, mel) if return_mel else (conds, lat)
+
+    def split_conds(self, conds):
+        """The graph's separate outputs: (save_bigvgan_conds_0..n-1 each (1, C_i, 1), bigvgan_cond_layer_speaker_embedding (1, C0, 1))."""
+        cfg = self.cfg
+        o = cfg.voc_initial
+        outs = []
+        for ch in cfg.voc_channels:
+            outs.append(conds[o:o + ch].reshape(1, ch, 1)); o += ch
+        return outs, conds[:cfg.voc_initial].reshape(1, cfg.voc_initial, 1)
