@@ -53,5 +53,5 @@ def test_graph_a_full_width_against_oracle():
     assert rel(conds, ref) < 2e-3, rel(conds, ref)
     assert np.abs(lat_o).max() > 0.1 and np.abs(ref).max() > 0.01
     with pytest.raises(Exception):
-        eng.run(np.zeros(100, np.int16))                                                                  # too short for the k15 / k5 stacks
+        eng.run(np.zeros(10, np.int16))                                                                  # too short for the k15 / k5 stacks
     eng.close()

@@ -487,7 +487,9 @@ void cond_run(Cond* e, const int16_t* audio, long L, float* conds_out, float* la
     const int nf = c.n_fft, nb = nf / 2 + 1, ldm = (nb + 7) / 8 * 8, half = nf / 2, d = c.d, H = c.heads, dk = c.dk();
     const long T = c.frames(L);
     const int T2 = (int)((T - 3) / 2 + 1), F2 = c.f2();
-    MI_REQUIRE(audio && L >= 1 && T >= 2 * c.kern && T2 >= 2 && T2 <= c.max_len && T < (1 << 20), "mi_indextts_cond_run: prompt too short or too long");
+    int maxpad = 1;
+    for (size_t i = 0; i < c.sk.size(); ++i) maxpad = std::max(maxpad, c.sd[i] * (c.sk[i] - 1) / 2);
+    MI_REQUIRE(audio && L >= 1 && T > maxpad + 1 && T2 >= 2 && T2 <= c.max_len && T < (1 << 20), "mi_indextts_cond_run: prompt too short or too long");
     // ---- mel front end (:132-135) ---------------------------------------------------------------------------------------
     const int16_t* da = audio;
     if (mem == MI_HOST) { e->a_dev.ensure((size_t)L * 2); MI_HIP(hipMemcpyAsync(e->a_dev.p, audio, (size_t)L * 2, hipMemcpyHostToDevice, s)); da = e->a_dev.as<int16_t>(); }
@@ -497,7 +499,7 @@ void cond_run(Cond* e, const int16_t* audio, long L, float* conds_out, float* la
     {
         ConvGemm g;      // framed GEMM: row f = padded[f * hop : f * hop + n_fft]
         g.dtype = MI_F32; g.x = e->padded.p; g.w = e->stft_w.p; g.out = e->spec.p;
-        g.B = 1; g.T_in = (int)T; g.M = (int)T; g.N = 2 * nb; g.Cin = nf; g.x_rstride = c.hop; g.x_bstride = Lp; g.out_rstride = 2 * nb; g.out_bstride = T * 2 * nb;
+        g.B = 1; g.T_in = (int)T; g.M = (int)T; g.N = 2 * nb; g.Cin = nf; g.x_rstride = c.hop; g.x_bstride = 0; g.out_rstride = 2 * nb; g.out_bstride = 0;
         launch_conv_gemm(g, s);
         launch_spec_mag(e->spec.as<float>(), e->mag.as<float>(), (int)T, nb, ldm, s);
         ConvGemm m;
