@@ -478,41 +478,59 @@ def run_indextts(args, world, rank, local, dev, dist, torch):
     gpt = IndexGPT(gcfg, blob_device=blob_t[:ng].contiguous(), dtype=args.dtype, device=local)
     voc = BigVGANVocoder(vcfg, blob_device=blob_t[ng:].contiguous(), dtype=args.dtype, device=local)
     del blob_t
-    n_text, n_cond, n_tok = 30, 32, args.tokens
+    n_text, n_tok = 30, args.tokens
     text = (np.arange(n_text, dtype=np.int32) * 37 + 11 * rank) % (gcfg.text_tokens - 2) + 2
-    conds = W.synth_normal_fast(100 + rank, "conds_latent", (1, n_cond, gcfg.hidden), std=0.5)
+    # graph A (Inference_IndexTTS_ONNX.py:700-707): 6 s of int16 prompt audio -> conds_latent (the GPT prompt's first rows) and
+    # the vocoder conditioning vectors; synthetic seeded weights like the other engines
+    from mi355tts.config import IndexCondConfig
+    from mi355tts.indextts import IndexCond
+    ccfg = IndexCondConfig()
+    cond_eng = IndexCond(ccfg, W.synth_state(W.cond_spec(ccfg), 9527, fast=True), device=local)
+    tt = np.arange(144000) / 24000.0
+    prompt_audio = np.clip(0.1 * 32767 * np.sin(2 * np.pi * 220.0 * tt) + W.synth_normal_fast(7 + rank, "prompt_audio", (144000,), std=500.0),
+                           -32768, 32767).astype(np.int16)
+    text_h = gpt.text_embed(text)
     mel_h, _ = gpt.mel_embed(gcfg.start_mel_token, 0)
-    prompt_np, concat_len = gpt.concat(conds, gpt.text_embed(text), mel_h)
-    P = int(concat_len[0])
-    prompt = torch.from_numpy(prompt_np[0]).to(dev)
+    n_cond = ccfg.latents
+
+    def graph_a():
+        vc, lat = cond_eng.run(prompt_audio)
+        pr, cl = gpt.concat(lat[None], text_h, mel_h)
+        return torch.from_numpy(vc).to(dev), torch.from_numpy(pr[0]).to(dev), int(cl[0]), pr
+
+    vconds, prompt, P, prompt_np = graph_a()
     toks = torch.zeros((n_tok,), dtype=torch.int32, device=dev)
     hid = torch.zeros((n_tok, gcfg.hidden), dtype=torch.float32, device=dev)
     ncond = vcfg.upsample_initial_channel + sum(vcfg.stage_channels(i) for i in range(vcfg.num_upsamples))
-    vconds = torch.from_numpy(W.synth_normal_fast(100 + rank, "conds", (ncond,), std=0.2)).to(dev)
+    assert ncond == cond_eng.ncond and gcfg.hidden == ccfg.model_dim
     wav = torch.empty((1, 1, (n_tok - 2) * vcfg.hop + 30), dtype=torch.int16, device=dev)
     audio_s = NB * wav.shape[-1] / vcfg.sampling_rate
     if NB > 1:      # NB sentences per step: different texts, one shared weight stream per decode step
         ps = []
         for b in range(NB):
             tb = (np.arange(n_text, dtype=np.int32) * 37 + 11 * rank + 101 * b) % (gcfg.text_tokens - 2) + 2
-            ps.append(gpt.concat(conds, gpt.text_embed(tb), mel_h)[0][0])
+            ps.append(gpt.concat(prompt_np[:, :n_cond], gpt.text_embed(tb), mel_h)[0][0])
         prompts_cat = torch.from_numpy(np.concatenate(ps, axis=0)).to(dev)
         toks_b = torch.zeros((NB, n_tok), dtype=torch.int32, device=dev)
         hid_b = torch.zeros((NB, n_tok, gcfg.hidden), dtype=torch.float32, device=dev)
 
+    state = {"vconds": vconds, "prompt": prompt}
+
     def gpt_leg():
         if NB == 1:
-            n = gpt.generate_torch(prompt, n_tok, toks, hid, stop_tokens=[])
+            n = gpt.generate_torch(state["prompt"], n_tok, toks, hid, stop_tokens=[])
             assert n == n_tok
         else:
             n = gpt.generate_batch_torch(prompts_cat, [P] * NB, [n_tok] * NB, toks_b, hid_b, stop_tokens=[])
             assert (n == n_tok).all()
 
     def step():
+        # prompt audio -> graph A -> prompt rows + vocoder conditioning (once per utterance, as the driver does), then
         # stop_tokens=[]: a fixed amount of work per sentence (random weights never emit the stop code on cue)
+        state["vconds"], state["prompt"], _, _ = graph_a()
         gpt_leg()
         for b in range(NB):
-            voc.run_latent_torch(hid if NB == 1 else hid_b[b], vconds, wav)
+            voc.run_latent_torch(hid if NB == 1 else hid_b[b], state["vconds"], wav)
 
     for _ in range(max(args.warmup, 2)):
         step()
@@ -542,7 +560,7 @@ def run_indextts(args, world, rank, local, dev, dist, torch):
     pg, pa = _lib.prof_get("conv_gemm"), _lib.prof_get("attn")
     dt = max_over_ranks(torch, dist, world, dt, dev)
     if rank != 0:
-        gpt.close(); voc.close()
+        gpt.close(); voc.close(); cond_eng.close()
         return
     esz = 4 if args.dtype == "f32" else 2
     achieved = pg["bytes"] / (pg["ms"] * 1e-3) / 1e9 if pg["ms"] > 0 else 0.0
@@ -552,8 +570,8 @@ def run_indextts(args, world, rank, local, dev, dist, torch):
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"IndexTTS-1.5 {args.dtype}: GPT-2 (24 x 1280, 20 heads) prompt pass of {P} rows + greedy decode of "
-                               f"{n_tok} mel codes + BigVGAN graph F, {NB} sentence(s) per GPU per step (BASELINE configs[4] "
-                               f"without graph A: conds_latent / speaker conditioning synthetic)",
+                               f"{n_tok} mel codes + BigVGAN graph F, {NB} sentence(s) per GPU per step, 6 s of int16 prompt audio through graph A "
+                               f"(Conformer / Perceiver / ECAPA) every step (BASELINE configs[4], all six graphs)",
                    "tokens": n_tok, "prompt_rows": P, "audio_seconds_per_step_per_gpu": audio_s,
                    "sentences_per_gpu": NB,
                    "rtf": dt / args.steps / audio_s, "gpt_leg_ms": gpt_s * 1e3, "decode_tokens_per_s": NB * n_tok / gpt_s,
@@ -586,7 +604,7 @@ def run_indextts(args, world, rank, local, dev, dist, torch):
                                 "sample": f"numpy oracle, fp32: prompt pass of {P} rows + {n_cpu - 1} decode steps of the "
                                           f"same GPT (graph E only, no vocoder leg), {cpu_s:.1f} s; audio = tokens x 1024 / 24 kHz"}
     print(json.dumps(line), flush=True)
-    gpt.close(); voc.close()
+    gpt.close(); voc.close(); cond_eng.close()
 
 
 def measure_bigvgan(torch, dist, world, rank, local, dev, dtype, B, F, steps, warmup, ixf):

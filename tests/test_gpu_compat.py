@@ -136,6 +136,34 @@ def test_indextts_f_session_like_the_reference_call(tmp_path, golden_dir):
     assert np.abs(wav.astype(np.int32) - g["wav_i16"].astype(np.int32)).max() <= 3
 
 
+def test_indextts_a_session_like_the_reference_call(tmp_path, golden_dir):
+    """all_outputs_A = ort_session_A.run_with_ort_values(out_name_A, {in_name_A0: audio}) and the hand-over of its first outputs to
+    session F's feed — Inference_IndexTTS_ONNX.py:700-707; output names / order of the export (Export_IndexTTS.py:337-355)."""
+    from mi355tts.config import IndexCondConfig
+    g = np.load(os.path.join(golden_dir, "indextts_a.npz"))
+    cfg = IndexCondConfig.small()
+    wfile = tmp_path / "ixa.npy"
+    np.save(wfile, W.pack_cond(cfg, W.synth_state(W.cond_spec(cfg), 9527)))
+    path = onnxruntime.save_model(str(tmp_path / "IndexTTS_A.mi355.json"), "IndexTTS_A", cfg, str(wfile), "f32")
+    ort_session_A = onnxruntime.InferenceSession(path, sess_options=onnxruntime.SessionOptions(), providers=[])
+    in_name_A0 = ort_session_A.get_inputs()[0].name
+    out_name_A = [o.name for o in ort_session_A.get_outputs()]
+    assert in_name_A0 == "audio" and out_name_A == ["save_bigvgan_conds_0", "save_bigvgan_conds_1", "bigvgan_cond_layer_speaker_embedding",
+                                                    "conds_latent"]
+    audio = onnxruntime.OrtValue.ortvalue_from_numpy(g["r_audio"].reshape(1, 1, -1), "cpu", 0)
+    all_outputs_A = ort_session_A.run_with_ort_values(out_name_A, {in_name_A0: audio})
+    for i in range(2):
+        o = all_outputs_A[i].numpy()
+        assert o.shape == (1, cfg.voc_channels[i], 1)
+        np.testing.assert_allclose(o.reshape(-1), g[f"r_cond_{i}"], atol=2e-4, rtol=1e-3)
+    np.testing.assert_allclose(all_outputs_A[2].numpy().reshape(-1), g["r_cond_layer"], atol=2e-4, rtol=1e-3)
+    lat = all_outputs_A[3].numpy()
+    assert lat.shape == (1, cfg.latents, cfg.model_dim)
+    np.testing.assert_allclose(lat[0], g["r_conds_latent"], atol=5e-4, rtol=1e-3)
+    with pytest.raises(onnxruntime.InvalidArgument):
+        ort_session_A.run(out_name_A, {in_name_A0: g["r_audio"].astype(np.float32).reshape(1, 1, -1)})
+
+
 def test_indextts_gpt_driver_loop_through_facade(tmp_path, golden_dir):
     """Inference_IndexTTS_ONNX.py:619-800 for one sentence with sessions B, C, D, E: same variable names and feed
     bookkeeping as the reference driver; out_key/out_value OrtValues are fed straight back as in_key/in_value."""

@@ -146,6 +146,9 @@ def _engine(kind: str, cfg, wfile: str, dtype: str, device: int):
         elif kind == "gpt":
             from .indextts import IndexGPT
             _ENGINES[key] = IndexGPT(cfg, blob=np.asarray(blob), dtype=dtype, device=device)
+        elif kind == "cond":
+            from .indextts import IndexCond
+            _ENGINES[key] = IndexCond(cfg, blob=np.asarray(blob), device=device)
         else:
             from .bigvgan import BigVGANVocoder
             _ENGINES[key] = BigVGANVocoder(cfg, blob=np.asarray(blob), dtype=dtype, device=device)
@@ -161,6 +164,11 @@ def _graph_io(graph: str, cfg, dtype: str):
     if graph == "BigVGAN":
         return ([NodeArg("mel_features", "tensor(float)", [1, cfg.num_mels, "mel_features_len"])],
                 [NodeArg("generated_wav", "tensor(int16)", [1, 1, "generated_len"])])
+    if graph == "IndexTTS_A":          # IndexTTS/Export_IndexTTS.py:337-355
+        outs = [NodeArg(f"save_bigvgan_conds_{i}", "tensor(float)", [1, ch, 1]) for i, ch in enumerate(cfg.voc_channels)]
+        outs.append(NodeArg("bigvgan_cond_layer_speaker_embedding", "tensor(float)", [1, cfg.voc_initial, 1]))
+        outs.append(NodeArg("conds_latent", "tensor(float)", [1, "ref_signal_len", cfg.model_dim]))
+        return [NodeArg("audio", "tensor(int16)", [1, 1, "audio_len"])], outs
     if graph == "IndexTTS_F":          # IndexTTS/Export_IndexTTS.py:497-520
         ins = [NodeArg(f"save_bigvgan_conds_{i}", "tensor(float)", [1, cfg.stage_channels(i), 1])
                for i in range(cfg.num_upsamples)]
@@ -209,7 +217,7 @@ def _graph_io(graph: str, cfg, dtype: str):
 
 
 _GPT_GRAPHS = ("IndexTTS_B", "IndexTTS_C", "IndexTTS_D", "IndexTTS_E")
-_GRAPHS = ("BigVGAN", "IndexTTS_F", "F5_Preprocess", "F5_Transformer", "F5_Decode") + _GPT_GRAPHS
+_GRAPHS = ("BigVGAN", "IndexTTS_A", "IndexTTS_F", "F5_Preprocess", "F5_Transformer", "F5_Decode") + _GPT_GRAPHS
 
 
 class _KVRef(OrtValue):
@@ -263,10 +271,16 @@ class InferenceSession:
         elif self._graph in _GPT_GRAPHS:
             from .config import IndexGPTConfig
             self._cfg = IndexGPTConfig(**c)
+        elif self._graph == "IndexTTS_A":
+            from .config import IndexCondConfig
+            for k in ("spk_channels", "spk_kernels", "spk_dilations", "voc_channels"):
+                c[k] = tuple(c[k])
+            self._cfg = IndexCondConfig(**c)
         else:
             self._cfg = F5Config(**c)
         wfile = os.path.join(os.path.dirname(os.path.abspath(path_or_bytes)), man["weights"])
-        kind = "bigvgan" if self._graph in ("BigVGAN", "IndexTTS_F") else "gpt" if self._graph in _GPT_GRAPHS else "f5"
+        kind = ("bigvgan" if self._graph in ("BigVGAN", "IndexTTS_F") else "gpt" if self._graph in _GPT_GRAPHS else
+                "cond" if self._graph == "IndexTTS_A" else "f5")
         self._eng = None if self._graph == "IndexTTS_D" else _engine(kind, self._cfg, wfile, self._dtype, device)
         self._kv_epoch = 0
         self._inputs, self._outputs = _graph_io(self._graph, self._cfg, self._dtype)
@@ -381,6 +395,13 @@ class InferenceSession:
 
     def _run(self, feed) -> Dict[str, np.ndarray]:
         g, e = self._graph, self._eng
+        if g == "IndexTTS_A":
+            conds, lat = e.run(self._chk(feed, "audio", np.int16, 3))
+            outs, cond0 = e.split_conds(conds)
+            res = {f"save_bigvgan_conds_{i}": o for i, o in enumerate(outs)}
+            res["bigvgan_cond_layer_speaker_embedding"] = cond0
+            res["conds_latent"] = lat[None]
+            return res
         if g == "IndexTTS_B":
             return {"text_hidden_state": e.text_embed(self._chk(feed, "text_ids", np.int32, 2))}
         if g == "IndexTTS_C":
