@@ -208,21 +208,6 @@ int         mi_gpt_generate_batch(mi_gpt* h, int nb, const float* prompts, const
 int         mi_bench_conv_gemm(int dtype, int B, int T, int Cin, int N, int taps, int dil, int with_res, int iters,
                                double* ms);
 
-/* test / tuning hook: tile-dispatch thresholds of the implicit-GEMM kernel ("gemm_big_tile_min", "gemm_n192_min",
- * "gemm_mid_tile_min", "gemm_dma3_k_min", "gemm_use_dma3", "gemm_use_dma", "gemm_big_tiles", "gemm_n192", "gemm_f32_dma", "gemm_ring4", "gemm_ring4_max", "gemm_buf", "gemm_f32_small", "gemm_f32_small_max", "gemm_small16_max", "gemm_sk" (stream-K linear layers: 0 off, 1 fp32, 2 also 16-bit), "gemm_sk_stages", "gemm_sk_max_tiles"), and
- * "gpt_mfma_min" (sentences from which mi_gpt_generate_batch runs its linears on MFMA; default 9), and
- * "aa_conv_deterministic" (1: one workgroup per CU in the fused AA+conv kernel, which makes the 16-bit BigVGAN output
- * bit-identical from run to run at +19 % forward time; default 0: a few of 10^7 samples may differ by one 16-bit ulp).
- * Arithmetic of fp32 engines (all keep fp32 values and fp32 accumulation, and pass the same parity gates):
- *   "gemm_f32_x3" (default 1): the big linear layers form every fp32 product as six exact bf16 x bf16 partial products on the
- *       bf16 matrix cores (three-way operand split, gemm_x3.hip); 0: native v_mfma_f32_32x32x2_f32.
- *   "attn_f32_x3" (default 2): attention with both products formed that way (V is then kept transposed, like in the 16-bit
- *       engines); 1: q.k only; 0: native fp32 MFMA.
- * Further tuning keys (defaults are the measured best): "gemm_ph8", "gemm_ph8_min_tiles", "gemm_ph8_order",
- * "gemm_ph8_split_max", "gemm_ph8_split_min_nk" (256x256 16-bit kernel); "gemm_sk_hybrid", "gemm_sk_producer",
- * "gemm_sk_qkv32"; "gemm_x3_wide" (wave layout 0 / 1 / 2), "gemm_x3_stages" (3 / 4), "gemm_x3_hybrid", "gemm_x3_qkv8";
- * "gemm_f32_n64_dma", "gemm_n64_dma16", "gemm_dma3_order"; "attn_z_max", "attn_z16_max", "attn_z_force" (key slices).
- * Changing an option invalidates the hipGraphs captured by existing handles.   */
 /* ---- IndexTTS graph A: prompt audio -> conditioning (cond.hip) -----------------------------------------------------------
  * Replaces ort_session_A of IndexTTS/Inference_IndexTTS_ONNX.py:700-712 (graph definition: IndexTTS_A,
  * IndexTTS/Export_IndexTTS.py:74-200): mel front end (0.1 s constant noise pad + 'constant'-padded STFT + HTK mel + log) ->
@@ -237,6 +222,22 @@ void        mi_indextts_cond_destroy(mi_cond* h);
 int         mi_indextts_cond_run(mi_cond* h, const int16_t* audio, int64_t L, float* conds, float* conds_latent, float* mel,
                                  int mem);
 
+/* test / tuning hook: tile-dispatch thresholds of the implicit-GEMM kernel ("gemm_big_tile_min", "gemm_n192_min",
+ * "gemm_mid_tile_min", "gemm_dma3_k_min", "gemm_use_dma3", "gemm_use_dma", "gemm_big_tiles", "gemm_n192", "gemm_f32_dma", "gemm_ring4", "gemm_ring4_max", "gemm_buf", "gemm_f32_small", "gemm_f32_small_max", "gemm_small16_max", "gemm_sk" (stream-K linear layers: 0 off, 1 fp32, 2 also 16-bit), "gemm_sk_stages", "gemm_sk_max_tiles"), and
+ * "gpt_mfma_min" (sentences from which mi_gpt_generate_batch runs its linears on MFMA; default 9), and
+ * "aa_conv_deterministic" (1: one workgroup per CU in the fused AA+conv kernel; a diagnostic since round 3 — the default, two per
+ * CU, is bit-identical from run to run now that the AA math no longer uses the op_sel encoding that was not).
+ * Arithmetic of fp32 engines (all keep fp32 values and fp32 accumulation, and pass the same parity gates):
+ *   "gemm_f32_x3" (default 1): the big linear layers form every fp32 product as six exact bf16 x bf16 partial products on the
+ *       bf16 matrix cores (three-way operand split; gemm_x3p.hip with both operands pre-split, gemm_x3.hip as its fallback); 0: native v_mfma_f32_32x32x2_f32.
+ *   "attn_f32_x3" (default 2): attention with both products formed that way (V is then kept transposed, like in the 16-bit
+ *       engines); 1: q.k only; 0: native fp32 MFMA.
+ * Further tuning keys (defaults are the measured best): "gemm_ph8", "gemm_ph8_min_tiles", "gemm_ph8_order",
+ * "gemm_ph8_split_max", "gemm_ph8_split_min_nk" (256x256 16-bit kernel); "gemm_sk_qkv32";
+ * "gemm_f32_x3p" (0: the round-2 kernel gemm_x3.hip instead of the panel-plane kernel gemm_x3p.hip), "gemm_x3p_grid" (XCD bands:
+ * 0 automatic, else 1 / 2 / 4 / 8 row bands), "gemm_x3p_noalign"; "attn_kv_planes" (0: the fp32 attention kernel splits K / V itself);
+ * "gemm_f32_n64_dma", "gemm_n64_dma16"; "attn_z_max", "attn_z16_max", "attn_z_force" (key slices).
+ * Changing an option invalidates the hipGraphs captured by existing handles.   */
 int         mi_set_option(const char* key, int64_t value);
 
 /* ---- profiling hooks (bench.py roofline leg) -------------------------------------------------

@@ -310,7 +310,7 @@ def test_bad_inputs_raise(small_voc):
 # only when the launch fills the chip) and compared with the oracle
 # ---------------------------------------------------------------------------------------------
 _DEFAULTS = {"gemm_big_tile_min": 160, "gemm_n192_min": 160, "gemm_mid_tile_min": 160, "gemm_dma3_k_min": 2048,
-             "gemm_use_dma3": 1, "gemm_use_dma": 1, "gemm_big_tiles": 1, "gemm_n192": 1, "gemm_f32_dma": 1, "gemm_ring4": 1, "gemm_ring4_max": 256, "gemm_buf": 1, "gemm_f32_small": 1, "gemm_f32_small_max": 1024, "gemm_small16_max": 256, "gemm_sk": 1, "gemm_sk_stages": 0, "gemm_ph8": 1, "gemm_ph8_min_tiles": 200, "gemm_ph8_order": 1, "gemm_ph8_split_max": 2, "gemm_ph8_split_min_nk": 24, "gemm_sk_hybrid": 0, "gemm_sk_producer": 0, "gemm_f32_x3": 1, "gemm_x3_wide": 2, "gemm_x3_stages": 4, "gemm_x3_big": 0,
+             "gemm_use_dma3": 1, "gemm_use_dma": 1, "gemm_big_tiles": 1, "gemm_n192": 1, "gemm_f32_dma": 1, "gemm_ring4": 1, "gemm_ring4_max": 256, "gemm_buf": 1, "gemm_f32_small": 1, "gemm_f32_small_max": 1024, "gemm_small16_max": 256, "gemm_sk": 1, "gemm_sk_stages": 0, "gemm_ph8": 1, "gemm_ph8_min_tiles": 200, "gemm_ph8_order": 1, "gemm_ph8_split_max": 2, "gemm_ph8_split_min_nk": 24, "gemm_f32_x3": 1,
              "gemm_f32_x3p": 1, "gemm_x3p_grid": 0, "gemm_x3p_noalign": 0}
 
 
@@ -363,11 +363,10 @@ def test_stream_k_linear_vs_oracle(gemm_options, dtype, tol, stages, Ci, Co, T, 
     """gemm_sk.hip: persistent workgroups over equal (tile, K chunk) ranges; tiles split between workgroups are summed in range
     order by the owner of the tile's first chunk.  Ragged M / N tails, every ring depth, partial tiles of 2..many pieces, and
     bit-identical results from run to run (the fix-up order is fixed).  The last two shapes have more tiles than persistent
-    workgroups (288 / 320 tiles): whole tiles first, stream-K for the remainder (gemm_sk_hybrid)."""
+    workgroups (288 / 320 tiles)."""
     from mi355tts import _lib
     _lib.set_option("gemm_sk", 2)
     _lib.set_option("gemm_sk_stages", stages)
-    _lib.set_option("gemm_sk_hybrid", 1)
     x = W.synth_normal(1, f"skx{Ci}{T}", (B, Ci, T))
     w = W.synth_normal(2, f"skw{Ci}{Co}", (Co, Ci, 1), std=1.0 / np.sqrt(Ci))
     b = W.synth_normal(3, "skb", (Co,), std=0.1)
@@ -379,16 +378,6 @@ def test_stream_k_linear_vs_oracle(gemm_options, dtype, tol, stages, Ci, Co, T, 
     else:
         assert rms(y - ref) / rms(ref) < tol
     assert np.array_equal(y, BV.conv1d(x, w, b, dtype=dtype))
-    if dtype == "f32" and stages in (0, 3):
-        _lib.set_option("gemm_sk_producer", 1)              # DMA issued by two extra waves: the same sums in the same order
-        assert np.array_equal(y, BV.conv1d(x, w, b, dtype=dtype))
-        _lib.set_option("gemm_sk_producer", 0)
-    _lib.set_option("gemm_sk_hybrid", 0)
-    yh = BV.conv1d(x, w, b, dtype=dtype)                    # pure stream-K: same products, other summation split
-    if dtype == "f32":
-        np.testing.assert_allclose(y, yh, atol=3e-5, rtol=1e-5)
-    else:
-        assert rms(y - yh) / rms(ref) < tol
     _lib.set_option("gemm_sk", 0)
     y0 = BV.conv1d(x, w, b, dtype=dtype)                    # one tile per workgroup: same products, other summation split
     if dtype == "f32":
@@ -431,19 +420,15 @@ def test_eight_phase_256_tile_linear_vs_oracle(gemm_options, dtype, tol, order, 
     assert rms(y - y0) / rms(ref) < 1e-3 * tol + 1e-6
 
 
-@pytest.mark.parametrize("shape", [0, 1, 2])
-@pytest.mark.parametrize("stages", [3, 4])
 @pytest.mark.parametrize("Ci,Co,T,B", [(256, 1000, 1500, 1), (1024, 1024, 1126, 2), (128, 3072, 700, 2), (256, 2048, 2252, 1),
                                         (2048, 1024, 1126, 2)])
-def test_f32_linear_as_exact_bf16_splits_vs_oracle(gemm_options, shape, stages, Ci, Co, T, B):
-    """gemm_x3.hip: every fp32 product as six exact bf16 x bf16 partial products (three-way split of both operands, fp32
-    accumulation).  Same gate as the native fp32 MFMA path (atol 3e-5 against the oracle), agreement with the native kernel
-    far inside that gate, an error against a float64 evaluation no larger than the native kernel's, every wave layout (64x64 / 32x128 per wave with four waves, 32x64 with
-    eight) and ring depth, ragged M / N tails, tiles split between workgroups, run-to-run identity."""
+def test_f32_linear_as_exact_bf16_splits_vs_oracle(gemm_options, Ci, Co, T, B):
+    """gemm_x3.hip (the round-2 kernel, now the fallback of gemm_x3p.hip): every fp32 product as six exact bf16 x bf16 partial
+    products (three-way split of both operands, fp32 accumulation).  Same gate as the native fp32 MFMA path (atol 3e-5 against
+    the oracle), agreement with the native kernel far inside that gate, an error against a float64 evaluation no larger than
+    the native kernel's, ragged M / N tails, tiles split between workgroups, run-to-run identity."""
     gemm_options("gemm_f32_x3", 1)
     gemm_options("gemm_f32_x3p", 0)                        # the round-2 kernel itself (panel-plane form: next test)
-    gemm_options("gemm_x3_wide", shape)
-    gemm_options("gemm_x3_stages", stages)
     x = W.synth_normal(1, f"x3x{Ci}{T}", (B, Ci, T))
     w = W.synth_normal(2, f"x3w{Ci}{Co}", (Co, Ci, 1), std=1.0 / np.sqrt(Ci))
     b = W.synth_normal(3, "x3b", (Co,), std=0.1)
@@ -455,13 +440,6 @@ def test_f32_linear_as_exact_bf16_splits_vs_oracle(gemm_options, shape, stages, 
     y0 = BV.conv1d(x, w, b, dtype="f32")                    # v_mfma_f32_32x32x2_f32
     np.testing.assert_allclose(y0, ref, atol=3e-5, rtol=1e-5)
     assert np.abs(y - y0).max() < 1e-5
-    if shape == 2 and stages == 4:
-        gemm_options("gemm_f32_x3", 1)
-        gemm_options("gemm_x3_big", 1)                      # 256x128 tiles, two stages (slower in the model: opt-in; kept correct)
-        yb = BV.conv1d(x, w, b, dtype="f32")
-        np.testing.assert_allclose(yb, ref, atol=3e-5, rtol=1e-5)
-        assert np.abs(yb - y0).max() < 1e-5
-        gemm_options("gemm_x3_big", 0)
     # the split loses nothing against native fp32: both sit at the same distance from a float64 evaluation
     ref64 = np.einsum("oc,bct->bot", w[:, :, 0].astype(np.float64), x.astype(np.float64)) + b.astype(np.float64)[None, :, None]
     e_x3, e_native = rms(y - ref64), rms(y0 - ref64)

@@ -430,7 +430,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvGemmDev
 static bool g_use_dma = true, g_xcd_order = false, g_use_dma3 = true, g_big_tiles = true;
 static long g_big_min = 160, g_n192_min = 160, g_mid_min = 160, g_k_min = 2048;
 static bool g_n192 = true, g_f32_dma = true, g_ring4 = true, g_f32_small = true;
-static long g_dma3_order = 0;      // 256-row conv kernels: 0 = row tiles fastest, 2 = XCD-aware with the N tiles of a row tile adjacent
 static long g_f32_small_max = 1024, g_small16_max = 256, g_f32_n64_dma = 1, g_n64_dma16 = 0;      // 16-bit: neutral (455 vs 457 ms at 8 utterances), off
 static long g_ring4_max = 256;
 // stream-K (gemm_sk.hip): 0 off ; 1 fp32 linear layers ; 2 also 16-bit ; g_sk_stages: ring depth override (0 = automatic) ;
@@ -438,7 +437,6 @@ static long g_ring4_max = 256;
 static long g_sk = 1, g_sk_stages = 0, g_sk_max_tiles = 2048, g_sk_order = -1;
 // whole tiles first, stream-K for the remainder only: measured SLOWER on the fp32 DiT layers (FF1 / FF2, 288 tiles: 87.0 vs
 // 83.7 us per launch — the remainder's eight-piece fix-ups cost more than the aligned K walk of the first phase gains): opt-in
-static long g_sk_hybrid = 0;
 // fp32 linear layers as six exact bf16 x bf16 partial products (gemm_x3.hip) when the caller supplies the weight planes
 static long g_x3 = 1;
 bool gemm_x3_enabled() { return g_x3 != 0; }
@@ -525,7 +523,7 @@ static void dispatch_tiles(const ConvGemmDev& d, int B, hipStream_t s) {
                 e.Tm = (d.M + 127) / 128; e.Tn = (d.N + 127) / 128; e.RT = e.Tm;
                 e.RC = d.M <= d.N ? 0 : 1;      // per-XCD groups: whole weight panels (x re-read 8x) when x is the smaller operand, else whole row tiles
                 if (g_sk_order >= 0) e.RC = (int)g_sk_order;
-                e.tail_tiles = (int)g_sk_hybrid;   // whole tiles first, stream-K only for the remainder (gemm_sk.hip)
+                e.tail_tiles = 0;
                 launch_linear_sk<T, TO>(e, (int)g_sk_stages, s);
                 return;
             }
@@ -543,14 +541,14 @@ static void dispatch_tiles(const ConvGemmDev& d, int B, hipStream_t s) {
                 // N = 192 / 384 (BigVGAN stages 2 and 1): a 192-wide tile has no padded columns (128-wide tiles waste 25 %
                 // of the MFMAs and DMA bytes at N = 192) and the fewest DMA bytes per useful flop after 256x256
                 ConvGemmDev e = d;
-                e.RC = (int)g_dma3_order; e.Tm = (d.M + 255) / 256; e.Tn = d.N / 192; e.RT = B * e.Tm;
+                e.RC = 0; e.Tm = (d.M + 255) / 256; e.Tn = d.N / 192; e.RT = B * e.Tm;
                 launch_conv_gemm_dma3<T, TO>(e, 192, s);
                 MI_HIP(hipGetLastError());
                 return;
             }
             if (g_use_dma3 && d.Cin % 8 == 0 && d.K % d.Cin == 0 && d.M > 128 && d.K > g_k_min) {
                 ConvGemmDev e = d;
-                e.RC = (int)g_dma3_order;
+                e.RC = 0;
                 const long blocks_128 = (long)B * ((d.M + 127) / 128) * ((d.N + 127) / 128);
                 const long blocks_256x128 = (long)B * ((d.M + 255) / 256) * ((d.N + 127) / 128);
                 const long blocks_256x256 = (long)B * ((d.M + 255) / 256) * ((d.N + 255) / 256);
@@ -645,7 +643,6 @@ bool gemm_set_option(const char* key, long v) {
     else if (k == "gemm_f32_small") g_f32_small = v != 0;
     else if (k == "gemm_f32_small_max") g_f32_small_max = v;
     else if (k == "gemm_f32_n64_dma") g_f32_n64_dma = v;
-    else if (k == "gemm_dma3_order") g_dma3_order = v;
     else if (k == "gemm_n64_dma16") g_n64_dma16 = v;
     else if (k == "gemm_small16_max") g_small16_max = v;
     else if (k == "gemm_ring4_max") g_ring4_max = v;
@@ -653,17 +650,10 @@ bool gemm_set_option(const char* key, long v) {
     else if (k == "gemm_sk_stages") g_sk_stages = v;
     else if (k == "gemm_sk_max_tiles") g_sk_max_tiles = v;
     else if (k == "gemm_sk_qkv32") g_sk_qkv32 = v;
-    else if (k == "gemm_sk_hybrid") g_sk_hybrid = v;
-    else if (k == "gemm_sk_producer") sk_set_producer(v);
     else if (k == "gemm_f32_x3") g_x3 = v;
     else if (k == "gemm_f32_x3p") g_x3p = v;
     else if (k == "gemm_x3p_noalign") x3p_set_option(0, v);
     else if (k == "gemm_x3p_grid") x3p_set_option(1, v);
-    else if (k == "gemm_x3_wide") x3_set_wide(v);
-    else if (k == "gemm_x3_stages") x3_set_stages(v);
-    else if (k == "gemm_x3_hybrid") x3_set_hybrid(v);
-    else if (k == "gemm_x3_qkv8") x3_set_qkv8(v);
-    else if (k == "gemm_x3_big") x3_set_big(v);
     else if (k == "gemm_ph8") g_ph8 = v;
     else if (k == "gemm_ph8_min_tiles") g_ph8_min_tiles = v;
     else if (k == "gemm_ph8_order") g_ph8_order = v;
@@ -749,24 +739,16 @@ void launch_conv_gemm(const ConvGemm& p_in, hipStream_t s) {
             if (const char* n = std::getenv("MI355TTS_NO_F32_SMALL")) g_f32_small = !(n[0] == '1');
             if (const char* n = std::getenv("MI355TTS_F32_SMALL_MAX")) g_f32_small_max = std::atol(n);
             if (const char* n = std::getenv("MI355TTS_F32_N64_DMA")) g_f32_n64_dma = std::atol(n);
-            if (const char* n = std::getenv("MI355TTS_DMA3_ORDER")) g_dma3_order = std::atol(n);
             if (const char* n = std::getenv("MI355TTS_N64_DMA16")) g_n64_dma16 = std::atol(n);
             if (const char* n = std::getenv("MI355TTS_SMALL16_MAX")) g_small16_max = std::atol(n);
             if (const char* n = std::getenv("MI355TTS_RING4_MAX")) g_ring4_max = std::atol(n);
             if (const char* n = std::getenv("MI355TTS_SK")) g_sk = std::atol(n);
             if (const char* n = std::getenv("MI355TTS_SK_STAGES")) g_sk_stages = std::atol(n);
             if (const char* n = std::getenv("MI355TTS_SK_ORDER")) g_sk_order = std::atol(n);
-            if (const char* n = std::getenv("MI355TTS_SK_HYBRID")) g_sk_hybrid = std::atol(n);
-            if (const char* n = std::getenv("MI355TTS_SK_PRODUCER")) sk_set_producer(std::atol(n));
             if (const char* n = std::getenv("MI355TTS_F32_X3")) g_x3 = std::atol(n);
             if (const char* n = std::getenv("MI355TTS_F32_X3P")) g_x3p = std::atol(n);
             if (const char* n = std::getenv("MI355TTS_X3P_NOALIGN")) x3p_set_option(0, std::atol(n));
             if (const char* n = std::getenv("MI355TTS_X3P_GRID")) x3p_set_option(1, std::atol(n));
-            if (const char* n = std::getenv("MI355TTS_X3_WIDE")) x3_set_wide(std::atol(n));
-            if (const char* n = std::getenv("MI355TTS_X3_STAGES")) x3_set_stages(std::atol(n));
-            if (const char* n = std::getenv("MI355TTS_X3_HYBRID")) x3_set_hybrid(std::atol(n));
-            if (const char* n = std::getenv("MI355TTS_X3_QKV8")) x3_set_qkv8(std::atol(n));
-            if (const char* n = std::getenv("MI355TTS_X3_BIG")) x3_set_big(std::atol(n));
             if (const char* n = std::getenv("MI355TTS_SK_QKV32")) g_sk_qkv32 = std::atol(n);
             if (const char* n = std::getenv("MI355TTS_PH8")) g_ph8 = std::atol(n);
             if (const char* n = std::getenv("MI355TTS_PH8_MIN")) g_ph8_min_tiles = std::atol(n);

@@ -450,14 +450,8 @@ typedef __attribute__((address_space(3))) void lds_void;
 template <typename T, typename TO> void launch_conv_gemm_dma3(const ConvGemmDev& e, int bn, hipStream_t s);
 // gemm_sk.hip: stream-K 128x128 kernel for plain linear layers (stages: 0 = automatic)
 template <typename T, typename TO> void launch_linear_sk(const ConvGemmDev& e, int stages, hipStream_t s);
-void sk_set_producer(long v);
 // gemm_x3.hip: fp32 linear layers as exact three-way bf16 splits on the stream-K frame
 void launch_linear_x3(const ConvGemmDev& e, hipStream_t s);
-void x3_set_wide(long v);
-void x3_set_stages(long v);
-void x3_set_hybrid(long v);
-void x3_set_qkv8(long v);
-void x3_set_big(long v);
 // gemm_ph8.hip: 256x256 eight-phase kernel for 16-bit linear layers with many row tiles
 template <typename T, typename TO> void launch_linear_ph8(const ConvGemmDev& e, hipStream_t s);
 void launch_linear_x3p(const ConvGemmDev& e, hipStream_t s);

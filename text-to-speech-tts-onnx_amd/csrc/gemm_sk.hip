@@ -392,12 +392,9 @@ __global__ __launch_bounds__(PROD ? 384 : 256, NST <= 2 ? 2 : 1) void linear_sk_
 #endif
 }
 
-// stages: 0 = automatic (fp32: three-stage ring, one workgroup per CU; 16-bit: two stages, two workgroups per CU)
-// measured on the fp32 DiT layers: interleaved DMA 83.9 us per launch, one producer wave 93.0 (it cannot issue 32 pieces in
-// the 3/4 chunk the MFMA waves leave it before the barrier), two producer waves 88.3 — the interleaved form stays the default
-static long g_sk_producer = 0;
-void sk_set_producer(long v) { g_sk_producer = v; }
-
+// stages: 0 = automatic (fp32: three-stage ring, one workgroup per CU; 16-bit: two stages, two workgroups per CU).
+// Round 3 pruned the A/B losers: the producer-wave form (PROD = true: 93.0 / 88.3 vs 83.9 us) is no longer
+// instantiated, the whole-tiles-first hybrid (87.0 / 87.2 vs 83.7 us) is no longer reachable (tail_tiles stays 0).
 template <typename T, typename TO>
 void launch_linear_sk(const ConvGemmDev& e, int stages, hipStream_t s) {
     constexpr int KC = 128 / (int)sizeof(T);
@@ -418,18 +415,6 @@ void launch_linear_sk(const ConvGemmDev& e, int stages, hipStream_t s) {
         prof_set_kernel("linear_sk_kernel<T, TO, " #LE ", " #NS ">", type_label<T>(), type_label<TO>());               \
         hipLaunchKernelGGL(kfn, grid, dim3(256), 0, s, e);                                                             \
     } while (0)
-    if constexpr (sizeof(T) == 4) {
-        if (nst == 3 && g_sk_producer) {
-            auto launch_p = [&](auto kfn, const char* name) {
-                prof_set_kernel(name, type_label<T>(), type_label<TO>());
-                hipLaunchKernelGGL(kfn, grid, dim3(384), 0, s, e);
-            };
-            if (e.lds_epi) launch_p(linear_sk_kernel<T, TO, true, 3, true>, "linear_sk_kernel<T, TO, true, 3, producer>");
-            else launch_p(linear_sk_kernel<T, TO, false, 3, true>, "linear_sk_kernel<T, TO, false, 3, producer>");
-            MI_HIP(hipGetLastError());
-            return;
-        }
-    }
     if (e.lds_epi) { if (nst == 2) SK_LAUNCH(true, 2); else if (nst == 3) SK_LAUNCH(true, 3); else SK_LAUNCH(true, 4); }
     else { if (nst == 2) SK_LAUNCH(false, 2); else if (nst == 3) SK_LAUNCH(false, 3); else SK_LAUNCH(false, 4); }
 #undef SK_LAUNCH

@@ -361,21 +361,14 @@ __global__ __launch_bounds__(SHAPE >= 2 ? 512 : 256, 1) void linear_x3_kernel(co
 #endif
 }
 
-// measured slower here as well (whole tiles first 67.4, pieces first 66.0 vs 63.3 us): the eight-piece fix-ups of the remainder
-// cost more than the better L2 hit rate gains
-static long g_x3_hybrid = 0;
-void x3_set_hybrid(long v) { g_x3_hybrid = v; }
-static long g_x3_big = 0;        // > 0: 256x128 tiles (layout 3) for launches with at least that many of them
-void x3_set_big(long v) { g_x3_big = v; }
-static long g_x3_qkv8 = 1;
-void x3_set_qkv8(long v) { g_x3_qkv8 = v; }
-static long g_x3_wide = 2, g_x3_stages = 4;      // wave layout of the plain-epilogue launches: 0 / 1 / 2, see the kernel
-void x3_set_wide(long v) { g_x3_wide = v; }
-void x3_set_stages(long v) { g_x3_stages = v == 3 ? 3 : 4; }
-
+// Round 3 pruned the A/B losers of this kernel: the launcher instantiates ONE layout — eight waves of 32x64, four-stage ring,
+// pure stream-K ranges — the round-2 default.  Measured and dropped: 64x64 x four waves 80.6 us, 32x128 x
+// four waves 70.2 us (eight waves: 64.0 us in the model); three stages +2 %; whole-tiles-first hybrids 67.4 / 66.0 vs 63.3 us;
+// 256x128 tiles with two stages QKV 113 vs 99 us.  (The template keeps those shapes' code paths; nothing instantiates them.)
+// This kernel is the fallback of gemm_x3p.hip (N not a multiple of 128, or the caller has no panel planes).
 void launch_linear_x3(const ConvGemmDev& e_in, hipStream_t s) {
     ConvGemmDev e = e_in;
-    e.tail_tiles = (int)g_x3_hybrid;
+    e.tail_tiles = 0;
     int dev = 0, cus = 256;
     MI_HIP(hipGetDevice(&dev));
     {
@@ -383,28 +376,15 @@ void launch_linear_x3(const ConvGemmDev& e_in, hipStream_t s) {
         if (!cu_count[dev & 15]) { hipDeviceProp_t pr; MI_HIP(hipGetDeviceProperties(&pr, dev)); cu_count[dev & 15] = pr.multiProcessorCount; }
         cus = cu_count[dev & 15];
     }
-    // 0: 64x64 x 4 waves ; 1: 32x128 x 4 ; 2: 32x64 x 8 ; 3: 256x128 tile, 64x64 x 8 ; the QKV epilogue wants 64-column head
-    // slices: layouts 0, 2, 3
-    int shape = e.epi == EPI_QKV_ROPE ? (g_x3_qkv8 && e.lds_epi ? 2 : 0) : (int)g_x3_wide;
-    if (g_x3_big && e.lds_epi && (long)((e.M + 255) / 256) * ((e.N + 127) / 128) >= g_x3_big) shape = 3;
-    if (shape == 3) { e.Tm = (e.M + 255) / 256; e.RT = e.Tm; }
-    const int P = std::min(cus, shape == 3 ? e.sk_slots / 2 : e.sk_slots) & ~7;
+    const int P = std::min(cus, e.sk_slots) & ~7;
     const dim3 grid(P);
-#define X3_LAUNCH(LE, SH, NS, NAME)                                                                                    \
-    do { prof_set_kernel(NAME, "", ""); hipLaunchKernelGGL((linear_x3_kernel<float, LE, SH, NS>), grid, dim3(SH >= 2 ? 512 : 256), 0, s, e); } while (0)
-    if (shape == 3) {
-        X3_LAUNCH(true, 3, 2, "linear_x3_kernel<float, true, 256x128, 2>");
-        MI_HIP(hipGetLastError());
-        return;
-    }
-    if (g_x3_stages == 4) {
-        if (e.lds_epi) { if (shape == 2) X3_LAUNCH(true, 2, 4, "linear_x3_kernel<float, true, 8 waves, 4>"); else if (shape == 1) X3_LAUNCH(true, 1, 4, "linear_x3_kernel<float, true, wide, 4>"); else X3_LAUNCH(true, 0, 4, "linear_x3_kernel<float, true, 64x64, 4>"); }
-        else { if (shape == 2) X3_LAUNCH(false, 2, 4, "linear_x3_kernel<float, false, 8 waves, 4>"); else if (shape == 1) X3_LAUNCH(false, 1, 4, "linear_x3_kernel<float, false, wide, 4>"); else X3_LAUNCH(false, 0, 4, "linear_x3_kernel<float, false, 64x64, 4>"); }
+    if (e.lds_epi) {
+        prof_set_kernel("linear_x3_kernel<float, true, 8 waves, 4>", "", "");
+        hipLaunchKernelGGL((linear_x3_kernel<float, true, 2, 4>), grid, dim3(512), 0, s, e);
     } else {
-        if (e.lds_epi) { if (shape == 2) X3_LAUNCH(true, 2, 3, "linear_x3_kernel<float, true, 8 waves, 3>"); else if (shape == 1) X3_LAUNCH(true, 1, 3, "linear_x3_kernel<float, true, wide, 3>"); else X3_LAUNCH(true, 0, 3, "linear_x3_kernel<float, true, 64x64, 3>"); }
-        else { if (shape == 2) X3_LAUNCH(false, 2, 3, "linear_x3_kernel<float, false, 8 waves, 3>"); else if (shape == 1) X3_LAUNCH(false, 1, 3, "linear_x3_kernel<float, false, wide, 3>"); else X3_LAUNCH(false, 0, 3, "linear_x3_kernel<float, false, 64x64, 3>"); }
+        prof_set_kernel("linear_x3_kernel<float, false, 8 waves, 4>", "", "");
+        hipLaunchKernelGGL((linear_x3_kernel<float, false, 2, 4>), grid, dim3(512), 0, s, e);
     }
-#undef X3_LAUNCH
     MI_HIP(hipGetLastError());
 }
 
