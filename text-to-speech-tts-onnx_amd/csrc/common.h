@@ -192,6 +192,7 @@ struct SkWorkspace {
     DevBuf ws, flags; int slots = 0;
     void ensure(int n_slots, hipStream_t s);
     void reset(hipStream_t s);       // flags back to zero (after a failed / aborted launch: see F5::recover)
+    bool tripped() const;            // the spin watchdog of a stream-K fix-up gave up (last flag word, gemm_x3p.hip): synchronous 4-byte read
     void attach(ConvGemm& g) const { g.sk_ws = ws.as<float>(); g.sk_flags = flags.as<int>(); g.sk_slots = slots; }
 };
 bool gemm_set_option(const char* key, long v);

@@ -515,6 +515,10 @@ void F5::stft(const int16_t* audio_dev, int U, long L) {
 
 // after a stream synchronisation: did the text-id kernel see an id outside the embedding table?
 void F5::check_text_ids() {
+    if (sk.tripped()) {             // a stream-K fix-up spin hit its bound (gemm_x3p.hip): the results of this call are not to be trusted
+        recover();
+        MI_REQUIRE(false, "f5: a split-tile hand-off timed out on the device (workspace reset; results of this call discarded)");
+    }
     if (!p_err.p) return;
     int flag = 0;
     MI_HIP(hipMemcpy(&flag, p_err.p, 4, hipMemcpyDeviceToHost));

@@ -827,6 +827,13 @@ void SkWorkspace::ensure(int n_slots, hipStream_t s) {
 // completes; a launch that faulted or was aborted (or a failed graph capture) may not have.  Consumers spin on these
 // flags, so whoever observes an error on the stream re-zeroes them before the next launch.  Errors are swallowed: this
 // runs on the error path.
+bool SkWorkspace::tripped() const {
+    if (!flags.p || slots <= 0) return false;
+    int v = 0;
+    if (hipMemcpy(&v, (const int*)flags.p + slots - 1, 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
+    return v != 0;
+}
+
 void SkWorkspace::reset(hipStream_t s) {
     if (!flags.p || slots <= 0) return;
     (void)hipMemsetAsync(flags.p, 0, (size_t)slots * 4, s);

@@ -390,12 +390,14 @@ __global__ __launch_bounds__(512, 1) void linear_x3p_kernel(const ConvGemmDev p)
                     const long q0 = (long)q_l * I / R, q1 = (long)(q_l + 1) * I / R;
                     if (q1 == q0) continue;
                     if (tid == 0) {
-                        // bounded spin (in-order workgroup dispatch makes the producer a lower workgroup id that is already
-                        // resident; the bound only turns a broken invariant into wrong numbers + an error word instead of a hang)
+                        // Bounded spin.  The producer of this flag is a LOWER workgroup id; the hand-off assumes in-order workgroup
+                        // dispatch (lower ids are resident or finished when this one runs), as gemm_sk.hip documents.  The bound
+                        // only turns a broken invariant into an error word (checked by the engine at its next synchronisation:
+                        // SkWorkspace::tripped) and wrong numbers instead of a hung GPU.
                         long spins = 0;
                         while (__hip_atomic_load(flags + slot0 + q_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
                             __builtin_amdgcn_s_sleep(2);
-                            if (++spins > (1L << 26)) { __hip_atomic_store(flags + P, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                            if (++spins > (1L << 26)) { __hip_atomic_store(flags + p.sk_slots - 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
                         }
                     }
                     __syncthreads();
@@ -466,7 +468,7 @@ void launch_linear_x3p(const ConvGemmDev& e_in, hipStream_t s) {
     }
     e.RT = best; e.RC = 8 / best;
     e.tail_tiles = (int)g_x3p_noalign;
-    const int P = std::min(cus, e.sk_slots - 8) & ~7;          // flags[P] is the watchdog's error word
+    const int P = std::min(cus, e.sk_slots - 8) & ~7;          // the LAST flag word is the watchdog's error word (SkWorkspace::tripped)
     const dim3 grid(P);
     if (e.lds_epi) {
 #if defined(MI355TTS_TUNING)
