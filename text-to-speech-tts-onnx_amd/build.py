@@ -17,7 +17,7 @@ OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "mi355tts", "libmi355tts.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-         "-Wno-unused-result", "-fno-gpu-rdc", "-DNDEBUG"]
+         "-Wno-unused-result", "-fno-gpu-rdc", "-DNDEBUG"] + os.environ.get("MI355TTS_EXTRA_FLAGS", "").split()
 
 
 def _sources():

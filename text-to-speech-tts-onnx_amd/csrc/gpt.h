@@ -68,7 +68,8 @@ struct Gpt {
     void kv_write(int layer, const float* keys_dev, const float* values_dev, int hist);
     void linear(const GLin& l, const void* x, int rows, void* out, int odt, int act, const float* res);
     void gemv(const GLin& l, const void* x, const float* ln_w, const float* ln_b, void* out, int odt, int act,
-              const float* res, void* kcl, void* vcl, int slot = 0);
+              const float* res, void* kcl, void* vcl, int slot = 0, const float* pre_w = nullptr, const float* pre_b = nullptr,
+              float* pre_out = nullptr);
 };
 
 }  // namespace mi

@@ -60,10 +60,28 @@ template <typename T> __device__ inline Pack16<T> ld16(const T* p) {
     *reinterpret_cast<uint4*>(&r) = *reinterpret_cast<const uint4*>(p);
     return r;
 }
+// wave-wide sum / max on the DPP path (no LDS crossbar round trips: six dependent ds_bpermute cost ~0.2 us per
+// reduction, a fifth of a decode-step GEMV's life): xor-1 and xor-2 inside the quads, mirrored halves and rows, then the
+// four row totals through SGPRs in a fixed order.  Every lane returns the same value.
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_value(float v, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
 __device__ inline float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_mov<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);     // row_half_mirror
+    v += dpp_mov<0x140>(v);     // row_mirror
+    return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
+}
+__device__ inline float wave_max(float v) {
+    v = fmaxf(v, dpp_mov<0xB1>(v));
+    v = fmaxf(v, dpp_mov<0x4E>(v));
+    v = fmaxf(v, dpp_mov<0x141>(v));
+    v = fmaxf(v, dpp_mov<0x140>(v));
+    return fmaxf(fmaxf(lane_value(v, 0), lane_value(v, 16)), fmaxf(lane_value(v, 32), lane_value(v, 48)));
 }
 // acc += dot(a[0..V), b[0..V)) with fp32 accumulation; 16-bit types use the packed dot instructions (v_dot2_f32_f16 /
 // v_dot2_f32_bf16: two multiply-adds per lane per issue, no conversions)
@@ -93,130 +111,235 @@ __device__ inline float gelu_new(float x) {
     return 0.5f * x * (1.f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));
 }
 
-// shared epilogue of the GEMV kernels: lane r < R holds output row n0 + r
-template <typename T, int R, bool QKV>
-__device__ inline void gemv_store(float (&acc)[R], int lane, int n0, int N, const float* bias, const float* res, void* out,
-                                  int out_f32, int act, T* kc, T* vc, const int* st, int max_seq) {
+// ---------------------------------------------------------------------------------------------------------------
+// Decode-step linear layer of ONE sentence: out[n] = act(dot(w[n, :], x') + bias[n]) (+ res[n]), one wave per R
+// output rows, lane l holds k = l*V + it*64*V .. +V of the row (V = elements per 16 bytes), fp32 FMAs, DPP reduction.
+// A decode step is a chain of ~120 of these launches, each a dependent load -> reduce -> store chain of a few us, so
+// the kernel is built around its latency, not its bandwidth (profiles/r3/gpt_decode_*_kernel_stats.csv: 7.3 -> 4.7 us
+// at 9.8 MB of weights; a trivial one-block kernel costs 4.4 us in the same graph):
+//   * every global read of the block is in flight before the first reduction, in the order x-side operands ->
+//     weights (loads return in order: the statistics must not queue behind the weight rows), all branch-free —
+//     a load under an exec-masked branch gets its own s_waitcnt vmcnt(0) from the compiler and the R x KI weight loads
+//     serialise (measured: 9.1 us instead of 4.7); the weight loads are non-temporal (every byte is used once);
+//   * the epilogue's bias / residual / cache position are fetched up front as well;
+//   * the x row is prepared ONCE per block and shared through LDS: LN form (x = fp32 residual row, K <= 2048):
+//     every wave derives the row statistics itself from registers (no block-wide reduction), then each wave turns one
+//     (iteration, 4-element group) slice into LayerNorm(x) for all; plain form: the 16-bit activation row;
+//   * `pre_w`: the row first goes through another LayerNorm with rownorm_kernel's lane map and arithmetic
+//     (f5_kernels.hip) — ln_f in front of the lm_head's final_norm, Export_IndexTTS.py:286-288 — and block 0 stores
+//     that intermediate row to `pre_out` (graph E's last_hidden_state output);
+//   * QKV: rows [hidden, 3*hidden) go straight into the K / V cache row st[GS_HIST] of this layer.
+#ifndef GPT_NT
+#define GPT_NT 1
+#endif
+#if GPT_NT
+#define GPT_WLOAD ldnt16
+#else
+#define GPT_WLOAD ld16
+#endif
+typedef unsigned int gd_u4 __attribute__((ext_vector_type(4)));
+template <typename T> __device__ inline Pack16<T> ldnt16(const T* p) {
+    Pack16<T> r;
+    *reinterpret_cast<gd_u4*>(&r) = __builtin_nontemporal_load(reinterpret_cast<const gd_u4*>(p));
+    return r;
+}
+
+template <typename T, int R, int KI, int WAVES, bool LN, bool QKV>
+__global__ __launch_bounds__(WAVES * 64) void gemv_d_kernel(const T* __restrict__ w, const void* __restrict__ xin,
+                                                            const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                                            const float* __restrict__ pre_w, const float* __restrict__ pre_b,
+                                                            float* __restrict__ pre_out,
+                                                            const float* __restrict__ bias, const float* res, void* out,
+                                                            int out_f32, int act, int N, int K, T* __restrict__ kc,
+                                                            T* __restrict__ vc, const int* __restrict__ st, int max_seq) {
+    constexpr int V = Pack16<T>::N;
+    constexpr int KP = KI * 64 * V;                       // padded K
+    __shared__ __attribute__((aligned(16))) float xs[LN ? KP : 4];
+    __shared__ __attribute__((aligned(16))) T xt[LN ? 8 : ((KI + WAVES - 1) / WAVES) * WAVES * 64 * V];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n0 = (blockIdx.x * WAVES + wave) * R;
+    // epilogue operands of the row this lane will store (lane r < R), fetched up front: after the reduction they would
+    // be one more dependent L2 round trip each
+    const int nrow = min(n0 + (lane < R ? lane : 0), N - 1);
+    const float bias_pre = bias ? bias[nrow] : 0.f;
+    const float res_pre = res ? res[nrow] : 0.f;
+    const int pos_pre = QKV ? st[GS_HIST] : 0;
+    Pack16<T> p[KI][R];
+    auto load_weights = [&]() {
+#pragma unroll
+    for (int it = 0; it < KI; ++it) {
+        const int k = lane * V + it * 64 * V;
+#pragma unroll
+        for (int r = 0; r < R; ++r)         // branch-free: padded lanes re-read k = 0 of the row and meet x = 0 in LDS
+            p[it][r] = GPT_WLOAD(w + (size_t)min(n0 + r, N - 1) * K + (k < K ? k : 0));
+    }
+    };
+    if constexpr (LN) {
+        const float* xf = (const float*)xin;
+        if (pre_w) {      // rownorm_kernel<float, 8>, NORM_LN_AFFINE, one wave per row: here wave 0
+            if (wave == 0) {
+                constexpr int MAXV = 8;
+                float4 v[MAXV];
+                float s = 0.f;
+#pragma unroll
+                for (int i = 0; i < MAXV; ++i) {
+                    const int c = (i * 64 + lane) * 4;
+                    v[i] = c < K ? *reinterpret_cast<const float4*>(xf + c) : make_float4(0, 0, 0, 0);
+                    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+                }
+                const float mean = wave_sum(s) / (float)K;
+                float q = 0.f;
+#pragma unroll
+                for (int i = 0; i < MAXV; ++i) {
+                    const int c = (i * 64 + lane) * 4;
+                    if (c < K) {
+                        const float d0 = v[i].x - mean, d1 = v[i].y - mean, d2 = v[i].z - mean, d3 = v[i].w - mean;
+                        q += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+                    }
+                }
+                const float inv = 1.0f / sqrtf(wave_sum(q) / (float)K + 1e-5f);
+#pragma unroll
+                for (int i = 0; i < MAXV; ++i) {
+                    const int c = (i * 64 + lane) * 4;
+                    if (c < K) {
+                        const float4 av = *reinterpret_cast<const float4*>(pre_w + c);
+                        const float4 bv = *reinterpret_cast<const float4*>(pre_b + c);
+                        float o[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+                        const float aa[4] = {av.x, av.y, av.z, av.w}, bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { const float n = (o[k] - mean) * inv; o[k] = n * aa[k] + bb[k]; }
+                        const float4 ov = make_float4(o[0], o[1], o[2], o[3]);
+                        *reinterpret_cast<float4*>(&xs[c]) = ov;
+                        if (blockIdx.x == 0 && pre_out) *reinterpret_cast<float4*>(pre_out + c) = ov;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        float xe[KI][V];
+#pragma unroll
+        for (int it = 0; it < KI; ++it) {
+            const int k = lane * V + it * 64 * V;
+            const bool ok = k < K;
+            const int kk = ok ? k : 0;
+#pragma unroll
+            for (int e = 0; e < V; e += 4) {
+                float4 v;
+                if (pre_w) v = *reinterpret_cast<const float4*>(&xs[kk + e]);      // uniform branch
+                else v = *reinterpret_cast<const float4*>(xf + kk + e);
+                xe[it][e] = ok ? v.x : 0.f; xe[it][e + 1] = ok ? v.y : 0.f; xe[it][e + 2] = ok ? v.z : 0.f; xe[it][e + 3] = ok ? v.w : 0.f;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // gamma / beta of the (iteration, 4-element group) items this wave turns into LayerNorm(x); then the weights:
+        // everything the block reads is in flight before the first reduction, in this order (loads return in order: the
+        // statistics must not wait behind the weight rows)
+        constexpr int QV = V / 4, NITEM = KI * QV, MYI = (NITEM + WAVES - 1) / WAVES;
+        float4 gq[MYI], bq[MYI];
+#pragma unroll
+        for (int m = 0; m < MYI; ++m) {
+            const int item = wave + m * WAVES;
+            const int k = lane * V + (item / QV) * 64 * V + (item % QV) * 4;
+            const int kk = item < NITEM && k < K ? k : 0;
+            gq[m] = *reinterpret_cast<const float4*>(ln_w + kk);
+            bq[m] = *reinterpret_cast<const float4*>(ln_b + kk);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        load_weights();
+        __builtin_amdgcn_sched_barrier(0);
+        float sum = 0.f;
+#pragma unroll
+        for (int it = 0; it < KI; ++it)
+#pragma unroll
+            for (int e = 0; e < V; ++e) sum += xe[it][e];
+        const float mean = wave_sum(sum) / (float)K;
+        float sq = 0.f;
+#pragma unroll
+        for (int it = 0; it < KI; ++it) {
+            const bool ok = lane * V + it * 64 * V < K;
+#pragma unroll
+            for (int e = 0; e < V; ++e) { const float d = ok ? xe[it][e] - mean : 0.f; sq = fmaf(d, d, sq); }
+        }
+        const float rstd = rsqrtf(wave_sum(sq) / (float)K + 1e-5f);
+        if (pre_w) __syncthreads();                       // every wave holds its share of the ln_f row: xs is reused
+        // LayerNorm(x) -> LDS, one (iteration, 4-element group) item per wave and round
+#pragma unroll
+        for (int item = 0; item < NITEM; ++item) {
+            if (item % WAVES == wave) {
+                const int it = item / QV, q = item % QV, m = item / WAVES;
+                const int k = lane * V + it * 64 * V + q * 4;
+                float4 o = make_float4(0, 0, 0, 0);
+                if (k < K) {
+                    const float4 g = gq[m], b = bq[m];
+                    o.x = (xe[it][q * 4 + 0] - mean) * rstd * g.x + b.x;
+                    o.y = (xe[it][q * 4 + 1] - mean) * rstd * g.y + b.y;
+                    o.z = (xe[it][q * 4 + 2] - mean) * rstd * g.z + b.z;
+                    o.w = (xe[it][q * 4 + 3] - mean) * rstd * g.w + b.w;
+                }
+                *reinterpret_cast<float4*>(&xs[k]) = o;
+            }
+        }
+        __syncthreads();
+    } else {
+        const T* xr = (const T*)xin;
+        constexpr int XI = (KI + WAVES - 1) / WAVES;       // the x row first (L2), then the weights (HBM)
+        gd_u4 xv[XI];                                      // bounds-checked buffer loads: 0 beyond K, no branch
+        const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)xr, 0, K * (int)sizeof(T), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < XI; ++i)
+            xv[i] = __builtin_amdgcn_raw_buffer_load_b128(rsx, (int)((threadIdx.x + i * WAVES * 64) * 16), 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_weights();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < XI; ++i) *reinterpret_cast<gd_u4*>(&xt[(threadIdx.x + i * WAVES * 64) * V]) = xv[i];
+        __syncthreads();
+    }
+    float acc[R];                                         // rows beyond N: computed on clamped rows, never stored
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int it = 0; it < KI; ++it) {
+        const int k = lane * V + it * 64 * V;
+        {
+            float xn[V];
+            if constexpr (LN) {
+#pragma unroll
+                for (int e = 0; e < V; e += 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(&xs[k + e]);
+                    xn[e] = v.x; xn[e + 1] = v.y; xn[e + 2] = v.z; xn[e + 3] = v.w;
+                }
+            } else {
+                const Pack16<T> xv = ld16(&xt[k]);
+#pragma unroll
+                for (int e = 0; e < V; ++e) xn[e] = (float)xv.v[e];
+            }
+#pragma unroll
+            for (int e = 0; e < V; ++e)
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[r] = fmaf((float)p[it][r].v[e], xn[e], acc[r]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
     if (lane < R && n0 + lane < N) {
         const int n = n0 + lane;
         float v = acc[0];
 #pragma unroll
         for (int r = 1; r < R; ++r) v = lane == r ? acc[r] : v;
-        v += bias ? bias[n] : 0.f;
+        v += bias_pre;
         if (act == ACT_GELU_TANH) v = gelu_new(v);
-        if (res) v += res[n];
+        v += res_pre;
         if (QKV) {
             const int hidden = N / 3;
             if (n >= hidden) {
                 const int c = n - hidden, which = c / hidden, cc = c % hidden;
-                const int pos = st[GS_HIST];
-                if (pos < max_seq) (which ? vc : kc)[((size_t)(cc >> 6) * max_seq + pos) * 64 + (cc & 63)] = (T)v;
+                if (pos_pre < max_seq) (which ? vc : kc)[((size_t)(cc >> 6) * max_seq + pos_pre) * 64 + (cc & 63)] = (T)v;
                 return;
             }
         }
         if (out_f32) ((float*)out)[n] = v; else ((T*)out)[n] = (T)v;
     }
-}
-
-// out[n] = act(dot(w[n, :], x) + bias[n]) (+ res[n]) ; one wave per R output rows, 16 bytes per lane per load.
-template <typename T, int R>
-__global__ __launch_bounds__(256) void gemv_kernel(const T* __restrict__ w, const T* __restrict__ x,
-                                                   const float* __restrict__ bias, const float* res, void* out,
-                                                   int out_f32, int act, int N, int K) {
-    constexpr int V = Pack16<T>::N;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int n0 = (blockIdx.x * 4 + wave) * R;
-    if (n0 >= N) return;
-    const T* wr[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) wr[r] = w + (size_t)min(n0 + r, N - 1) * K;
-    float acc[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = 0.f;
-#pragma unroll 4
-    for (int k = lane * V; k < K; k += 64 * V) {
-        Pack16<T> p[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) p[r] = ld16(wr[r] + k);
-        const Pack16<T> xv = ld16(x + k);
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-#pragma unroll
-            for (int e = 0; e < V; ++e) acc[r] = fmaf((float)p[r].v[e], (float)xv.v[e], acc[r]);
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
-    gemv_store<T, R, false>(acc, lane, n0, N, bias, res, out, out_f32, act, nullptr, nullptr, nullptr, 0);
-}
-
-// LayerNorm fused in front: x is the fp32 residual row (K = hidden <= 2048) and x' = LayerNorm(x) * ln_w + ln_b is formed
-// on the fly.  Every wave derives the row statistics itself (two-pass, from registers) — no extra launch, no block
-// barrier — and all of its weight / x / gamma / beta loads (KI compile-time iterations) are issued BEFORE the
-// statistics are reduced, so the HBM latency of the weight rows overlaps the reduction.
-//   QKV: rows [hidden, 3*hidden) go straight into the K / V cache row st[GS_HIST] of this layer.
-template <typename T, int R, int KI, bool QKV>
-__global__ __launch_bounds__(256) void gemv_ln_kernel(const T* __restrict__ w, const float* __restrict__ xf,
-                                                      const float* __restrict__ ln_w, const float* __restrict__ ln_b,
-                                                      const float* __restrict__ bias, void* out, int out_f32, int act,
-                                                      int N, int K, T* __restrict__ kc, T* __restrict__ vc,
-                                                      const int* __restrict__ st, int max_seq) {
-    constexpr int V = Pack16<T>::N;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int n0 = (blockIdx.x * 4 + wave) * R;
-    if (n0 >= N) return;
-    const T* wr[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) wr[r] = w + (size_t)min(n0 + r, N - 1) * K;
-    Pack16<T> p[KI][R];
-    float xe[KI][V], ge[KI][V], be[KI][V];
-#pragma unroll
-    for (int it = 0; it < KI; ++it) {
-        const int k = lane * V + it * 64 * V;
-        const bool ok = k < K;
-        const int kk = ok ? k : 0;
-#pragma unroll
-        for (int r = 0; r < R; ++r) p[it][r] = ld16(wr[r] + kk);
-#pragma unroll
-        for (int e = 0; e < V; e += 4) {
-            const float4 v = *(const float4*)(xf + kk + e), g = *(const float4*)(ln_w + kk + e), bb = *(const float4*)(ln_b + kk + e);
-            xe[it][e] = v.x; xe[it][e + 1] = v.y; xe[it][e + 2] = v.z; xe[it][e + 3] = v.w;
-            ge[it][e] = ok ? g.x : 0.f; ge[it][e + 1] = ok ? g.y : 0.f; ge[it][e + 2] = ok ? g.z : 0.f; ge[it][e + 3] = ok ? g.w : 0.f;
-            be[it][e] = ok ? bb.x : 0.f; be[it][e + 1] = ok ? bb.y : 0.f; be[it][e + 2] = ok ? bb.z : 0.f; be[it][e + 3] = ok ? bb.w : 0.f;
-        }
-        if (!ok) {
-#pragma unroll
-            for (int e = 0; e < V; ++e) xe[it][e] = 0.f;
-        }
-    }
-    // statistics over exactly the elements this wave holds (each x element is held once across the wave)
-    float sum = 0.f;
-#pragma unroll
-    for (int it = 0; it < KI; ++it)
-#pragma unroll
-        for (int e = 0; e < V; ++e) sum += xe[it][e];
-    const float mean = wave_sum(sum) / (float)K;
-    float sq = 0.f;
-#pragma unroll
-    for (int it = 0; it < KI; ++it) {
-        const bool ok = lane * V + it * 64 * V < K;
-#pragma unroll
-        for (int e = 0; e < V; ++e) { const float d = ok ? xe[it][e] - mean : 0.f; sq = fmaf(d, d, sq); }
-    }
-    const float rstd = rsqrtf(wave_sum(sq) / (float)K + 1e-5f);
-    float acc[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = 0.f;
-#pragma unroll
-    for (int it = 0; it < KI; ++it)
-#pragma unroll
-        for (int e = 0; e < V; ++e) {
-            const float xn = (xe[it][e] - mean) * rstd * ge[it][e] + be[it][e];     // padded lanes: g = b = 0 -> 0
-#pragma unroll
-            for (int r = 0; r < R; ++r) acc[r] = fmaf((float)p[it][r].v[e], xn, acc[r]);
-        }
-#pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
-    gemv_store<T, R, QKV>(acc, lane, n0, N, bias, nullptr, out, out_f32, act, kc, vc, st, max_seq);
 }
 
 // NV per-lane partial sums -> full sums: after the call, lane l holds the total of value index
@@ -542,25 +665,25 @@ __global__ __launch_bounds__(256) void gpt_attn1_kernel(const T* __restrict__ qk
     float m_run = -INFINITY, l_run = 0.f, acc[V];
 #pragma unroll
     for (int e = 0; e < V; ++e) acc[e] = 0.f;
-    for (int base = wave * 64; base < kv; base += 256) {
+    struct Pass { Pack16<T> kp[CH], vp[NIT]; };
+    auto load_pass = [&](Pass& ps, int base) {
         const int j = base + lane;
-        const bool kok = j < kv;
-        Pack16<T> kp[CH], vp[NIT];
-        const T* kr = kb + (size_t)(kok ? j : base) * 64;
+        const T* kr = kb + (size_t)(j < kv ? j : base) * 64;
 #pragma unroll
-        for (int cc = 0; cc < CH; ++cc) kp[cc] = ld16(kr + cc * V);
+        for (int cc = 0; cc < CH; ++cc) ps.kp[cc] = ld16(kr + cc * V);
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int jj = base + it * KPI + g;
-            vp[it] = ld16(vb + (size_t)(jj < kv ? jj : base) * 64 + c * V);
+            ps.vp[it] = ld16(vb + (size_t)(jj < kv ? jj : base) * 64 + c * V);
         }
+    };
+    auto fold_pass = [&](const Pass& ps, int base) {
+        const bool kok = base + lane < kv;
         float s = 0.f;
 #pragma unroll
-        for (int cc = 0; cc < CH; ++cc) s = dot_pack(kp[cc], q[cc], s);
+        for (int cc = 0; cc < CH; ++cc) s = dot_pack(ps.kp[cc], q[cc], s);
         s = kok ? s : -INFINITY;
-        float mw = s;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mw = fmaxf(mw, __shfl_xor(mw, o, 64));
+        const float mw = wave_max(s);
         const float m_new = fmaxf(m_run, mw);              // finite: the pass holds at least one key
         const float pj = kok ? __expf(s - m_new) : 0.f;
         const float corr = __expf(m_run - m_new);          // exp(-inf) = 0 on the first pass
@@ -572,7 +695,25 @@ __global__ __launch_bounds__(256) void gpt_attn1_kernel(const T* __restrict__ qk
         for (int it = 0; it < NIT; ++it) {
             const float pk = __shfl(pj, it * KPI + g, 64);  // 0 for keys beyond kv
 #pragma unroll
-            for (int e = 0; e < V; ++e) acc[e] = fmaf(pk, (float)vp[it].v[e], acc[e]);
+            for (int e = 0; e < V; ++e) acc[e] = fmaf(pk, (float)ps.vp[it].v[e], acc[e]);
+        }
+    };
+    // the wave's passes (every fourth 64-key block), the next one in flight while the current one is folded in
+    int base = wave * 64;
+    if (base < kv) {
+        Pass pa, pb;
+        load_pass(pa, base);
+        for (;;) {
+            bool more = base + 256 < kv;
+            if (more) load_pass(pb, base + 256);
+            fold_pass(pa, base);
+            if (!more) break;
+            base += 256;
+            more = base + 256 < kv;
+            if (more) load_pass(pa, base + 256);
+            fold_pass(pb, base);
+            if (!more) break;
+            base += 256;
         }
     }
 #pragma unroll
@@ -624,7 +765,9 @@ __global__ __launch_bounds__(256) void gpt_embed_state_kernel(const int* __restr
 __global__ __launch_bounds__(1024) void gpt_pick_kernel(const float* __restrict__ logits, float* __restrict__ pen,
                                                         const float* __restrict__ last, int* __restrict__ st,
                                                         int* __restrict__ toks, float* __restrict__ hid, int codes,
-                                                        int hidden, int rows, const float* __restrict__ rep_dev, int max_tok) {
+                                                        int hidden, int rows, const float* __restrict__ rep_dev, int max_tok,
+                                                        const float* __restrict__ emb, const float* __restrict__ pos,
+                                                        int max_pos, float* xa, float* xb) {
     __shared__ float bv[16];
     __shared__ int bi[16];
     __shared__ int slot;
@@ -674,6 +817,14 @@ __global__ __launch_bounds__(1024) void gpt_pick_kernel(const float* __restrict_
     __syncthreads();
     if (slot >= 0)
         for (int c = tid; c < hidden; c += 1024) hid[(size_t)slot * hidden + c] = last[c];
+    // graph C for the next decode step (IndexTTS_C.forward, Export_IndexTTS.py:222-225) from the state just written:
+    // the step's input row, so that a decode step does not start with a launch of its own for it
+    const int id = min(max(st[GS_TOKEN], 0), codes - 1), g = min(max(st[GS_GEN_LEN], 0), max_pos - 1);
+    for (int c = tid; c < hidden; c += 1024) {
+        const float v = emb[(size_t)id * hidden + c] + pos[(size_t)g * hidden + c];
+        if (xa) xa[c] = v;
+        if (xb) xb[(size_t)blockIdx.x * hidden + c] = v;
+    }
 }
 
 // cache <-> the reference's tensor layouts: keys (H, D, hist), values (H, hist, D), fp32
@@ -794,47 +945,63 @@ void Gpt::linear(const GLin& l, const void* x, int rows, void* out, int odt, int
     launch_conv_gemm(g, stream);
 }
 
-// single-row linear layer: weight-streaming GEMV.  ln_w != nullptr: x is the fp32 residual row, LayerNorm fused in.
-// kcl != nullptr: QKV epilogue (k and v rows go to the cache).
+// single-row linear layer: weight-streaming GEMV (gemv_d_kernel).  ln_w != nullptr: x is the fp32 residual row,
+// LayerNorm fused in (pre_w: a first LayerNorm in front of it, its row also stored to pre_out).  kcl != nullptr: QKV
+// epilogue (k and v rows go to the cache).
+template <typename T, int R, int KI, bool LN, bool QKV>
+static void gemv_d_launch(const Gpt::GLin& l, const void* x, const float* ln_w, const float* ln_b, const float* pre_w,
+                          const float* pre_b, float* pre_out, const float* res, void* out, int of, int act, void* kcl,
+                          void* vcl, const int* st, int max_seq, hipStream_t s) {
+    constexpr int WAVES = LN ? 8 : 4;
+    const dim3 grid((unsigned)((l.n + WAVES * R - 1) / (WAVES * R)));
+    hipLaunchKernelGGL((gemv_d_kernel<T, R, KI, WAVES, LN, QKV>), grid, dim3(WAVES * 64), 0, s, (const T*)l.w.p, x, ln_w,
+                       ln_b, pre_w, pre_b, pre_out, l.b.as<float>(), res, out, of, act, l.n, l.k, (T*)kcl, (T*)vcl, st, max_seq);
+}
+template <typename T>
+static void gemv_d_dispatch(const Gpt::GLin& l, const void* x, const float* ln_w, const float* ln_b, const float* pre_w,
+                            const float* pre_b, float* pre_out, const float* res, void* out, int of, int act, void* kcl,
+                            void* vcl, const int* st, int max_seq, hipStream_t s) {
+    constexpr int V = 16 / (int)sizeof(T);
+    const int ki = (l.k + 64 * V - 1) / (64 * V);
+#define GD(RR, KK, LNN, QK) gemv_d_launch<T, RR, KK, LNN, QK>(l, x, ln_w, ln_b, pre_w, pre_b, pre_out, res, out, of, act, kcl, vcl, st, max_seq, s)
+    if (ln_w) {
+        MI_REQUIRE(ki <= 8, "gemv: the fused LayerNorm supports K <= 2048");
+        const bool r2 = l.n >= 2048;
+#define GD_K(RR, QK)                                                                              \
+    do {                                                                                          \
+        if (ki <= 1) GD(RR, 1, true, QK); else if (ki == 2) GD(RR, 2, true, QK);                   \
+        else if (ki == 3) GD(RR, 3, true, QK); else if (ki == 4) GD(RR, 4, true, QK);              \
+        else if (ki == 5) GD(RR, 5, true, QK); else if (ki == 6) GD(RR, 6, true, QK);              \
+        else GD(RR, 8, true, QK);                                                                 \
+    } while (0)
+        if (kcl) { if (r2) GD_K(2, true); else GD_K(1, true); }
+        else { if (r2) GD_K(2, false); else GD_K(1, false); }
+#undef GD_K
+    } else {
+        MI_REQUIRE(ki <= 32, "gemv: K <= 8192");
+        if (ki <= 1) GD(1, 1, false, false); else if (ki == 2) GD(1, 2, false, false);
+        else if (ki == 3) GD(1, 3, false, false); else if (ki == 4) GD(1, 4, false, false);
+        else if (ki == 5) GD(1, 5, false, false); else if (ki == 6) GD(1, 6, false, false);
+        else if (ki <= 8) GD(1, 8, false, false); else if (ki <= 10) GD(1, 10, false, false);
+        else if (ki <= 12) GD(1, 12, false, false); else if (ki <= 16) GD(1, 16, false, false);
+        else if (ki <= 20) GD(1, 20, false, false); else GD(1, 32, false, false);
+    }
+#undef GD
+}
+
 void Gpt::gemv(const GLin& l, const void* x, const float* ln_w, const float* ln_b, void* out, int odt, int act,
-               const float* res, void* kcl, void* vcl, int slot) {
+               const float* res, void* kcl, void* vcl, int slot, const float* pre_w, const float* pre_b, float* pre_out) {
     MI_REQUIRE(l.k % 8 == 0, "gemv: K must be a multiple of 8");
     const int of = odt == MI_F32;
     MI_REQUIRE(of || odt == dtype, "gemv: output dtype");
     MI_REQUIRE(!kcl || ln_w, "gemv: the QKV epilogue comes with the fused LayerNorm");
     MI_REQUIRE(!ln_w || !res, "gemv: the fused-LayerNorm variant has no residual input");
-    // rows per wave: 2 when there are enough rows to fill the chip twice over, else 1 (more waves in flight)
-    const int R = l.n >= 4096 ? 2 : 1;
-    const dim3 grid((unsigned)((l.n + 4 * R - 1) / (4 * R)));
+    MI_REQUIRE(!pre_w || ln_w, "gemv: the leading LayerNorm comes with the fused one");
     ProfScope ps(FAM_CONV_GEMM, stream, (double)l.n * l.k * dtype_size(dtype), 2.0 * l.n * l.k);
     const int* st = state.as<int>() + (size_t)slot * GS_WORDS;
-    const int V = 16 / (int)dtype_size(dtype);
-    const int KI = (l.k + 64 * V - 1) / (64 * V);
-    if (ln_w) {
-        MI_REQUIRE(KI <= 8, "gemv: fused LayerNorm supports K <= 2048");
-#define GL(T, RR, KK, QK) hipLaunchKernelGGL((gemv_ln_kernel<T, RR, KK, QK>), grid, dim3(256), 0, stream, (const T*)l.w.p, (const float*)x, ln_w, ln_b, l.b.as<float>(), out, of, act, l.n, l.k, (T*)kcl, (T*)vcl, st, cfg.max_seq)
-#define GL_K(T, RR, QK)                                                                   \
-    do {                                                                                  \
-        if (KI <= 1) GL(T, RR, 1, QK); else if (KI == 2) GL(T, RR, 2, QK);                 \
-        else if (KI == 3) GL(T, RR, 3, QK); else if (KI == 4) GL(T, RR, 4, QK);            \
-        else if (KI <= 6) GL(T, RR, 6, QK); else GL(T, RR, 8, QK);                          \
-    } while (0)
-#define GL_T(T)                                                                           \
-    do {                                                                                  \
-        if (kcl) { if (R == 2) GL_K(T, 2, true); else GL_K(T, 1, true); }                  \
-        else { if (R == 2) GL_K(T, 2, false); else GL_K(T, 1, false); }                    \
-    } while (0)
-        if (dtype == MI_F32) GL_T(float); else if (dtype == MI_F16) GL_T(f16); else GL_T(bf16);
-#undef GL_T
-#undef GL_K
-#undef GL
-    } else {
-#define GV(T, RR) hipLaunchKernelGGL((gemv_kernel<T, RR>), grid, dim3(256), 0, stream, (const T*)l.w.p, (const T*)x, l.b.as<float>(), res, out, of, act, l.n, l.k)
-#define GV_T(T) do { if (R == 2) GV(T, 2); else GV(T, 1); } while (0)
-        if (dtype == MI_F32) GV_T(float); else if (dtype == MI_F16) GV_T(f16); else GV_T(bf16);
-#undef GV_T
-#undef GV
-    }
+    if (dtype == MI_F32) gemv_d_dispatch<float>(l, x, ln_w, ln_b, pre_w, pre_b, pre_out, res, out, of, act, kcl, vcl, st, cfg.max_seq, stream);
+    else if (dtype == MI_F16) gemv_d_dispatch<f16>(l, x, ln_w, ln_b, pre_w, pre_b, pre_out, res, out, of, act, kcl, vcl, st, cfg.max_seq, stream);
+    else gemv_d_dispatch<bf16>(l, x, ln_w, ln_b, pre_w, pre_b, pre_out, res, out, of, act, kcl, vcl, st, cfg.max_seq, stream);
     MI_HIP(hipGetLastError());
 }
 
@@ -892,11 +1059,14 @@ void Gpt::forward_rows(int rows, int flag, int slot) {
         }
     }
     const float* xl = x + (size_t)(rows - 1) * h;
-    launch_rownorm(NORM_LN_AFFINE, xl, last_s, MI_F32, lnf_w.as<float>(), lnf_b.as<float>(), 1, h, 1e-5f, s);
-    gemv(head, last_s, fn_w.as<float>(), fn_b.as<float>(), logits_s, MI_F32, ACT_NONE, nullptr, nullptr, nullptr);
+    // ln_f (-> last_hidden_state) and final_norm in front of the lm_head, one launch
+    gemv(head, xl, fn_w.as<float>(), fn_b.as<float>(), logits_s, MI_F32, ACT_NONE, nullptr, nullptr, nullptr, 0,
+         lnf_w.as<float>(), lnf_b.as<float>(), last_s);
     hipLaunchKernelGGL(gpt_pick_kernel, dim3(1), dim3(1024), 0, s, logits_s, pen.as<float>() + (size_t)slot * c.mel_codes,
                        last_s, state.as<int>() + (size_t)slot * GS_WORDS, toks.as<int>() + (size_t)slot * S,
-                       hid.as<float>() + (size_t)slot * S * h, c.mel_codes, h, rows, rep_dev.as<float>(), S);
+                       hid.as<float>() + (size_t)slot * S * h, c.mel_codes, h, rows, rep_dev.as<float>(), S,
+                       mel_emb.as<float>(), mel_pos.as<float>(), c.max_mel_pos, slot == 0 ? X.as<float>() : nullptr,
+                       Xd.as<float>() + (size_t)slot * h);
     MI_HIP(hipGetLastError());
 }
 
@@ -906,12 +1076,8 @@ void Gpt::set_rep_value(float v) {
     MI_HIP(hipStreamSynchronize(stream));
 }
 
-void Gpt::decode_step_eager() {
-    hipLaunchKernelGGL(gpt_embed_state_kernel, dim3(1), dim3(256), 0, stream, state.as<int>(), mel_emb.as<float>(),
-                       mel_pos.as<float>(), X.as<float>(), cfg.hidden, cfg.mel_codes, cfg.max_mel_pos, -1, -1);
-    MI_HIP(hipGetLastError());
-    forward_rows(1, 0);
-}
+// X row 0 holds graph C's output for the state: written by the pick kernel of the step (or prompt pass) before
+void Gpt::decode_step_eager() { forward_rows(1, 0); }
 
 void Gpt::check_graph_epoch() {
     if (graph_epoch == option_epoch()) return;
@@ -997,10 +1163,7 @@ void Gpt::decode_batch_eager(int nb) {
     const int h = c.hidden, S = c.max_seq;
     hipStream_t s = stream;
     const size_t es = dtype_size(dtype);
-    float* x = Xd.as<float>();
-    hipLaunchKernelGGL(gpt_embed_state_kernel, dim3(nb), dim3(256), 0, s, state.as<int>(), mel_emb.as<float>(),
-                       mel_pos.as<float>(), x, h, c.mel_codes, c.max_mel_pos, -1, -1);
-    MI_HIP(hipGetLastError());
+    float* x = Xd.as<float>();                 // row b = graph C of slot b's state, written by the pick kernel before
     for (int li = 0; li < c.layers; ++li) {
         Layer& l = L[li];
         char* kcl = (char*)kc.p + (size_t)li * h * S * es;          // slot 0's layer; slots are slot_cache_elems apart
@@ -1022,7 +1185,8 @@ void Gpt::decode_batch_eager(int nb) {
     launch_rownorm(NORM_LN_AFFINE, last.as<float>(), zd.p, dtype, fn_w.as<float>(), fn_b.as<float>(), nb, h, 1e-5f, s);
     gemv_b(head, zd.p, nb, logits.p, MI_F32, ACT_NONE, nullptr, nullptr, nullptr);
     hipLaunchKernelGGL(gpt_pick_kernel, dim3(nb), dim3(1024), 0, s, logits.as<float>(), pen.as<float>(), last.as<float>(),
-                       state.as<int>(), toks.as<int>(), hid.as<float>(), c.mel_codes, h, 1, rep_dev.as<float>(), S);
+                       state.as<int>(), toks.as<int>(), hid.as<float>(), c.mel_codes, h, 1, rep_dev.as<float>(), S,
+                       mel_emb.as<float>(), mel_pos.as<float>(), c.max_mel_pos, (float*)nullptr, Xd.as<float>());
     MI_HIP(hipGetLastError());
 }
 
