@@ -314,8 +314,15 @@ class F5Bench:
         gemm_like = [k for k in kernels if k["family"] in ("conv_gemm", "attn")]
         note = ("HIP events on the engine's stream around every launch, one separate eager pass after the timed region (the timed "
                 "region replays a hipGraph; events cannot be recorded into it); flops = 2*M*N*K of the launch")
-        if gemm_like and ("linear_x3_kernel" in gemm_like[0]["kernel"] or "linear_x3p_kernel" in gemm_like[0]["kernel"]):
-            # fp32 products formed as six exact bf16 x bf16 partial products (gemm_x3p.hip / gemm_x3.hip): the kernel runs on the bf16 pipes,
+        dom = gemm_like[0]["kernel"] if gemm_like else ""
+        if "linear_x3p_kernel<float, true, 2>" in dom or "linear_x3p_kernel<float, false, 2>" in dom:
+            # fp32 products as THREE fp16 x fp16 partial products (operands as {hi, lo * 2^11} fp16 pairs, two accumulator sets:
+            # gemm_x3p.hip NP = 2): the ceiling is the dense fp16 MFMA peak / 3 in fp32-equivalent flops
+            peak = MFMA_F16_PEAK_TF / 3.0
+            note += ("; this kernel computes every fp32 product as 3 fp16 MFMA partial products (operands as fp16 {hi, lo} pairs, 22 "
+                     "significant bits, fp32 accumulate): peak = 2500 / 3 TFLOP/s of fp32-equivalent work, achieved counts 2*M*N*K once")
+        elif "linear_x3_kernel" in dom or "linear_x3p_kernel" in dom:
+            # fp32 products formed as six exact bf16 x bf16 partial products (gemm_x3p.hip NP = 3 / gemm_x3.hip): the kernel runs on the bf16 pipes,
             # so its ceiling is the dense bf16 MFMA peak / 6 in fp32-equivalent flops, not the fp32 MFMA peak
             peak = MFMA_F16_PEAK_TF / 6.0
             note += ("; this kernel computes every fp32 product as 6 bf16 MFMA partial products (3-way exact operand split, fp32 "
@@ -424,9 +431,10 @@ def run_f5(args, world, rank, local, dev, dist, torch):
                    "audio_seconds_per_step_per_gpu": res["audio_seconds_per_step_per_gpu"], "rtf": res["rtf"],
                    "weights": "synthetic seeded (337 M DiT + 13.5 M Vocos params)", "weight_bcast_ms": fb.bcast_ms,
                    "collective_backend": dist.get_backend() if world > 1 else None,
-                   "arithmetic": ("fp32 values, fp32 accumulation; the DiT linear layers and both products of attention form each fp32 "
-                                  "product as six exact bf16 x bf16 partial products (3-way operand split, gemm_x3p.hip) — same fp32 parity "
-                                  "gates as the native fp32 MFMA path, which is timed in secondary.f5_f32_native_mfma") if args.dtype == "f32" else "16-bit operands, fp32 accumulation, fp32 residual stream",
+                   "arithmetic": ("fp32 values, fp32 accumulation; the DiT linear layers form each fp32 product as three fp16 x fp16 partial products "
+                                  "(operands as fp16 {hi, lo * 2^11} pairs = 22 significant bits, gemm_x3p.hip: measured error against float64 "
+                                  "BELOW the native fp32 MFMA's), both products of attention as six exact bf16 x bf16 partial products (3-way "
+                                  "split) — same fp32 parity gates as the native fp32 MFMA path, which is timed in secondary.f5_f32_native_mfma") if args.dtype == "f32" else "16-bit operands, fp32 accumulation, fp32 residual stream",
                    "end_to_end_TFLOP_per_step": res["end_to_end_TFLOP_per_step"],
                    "end_to_end_TFLOP_per_s": res["end_to_end_TFLOP_per_s"],
                    "inputs": "audio / text ids / injected noise resident in HBM, int16 waveform left in HBM",

@@ -228,8 +228,12 @@ int         mi_indextts_cond_run(mi_cond* h, const int16_t* audio, int64_t L, fl
  * "aa_conv_deterministic" (1: one workgroup per CU in the fused AA+conv kernel; a diagnostic since round 3 — the default, two per
  * CU, is bit-identical from run to run now that the AA math no longer uses the op_sel encoding that was not).
  * Arithmetic of fp32 engines (all keep fp32 values and fp32 accumulation, and pass the same parity gates):
- *   "gemm_f32_x3" (default 1): the big linear layers form every fp32 product as six exact bf16 x bf16 partial products on the
- *       bf16 matrix cores (three-way operand split; gemm_x3p.hip with both operands pre-split, gemm_x3.hip as its fallback); 0: native v_mfma_f32_32x32x2_f32.
+ *   "gemm_f32_x3" (default 1): the big linear layers form every fp32 product from 16-bit partial products on the 16-bit matrix
+ *       cores with both operands pre-split (gemm_x3p.hip; gemm_x3.hip as its fallback); 0: native v_mfma_f32_32x32x2_f32.
+ *   "gemm_f32_planes" (default 2; read when an engine splits its weights, i.e. at mi_f5_create): the operand format of that
+ *       path.  2: fp16 pairs {hi = fp16(a), lo = fp16((a - hi) * 2^11)} — 22 significant bits, |a| clamped at 65504 — three
+ *       partial products per fp32 product on two accumulator sets; measured error against float64 below the native fp32
+ *       MFMA's.  3: three bf16 planes (exact split), six partial products.
  *   "attn_f32_x3" (default 2): attention with both products formed that way (V is then kept transposed, like in the 16-bit
  *       engines); 1: q.k only; 0: native fp32 MFMA.
  * Further tuning keys (defaults are the measured best): "gemm_ph8", "gemm_ph8_min_tiles", "gemm_ph8_order",

@@ -311,7 +311,7 @@ def test_bad_inputs_raise(small_voc):
 # ---------------------------------------------------------------------------------------------
 _DEFAULTS = {"gemm_big_tile_min": 160, "gemm_n192_min": 160, "gemm_mid_tile_min": 160, "gemm_dma3_k_min": 2048,
              "gemm_use_dma3": 1, "gemm_use_dma": 1, "gemm_big_tiles": 1, "gemm_n192": 1, "gemm_f32_dma": 1, "gemm_ring4": 1, "gemm_ring4_max": 256, "gemm_buf": 1, "gemm_f32_small": 1, "gemm_f32_small_max": 1024, "gemm_small16_max": 256, "gemm_sk": 1, "gemm_sk_stages": 0, "gemm_ph8": 1, "gemm_ph8_min_tiles": 200, "gemm_ph8_order": 1, "gemm_ph8_split_max": 2, "gemm_ph8_split_min_nk": 24, "gemm_f32_x3": 1,
-             "gemm_f32_x3p": 1, "gemm_x3p_grid": 0, "gemm_x3p_noalign": 0}
+             "gemm_f32_x3p": 1, "gemm_x3p_grid": 0, "gemm_x3p_noalign": 0, "gemm_f32_planes": 2}
 
 
 @pytest.fixture
@@ -446,16 +446,19 @@ def test_f32_linear_as_exact_bf16_splits_vs_oracle(gemm_options, Ci, Co, T, B):
     assert e_x3 < 1.5 * e_native + 1e-9, (e_x3, e_native)
 
 
+@pytest.mark.parametrize("planes", [2, 3])
 @pytest.mark.parametrize("grid", [0, 1, 2, 4, 8])
 @pytest.mark.parametrize("noalign", [0, 1])
 @pytest.mark.parametrize("Ci,Co,T,B", [(1024, 1024, 1126, 2), (1024, 3072, 1126, 2), (2048, 1024, 1126, 2), (1024, 2048, 2252, 1),
                                         (256, 1024, 1500, 1), (1024, 1024, 1126, 6), (64, 1280, 700, 2)])
-def test_f32_linear_panel_planes_vs_oracle(gemm_options, grid, noalign, Ci, Co, T, B):
-    """gemm_x3p.hip (round 3): the same exact bf16 splits with BOTH operands pre-split into panel planes, eight waves as
-    two k16 groups, 2-D XCD bands (gemm_x3p_grid = GR, 0 = automatic) and the cyclic K walk (gemm_x3p_noalign = 1 switches
-    it off).  Same gates as the round-2 kernel: atol 3e-5 against the oracle, < 1e-5 from the native fp32 MFMA, error
-    against float64 no larger than native, run-to-run identity; the DiT shapes at one utterance (M = 2252) and three
-    (M = 6756: several tiles per workgroup), K = 64 ... 2048, a ragged last row panel."""
+def test_f32_linear_panel_planes_vs_oracle(gemm_options, planes, grid, noalign, Ci, Co, T, B):
+    """gemm_x3p.hip (round 3): BOTH operands pre-split into panel planes — three bf16 planes (six exact partial products)
+    or two fp16 planes {hi, lo * 2^11} (three partial products on two accumulator sets) — eight waves as two k16 groups,
+    2-D XCD bands (gemm_x3p_grid = GR, 0 = automatic) and the cyclic K walk (gemm_x3p_noalign = 1 switches it off).  Same
+    gates as the round-2 kernel: atol 3e-5 against the oracle, < 1e-5 from the native fp32 MFMA, error against float64 no
+    larger than native, run-to-run identity; the DiT shapes at one utterance (M = 2252) and three (M = 6756: several tiles
+    per workgroup), K = 64 ... 2048, a ragged last row panel."""
+    gemm_options("gemm_f32_planes", planes)
     gemm_options("gemm_f32_x3", 1)
     gemm_options("gemm_f32_x3p", 1)
     gemm_options("gemm_x3p_grid", grid)
@@ -476,6 +479,32 @@ def test_f32_linear_panel_planes_vs_oracle(gemm_options, grid, noalign, Ci, Co, 
     ref64 = np.einsum("oc,bct->bot", w[:, :, 0].astype(np.float64), x.astype(np.float64)) + b.astype(np.float64)[None, :, None]
     e_x3, e_native = rms(y - ref64), rms(y0 - ref64)
     assert e_x3 < 1.5 * e_native + 1e-9, (e_x3, e_native)
+
+
+@pytest.mark.parametrize("scale", [1e-6, 1e-3, 1.0, 300.0, 3e4])
+def test_f32_linear_fp16_pairs_over_the_operand_range(gemm_options, scale):
+    """The two-plane form stores an operand as fp16(a) and fp16((a - hi) * 2^11): 22 significant bits with the residual
+    kept in the exponent range of the value, |a| clamped at 65504.  Its error is relative (2^-23) down to |a| ~ 2^-12 and
+    ABSOLUTE (2^-36 = 1.5e-11 per operand) below that, where fp16(a) itself goes subnormal.  Operands from 1e-3 to 3e4 in
+    magnitude: the relative error against float64 stays at the native fp32 MFMA's (and the three-plane form's); a tensor
+    that is 1e-6 throughout: inside the absolute floor."""
+    Ci, Co, T, B = 1024, 1024, 1126, 2
+    x = (W.synth_normal(1, f"rx{Ci}{T}", (B, Ci, T)) * scale).astype(np.float32)
+    x = np.clip(x, -65000.0, 65000.0)
+    w = W.synth_normal(2, f"rw{Ci}{Co}", (Co, Ci, 1), std=1.0 / np.sqrt(Ci))
+    ref64 = np.einsum("oc,bct->bot", w[:, :, 0].astype(np.float64), x.astype(np.float64))
+    err = {}
+    for name, opts in (("pairs", {"gemm_f32_planes": 2}), ("bf16x3", {"gemm_f32_planes": 3}), ("native", {"gemm_f32_x3": 0})):
+        gemm_options("gemm_f32_x3", 1); gemm_options("gemm_f32_x3p", 1)
+        for k, v in opts.items():
+            gemm_options(k, v)
+        err[name] = rms(BV.conv1d(x, w, None, dtype="f32") - ref64)
+    rel = {k: v / rms(ref64) for k, v in err.items()}
+    print(f"scale {scale:g}: relative rms error against float64: {rel}")
+    if scale >= 1e-3:
+        assert rel["pairs"] < 1.5 * rel["native"] and rel["pairs"] < 1.5 * rel["bf16x3"] and rel["pairs"] < 1e-6, rel
+    else:       # sum over K of w * (2^-36 operand error): sqrt(K) * rms(w) = 1 here
+        assert err["pairs"] < 4 * 2.0 ** -36, err
 
 
 @pytest.mark.parametrize("f32_dma,small,buf", [(1, 1, 1), (1, 0, 1), (1, 1, 0), (1, 0, 0), (0, 1, 1)])

@@ -340,21 +340,23 @@ def gfull(golden_dir):
     return np.load(os.path.join(golden_dir, "f5_full.npz"))
 
 
-@pytest.mark.parametrize("native", [False, True], ids=["bf16x3-splits", "native-fp32-mfma"])
-def test_full_size_fp32_against_reference_fixture(full, gfull, native):
+@pytest.mark.parametrize("form", ["fp16-pairs", "bf16x3-splits", "native-fp32-mfma"])
+def test_full_size_fp32_against_reference_fixture(full, gfull, form):
     """configs[2]: fp32, one utterance, NFE grid 32 — the north-star gate (waveform <= 1e-3 RMS) on the north-star config.
-    Both fp32 forms of the engine: the default (linear layers and attention as exact bf16 splits) and the native fp32 MFMA
-    (gemm_f32_x3 = 0, attn_f32_x3 = 0: what bench.py times as secondary.f5_f32_native_mfma)."""
+    All three fp32 forms of the engine: the default (linear layers as fp16 {hi, lo} pairs: gemm_f32_planes = 2, attention as
+    exact bf16 splits), the linear layers as three bf16 planes (gemm_f32_planes = 3: round 3's first form) and the native
+    fp32 MFMA (gemm_f32_x3 = 0, attn_f32_x3 = 0: what bench.py times as secondary.f5_f32_native_mfma)."""
     from mi355tts import _lib
-    if native:
+    if form == "native-fp32-mfma":
         _lib.set_option("gemm_f32_x3", 0); _lib.set_option("attn_f32_x3", 0)
+    _lib.set_option("gemm_f32_planes", 3 if form == "bf16x3-splits" else 2)       # read when the engine splits its weights
     try:
-        _full_size_fp32_body(full, gfull, native)
+        _full_size_fp32_body(full, gfull, form)
     finally:
-        _lib.set_option("gemm_f32_x3", 1); _lib.set_option("attn_f32_x3", 2)
+        _lib.set_option("gemm_f32_x3", 1); _lib.set_option("attn_f32_x3", 2); _lib.set_option("gemm_f32_planes", 2)
 
 
-def _full_size_fp32_body(full, gfull, native):
+def _full_size_fp32_body(full, gfull, form):
     cfg, raw, audio, ids, N, noise = full
     assert int(gfull["N"]) == N
     eng = F5Engine(cfg, raw, dtype="f32")
@@ -378,7 +380,7 @@ def _full_size_fp32_body(full, gfull, native):
     assert err < 1e-3, err                                               # THE north-star gate
     assert rms(gfull["e2e_i16"]) > 500
     eng.close()
-    print(f"F5 full size fp32 ({'native fp32 MFMA' if native else 'bf16x3 splits'}) vs reference: DiT eval rel {e_pred:.2e}, "
+    print(f"F5 full size fp32 ({form}) vs reference: DiT eval rel {e_pred:.2e}, "
           f"31-step state rel {e_loop:.2e}, waveform rms {err:.2e}")
 
 

@@ -421,9 +421,9 @@ template <bool SPLIT2, bool KVP = false>
 __global__ __launch_bounds__(256, 2) void attn_x3f_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                        const float* __restrict__ v, float* __restrict__ o, int H, int N,
                                                        float* __restrict__ ws, int* __restrict__ cnt,
-                                                       unsigned char* __restrict__ o_planes) {
+                                                       unsigned char* __restrict__ o_planes, int o_np) {
     // o_planes != null: the output leaves as gemm_x3p.hip panel planes of the [B * N][H * 64] matrix (the A operand of the O
-    // projection), three-way split here, instead of fp32 rows in o
+    // projection), split here (o_np = 3 bf16 planes | 2 fp16 planes), instead of fp32 rows in o
     using MF = Mfma<bf16>;
     using Frag = bf16x8;
     constexpr int D = 64, KT = 64;
@@ -768,12 +768,17 @@ __global__ __launch_bounds__(256, 2) void attn_x3f_kernel(const float* __restric
                 if (o_planes) {
                     // columns h*64 + dt*32 + 8g + 4hi .. +3: half (8 bytes) of the k-slot s8 = h*8 + dt*4 + g of every plane
                     uint2 w1, w2, w3;
-                    x3_split_pair(vals[0], vals[1], w1.x, w2.x, w3.x);
-                    x3_split_pair(vals[2], vals[3], w1.y, w2.y, w3.y);
-                    unsigned char* dst = o_planes + x3p_slot_offset(row, h * 8 + dt * 4 + g, (H * D) >> 5) + 8 * hi;
+                    unsigned char* dst = o_planes + x3p_slot_offset(row, h * 8 + dt * 4 + g, (H * D) >> 5, o_np) + 8 * hi;
+                    if (o_np == 3) {
+                        x3_split_pair(vals[0], vals[1], w1.x, w2.x, w3.x);
+                        x3_split_pair(vals[2], vals[3], w1.y, w2.y, w3.y);
+                        *reinterpret_cast<uint2*>(dst + 2 * X3P_PLANE) = w3;
+                    } else {
+                        x2_split_pair(vals[0], vals[1], w1.x, w2.x);
+                        x2_split_pair(vals[2], vals[3], w1.y, w2.y);
+                    }
                     *reinterpret_cast<uint2*>(dst) = w1;
                     *reinterpret_cast<uint2*>(dst + X3P_PLANE) = w2;
-                    *reinterpret_cast<uint2*>(dst + 2 * X3P_PLANE) = w3;
                 } else {
                     float* dst = ob + dt * 32 + 8 * g + 4 * hi;
                     *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(vals);
@@ -833,7 +838,8 @@ bool attention_can_write_planes(int N, int BH, int dtype) {
 }
 
 void launch_attention(const void* q, const void* k, const void* v, void* o, int BH, int H, int N, int dtype, hipStream_t s,
-                      float* ws, long ws_floats, int* cnt, long cnt_n, void* o_planes, int kv_planes) {
+                      float* ws, long ws_floats, int* cnt, long cnt_n, void* o_planes, int kv_planes, int o_np) {
+    MI_REQUIRE(o_np == 2 || o_np == 3, "attention: 2 or 3 output planes");
     MI_REQUIRE(!o_planes || attention_can_write_planes(N, BH, dtype), "attention: panel-plane output needs the fp32 split kernel");
     MI_REQUIRE(!kv_planes || attention_can_write_planes(N, BH, dtype), "attention: pre-split K / V need the fp32 split kernel");
     MI_REQUIRE(BH % H == 0 && N > 0, "attention: bad shape");
@@ -880,10 +886,10 @@ void launch_attention(const void* q, const void* k, const void* v, void* o, int 
             if (g_attn_x3 == 2) {
                 if (kv_planes) {
                     prof_set_kernel("attn_x3f_kernel<true, pre-split K V>", "", "");
-                    hipLaunchKernelGGL((attn_x3f_kernel<true, true>), dim3((N + 63) / 64, BH, Z), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt, (unsigned char*)o_planes);
+                    hipLaunchKernelGGL((attn_x3f_kernel<true, true>), dim3((N + 63) / 64, BH, Z), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt, (unsigned char*)o_planes, o_np);
                 } else {
                 prof_set_kernel("attn_x3f_kernel<true>", "", "");
-                hipLaunchKernelGGL((attn_x3f_kernel<true>), dim3((N + 63) / 64, BH, Z), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt, (unsigned char*)o_planes);
+                hipLaunchKernelGGL((attn_x3f_kernel<true>), dim3((N + 63) / 64, BH, Z), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt, (unsigned char*)o_planes, o_np);
                 }
             } else if (g_attn_x3 == 1) {
                 prof_set_kernel("attn_kernel<float, true, x3>", "", "");
@@ -893,10 +899,10 @@ void launch_attention(const void* q, const void* k, const void* v, void* o, int 
         } else if (g_attn_x3 == 2) {
             if (kv_planes) {
                 prof_set_kernel("attn_x3f_kernel<false, pre-split K V>", "", "");
-                hipLaunchKernelGGL((attn_x3f_kernel<false, true>), dim3((N + 127) / 128, BH), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt, (unsigned char*)o_planes);
+                hipLaunchKernelGGL((attn_x3f_kernel<false, true>), dim3((N + 127) / 128, BH), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt, (unsigned char*)o_planes, o_np);
             } else {
             prof_set_kernel("attn_x3f_kernel<false>", "", "");
-            hipLaunchKernelGGL((attn_x3f_kernel<false>), dim3((N + 127) / 128, BH), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt, (unsigned char*)o_planes);
+            hipLaunchKernelGGL((attn_x3f_kernel<false>), dim3((N + 127) / 128, BH), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt, (unsigned char*)o_planes, o_np);
             }
         } else if (g_attn_x3 == 1) {
             prof_set_kernel("attn_kernel<float, false, x3>", "", "");

@@ -428,10 +428,11 @@ void unit_conv1d(const float* x, int B, int Cin, int T, const float* w, const fl
     }
     DevBuf dxp, dw3p;
     if (p.w3 && gemm_x3p_enabled() && padding == 0 && Cout % 128 == 0 && cigp % 32 == 0) {     // ... and its panel-plane form (gemm_x3p.hip)
-        dxp.ensure((size_t)x3p_bytes((long)B * T, cigp)); dw3p.ensure((size_t)x3p_bytes(Cout, cigp));
-        x3p_split_rows(dxl.as<float>(), Cp, dxp.p, B * T, cigp, ts.s);
-        x3p_split_rows(dw.as<float>(), cigp, dw3p.p, Cout, cigp, ts.s);
-        p.xp = dxp.p; p.w3p = dw3p.p;
+        const int np = x3p_planes();
+        dxp.ensure((size_t)x3p_bytes((long)B * T, cigp, np)); dw3p.ensure((size_t)x3p_bytes(Cout, cigp, np));
+        x3p_split_rows(dxl.as<float>(), Cp, dxp.p, B * T, cigp, ts.s, np);
+        x3p_split_rows(dw.as<float>(), cigp, dw3p.p, Cout, cigp, ts.s, np);
+        p.xp = dxp.p; p.w3p = dw3p.p; p.np = np;
     }
     launch_conv_gemm(p, ts.s);
     launch_nlc_to_ncl(dyl.p, dy.as<float>(), B, Cout, To, dtype, ts.s);

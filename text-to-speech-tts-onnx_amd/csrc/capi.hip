@@ -704,10 +704,11 @@ int mi_bench_conv_gemm(int dtype, int B, int T, int Cin, int N, int taps, int di
         }
         DevBuf xp, w3p;
         if (p.w3 && gemm_x3p_enabled() && N % 128 == 0 && Cin % 32 == 0 && p.pad == 0) {       // ... and the panel-plane form (gemm_x3p.hip)
-            xp.ensure((size_t)x3p_bytes((long)B * T, Cin)); w3p.ensure((size_t)x3p_bytes(N, Cin));
-            x3p_split_rows((const float*)x.p, Cin, xp.p, B * T, Cin, s);
-            x3p_split_rows((const float*)w.p, Cin, w3p.p, N, Cin, s);
-            p.xp = xp.p; p.w3p = w3p.p;
+            const int np = x3p_planes();
+            xp.ensure((size_t)x3p_bytes((long)B * T, Cin, np)); w3p.ensure((size_t)x3p_bytes(N, Cin, np));
+            x3p_split_rows((const float*)x.p, Cin, xp.p, B * T, Cin, s, np);
+            x3p_split_rows((const float*)w.p, Cin, w3p.p, N, Cin, s, np);
+            p.xp = xp.p; p.w3p = w3p.p; p.np = np;
         }
         for (int i = 0; i < 3; ++i) launch_conv_gemm(p, s);
         hipEvent_t e0, e1;

@@ -168,7 +168,7 @@ struct ConvGemm {
     // fp32 linear layers through the bf16 pipes (gemm_x3.hip): the weights split into three bf16 planes [3][N][K] (split3_planes)
     const void* w3 = nullptr;
     // gemm_x3p.hip (round 3): both operands as pre-split, pre-tiled "panel planes" (x3p_split_rows): xp replaces x, w3p replaces w3
-    const void* xp = nullptr; const void* w3p = nullptr;
+    const void* xp = nullptr; const void* w3p = nullptr; int np = 3;        // np: planes per operand (3 bf16 | 2 fp16), both operands alike
     // ... and its output as panel planes too (the A operand of the NEXT linear layer: FF1 -> FF2), instead of rows in `out`;
     // plain epilogue only: bias + activation, no residual / gate / accumulate
     void* out_planes = nullptr;
@@ -177,14 +177,20 @@ void launch_conv_gemm(const ConvGemm& p, hipStream_t s);
 // gemm_x3p.hip panel planes: [panel = row / 128][chunk = k / 32][plane 0..2][row % 128][32 bf16], the four 16-byte k-slots of a
 // 64-byte row XOR-swizzled by (row >> 2) & 3
 constexpr int X3P_PLANE = 128 * 32 * 2;          // one plane of one (panel, chunk): 128 rows x 64 bytes
-constexpr int X3P_CHUNK = 3 * X3P_PLANE;         // 24 KB
-// byte offset of the 16-byte slot holding k = 8 * s8 .. 8 * s8 + 7 of `row` in plane 0 (planes 1, 2: + X3P_PLANE each)
-__host__ __device__ inline long x3p_slot_offset(long row, int s8, int nch) {
+constexpr int X3P_CHUNK = 3 * X3P_PLANE;         // 24 KB (three bf16 planes)
+// Two number formats share the layout (np = planes per operand):
+//   np = 3: a = a1 + a2 + a3 in bf16 (x3_split_pair), six partial products per block            -> 2500 / 6 TFLOP/s ceiling
+//   np = 2: a = hi + lo * 2^-11 in fp16 (x2_split_pair: 22-bit operands, |a| <= 65504), three partial products per block
+//           on two accumulators (hi*hi ; hi*lo + lo*hi)                                          -> 2500 / 3 TFLOP/s ceiling
+__host__ __device__ inline int x3p_chunk_bytes(int np) { return np * X3P_PLANE; }
+// byte offset of the 16-byte slot holding k = 8 * s8 .. 8 * s8 + 7 of `row` in plane 0 (the other planes: + X3P_PLANE each)
+__host__ __device__ inline long x3p_slot_offset(long row, int s8, int nch, int np = 3) {
     const int r = (int)(row & 127);
-    return ((row >> 7) * nch + (s8 >> 2)) * (long)X3P_CHUNK + r * 64 + (((s8 & 3) ^ ((r >> 2) & 3)) << 4);
+    return ((row >> 7) * nch + (s8 >> 2)) * (long)(np * X3P_PLANE) + r * 64 + (((s8 & 3) ^ ((r >> 2) & 3)) << 4);
 }
-long x3p_bytes(long rows, long K);                                                    // bytes of the panel planes of a [rows][K] matrix
-void x3p_split_rows(const float* x, long ld, void* planes, int rows, int K, hipStream_t s);
+long x3p_bytes(long rows, long K, int np = 3);                                        // bytes of the panel planes of a [rows][K] matrix
+void x3p_split_rows(const float* x, long ld, void* planes, int rows, int K, hipStream_t s, int np = 3);
+int x3p_planes();                                  // option "gemm_f32_planes": the format new planes are built in (3 or 2)
 bool gemm_x3p_enabled();
 bool gemm_x3p_would_run(const ConvGemm& p);        // p.xp / p.w3p set: will launch_conv_gemm(p) take the panel-plane kernel?
 // owner of a stream-K workspace (one per engine handle / stream)

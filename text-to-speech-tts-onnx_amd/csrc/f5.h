@@ -60,6 +60,7 @@ struct F5 {
     DevBuf attn_ws, attn_cnt; // key-sliced fp32 attention: partial (m, l, O) per 64-query tile and slice, ticket counters
     long attn_ws_floats = 0, attn_cnt_n = 0;
     int ws_U = 0, ws_N = 0;
+    int np = 3;              // planes per operand of the panel-plane GEMMs, fixed when the weights are split (x3p_planes())
     DevBuf Ap, Ap2;          // fp32 engines: the A operand of the big linear layers as panel planes (gemm_x3p.hip): dim / ff columns
     DevBuf d_noise, d_cmt, d_cmtd, cat, h32, hT, c1, X, Ub, qb, kb, vb, Ob, Hff, pred;
     DevBuf p_audio, p_pad, p_spec, p_mag, p_mel, p_ids, p_tid, p_err, p_tx, p_ty, p_ty2, p_ss;

@@ -74,6 +74,7 @@ static inline float siluf(float v) { return v / (1.f + expf(-v)); }
 static inline float round_f16(float v) { return (float)(f16)v; }
 
 F5::F5(const F5Cfg& c, const float* w, int64_t nw, int dt, int dev, int mem) : cfg(c), dtype(dt), device(dev) {
+    np = x3p_planes();
     MI_REQUIRE(dt == MI_F32 || dt == MI_F16 || dt == MI_BF16, "f5: bad dtype");
     MI_REQUIRE(nw == f5_param_count(c), "f5: weight blob size does not match the config");
     MI_HIP(hipSetDevice(dev));
@@ -200,8 +201,8 @@ F5::F5(const F5Cfg& c, const float* w, int64_t nw, int dt, int dev, int mem) : c
                 L->w3.ensure((size_t)3 * L->n * L->k * 2);
                 split3_planes(L->w.as<float>(), L->w3.p, (long)L->n * L->k, s);
                 if (L->n % 128 == 0 && L->k % 32 == 0) {
-                    L->w3p.ensure((size_t)x3p_bytes(L->n, L->k));
-                    x3p_split_rows(L->w.as<float>(), L->k, L->w3p.p, L->n, L->k, s);
+                    L->w3p.ensure((size_t)x3p_bytes(L->n, L->k, np));
+                    x3p_split_rows(L->w.as<float>(), L->k, L->w3p.p, L->n, L->k, s, np);
                 }
             }
         }
@@ -366,7 +367,7 @@ void F5::ensure_workspace(int U, int N) {
         if (vbytes > vb.bytes) { vb.ensure(vbytes); MI_HIP(hipMemsetAsync(vb.p, 0, vbytes, stream)); }
     }
     Hff.ensure(rows * c.ff() * es);
-    if (dtype == MI_F32) { Ap.ensure((size_t)x3p_bytes((long)rows, c.dim)); Ap2.ensure((size_t)x3p_bytes((long)rows, c.ff())); }
+    if (dtype == MI_F32) { Ap.ensure((size_t)x3p_bytes((long)rows, c.dim, np)); Ap2.ensure((size_t)x3p_bytes((long)rows, c.ff(), np)); }
     pred.ensure(rows * c.mel * 4);
     // preprocess temporaries
     const int ti = c.text_dim * c.conv_mult;
@@ -397,10 +398,10 @@ void F5::gemm(int dt, const void* x, long xb, long xr, int K, const Lin& L, void
     if (dt == MI_F32 && L.w3p.p && g.B == 1 && Ap.p && gemm_x3p_enabled()) {
         // fp32 big linear layer: the rows as panel planes — written by their producer (planes_ready) or by a separate pass here
         void* planes = in_planes ? const_cast<void*>(in_planes) : (K <= cfg.dim ? Ap.p : Ap2.p);
-        g.xp = planes; g.w3p = L.w3p.p; g.out_planes = out_planes;
+        g.xp = planes; g.w3p = L.w3p.p; g.np = np; g.out_planes = out_planes;
         if (!planes_ready) {
             MI_REQUIRE(!out_planes, "f5: out_planes is only requested after gemm_x3p_would_run()");
-            if (gemm_x3p_would_run(g)) x3p_split_rows((const float*)x, xr, planes, g.M, K, stream);
+            if (gemm_x3p_would_run(g)) x3p_split_rows((const float*)x, xr, planes, g.M, K, stream, np);
             else { g.xp = nullptr; g.w3p = nullptr; }
         }
     } else {
@@ -587,7 +588,7 @@ void F5::dit_eval(int U, int N, int k) {
             sk.attach(g);
             bool fused = false;
             if (dtype == MI_F32 && bk.qkv.w3p.p && Ap.p && gemm_x3p_enabled()) {
-                g.xp = Ap.p; g.w3p = bk.qkv.w3p.p;
+                g.xp = Ap.p; g.w3p = bk.qkv.w3p.p; g.np = np;
                 fused = gemm_x3p_would_run(g);
                 if (!fused) { g.xp = nullptr; g.w3p = nullptr; }
             }
@@ -595,7 +596,7 @@ void F5::dit_eval(int U, int N, int k) {
             kvp = fused && attention_takes_kv_planes(N, B * H, dtype);
             if (kvp) { g.kv_planes = 1; g.k_ld = g.v_ld = (long)((N + 63) / 64 * 64); }
             // AdaLN: LN(x) * (1 + scale) + shift — straight into the panel planes the QKV GEMM reads, or as rows
-            if (fused) launch_rownorm_x3p(X.as<float>(), Ap.p, m + d, m, rows, d, 1e-6f, s);
+            if (fused) launch_rownorm_x3p(X.as<float>(), Ap.p, m + d, m, rows, d, 1e-6f, s, np);
             else launch_rownorm(NORM_LN_MOD, X.as<float>(), Ub.p, dtype, m + d, m, rows, d, 1e-6f, s);
             launch_conv_gemm(g, s);
         }
@@ -604,33 +605,33 @@ void F5::dit_eval(int U, int N, int k) {
             bool fused = false;
             if (dtype == MI_F32 && bk.o.w3p.p && Ap.p && gemm_x3p_enabled() && attention_can_write_planes(N, B * H, dtype)) {
                 ConvGemm g;
-                g.dtype = dtype; g.out_dtype = MI_F32; g.x = Ob.p; g.w = bk.o.w.p; g.w3 = bk.o.w3.p; g.xp = Ap.p; g.w3p = bk.o.w3p.p;
+                g.dtype = dtype; g.out_dtype = MI_F32; g.x = Ob.p; g.w = bk.o.w.p; g.w3 = bk.o.w3.p; g.xp = Ap.p; g.w3p = bk.o.w3p.p; g.np = np;
                 g.bias = bk.o.b.as<float>(); g.out = X.p; g.res = X.p; g.gate = m + 2 * d; g.B = 1; g.T_in = B * N; g.M = B * N; g.N = d; g.Cin = d;
                 g.x_bstride = (long)N * d; g.x_rstride = d; g.out_bstride = (long)N * d; g.out_rstride = d;
                 sk.attach(g);
                 fused = gemm_x3p_would_run(g);
             }
             launch_attention(qb.p, kb.p, vb.p, Ob.p, B * H, H, N, dtype, s, attn_ws.as<float>(), attn_ws_floats, attn_cnt.as<int>(), attn_cnt_n,
-                             fused ? Ap.p : nullptr, kvp ? 1 : 0);
+                             fused ? Ap.p : nullptr, kvp ? 1 : 0, np);
             gemm(dtype, Ob.p, (long)N * d, d, d, bk.o, X.p, MI_F32, (long)N * d, d, B, N, ACT_NONE, X.p, m + 2 * d, fused, Ap.p);
         }
         {
             bool fused = false;
             if (dtype == MI_F32 && bk.ff1.w3p.p && Ap.p && gemm_x3p_enabled()) {
                 ConvGemm g;      // the FF1 launch as F5::gemm will build it, to ask whether the panel-plane kernel takes it
-                g.dtype = dtype; g.out_dtype = dtype; g.x = Ub.p; g.w = bk.ff1.w.p; g.w3 = bk.ff1.w3.p; g.xp = Ap.p; g.w3p = bk.ff1.w3p.p;
+                g.dtype = dtype; g.out_dtype = dtype; g.x = Ub.p; g.w = bk.ff1.w.p; g.w3 = bk.ff1.w3.p; g.xp = Ap.p; g.w3p = bk.ff1.w3p.p; g.np = np;
                 g.bias = bk.ff1.b.as<float>(); g.out = Hff.p; g.B = 1; g.T_in = B * N; g.M = B * N; g.N = ff; g.Cin = d; g.taps = 1;
                 g.x_bstride = (long)N * d; g.x_rstride = d; g.out_bstride = (long)N * ff; g.out_rstride = ff; g.act = ACT_GELU_TANH;
                 sk.attach(g);
                 fused = gemm_x3p_would_run(g);
             }
-            if (fused) launch_rownorm_x3p(X.as<float>(), Ap.p, m + 4 * d, m + 3 * d, rows, d, 1e-6f, s);
+            if (fused) launch_rownorm_x3p(X.as<float>(), Ap.p, m + 4 * d, m + 3 * d, rows, d, 1e-6f, s, np);
             else launch_rownorm(NORM_LN_MOD, X.as<float>(), Ub.p, dtype, m + 4 * d, m + 3 * d, rows, d, 1e-6f, s);
             // FF1's GELU output: as the panel planes FF2 reads (Ap2), when both GEMMs take the panel-plane kernel
             bool fused2 = false;
             if (fused && bk.ff2.w3p.p && Ap2.p) {
                 ConvGemm g;
-                g.dtype = dtype; g.out_dtype = MI_F32; g.x = Hff.p; g.w = bk.ff2.w.p; g.w3 = bk.ff2.w3.p; g.xp = Ap2.p; g.w3p = bk.ff2.w3p.p;
+                g.dtype = dtype; g.out_dtype = MI_F32; g.x = Hff.p; g.w = bk.ff2.w.p; g.w3 = bk.ff2.w3.p; g.xp = Ap2.p; g.w3p = bk.ff2.w3p.p; g.np = np;
                 g.bias = bk.ff2.b.as<float>(); g.out = X.p; g.res = X.p; g.gate = m + 5 * d; g.B = 1; g.T_in = B * N; g.M = B * N; g.N = d; g.Cin = ff;
                 g.x_bstride = (long)N * ff; g.x_rstride = ff; g.out_bstride = (long)N * d; g.out_rstride = d;
                 sk.attach(g);

@@ -9,7 +9,8 @@ enum { NORM_LN_MOD = 0, NORM_LN_AFFINE = 1, NORM_L2 = 2 };
 void launch_rownorm(int mode, const float* x, void* y, int out_dtype, const float* a, const float* b, long rows, int D,
                     float eps, hipStream_t s);
 // LN_MOD with the result as gemm_x3p.hip panel planes (three-way bf16 split of the fp32 value) instead of fp32 rows
-void launch_rownorm_x3p(const float* x, void* planes, const float* a, const float* b, long rows, int D, float eps, hipStream_t s);
+void launch_rownorm_x3p(const float* x, void* planes, const float* a, const float* b, long rows, int D, float eps, hipStream_t s,
+                        int np = 3);
 void launch_dwconv7(const float* x, float* y, const float* w, const float* bias, int B, int T, int C, hipStream_t s);
 void launch_grn(float* y, float* ss_scratch, const float* gamma, const float* beta, int B, int T, int C, hipStream_t s);
 // ids [U][N]; out slabs 2u (text) / 2u+1 (drop)
@@ -34,7 +35,7 @@ void launch_cfg_update(float* noise, const float* pred, int U, int N, int M, flo
 // counter per tile); without them every query tile is one workgroup
 void launch_attention(const void* q, const void* k, const void* v, void* o, int BH, int H, int N, int dtype, hipStream_t s,
                       float* ws = nullptr, long ws_floats = 0, int* cnt = nullptr, long cnt_n = 0, void* o_planes = nullptr,
-                      int kv_planes = 0);
+                      int kv_planes = 0, int o_np = 3);
 // kv_planes (fp32 engines, both products split): k and v are the pre-split bf16 planes the QKV epilogue wrote (ConvGemm::kv_planes:
 // k [BH][3][ld][64], v [BH][3][64][ld], ld = N rounded up to 64, pad keys of v zero) — ask attention_takes_kv_planes() first
 bool attention_takes_kv_planes(int N, int BH, int dtype);

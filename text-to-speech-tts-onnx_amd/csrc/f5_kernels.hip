@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ 
 // LayerNorm + AdaLN modulation with the result written as gemm_x3p.hip panel planes (three-way bf16 split of the fp32
 // value, x3_split.h) instead of fp32 rows: the A operand of the QKV / FF1 GEMMs needs no separate split pass.  One wave
 // per row, a lane holds 8 consecutive columns per pass (one 16-byte k-slot of each plane).
-template <int MAXP>
+template <int MAXP, int NP>
 __global__ __launch_bounds__(256) void rownorm_x3p_kernel(const float* __restrict__ x, unsigned char* __restrict__ planes,
                                                           const float* __restrict__ a, const float* __restrict__ b,
                                                           long rows, int D, float eps) {
@@ -129,26 +129,26 @@ __global__ __launch_bounds__(256) void rownorm_x3p_kernel(const float* __restric
             const float aa[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
             for (int k = 0; k < 8; ++k) o[k] = (o[k] - mean) * inv * (1.f + aa[k]) + bb[k];
-            unsigned p1[4], p2[4], p3[4];
+            x3_u4 pl[NP];
+            xnp_split8<NP>(o, pl);
+            unsigned char* dst = planes + x3p_slot_offset(row, s8, nch, NP);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) x3_split_pair(o[2 * k], o[2 * k + 1], p1[k], p2[k], p3[k]);
-            unsigned char* dst = planes + x3p_slot_offset(row, s8, nch);
-            *reinterpret_cast<x3_u4*>(dst) = x3_u4{p1[0], p1[1], p1[2], p1[3]};
-            *reinterpret_cast<x3_u4*>(dst + X3P_PLANE) = x3_u4{p2[0], p2[1], p2[2], p2[3]};
-            *reinterpret_cast<x3_u4*>(dst + 2 * X3P_PLANE) = x3_u4{p3[0], p3[1], p3[2], p3[3]};
+            for (int q = 0; q < NP; ++q) *reinterpret_cast<x3_u4*>(dst + q * X3P_PLANE) = pl[q];
         }
     }
 }
 
-void launch_rownorm_x3p(const float* x, void* planes, const float* a, const float* b, long rows, int D, float eps, hipStream_t s) {
+void launch_rownorm_x3p(const float* x, void* planes, const float* a, const float* b, long rows, int D, float eps, hipStream_t s, int np) {
     MI_REQUIRE(D % 32 == 0 && D <= 2048, "rownorm_x3p: D must be whole 32-deep chunks and <= 2048");
+    MI_REQUIRE(np == 2 || np == 3, "rownorm_x3p: 2 or 3 planes");
     dim3 grid((unsigned)((rows + 3) / 4));
-    ProfScope ps(FAM_NORM, s, (double)rows * D * (4.0 + 6.0), 8.0 * rows * D);
-    prof_set_kernel("rownorm_x3p_kernel", "", "");
+    ProfScope ps(FAM_NORM, s, (double)rows * D * (4.0 + 2.0 * np), 8.0 * rows * D);
+    prof_set_kernel(np == 3 ? "rownorm_x3p_kernel<3 planes>" : "rownorm_x3p_kernel<2 planes>", "", "");
     const int mp = (D + 511) / 512;
-    if (mp == 1) hipLaunchKernelGGL((rownorm_x3p_kernel<1>), grid, dim3(256), 0, s, x, (unsigned char*)planes, a, b, rows, D, eps);
-    else if (mp == 2) hipLaunchKernelGGL((rownorm_x3p_kernel<2>), grid, dim3(256), 0, s, x, (unsigned char*)planes, a, b, rows, D, eps);
-    else hipLaunchKernelGGL((rownorm_x3p_kernel<4>), grid, dim3(256), 0, s, x, (unsigned char*)planes, a, b, rows, D, eps);
+#define RNP(MP, NPL) hipLaunchKernelGGL((rownorm_x3p_kernel<MP, NPL>), grid, dim3(256), 0, s, x, (unsigned char*)planes, a, b, rows, D, eps)
+    if (np == 3) { if (mp == 1) RNP(1, 3); else if (mp == 2) RNP(2, 3); else RNP(4, 3); }
+    else { if (mp == 1) RNP(1, 2); else if (mp == 2) RNP(2, 2); else RNP(4, 2); }
+#undef RNP
     MI_HIP(hipGetLastError());
 }
 

@@ -442,6 +442,13 @@ static long g_x3 = 1;
 bool gemm_x3_enabled() { return g_x3 != 0; }
 // ... with both operands as panel planes (gemm_x3p.hip, round 3) when the caller supplies them
 static long g_x3p = 1;
+// number format of the panel planes built from now on: 3 = three bf16 planes (six products), 2 = fp16 {hi, lo} planes (three products)
+static long g_x3p_np = 0;          // 0: not set by mi_set_option -> MI355TTS_F32_PLANES, else 2
+int x3p_planes() {
+    if (g_x3p_np == 2 || g_x3p_np == 3) return (int)g_x3p_np;
+    static const int env = [] { const char* e = std::getenv("MI355TTS_F32_PLANES"); return e ? std::atoi(e) : 0; }();
+    return env == 3 ? 3 : 2;
+}
 bool gemm_x3p_enabled() { return g_x3 != 0 && g_x3p != 0; }
 // fp32 QKV + RoPE: its scatter epilogue is slow and in a persistent launch every workgroup runs it at the same time at the
 // end (in-model 184 us against 138 us for the 64x64 tiles, whose epilogues overlap other workgroups' main loops): off
@@ -652,6 +659,7 @@ bool gemm_set_option(const char* key, long v) {
     else if (k == "gemm_sk_qkv32") g_sk_qkv32 = v;
     else if (k == "gemm_f32_x3") g_x3 = v;
     else if (k == "gemm_f32_x3p") g_x3p = v;
+    else if (k == "gemm_f32_planes") { if (v != 2 && v != 3) return false; g_x3p_np = v; }
     else if (k == "gemm_x3p_noalign") x3p_set_option(0, v);
     else if (k == "gemm_x3p_grid") x3p_set_option(1, v);
     else if (k == "gemm_ph8") g_ph8 = v;
@@ -683,7 +691,8 @@ static bool x3p_eligible(const ConvGemm& p) {
     q.w3 = p.w3p;                                     // same conditions as the round-2 kernel (q.w3 only has to be non-null)
     if (!x3_eligible(q)) return false;
     const long nch = p.Cin / 32;
-    return p.N % 128 == 0 && ((long)(p.M + 127) / 128) * nch * 24576 < 0x7fff0000L && ((long)p.N / 128) * nch * 24576 < 0x7fff0000L;
+    const long chb = x3p_chunk_bytes(p.np);
+    return (p.np == 2 || p.np == 3) && p.N % 128 == 0 && ((long)(p.M + 127) / 128) * nch * chb < 0x7fff0000L && ((long)p.N / 128) * nch * chb < 0x7fff0000L;
 }
 
 bool gemm_x3p_would_run(const ConvGemm& p) { return x3p_eligible(p) && p.B == 1 && p.G == 1; }
@@ -716,7 +725,7 @@ void launch_conv_gemm(const ConvGemm& p_in, hipStream_t s) {
     const bool use_x3p = x3p_eligible(p);
     const bool use_x3 = use_x3p || x3_eligible(p);
     d.w3 = use_x3 ? p.w3 : nullptr;
-    d.xp = use_x3p ? p.xp : nullptr; d.w3p = use_x3p ? p.w3p : nullptr;
+    d.xp = use_x3p ? p.xp : nullptr; d.w3p = use_x3p ? p.w3p : nullptr; d.np = p.np;
     d.out_planes = nullptr;
     if (p.out_planes) {
         MI_REQUIRE(use_x3p && p.epi == EPI_PLAIN && !p.res && !p.gate && !p.accumulate && p.alpha == 1.f && p.N % 32 == 0,

@@ -39,7 +39,7 @@ struct ConvGemmDev {
     int Tm, Tn, RT, RC;    // XCD-aware tile order (DMA kernel): M-tiles per batch item, N-tiles, row tiles (B*Tm), rows per XCD
     float* sk_ws; int* sk_flags; int sk_slots;   // stream-K (gemm_sk.hip): 64 KB partial-tile slot + flag per persistent workgroup
     const void* w3;                              // gemm_x3.hip: weight planes [3][N][K] bf16 (null: not available)
-    const void* xp; const void* w3p;             // gemm_x3p.hip: A and B as panel planes (null: not available)
+    const void* xp; const void* w3p; int np;     // gemm_x3p.hip: A and B as panel planes (null: not available), np planes each (3 bf16 | 2 fp16)
     void* out_planes;                            // gemm_x3p.hip: output as panel planes of an [M][N] matrix (null: rows in `out`)
     int kv_planes; long k_ld;                    // EPI_QKV_ROPE, fp32: K and V^T leave as three bf16 planes (attention.hip KVP): out2 = [bh][3][k_ld][64], out3 = [bh][3][64][v_ld]
     int tail_tiles, tail_split;                  // gemm_ph8.hip: the last tail_tiles tiles are cut into tail_split K slices (0 / 1: none)

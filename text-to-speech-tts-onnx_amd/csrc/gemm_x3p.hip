@@ -37,10 +37,11 @@
 
 namespace mi {
 
-long x3p_bytes(long rows, long K) { return ((rows + 127) / 128) * (K / 32) * (long)X3P_CHUNK; }
+long x3p_bytes(long rows, long K, int np) { return ((rows + 127) / 128) * (K / 32) * (long)x3p_chunk_bytes(np); }
 
 // fp32 rows [rows][ld] (K columns used) -> panel planes.  One thread = one 16-byte k-slot (8 values) of one row; rows in
 // [rows, rows_pad) are written as zeros (the last row panel is always whole).
+template <int NP>
 __global__ __launch_bounds__(256) void x3p_split_rows_kernel(const float* __restrict__ x, long ld, unsigned char* __restrict__ out,
                                                              int rows, int K, long total) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -52,21 +53,27 @@ __global__ __launch_bounds__(256) void x3p_split_rows_kernel(const float* __rest
         const float4* src = reinterpret_cast<const float4*>(x + (long)row * ld + s8 * 8);
         v0 = src[0]; v1 = src[1];
     }
-    unsigned a[4], b[4], c[4];
-    x3_split_pair(v0.x, v0.y, a[0], b[0], c[0]); x3_split_pair(v0.z, v0.w, a[1], b[1], c[1]);
-    x3_split_pair(v1.x, v1.y, a[2], b[2], c[2]); x3_split_pair(v1.z, v1.w, a[3], b[3], c[3]);
-    unsigned char* dst = out + x3p_slot_offset(row, s8, K >> 5);
-    *reinterpret_cast<x3_u4*>(dst) = x3_u4{a[0], a[1], a[2], a[3]};
-    *reinterpret_cast<x3_u4*>(dst + X3P_PLANE) = x3_u4{b[0], b[1], b[2], b[3]};
-    *reinterpret_cast<x3_u4*>(dst + 2 * X3P_PLANE) = x3_u4{c[0], c[1], c[2], c[3]};
+    const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    x3_u4 pl[NP];
+    xnp_split8<NP>(v, pl);
+    unsigned char* dst = out + x3p_slot_offset(row, s8, K >> 5, NP);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) *reinterpret_cast<x3_u4*>(dst + q * X3P_PLANE) = pl[q];
 }
 
-void x3p_split_rows(const float* x, long ld, void* planes, int rows, int K, hipStream_t s) {
+void x3p_split_rows(const float* x, long ld, void* planes, int rows, int K, hipStream_t s, int np) {
     MI_REQUIRE(K % 32 == 0 && ld % 4 == 0 && ((uintptr_t)x % 16) == 0, "x3p_split_rows: K must be whole 32-deep chunks, rows 16-byte aligned");
+    MI_REQUIRE(np == 2 || np == 3, "x3p_split_rows: 2 or 3 planes");
     const int rows_pad = (rows + 127) / 128 * 128;
     const long total = (long)rows_pad * (K / 8);
-    prof_set_kernel("x3p_split_rows_kernel", "", "");
-    hipLaunchKernelGGL(x3p_split_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, ld, (unsigned char*)planes, rows, K, total);
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (np == 3) {
+        prof_set_kernel("x3p_split_rows_kernel<3>", "", "");
+        hipLaunchKernelGGL(x3p_split_rows_kernel<3>, grid, dim3(256), 0, s, x, ld, (unsigned char*)planes, rows, K, total);
+    } else {
+        prof_set_kernel("x3p_split_rows_kernel<2>", "", "");
+        hipLaunchKernelGGL(x3p_split_rows_kernel<2>, grid, dim3(256), 0, s, x, ld, (unsigned char*)planes, rows, K, total);
+    }
     MI_HIP(hipGetLastError());
 }
 
@@ -82,7 +89,7 @@ __device__ __forceinline__ void x3p_dma16(RSRC rsrc, int voff, unsigned lds_dst)
 // Epilogue with the OUTPUT as panel planes of the [M][N] result (the A operand of the next linear layer; FF1 -> FF2):
 // bias + activation on the accumulators, the 64x64 wave tile through LDS, then every lane takes 8 consecutive columns of
 // a row (one 16-byte k-slot of the next GEMM), splits them three ways and stores 16 bytes per plane.
-template <int TM, int TN>
+template <int TM, int TN, int NP>
 __device__ __forceinline__ void x3p_epilogue_planes(f32x16 (&acc)[TM][TN], const ConvGemmDev& p, int m0, int n0, int wm, int wn,
                                                     int lr, int lk, float* stage) {
     const int lane = lk * 32 + lr;
@@ -117,14 +124,13 @@ __device__ __forceinline__ void x3p_epilogue_planes(f32x16 (&acc)[TM][TN], const
         const int m = m0 + wm * (32 * TM) + rr;                 // wm counts (32 * TM)-row blocks
         const float4 t0 = *reinterpret_cast<const float4*>(&stage[rr * 64 + c8]);
         const float4 t1 = *reinterpret_cast<const float4*>(&stage[rr * 64 + c8 + 4]);
-        unsigned p1[4], p2[4], p3[4];
-        x3_split_pair(t0.x, t0.y, p1[0], p2[0], p3[0]); x3_split_pair(t0.z, t0.w, p1[1], p2[1], p3[1]);
-        x3_split_pair(t1.x, t1.y, p1[2], p2[2], p3[2]); x3_split_pair(t1.z, t1.w, p1[3], p2[3], p3[3]);
+        const float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+        x3_u4 pl[NP];
+        xnp_split8<NP>(v, pl);
         if (m < p.M) {
-            unsigned char* dst = planes + x3p_slot_offset(m, s8, nch_out);
-            *reinterpret_cast<x3_u4*>(dst) = x3_u4{p1[0], p1[1], p1[2], p1[3]};
-            *reinterpret_cast<x3_u4*>(dst + X3P_PLANE) = x3_u4{p2[0], p2[1], p2[2], p2[3]};
-            *reinterpret_cast<x3_u4*>(dst + 2 * X3P_PLANE) = x3_u4{p3[0], p3[1], p3[2], p3[3]};
+            unsigned char* dst = planes + x3p_slot_offset(m, s8, nch_out, NP);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) *reinterpret_cast<x3_u4*>(dst + q * X3P_PLANE) = pl[q];
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -142,6 +148,11 @@ __device__ __forceinline__ void x3p_dma16_off(RSRC rsrc, int voff) {
     else asm volatile("buffer_load_dwordx4 %0, %1, 0 offen offset:3072 lds" :: "v"(voff), "s"(rsrc) : "memory");
 #endif
 }
+template <int N> __device__ __forceinline__ void x3p_wait_vm() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+#endif
+}
 __device__ __forceinline__ void x3p_set_m0(unsigned v) {
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" :: "s"(v) : "memory", "m0");
@@ -152,13 +163,27 @@ __device__ __forceinline__ void x3p_set_m0(unsigned v) {
 // p.Tm, p.Tn tiles ; p.RT = GR, p.RC = GC (XCD bands) ; p.tail_tiles bit0 = no cyclic K alignment (A/B switch)
 // DBG (tuning builds of the same kernel, MI355TTS_GEMM_DBG): bit 0 no LDS-DMA, bit 1 no fragment reads, bit 3 no MFMA; p.dbg bit 2
 // (run time): no fix-up / epilogue
-template <typename TO, bool LEPI, int DBG = 0>
+// NP = 3: bf16 planes, six products on one accumulator set.  NP = 2: fp16 {hi, lo * 2^11} planes, three products per block
+// on TWO accumulator sets — accA += hi*hi, accB += lo*hi + hi*lo (both carry the 2^11 of one low part) — combined once per
+// tile as accA + 2^-11 * accB; the lo*lo term (2^-22 of the product, below the fp32 rounding of the sum) is dropped.
+template <typename TO, bool LEPI, int NP, int DBG = 0>
 __global__ __launch_bounds__(512, 1) void linear_x3p_kernel(const ConvGemmDev p) {
-    using MF = Mfma<bf16>;
+    using MF = std::conditional_t<NP == 3, Mfma<bf16>, Mfma<f16>>;
     using Frag = typename MF::Frag;
-    constexpr int BM = 128, BN = 128, WM = 64, WN = 64, TM = 2, TN = 2, NST = 3;
-    constexpr int STAGE = 2 * X3P_CHUNK;                        // 48 KB: A chunk then B chunk
-    constexpr int PER = 6;                                      // DMA instructions per wave per chunk (48 x 1 KB over 8 waves)
+    constexpr int BM = 128, BN = 128, WM = 64, WN = 64, TM = 2, TN = 2;
+#ifndef X3P_NST2
+#define X3P_NST2 4
+#endif
+    // LDS stages: a chunk is requested NST - 1 chunk times before its barrier.  Three for NP = 3 (a chunk time is ~3000 clk);
+    // with half the MFMAs per chunk (NP = 2) the same distance in TIME needs one stage more (32 KB stages: 128 KB)
+    constexpr int NST = NP == 3 ? 3 : X3P_NST2;
+    constexpr int CHB = NP * X3P_PLANE;                         // bytes of one operand chunk
+    constexpr int STAGE = 2 * CHB;                              // 48 | 32 KB: A chunk then B chunk
+    constexpr int PER = 2 * NP;                                 // DMA instructions per wave per chunk (1 KB each, 8 waves)
+    constexpr int NT = NP == 3 ? 6 : 3;                         // partial products per block
+    constexpr int NM = 4 * NT, NR = 4 * NP;                     // MFMAs and fragment reads per wave per chunk
+    constexpr int KB = NR + PER;                                // the boundary sits in front of MFMA KB (after the loop if KB == NM)
+    static_assert(KB <= NM, "x3p: reads and DMA pieces must fit under the chunk's MFMAs");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE];
     (void)smem;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -186,13 +211,13 @@ __global__ __launch_bounds__(512, 1) void linear_x3p_kernel(const ConvGemmDev p)
     constexpr int OOB = 0x7fffff00;
     const unsigned smem_lds = (unsigned)(unsigned long)(const __attribute__((address_space(3))) void*)smem;
     int* flags = p.sk_flags;
-    const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)(opA ? p.x : p.w3), 0, (int)((long)(opA ? p.Tm : p.Tn) * nch * X3P_CHUNK), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)(opA ? p.x : p.w3), 0, (int)((long)(opA ? p.Tm : p.Tn) * nch * CHB), 0x00020000);
     const int lane16 = lane * 16;
-    const unsigned lds_part = (unsigned)((opA ? 0 : X3P_CHUNK) + w4 * PER * 1024);
+    const unsigned lds_part = (unsigned)((opA ? 0 : CHB) + w4 * PER * 1024);
     // fragment addresses inside a stage: row (wm*64 + i*32 + lr) of plane pl, k-slot 2*kg + lk, swizzled
     const int sw = (lr >> 2) & 3;
     const unsigned fa_off = (unsigned)((wm * WM + lr) * 64 + (((2 * kg + lk) ^ sw) << 4));
-    const unsigned fb_off = (unsigned)(X3P_CHUNK + (wn * WN + lr) * 64 + (((2 * kg + lk) ^ sw) << 4));
+    const unsigned fb_off = (unsigned)(CHB + (wn * WN + lr) * 64 + (((2 * kg + lk) ^ sw) << 4));
 
     while (it < it1) {
         const int tile_g = (int)(it / nch);
@@ -213,7 +238,7 @@ __global__ __launch_bounds__(512, 1) void linear_x3p_kernel(const ConvGemmDev p)
         // per-lane byte offsets of this wave's six 1 KB pieces of a chunk (A chunk for waves 0-3, B chunk for waves 4-7)
         int vb[PER];
         {
-            const int d_base = (int)((long)(opA ? mt : nt) * nch * X3P_CHUNK) + lane16 + w4 * PER * 1024;
+            const int d_base = (int)((long)(opA ? mt : nt) * nch * CHB) + lane16 + w4 * PER * 1024;
 #pragma unroll
             for (int j = 0; j < PER; ++j) vb[j] = d_base + j * 1024;
         }
@@ -221,7 +246,7 @@ __global__ __launch_bounds__(512, 1) void linear_x3p_kernel(const ConvGemmDev p)
         // writes zeros, nothing is fetched (keeps the vmcnt arithmetic uniform)
         auto chunk_off = [&](int local) __attribute__((always_inline)) -> int {
             int ph = local + shift; if (ph >= nch) ph -= nch;
-            return __builtin_amdgcn_readfirstlane(local < ce ? ph * X3P_CHUNK : OOB);
+            return __builtin_amdgcn_readfirstlane(local < ce ? ph * CHB : OOB);
         };
         auto issue = [&](int st, int local) __attribute__((always_inline)) {
             const int coff = chunk_off(local);
@@ -231,52 +256,58 @@ __global__ __launch_bounds__(512, 1) void linear_x3p_kernel(const ConvGemmDev p)
             for (int j = 0; j < PER; ++j) x3p_dma16(rsd, (int)((unsigned)vb[j] + (unsigned)coff), base + (unsigned)(j * 1024));
         };
 
-        f32x16 acc[TM][TN];
+        constexpr int NACC = NP == 3 ? 1 : 2;
+        f32x16 accs[NACC][TM][TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int a = 0; a < NACC; ++a)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        Frag fa[2][TM][3], fb[2][TN][3];                        // [register set][block][plane]
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) accs[a][i][j][r] = 0.f;
+        Frag fa[2][TM][NP], fb[2][TN][NP];                      // [register set][block][plane]
         if constexpr (DBG & 2) {
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) { fa[a][b][c] = Frag{}; fb[a][b][c] = Frag{}; }
+                    for (int c = 0; c < NP; ++c) { fa[a][b][c] = Frag{}; fb[a][b][c] = Frag{}; }
         }
-        // one of the 12 fragment reads of a chunk: q < 6: A (block q / 3, plane q % 3) ; else B
+        // one of the NR fragment reads of a chunk: q < 2 * NP: A (block q / NP, plane q % NP) ; else B
         auto ldfrag1 = [&](const unsigned char* sa, const unsigned char* sb, auto SET, int q) __attribute__((always_inline)) {
             constexpr int set = decltype(SET)::value;
             if constexpr (DBG & 2) return;
-            if (q < 6) fa[set][q / 3][q % 3] = *reinterpret_cast<const Frag*>(sa + (q / 3) * (32 * 64) + (q % 3) * X3P_PLANE);
-            else { const int qq = q - 6; fb[set][qq / 3][qq % 3] = *reinterpret_cast<const Frag*>(sb + (qq / 3) * (32 * 64) + (qq % 3) * X3P_PLANE); }
+            if (q < 2 * NP) fa[set][q / NP][q % NP] = *reinterpret_cast<const Frag*>(sa + (q / NP) * (32 * 64) + (q % NP) * X3P_PLANE);
+            else { const int qq = q - 2 * NP; fb[set][qq / NP][qq % NP] = *reinterpret_cast<const Frag*>(sb + (qq / NP) * (32 * 64) + (qq % NP) * X3P_PLANE); }
         };
-        // MFMA k of a chunk (0..23): term t = k / 4 (small to large), block k % 4
+        // MFMA k of a chunk (0 .. NM-1): term t = k / 4 (small to large), block k % 4
         auto mma1 = [&](auto SET, int k) __attribute__((always_inline)) {
             constexpr int set = decltype(SET)::value;
-            constexpr int TA[6] = {0, 1, 2, 0, 1, 0}, TB[6] = {2, 1, 0, 1, 0, 0};
+            constexpr int TA3[6] = {0, 1, 2, 0, 1, 0}, TB3[6] = {2, 1, 0, 1, 0, 0};
+            constexpr int TA2[3] = {1, 0, 0}, TB2[3] = {0, 1, 0}, AC2[3] = {1, 1, 0};   // lo*hi, hi*lo -> accB ; hi*hi -> accA
             const int t = k >> 2, i = (k >> 1) & 1, j = k & 1;
             if constexpr (DBG & 8) return;
-            acc[i][j] = MF::mma(fa[set][i][TA[t]], fb[set][j][TB[t]], acc[i][j]);
+            if constexpr (NP == 3) accs[0][i][j] = MF::mma(fa[set][i][TA3[t]], fb[set][j][TB3[t]], accs[0][i][j]);
+            else accs[AC2[t]][i][j] = MF::mma(fa[set][i][TA2[t]], fb[set][j][TB2[t]], accs[AC2[t]][i][j]);
         };
 #define X3P_SB() __builtin_amdgcn_sched_barrier(0)
         // ---- prologue: chunks cb, cb+1, cb+2 requested; chunk cb's fragments into set 0 ----
-        issue(0, cb); issue(1, cb + 1); issue(2, cb + 2);
-        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < NST; ++q) issue(q, cb + q);
+        x3p_wait_vm<(NST - 1) * PER>();
         __builtin_amdgcn_s_barrier();
 #pragma unroll
-        for (int q = 0; q < 12; ++q) ldfrag1(smem + fa_off, smem + fb_off, std::integral_constant<int, 0>{}, q);
+        for (int q = 0; q < NR; ++q) ldfrag1(smem + fa_off, smem + fb_off, std::integral_constant<int, 0>{}, q);
         if constexpr (DBG & 16) {       // tuning: REAL operand values in both register sets, then a loop of MFMAs only
 #pragma unroll
-            for (int q = 0; q < 12; ++q) ldfrag1(smem + fa_off, smem + fb_off, std::integral_constant<int, 1>{}, q);
+            for (int q = 0; q < NR; ++q) ldfrag1(smem + fa_off, smem + fb_off, std::integral_constant<int, 1>{}, q);
         }
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        x3p_wait_vm<(NST - 2) * PER>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                           // chunk cb+1 landed, stage 0 free
-        int st_next = 1, st_free = 0;                           // stage of chunk c+1 ; stage chunk c+3 goes to (= stage of chunk c)
+        int st_next = 1, st_free = 0;                           // stage of chunk c+1 ; stage chunk c+NST goes to (= stage of chunk c)
         // One chunk: 24 MFMAs on the fragments of chunk c (register set SET).  Under twelve of them the fragments of chunk c+1
         // are read into the other set (past the piece they are stale LDS, never used), under six this wave's six pieces of
         // chunk c+3 are requested; then the boundary, then the last six MFMAs.  Measured (profiles/r3/x3p_ablation_*.txt,
@@ -290,25 +321,26 @@ __global__ __launch_bounds__(512, 1) void linear_x3p_kernel(const ConvGemmDev p)
             const bool more = c + 1 < n;
             const unsigned char* sa = smem + st_next * STAGE + fa_off;
             const unsigned char* sb = smem + st_next * STAGE + fb_off;
-            const int coff = chunk_off(cb + c + 3);
+            const int coff = chunk_off(cb + c + NST);
             const unsigned ldsd = __builtin_amdgcn_readfirstlane(smem_lds + (unsigned)(st_free * STAGE) + lds_part);
+            auto boundary = [&]() __attribute__((always_inline)) {
+                // chunk c+2 has landed (this wave's PER pieces of chunk c+3 may stay in flight), the fragments of chunk c+1 are
+                // in registers (its stage is free); for NP = 3 the last six MFMAs run behind the barrier
+                x3p_wait_vm<(NST - 2) * PER>();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            };
 #pragma unroll
-            for (int k = 0; k < 24; ++k) {
-                if (k == 18 && more) {
-                    // boundary: chunk c+2 has landed (this wave's six pieces of chunk c+3 may stay in flight), the fragments
-                    // of chunk c+1 are in registers (its stage is free); the last six MFMAs run behind the barrier
-                    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                }
+            for (int k = 0; k < NM; ++k) {
+                if (k == KB && more) boundary();
                 X3P_SB(); mma1(SET, k); X3P_SB();
                 if constexpr (DBG & 16) continue;
-                if (k < 12) ldfrag1(sa, sb, NSET{}, k);
-                else if (k < 18) {
+                if (k < NR) ldfrag1(sa, sb, NSET{}, k);
+                else if (k < KB) {
                     if constexpr (!(DBG & 1)) {
                         // pieces 0-3 under one M0 value, pieces 4-5 under the next (instruction offsets 0 / 1 / 2 / 3 KB move the
                         // global and the LDS address together)
-                        const int dj = k - 12;
+                        const int dj = k - NR;
                         if (dj == 0) x3p_set_m0(ldsd); else if (dj == 4) x3p_set_m0(ldsd + 4096u);
                         const int v0 = (int)((unsigned)vb[dj & 4] + (unsigned)coff);
                         if ((dj & 3) == 0) x3p_dma16_off<0>(rsd, v0); else if ((dj & 3) == 1) x3p_dma16_off<1024>(rsd, v0);
@@ -316,6 +348,7 @@ __global__ __launch_bounds__(512, 1) void linear_x3p_kernel(const ConvGemmDev p)
                     }
                 }
             }
+            if constexpr (KB == NM) { if (more) boundary(); }
         };
         for (int c = 0; c < n; c += 2) {
             body(c, std::integral_constant<int, 0>{});
@@ -329,6 +362,15 @@ __global__ __launch_bounds__(512, 1) void linear_x3p_kernel(const ConvGemmDev p)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        f32x16 (&acc)[TM][TN] = accs[0];
+        if constexpr (NP == 2) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = __builtin_fmaf(accs[1][i][j][r], 0x1p-11f, acc[i][j][r]);
+        }
 
         // ---- the two k16 groups meet.  Wave (group g, sub-tile w4) holds a 64x64 partial sum; the two waves of a sub-tile SWAP
         //      halves through LDS: group 0 keeps rows 0-31 and receives group 1's, group 1 keeps rows 32-63 and receives group
@@ -423,7 +465,7 @@ __global__ __launch_bounds__(512, 1) void linear_x3p_kernel(const ConvGemmDev p)
             if constexpr (LEPI) {
                 float* stage = reinterpret_cast<float*>(smem) + wave * 2176;        // 32 x 64 floats per wave (32 x 65 for the transposed-V path)
                 if (p.epi == EPI_QKV_ROPE) gemm_epilogue_qkv_lds<TO, 1>(h, p, m0, n0, 0, wm2, wn, lr, lk, stage);
-                else if (p.out_planes) x3p_epilogue_planes<1, TN>(h, p, m0, n0, wm2, wn, lr, lk, stage);
+                else if (p.out_planes) x3p_epilogue_planes<1, TN, NP>(h, p, m0, n0, wm2, wn, lr, lk, stage);
                 else gemm_epilogue_lds<TO, 1, TN, 32, WN>(h, p, m0, n0, 0, 0, wm2, wn, lr, lk, stage);
             } else {
                 gemm_epilogue<TO, 1, TN, 32, WN>(h, p, m0, n0, 0, 0, wm2, wn, lr, lk);
@@ -470,22 +512,34 @@ void launch_linear_x3p(const ConvGemmDev& e_in, hipStream_t s) {
     e.tail_tiles = (int)g_x3p_noalign;
     const int P = std::min(cus, e.sk_slots - 8) & ~7;          // the LAST flag word is the watchdog's error word (SkWorkspace::tripped)
     const dim3 grid(P);
-    if (e.lds_epi) {
+    MI_REQUIRE(e.np == 2 || e.np == 3, "linear_x3p: 2 or 3 planes per operand");
+    if (e.np == 2) {
+#if defined(MI355TTS_TUNING)
+#define X2_TUNE(D, LABEL) case D: prof_set_kernel("linear_x3p_kernel<float, true, 2, " LABEL ">", "", ""); hipLaunchKernelGGL((linear_x3p_kernel<float, true, 2, D>), grid, dim3(512), 0, s, e); MI_HIP(hipGetLastError()); return;
+        if (e.lds_epi) switch (e.dbg & 27) {
+            X2_TUNE(1, "noDMA") X2_TUNE(2, "noLDSread") X2_TUNE(3, "noDMA noLDSread") X2_TUNE(8, "noMFMA") X2_TUNE(9, "noDMA noMFMA") X2_TUNE(10, "noLDSread noMFMA") X2_TUNE(16, "MFMA on real operands only")
+            default: break;
+        }
+#undef X2_TUNE
+#endif
+        if (e.lds_epi) { prof_set_kernel("linear_x3p_kernel<float, true, 2>", "", ""); hipLaunchKernelGGL((linear_x3p_kernel<float, true, 2>), grid, dim3(512), 0, s, e); }
+        else { prof_set_kernel("linear_x3p_kernel<float, false, 2>", "", ""); hipLaunchKernelGGL((linear_x3p_kernel<float, false, 2>), grid, dim3(512), 0, s, e); }
+    } else if (e.lds_epi) {
 #if defined(MI355TTS_TUNING)
         switch (e.dbg & 27) {       // tuning instantiations (build.py --tuning, MI355TTS_GEMM_DBG)
-            case 1: prof_set_kernel("linear_x3p_kernel<float, true, noDMA>", "", ""); hipLaunchKernelGGL((linear_x3p_kernel<float, true, 1>), grid, dim3(512), 0, s, e); MI_HIP(hipGetLastError()); return;
-            case 2: prof_set_kernel("linear_x3p_kernel<float, true, noLDSread>", "", ""); hipLaunchKernelGGL((linear_x3p_kernel<float, true, 2>), grid, dim3(512), 0, s, e); MI_HIP(hipGetLastError()); return;
-            case 3: prof_set_kernel("linear_x3p_kernel<float, true, noDMA noLDSread>", "", ""); hipLaunchKernelGGL((linear_x3p_kernel<float, true, 3>), grid, dim3(512), 0, s, e); MI_HIP(hipGetLastError()); return;
-            case 8: prof_set_kernel("linear_x3p_kernel<float, true, noMFMA>", "", ""); hipLaunchKernelGGL((linear_x3p_kernel<float, true, 8>), grid, dim3(512), 0, s, e); MI_HIP(hipGetLastError()); return;
-            case 16: prof_set_kernel("linear_x3p_kernel<float, true, MFMA on real operands only>", "", ""); hipLaunchKernelGGL((linear_x3p_kernel<float, true, 16>), grid, dim3(512), 0, s, e); MI_HIP(hipGetLastError()); return;
+            case 1: prof_set_kernel("linear_x3p_kernel<float, true, 3, noDMA>", "", ""); hipLaunchKernelGGL((linear_x3p_kernel<float, true, 3, 1>), grid, dim3(512), 0, s, e); MI_HIP(hipGetLastError()); return;
+            case 2: prof_set_kernel("linear_x3p_kernel<float, true, 3, noLDSread>", "", ""); hipLaunchKernelGGL((linear_x3p_kernel<float, true, 3, 2>), grid, dim3(512), 0, s, e); MI_HIP(hipGetLastError()); return;
+            case 3: prof_set_kernel("linear_x3p_kernel<float, true, 3, noDMA noLDSread>", "", ""); hipLaunchKernelGGL((linear_x3p_kernel<float, true, 3, 3>), grid, dim3(512), 0, s, e); MI_HIP(hipGetLastError()); return;
+            case 8: prof_set_kernel("linear_x3p_kernel<float, true, 3, noMFMA>", "", ""); hipLaunchKernelGGL((linear_x3p_kernel<float, true, 3, 8>), grid, dim3(512), 0, s, e); MI_HIP(hipGetLastError()); return;
+            case 16: prof_set_kernel("linear_x3p_kernel<float, true, 3, MFMA on real operands only>", "", ""); hipLaunchKernelGGL((linear_x3p_kernel<float, true, 3, 16>), grid, dim3(512), 0, s, e); MI_HIP(hipGetLastError()); return;
             default: break;
         }
 #endif
-        prof_set_kernel("linear_x3p_kernel<float, true>", "", "");
-        hipLaunchKernelGGL((linear_x3p_kernel<float, true>), grid, dim3(512), 0, s, e);
+        prof_set_kernel("linear_x3p_kernel<float, true, 3>", "", "");
+        hipLaunchKernelGGL((linear_x3p_kernel<float, true, 3>), grid, dim3(512), 0, s, e);
     } else {
-        prof_set_kernel("linear_x3p_kernel<float, false>", "", "");
-        hipLaunchKernelGGL((linear_x3p_kernel<float, false>), grid, dim3(512), 0, s, e);
+        prof_set_kernel("linear_x3p_kernel<float, false, 3>", "", "");
+        hipLaunchKernelGGL((linear_x3p_kernel<float, false, 3>), grid, dim3(512), 0, s, e);
     }
     MI_HIP(hipGetLastError());
 }
