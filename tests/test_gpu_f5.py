@@ -385,10 +385,12 @@ def _full_size_fp32_body(full, gfull, form):
 
 
 def test_full_size_fp32_fused_producers_are_bit_neutral(full):
-    """Round 3 moved the three-way bf16 split of the fp32 operands out of the consumers into their producers (rownorm /
-    attention / FF1 epilogue write the next GEMM's panel planes, the QKV epilogue writes K and V^T as planes for attention).
-    The split is a function of the fp32 value alone, so WHERE it happens must not change a bit: K / V planes on vs off give
-    identical DiT evaluations (one and three utterances: both attention tilings)."""
+    """Round 3 moved the split of the fp32 operands out of the consumers into their producers (rownorm / attention / FF1
+    epilogue write the next GEMM's panel planes, the QKV epilogue writes K and V^T as planes for attention).  The split is a
+    function of the fp32 value alone, so WHERE it happens must not change a bit: with the three-bf16-plane attention format
+    (attn_f32_planes = 3, the only one the in-kernel split produces) K / V planes on vs off give identical DiT evaluations
+    (one and three utterances: both attention tilings).  The default fp16-pair format (attn_f32_planes = 2) is other
+    arithmetic: it must sit as close to the three-plane result as the native fp32 MFMA path does."""
     from mi355tts import _lib
     cfg, raw, audio, ids, N, noise = full
     eng = F5Engine(cfg, raw, dtype="f32")
@@ -396,13 +398,19 @@ def test_full_size_fp32_fused_producers_are_bit_neutral(full):
         for U in (1, 3):
             o = [eng.preprocess(audio[u].reshape(1, 1, -1), ids[u].reshape(1, -1), np.array([N]), noise=noise[u]) for u in range(U)]
             cmt = np.concatenate([x["cat_mel_text"] for x in o]); cmtd = np.concatenate([x["cat_mel_text_drop"] for x in o])
+            pairs = eng.dit_eval(noise[:U], cmt, cmtd, 5)
+            _lib.set_option("attn_f32_planes", 3)
             a = eng.dit_eval(noise[:U], cmt, cmtd, 5)
             _lib.set_option("attn_kv_planes", 0)
             b = eng.dit_eval(noise[:U], cmt, cmtd, 5)
             _lib.set_option("attn_kv_planes", 1)
+            _lib.set_option("attn_f32_planes", 2)
             assert np.array_equal(a, b), (U, np.abs(a - b).max())
+            e = rms(pairs - a) / rms(a)
+            print(f"U={U}: DiT evaluation, fp16-pair attention against three-plane attention: rel rms {e:.2e}")
+            assert e < 2e-6 and not np.array_equal(pairs, a), e
     finally:
-        _lib.set_option("attn_kv_planes", 1)
+        _lib.set_option("attn_kv_planes", 1); _lib.set_option("attn_f32_planes", 2)
         eng.close()
 
 

@@ -23,6 +23,7 @@
 #include "f5_kernels.h"
 #include "x3_split.h"
 #include <cstdlib>
+#include <type_traits>
 #include <string>
 #include <algorithm>
 
@@ -417,22 +418,26 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const T* __restrict__ q, c
 // LDS as they are, instead of 8 float4 loads + 176 VALU of splitting per thread and stage — work that every one of the
 // N / 64 query tiles of a head repeated on the same K / V values (with the key-split 64-query workgroups a wave multiplies
 // ONE 32x32 tile per stage: the stage split was as many VALU cycles as the tile's softmax and P split together).
-template <bool SPLIT2, bool KVP = false>
+// NP = 2 (only with KVP): K / V^T arrive as fp16 {hi, lo * 2^11} pairs (x3_split.h) and Q / P are split the same way: three
+// partial products per block on two accumulator sets (hi*hi ; hi*lo + lo*hi) for S and for O, combined as A + 2^-11 B —
+// half the MFMAs of the three-plane form, 4 instead of 6 bytes per K / V element.
+template <bool SPLIT2, bool KVP = false, int NP = 3>
 __global__ __launch_bounds__(256, 2) void attn_x3f_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                        const float* __restrict__ v, float* __restrict__ o, int H, int N,
                                                        float* __restrict__ ws, int* __restrict__ cnt,
                                                        unsigned char* __restrict__ o_planes, int o_np) {
     // o_planes != null: the output leaves as gemm_x3p.hip panel planes of the [B * N][H * 64] matrix (the A operand of the O
     // projection), split here (o_np = 3 bf16 planes | 2 fp16 planes), instead of fp32 rows in o
-    using MF = Mfma<bf16>;
-    using Frag = bf16x8;
+    static_assert(NP == 3 || (NP == 2 && KVP), "attn_x3f: the two-plane form reads pre-split K / V");
+    using MF = std::conditional_t<NP == 3, Mfma<bf16>, Mfma<f16>>;
+    using Frag = typename MF::Frag;
     constexpr int D = 64, KT = 64;
     constexpr int LDK = D + 8, LDV = KT + 4;                // bf16 elements per plane row
     constexpr int KPL = KT * LDK, VPL = D * LDV;            // elements per plane
-    __shared__ __attribute__((aligned(16))) bf16 smem[3 * KPL + 3 * VPL];
+    __shared__ __attribute__((aligned(16))) bf16 smem[NP * KPL + NP * VPL];            // 16-bit storage (bf16 or fp16 bit patterns)
     static_assert(sizeof(smem) >= (2 * 32 * 64 + 2 * 64 * 2 + 4) * sizeof(float), "merge buffer fits the stage");
     bf16* Ks = smem;
-    bf16* Vs = smem + 3 * KPL;
+    bf16* Vs = smem + NP * KPL;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, hi = lane >> 5;
     const int bh = blockIdx.y;
@@ -441,8 +446,8 @@ __global__ __launch_bounds__(256, 2) void attn_x3f_kernel(const float* __restric
     const float* kb = k + (long)bh * N * D;
     const long vld = KVP ? (long)((N + 63) / 64 * 64) : (long)((N + 7) / 8 * 8);
     const float* vb = v + (long)bh * D * vld;
-    const bf16* kpb = reinterpret_cast<const bf16*>(k) + (long)bh * 3 * vld * D;      // KVP: planes [3][kld][64], kld = vld
-    const bf16* vpb = reinterpret_cast<const bf16*>(v) + (long)bh * 3 * D * vld;      // KVP: planes [3][64][vld]
+    const bf16* kpb = reinterpret_cast<const bf16*>(k) + (long)bh * NP * vld * D;     // KVP: planes [NP][kld][64], kld = vld
+    const bf16* vpb = reinterpret_cast<const bf16*>(v) + (long)bh * NP * D * vld;     // KVP: planes [NP][64][vld]
 
     auto split4 = [&](const float4 a, uint2& w1, uint2& w2, uint2& w3) __attribute__((always_inline)) {
         x3_split_pair(a.x, a.y, w1.x, w2.x, w3.x);
@@ -456,8 +461,16 @@ __global__ __launch_bounds__(256, 2) void attn_x3f_kernel(const float* __restric
         f3 = __builtin_bit_cast(Frag, x3_u4{a3.x, a3.y, b3.x, b3.y});
     };
 
-    // ---- Q: three bf16 pieces of log2(e) * Q[q0 + lr][16 ks + 8 hi .. +8] ------------------------------------------------
-    Frag qf3[4][3];
+    auto split8h = [&](const float4 a, const float4 b, Frag& f1, Frag& f2) __attribute__((always_inline)) {
+        unsigned h[4], l[4];
+        x2_split_pair(a.x, a.y, h[0], l[0]); x2_split_pair(a.z, a.w, h[1], l[1]);
+        x2_split_pair(b.x, b.y, h[2], l[2]); x2_split_pair(b.z, b.w, h[3], l[3]);
+        f1 = __builtin_bit_cast(Frag, x3_u4{h[0], h[1], h[2], h[3]});
+        f2 = __builtin_bit_cast(Frag, x3_u4{l[0], l[1], l[2], l[3]});
+    };
+
+    // ---- Q: the NP pieces of log2(e) * Q[q0 + lr][16 ks + 8 hi .. +8] ------------------------------------------------
+    Frag qf3[4][NP];
     {
         const int qr = q0 + lr;
         const bool ok = qr < N;
@@ -470,19 +483,20 @@ __global__ __launch_bounds__(256, 2) void attn_x3f_kernel(const float* __restric
                 b = *reinterpret_cast<const float4*>(qb + (long)qr * D + ks * 16 + hi * 8 + 4);
             }
             a.x *= L2E; a.y *= L2E; a.z *= L2E; a.w *= L2E; b.x *= L2E; b.y *= L2E; b.z *= L2E; b.w *= L2E;
-            split8(a, b, qf3[ks][0], qf3[ks][1], qf3[ks][2]);
+            if constexpr (NP == 3) split8(a, b, qf3[ks][0], qf3[ks][1], qf3[ks][2]); else split8h(a, b, qf3[ks][0], qf3[ks][1]);
         }
     }
 
     // ---- stage loads: 64 keys x 64 d of K (rows = keys) and of V^T (rows = d), four float4 per thread each ----------------
     float4 kreg[KVP ? 1 : 4], vreg[KVP ? 1 : 4];
-    x3_u4 kpl[KVP ? 6 : 1], vpl[KVP ? 6 : 1];
+    constexpr int NU = 2 * NP;                              // KVP: 16-byte units per thread and operand per stage
+    x3_u4 kpl[KVP ? NU : 1], vpl[KVP ? NU : 1];
     auto load_regs = [&](int key0) {
         if constexpr (KVP) {
             // unit u = tid + 256 i: plane u / 512 ; K: key (u % 512) / 8, 8 d's ; V^T: d (u % 512) / 8, 8 keys.  Rows past N are
             // inside the padded planes (K: any finite-or-not value, masked below; V: zero since allocation)
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
+            for (int i = 0; i < NU; ++i) {
                 const int u = tid + i * 256, pl = u >> 9, r = (u & 511) >> 3, c = u & 7;
                 kpl[i] = *reinterpret_cast<const x3_u4*>(kpb + ((long)pl * vld + key0 + r) * D + c * 8);
                 vpl[i] = *reinterpret_cast<const x3_u4*>(vpb + ((long)pl * D + r) * vld + key0 + c * 8);
@@ -491,7 +505,7 @@ __global__ __launch_bounds__(256, 2) void attn_x3f_kernel(const float* __restric
                 // last stage: the V^T values of keys >= N meet probabilities that are exactly zero, but 0 x NaN is NaN and
                 // the pad columns hold whatever the buffer held before (another layout, another mode): clear them here
 #pragma unroll
-                for (int i = 0; i < 6; ++i) {
+                for (int i = 0; i < NU; ++i) {
                     const int keep = N - (key0 + ((tid + i * 256) & 7) * 8);          // valid keys among this unit's eight
                     if (keep < 8) {
                         unsigned w[4] = {vpl[i].x, vpl[i].y, vpl[i].z, vpl[i].w};
@@ -517,7 +531,7 @@ __global__ __launch_bounds__(256, 2) void attn_x3f_kernel(const float* __restric
     auto store_lds = [&]() {
         if constexpr (KVP) {
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
+            for (int i = 0; i < NU; ++i) {
                 const int u = tid + i * 256, pl = u >> 9, r = (u & 511) >> 3, c = u & 7;
                 *reinterpret_cast<x3_u4*>(Ks + pl * KPL + r * LDK + c * 8) = kpl[i];                 // 144-byte rows: 16-byte aligned
                 uint2* vd = reinterpret_cast<uint2*>(Vs + pl * VPL + r * LDV + c * 8);                // 136-byte rows: 8-byte aligned
@@ -542,8 +556,13 @@ __global__ __launch_bounds__(256, 2) void attn_x3f_kernel(const float* __restric
     };
 
     f32x16 oacc[2];
+    f32x16 oaccb[NP == 2 ? 2 : 1];                          // NP = 2: the 2^11-scaled cross terms of O
 #pragma unroll
     for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.f; oacc[1][r] = 0.f; }
+    if constexpr (NP == 2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { oaccb[0][r] = 0.f; oaccb[1][r] = 0.f; }
+    }
     float m_run = -INFINITY, l_run = 0.f;
 
     const int nstage_all = (N + KT - 1) / KT;
@@ -563,14 +582,29 @@ __global__ __launch_bounds__(256, 2) void attn_x3f_kernel(const float* __restric
             f32x16 sacc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+            f32x16 saccb;
+            if constexpr (NP == 2) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) saccb[r] = 0.f;
+            }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                Frag kf[3];
+                Frag kf[NP];
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
+                for (int pl = 0; pl < NP; ++pl)
                     kf[pl] = *reinterpret_cast<const Frag*>(Ks + pl * KPL + (kt * 32 + lr) * LDK + ks * 16 + hi * 8);
+                if constexpr (NP == 3) {
 #pragma unroll
-                for (int t = 0; t < 6; ++t) sacc = MF::mma(kf[TA[t]], qf3[ks][TB[t]], sacc);
+                    for (int t = 0; t < 6; ++t) sacc = MF::mma(kf[TA[t]], qf3[ks][TB[t]], sacc);
+                } else {
+                    saccb = MF::mma(kf[1], qf3[ks][0], saccb);
+                    saccb = MF::mma(kf[0], qf3[ks][1], saccb);
+                    sacc = MF::mma(kf[0], qf3[ks][0], sacc);
+                }
+            }
+            if constexpr (NP == 2) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[r] = __builtin_fmaf(saccb[r], 0x1p-11f, sacc[r]);
             }
             if (key0 + 32 > N) {
 #pragma unroll
@@ -590,6 +624,10 @@ __global__ __launch_bounds__(256, 2) void attn_x3f_kernel(const float* __restric
                 m_run = m_new;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
+                if constexpr (NP == 2) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { oaccb[0][r] *= alpha; oaccb[1][r] *= alpha; }
+                }
             }
             typedef float f2 __attribute__((ext_vector_type(2)));
             float p[16];
@@ -608,22 +646,32 @@ __global__ __launch_bounds__(256, 2) void attn_x3f_kernel(const float* __restric
             // ---- O^T += V^T P^T: the probabilities a lane holds are the B operand (keys in accumulator-row order) ------------
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                Frag pf[3];
-                split8(float4{p[8 * s2], p[8 * s2 + 1], p[8 * s2 + 2], p[8 * s2 + 3]},
-                       float4{p[8 * s2 + 4], p[8 * s2 + 5], p[8 * s2 + 6], p[8 * s2 + 7]}, pf[0], pf[1], pf[2]);
+                Frag pf[NP];
+                if constexpr (NP == 3)
+                    split8(float4{p[8 * s2], p[8 * s2 + 1], p[8 * s2 + 2], p[8 * s2 + 3]},
+                           float4{p[8 * s2 + 4], p[8 * s2 + 5], p[8 * s2 + 6], p[8 * s2 + 7]}, pf[0], pf[1], pf[2]);
+                else
+                    split8h(float4{p[8 * s2], p[8 * s2 + 1], p[8 * s2 + 2], p[8 * s2 + 3]},
+                            float4{p[8 * s2 + 4], p[8 * s2 + 5], p[8 * s2 + 6], p[8 * s2 + 7]}, pf[0], pf[1]);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
-                    Frag vf[3];
+                    Frag vf[NP];
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) {
+                    for (int pl = 0; pl < NP; ++pl) {
                         const bf16* row = Vs + pl * VPL + (dt * 32 + lr) * LDV + kt * 32 + 16 * s2 + 4 * hi;
                         uint2 a2[2];
                         a2[0] = *reinterpret_cast<const uint2*>(row);
                         a2[1] = *reinterpret_cast<const uint2*>(row + 8);
                         vf[pl] = __builtin_bit_cast(Frag, x3_u4{a2[0].x, a2[0].y, a2[1].x, a2[1].y});
                     }
+                    if constexpr (NP == 3) {
 #pragma unroll
-                    for (int t = 0; t < 6; ++t) oacc[dt] = MF::mma(vf[TA[t]], pf[TB[t]], oacc[dt]);
+                        for (int t = 0; t < 6; ++t) oacc[dt] = MF::mma(vf[TA[t]], pf[TB[t]], oacc[dt]);
+                    } else {
+                        oaccb[dt] = MF::mma(vf[1], pf[0], oaccb[dt]);
+                        oaccb[dt] = MF::mma(vf[0], pf[1], oaccb[dt]);
+                        oacc[dt] = MF::mma(vf[0], pf[0], oacc[dt]);
+                    }
                 }
             }
         };
@@ -641,6 +689,12 @@ __global__ __launch_bounds__(256, 2) void attn_x3f_kernel(const float* __restric
             store_lds();
             __syncthreads();
         }
+    }
+    if constexpr (NP == 2) {
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[dt][r] = __builtin_fmaf(oaccb[dt][r], 0x1p-11f, oacc[dt][r]);
     }
     bool owner = true;                                              // this wave holds a finished 32-query result
     if constexpr (SPLIT2) {
@@ -791,6 +845,7 @@ __global__ __launch_bounds__(256, 2) void attn_x3f_kernel(const float* __restric
 // fp32 attention: 0 = native fp32 MFMA ; 1 = q.k as exact bf16 splits (attn_kernel X3S) ; 2 = both products (attn_x3f_kernel;
 // V then arrives transposed like in the 16-bit engines: attention_v_ld() tells the QKV epilogue)
 static int g_attn_x3 = 2;
+static int g_attn_np = 2;                                // format of the pre-split K / V^T (and of Q / P inside the kernel): 2 fp16 pairs | 3 bf16 planes
 static int g_attn_split = 1;                             // 64-query workgroups with the keys split between wave pairs when the grid is small
 static int g_attn_zmax = 4, g_attn_z16 = 1, g_attn_zforce = 0;      // zforce (tests): exactly that many slices, even empty ones
 static int g_attn_kvp = 1;                               // fp32, both products split: K / V^T pre-split by the QKV epilogue (A/B: attn_kv_planes)
@@ -806,6 +861,7 @@ static void attn_env_once() {
         if (const char* z = std::getenv("MI355TTS_ATTN_X3")) g_attn_x3 = std::max(0, std::min(2, std::atoi(z)));
         if (const char* z = std::getenv("MI355TTS_ATTN_Z16")) g_attn_z16 = std::max(1, std::min(4, std::atoi(z)));
         if (const char* z = std::getenv("MI355TTS_ATTN_KVP")) g_attn_kvp = std::atoi(z) != 0;
+        if (const char* z = std::getenv("MI355TTS_ATTN_PLANES")) g_attn_np = std::atoi(z) == 3 ? 3 : 2;
     });
 }
 long attention_v_ld(int N, int dtype) {
@@ -820,6 +876,7 @@ bool attn_set_option(const char* key, long v) {
     else if (k == "attn_f32_x3") g_attn_x3 = (int)std::max(0L, std::min(2L, v));
     else if (k == "attn_split") g_attn_split = v != 0;
     else if (k == "attn_kv_planes") g_attn_kvp = v != 0;
+    else if (k == "attn_f32_planes") { if (v != 2 && v != 3) return false; g_attn_np = (int)v; }
     else if (k == "attn_z_force") g_attn_zforce = (int)std::max(0L, std::min(4L, v));
     else return false;
     return true;
@@ -830,6 +887,8 @@ bool attention_takes_kv_planes(int N, int BH, int dtype) {
     (void)N; (void)BH;
     return dtype == MI_F32 && g_attn_x3 == 2 && g_attn_kvp != 0;
 }
+
+int attention_kv_planes_format() { attn_env_once(); return g_attn_np; }
 
 bool attention_can_write_planes(int N, int BH, int dtype) {
     attn_env_once();
@@ -842,6 +901,7 @@ void launch_attention(const void* q, const void* k, const void* v, void* o, int 
     MI_REQUIRE(o_np == 2 || o_np == 3, "attention: 2 or 3 output planes");
     MI_REQUIRE(!o_planes || attention_can_write_planes(N, BH, dtype), "attention: panel-plane output needs the fp32 split kernel");
     MI_REQUIRE(!kv_planes || attention_can_write_planes(N, BH, dtype), "attention: pre-split K / V need the fp32 split kernel");
+    MI_REQUIRE(kv_planes == 0 || kv_planes == 1 || kv_planes == 2 || kv_planes == 3, "attention: kv_planes is 0, 2 or 3 (1 = 3)");
     MI_REQUIRE(BH % H == 0 && N > 0, "attention: bad shape");
     const double esz = (double)dtype_size(dtype);
     ProfScope ps(FAM_ATTN, s, 4.0 * BH * N * 64.0 * esz, 4.0 * BH * (double)N * N * 64.0);
@@ -884,7 +944,10 @@ void launch_attention(const void* q, const void* k, const void* v, void* o, int 
             // ... and cut the key range into Z slices when that evens out the workgroups per CU
             const int Z = pick_z(1);
             if (g_attn_x3 == 2) {
-                if (kv_planes) {
+                if (kv_planes == 2) {
+                    prof_set_kernel("attn_x3f_kernel<true, pre-split K V, fp16 pairs>", "", "");
+                    hipLaunchKernelGGL((attn_x3f_kernel<true, true, 2>), dim3((N + 63) / 64, BH, Z), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt, (unsigned char*)o_planes, o_np);
+                } else if (kv_planes) {
                     prof_set_kernel("attn_x3f_kernel<true, pre-split K V>", "", "");
                     hipLaunchKernelGGL((attn_x3f_kernel<true, true>), dim3((N + 63) / 64, BH, Z), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt, (unsigned char*)o_planes, o_np);
                 } else {
@@ -897,7 +960,10 @@ void launch_attention(const void* q, const void* k, const void* v, void* o, int 
             } else
                 ATTN_LAUNCH(float, true, dim3((N + 63) / 64, BH, Z), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt);
         } else if (g_attn_x3 == 2) {
-            if (kv_planes) {
+            if (kv_planes == 2) {
+                prof_set_kernel("attn_x3f_kernel<false, pre-split K V, fp16 pairs>", "", "");
+                hipLaunchKernelGGL((attn_x3f_kernel<false, true, 2>), dim3((N + 127) / 128, BH), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt, (unsigned char*)o_planes, o_np);
+            } else if (kv_planes) {
                 prof_set_kernel("attn_x3f_kernel<false, pre-split K V>", "", "");
                 hipLaunchKernelGGL((attn_x3f_kernel<false, true>), dim3((N + 127) / 128, BH), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt, (unsigned char*)o_planes, o_np);
             } else {

@@ -576,7 +576,8 @@ void F5::dit_eval(int U, int N, int k) {
     for (int i = 0; i < c.depth; ++i) {
         const Block& bk = blocks[i];
         const float* m = modk + (size_t)i * 6 * d;       // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
-        bool kvp = false;                                // this block's K / V^T leave the QKV epilogue as bf16 planes
+        bool kvp = false;                                // this block's K / V^T leave the QKV epilogue pre-split for the attention kernel
+        const int kvp_fmt = attention_kv_planes_format();   // ... as 2 fp16 planes or 3 bf16 planes
         {
             ConvGemm g;
             g.dtype = dtype; g.x = Ub.p; g.w = bk.qkv.w.p; g.w3 = bk.qkv.w3.p; g.bias = bk.qkv.b.as<float>();
@@ -594,7 +595,7 @@ void F5::dit_eval(int U, int N, int k) {
             }
             // K and V^T pre-split for the attention kernel (only the LDS-staged fp32 QKV epilogue of the panel-plane GEMM writes them)
             kvp = fused && attention_takes_kv_planes(N, B * H, dtype);
-            if (kvp) { g.kv_planes = 1; g.k_ld = g.v_ld = (long)((N + 63) / 64 * 64); }
+            if (kvp) { g.kv_planes = kvp_fmt; g.k_ld = g.v_ld = (long)((N + 63) / 64 * 64); }
             // AdaLN: LN(x) * (1 + scale) + shift — straight into the panel planes the QKV GEMM reads, or as rows
             if (fused) launch_rownorm_x3p(X.as<float>(), Ap.p, m + d, m, rows, d, 1e-6f, s, np);
             else launch_rownorm(NORM_LN_MOD, X.as<float>(), Ub.p, dtype, m + d, m, rows, d, 1e-6f, s);
@@ -612,7 +613,7 @@ void F5::dit_eval(int U, int N, int k) {
                 fused = gemm_x3p_would_run(g);
             }
             launch_attention(qb.p, kb.p, vb.p, Ob.p, B * H, H, N, dtype, s, attn_ws.as<float>(), attn_ws_floats, attn_cnt.as<int>(), attn_cnt_n,
-                             fused ? Ap.p : nullptr, kvp ? 1 : 0, np);
+                             fused ? Ap.p : nullptr, kvp ? kvp_fmt : 0, np);
             gemm(dtype, Ob.p, (long)N * d, d, d, bk.o, X.p, MI_F32, (long)N * d, d, B, N, ACT_NONE, X.p, m + 2 * d, fused, Ap.p);
         }
         {

@@ -39,6 +39,7 @@ void launch_attention(const void* q, const void* k, const void* v, void* o, int 
 // kv_planes (fp32 engines, both products split): k and v are the pre-split bf16 planes the QKV epilogue wrote (ConvGemm::kv_planes:
 // k [BH][3][ld][64], v [BH][3][64][ld], ld = N rounded up to 64, pad keys of v zero) — ask attention_takes_kv_planes() first
 bool attention_takes_kv_planes(int N, int BH, int dtype);
+int attention_kv_planes_format();        // 2: fp16 {hi, lo} pairs (option "attn_f32_planes", default) | 3: three bf16 planes — pass it as kv_planes
 // o_planes (fp32 engines, both products split): the output as gemm_x3p.hip panel planes of the [B * N][H * 64] matrix instead
 // of rows in o — ask attention_can_write_planes() first
 bool attention_can_write_planes(int N, int BH, int dtype);

@@ -41,7 +41,7 @@ struct ConvGemmDev {
     const void* w3;                              // gemm_x3.hip: weight planes [3][N][K] bf16 (null: not available)
     const void* xp; const void* w3p; int np;     // gemm_x3p.hip: A and B as panel planes (null: not available), np planes each (3 bf16 | 2 fp16)
     void* out_planes;                            // gemm_x3p.hip: output as panel planes of an [M][N] matrix (null: rows in `out`)
-    int kv_planes; long k_ld;                    // EPI_QKV_ROPE, fp32: K and V^T leave as three bf16 planes (attention.hip KVP): out2 = [bh][3][k_ld][64], out3 = [bh][3][64][v_ld]
+    int kv_planes; long k_ld;                    // EPI_QKV_ROPE, fp32: K and V^T leave pre-split (attention.hip KVP), np = kv_planes planes (3 bf16 | 2 fp16 pairs; 1 = 3): out2 = [bh][np][k_ld][64], out3 = [bh][np][64][v_ld]
     int tail_tiles, tail_split;                  // gemm_ph8.hip: the last tail_tiles tiles are cut into tail_split K slices (0 / 1: none)
 };
 
@@ -378,6 +378,16 @@ __device__ __forceinline__ void gemm_epilogue_qkv_lds(f32x16 (&acc)[TMQ][2], con
                 if constexpr (sizeof(TO) == 4) if (p.kv_planes && which == 1) {
                     // K for the fp32 attention kernel with pre-split operands: the three bf16 pieces of the row's eight values,
                     // one 16-byte store per plane ([bh][plane][key][64])
+                    if (p.kv_planes == 2) {          // fp16 {hi, lo} pairs: [bh][2][key][64]
+                        x3_u4 pl[2];
+                        xnp_split8<2>(x, pl);
+                        bf16* kp = (bf16*)p.out2 + ((((long)b + biv[gi]) * p.heads + hh) * 2 * p.k_ld + mv[gi]) * 64 + c8;
+                        if (okv[gi]) {
+                            *reinterpret_cast<x3_u4*>(kp) = pl[0];
+                            *reinterpret_cast<x3_u4*>(kp + p.k_ld * 64) = pl[1];
+                        }
+                        continue;
+                    }
                     unsigned p1[4], p2[4], p3[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) x3_split_pair(x[2 * q], x[2 * q + 1], p1[q], p2[q], p3[q]);
@@ -417,8 +427,21 @@ __device__ __forceinline__ void gemm_epilogue_qkv_lds(f32x16 (&acc)[TMQ][2], con
             TO* dst = base + (((long)b + bi) * p.heads + hh) * 64 * p.v_ld + m;
             if (sizeof(TO) == 4 && p.kv_planes) {   // (fp32 instantiations only reach this with kv_planes set)
                 // V^T as three bf16 planes [bh][plane][d][v_ld]: 2-byte stores, 32 consecutive keys per instruction
-                unsigned short* vp = (unsigned short*)p.out3 + (((long)b + bi) * p.heads + hh) * 3 * 64 * p.v_ld + m;
                 const long pstride = 64 * p.v_ld;
+                if (p.kv_planes == 2) {              // fp16 {hi, lo} pairs: [bh][2][d][v_ld]
+                    unsigned short* vp = (unsigned short*)p.out3 + (((long)b + bi) * p.heads + hh) * 2 * 64 * p.v_ld + m;
+#pragma unroll 8
+                    for (int d = 0; d < 32; ++d) {
+                        const int dd = dh * 32 + d;
+                        unsigned ph, pl;
+                        x2_split_pair(stage[row * 65 + dd], 0.f, ph, pl);
+                        if (ok) {
+                            vp[(long)dd * p.v_ld] = (unsigned short)ph;
+                            vp[pstride + (long)dd * p.v_ld] = (unsigned short)pl;
+                        }
+                    }
+                } else {
+                unsigned short* vp = (unsigned short*)p.out3 + (((long)b + bi) * p.heads + hh) * 3 * 64 * p.v_ld + m;
 #pragma unroll 8
                 for (int d = 0; d < 32; ++d) {
                     const int dd = dh * 32 + d;
@@ -429,6 +452,7 @@ __device__ __forceinline__ void gemm_epilogue_qkv_lds(f32x16 (&acc)[TMQ][2], con
                         vp[pstride + (long)dd * p.v_ld] = (unsigned short)p2;
                         vp[2 * pstride + (long)dd * p.v_ld] = (unsigned short)p3;
                     }
+                }
                 }
             } else {
 #pragma unroll 8
