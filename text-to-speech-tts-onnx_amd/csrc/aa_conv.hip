@@ -12,6 +12,7 @@
 //   3. implicit-GEMM on MFMA: A fragments are read from the LDS tile at row offsets tap*dilation (im2col
 //      never exists), B fragments (weights [co][tap][ci]) stream from L2
 //   4. accumulators -> LDS (fp32) -> coalesced epilogue (bias, residual, alpha, accumulate) -> HBM
+#include <atomic>
 #include "common.h"
 #include "mfma.h"
 #include "aa_math.h"
@@ -22,7 +23,7 @@ namespace mi {
 extern __constant__ float c_h_fused[12];
 __constant__ float c_h_fused[12];
 
-static long g_aa_lds_min = -1;        // > 80 KB: one workgroup per CU (bit-reproducible 16-bit tiles), see launch_t
+static std::atomic<long> g_aa_lds_min = -1;        // > 80 KB: one workgroup per CU (bit-reproducible 16-bit tiles), see launch_t
 bool aa_conv_set_option(const char* key, long v) {
     if (std::string(key) != "aa_conv_deterministic") return false;
     g_aa_lds_min = v ? 82 * 1024 : 0;

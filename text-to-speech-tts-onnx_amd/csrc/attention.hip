@@ -17,6 +17,7 @@
 //   fp32 : v_mfma_f32_32x32x2_f32 (exact fp32 products, K = 2 keys per instruction)
 //   f16/bf16 : v_mfma_f32_32x32x16 — V is staged transposed ([d][key]) so that the 8 keys a lane feeds
 //                 per instruction are two contiguous 8-byte LDS reads.
+#include <atomic>
 #include "common.h"
 #include <mutex>
 #include "mfma.h"
@@ -844,11 +845,11 @@ __global__ __launch_bounds__(256, 2) void attn_x3f_kernel(const float* __restric
 // key slices of the SPLIT2 form: at most g_attn_zmax for fp32, g_attn_z16 for 16-bit operands (1 = off: no gain measured)
 // fp32 attention: 0 = native fp32 MFMA ; 1 = q.k as exact bf16 splits (attn_kernel X3S) ; 2 = both products (attn_x3f_kernel;
 // V then arrives transposed like in the 16-bit engines: attention_v_ld() tells the QKV epilogue)
-static int g_attn_x3 = 2;
-static int g_attn_np = 2;                                // format of the pre-split K / V^T (and of Q / P inside the kernel): 2 fp16 pairs | 3 bf16 planes
-static int g_attn_split = 1;                             // 64-query workgroups with the keys split between wave pairs when the grid is small
-static int g_attn_zmax = 4, g_attn_z16 = 1, g_attn_zforce = 0;      // zforce (tests): exactly that many slices, even empty ones
-static int g_attn_kvp = 1;                               // fp32, both products split: K / V^T pre-split by the QKV epilogue (A/B: attn_kv_planes)
+static std::atomic<int> g_attn_x3 = 2;
+static std::atomic<int> g_attn_np = 2;                                // format of the pre-split K / V^T (and of Q / P inside the kernel): 2 fp16 pairs | 3 bf16 planes
+static std::atomic<int> g_attn_split = 1;                             // 64-query workgroups with the keys split between wave pairs when the grid is small
+static std::atomic<int> g_attn_zmax = 4, g_attn_z16 = 1, g_attn_zforce = 0;      // zforce (tests): exactly that many slices, even empty ones
+static std::atomic<int> g_attn_kvp = 1;                               // fp32, both products split: K / V^T pre-split by the QKV epilogue (A/B: attn_kv_planes)
 // The MI355TTS_ATTN_* environment overrides are read ONCE, before the first use of any of the globals above by ANY of the
 // three entry points: F5::dit_eval asks attention_v_ld() for the V layout of the QKV epilogue before the first
 // launch_attention() of the process, and a lazy read inside launch_attention() made that first block write V transposed
@@ -926,7 +927,7 @@ void launch_attention(const void* q, const void* k, const void* v, void* o, int 
             cus = cu_count[dev & 15];
         }
         if (g_attn_zforce > 0)
-            return (ws && cnt && units * g_attn_zforce * (2 * 32 * 64 + 2 * 64 * 2) <= ws_floats && units <= cnt_n) ? g_attn_zforce : 1;
+            return (ws && cnt && units * g_attn_zforce * (2 * 32 * 64 + 2 * 64 * 2) <= ws_floats && units <= cnt_n) ? (int)g_attn_zforce : 1;
         int Z = 1;
         double best = 1e30;
         const int zm = dtype == MI_F32 ? zmax : std::min(zmax, zlimit16);

@@ -19,6 +19,7 @@
 // fp32 accumulate always.  4 waves per workgroup, each owning a (WM x WN) sub-tile of 32x32 MFMA
 // tiles.  K is streamed in KC-wide chunks: global -> registers (next chunk, issued before the
 // MFMAs of the current one) -> LDS -> fragments.
+#include <atomic>
 #include "common.h"
 #include <mutex>
 #include "mfma.h"
@@ -427,23 +428,23 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvGemmDev
     }
 }
 
-static bool g_use_dma = true, g_xcd_order = false, g_use_dma3 = true, g_big_tiles = true;
-static long g_big_min = 160, g_n192_min = 160, g_mid_min = 160, g_k_min = 2048;
-static bool g_n192 = true, g_f32_dma = true, g_ring4 = true, g_f32_small = true;
-static long g_f32_small_max = 1024, g_small16_max = 256, g_f32_n64_dma = 1, g_n64_dma16 = 0;      // 16-bit: neutral (455 vs 457 ms at 8 utterances), off
-static long g_ring4_max = 256;
+static std::atomic<bool> g_use_dma = true, g_xcd_order = false, g_use_dma3 = true, g_big_tiles = true;
+static std::atomic<long> g_big_min = 160, g_n192_min = 160, g_mid_min = 160, g_k_min = 2048;
+static std::atomic<bool> g_n192 = true, g_f32_dma = true, g_ring4 = true, g_f32_small = true;
+static std::atomic<long> g_f32_small_max = 1024, g_small16_max = 256, g_f32_n64_dma = 1, g_n64_dma16 = 0;      // 16-bit: neutral (455 vs 457 ms at 8 utterances), off
+static std::atomic<long> g_ring4_max = 256;
 // stream-K (gemm_sk.hip): 0 off ; 1 fp32 linear layers ; 2 also 16-bit ; g_sk_stages: ring depth override (0 = automatic) ;
 // g_sk_max_tiles: only launches with at most this many 128x128 tiles (beyond that one tile per workgroup balances by itself)
-static long g_sk = 1, g_sk_stages = 0, g_sk_max_tiles = 2048, g_sk_order = -1;
+static std::atomic<long> g_sk = 1, g_sk_stages = 0, g_sk_max_tiles = 2048, g_sk_order = -1;
 // whole tiles first, stream-K for the remainder only: measured SLOWER on the fp32 DiT layers (FF1 / FF2, 288 tiles: 87.0 vs
 // 83.7 us per launch — the remainder's eight-piece fix-ups cost more than the aligned K walk of the first phase gains): opt-in
 // fp32 linear layers as six exact bf16 x bf16 partial products (gemm_x3.hip) when the caller supplies the weight planes
-static long g_x3 = 1;
+static std::atomic<long> g_x3 = 1;
 bool gemm_x3_enabled() { return g_x3 != 0; }
 // ... with both operands as panel planes (gemm_x3p.hip, round 3) when the caller supplies them
-static long g_x3p = 1;
+static std::atomic<long> g_x3p = 1;
 // number format of the panel planes built from now on: 3 = three bf16 planes (six products), 2 = fp16 {hi, lo} planes (three products)
-static long g_x3p_np = 0;          // 0: not set by mi_set_option -> MI355TTS_F32_PLANES, else 2
+static std::atomic<long> g_x3p_np = 0;          // 0: not set by mi_set_option -> MI355TTS_F32_PLANES, else 2
 int x3p_planes() {
     if (g_x3p_np == 2 || g_x3p_np == 3) return (int)g_x3p_np;
     static const int env = [] { const char* e = std::getenv("MI355TTS_F32_PLANES"); return e ? std::atoi(e) : 0; }();
@@ -452,13 +453,13 @@ int x3p_planes() {
 bool gemm_x3p_enabled() { return g_x3 != 0 && g_x3p != 0; }
 // fp32 QKV + RoPE: its scatter epilogue is slow and in a persistent launch every workgroup runs it at the same time at the
 // end (in-model 184 us against 138 us for the 64x64 tiles, whose epilogues overlap other workgroups' main loops): off
-static long g_sk_qkv32 = 0;
+static std::atomic<long> g_sk_qkv32 = 0;
 // 256x256 eight-phase kernel (gemm_ph8.hip) for 16-bit linear layers with at least g_ph8_min_tiles tiles of 256x256
-static long g_ph8 = 1, g_ph8_min_tiles = 200, g_ph8_order = 1;
+static std::atomic<long> g_ph8 = 1, g_ph8_min_tiles = 200, g_ph8_order = 1;
 static DevBuf g_zero_page[16];
 
 // buffer-descriptor DMA (BUF kernels): whole 64-deep chunks only, and every byte offset must fit the 32-bit range check
-static bool g_buf = true;
+static std::atomic<bool> g_buf = true;
 static bool buf_ok(const ConvGemmDev& d, int esz = 2) {
     const long a_bytes = (((long)d.T_in - 1) * d.x_rstride + d.Cin) * esz, b_bytes = (long)d.N * d.K * esz;
     return g_buf && d.Cin % (128 / esz) == 0 && a_bytes + (long)512 * d.x_rstride * esz < 0x7fff0000L && b_bytes < 0x7fff0000L;

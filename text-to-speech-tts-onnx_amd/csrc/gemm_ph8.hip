@@ -34,6 +34,7 @@
 //
 // The DMA instructions are issued from inline asm (see gemm_sk.hip: hipcc drains vmcnt in front of a ds_read that follows
 // a builtin LDS-DMA).  Epilogues: the shared LDS-staged ones (gemm_epilogue.h) on the wave's contiguous 128x64 tile.
+#include <atomic>
 #include "common.h"
 #include "mfma.h"
 #include "gemm_epilogue.h"
@@ -311,7 +312,7 @@ __global__ __launch_bounds__(512, 1) void linear_ph8_kernel(const ConvGemmDev p)
 #endif
 }
 
-static long g_ph8_split_max = 2, g_ph8_split_min_nk = 24;      // measured: a gain only for the K = 2048 layer (FF2, 32 K tiles), two slices
+static std::atomic<long> g_ph8_split_max = 2, g_ph8_split_min_nk = 24;      // measured: a gain only for the K = 2048 layer (FF2, 32 K tiles), two slices
 void ph8_set_split_min_nk(long v) { g_ph8_split_min_nk = v; }
 void ph8_set_split_max(long v) { g_ph8_split_max = v < 1 ? 1 : v > 4 ? 4 : v; }       // the kernel's fix-up is unrolled for at most 4 slices
 

@@ -28,6 +28,7 @@
 //    CYCLICALLY from a per-tile start chunk chosen so that all workgroups of the launch are at the same physical chunk at
 //    the same time (ranges still differ by (range length mod chunks-per-tile) for their tail pieces): the workgroups of an
 //    XCD that share a row or weight panel request the same 24 KB within a few chunk times of each other.
+#include <atomic>
 #include "common.h"
 #include "mfma.h"
 #include "gemm_epilogue.h"
@@ -477,7 +478,7 @@ __global__ __launch_bounds__(512, 1) void linear_x3p_kernel(const ConvGemmDev p)
 #endif
 }
 
-static long g_x3p_noalign = 0, g_x3p_grid = 0;       // A/B switches: 1 = no cyclic K alignment ; grid: 0 = automatic, else GR (1, 2, 4, 8)
+static std::atomic<long> g_x3p_noalign = 0, g_x3p_grid = 0;       // A/B switches: 1 = no cyclic K alignment ; grid: 0 = automatic, else GR (1, 2, 4, 8)
 void x3p_set_option(int which, long v) { if (which == 0) g_x3p_noalign = v; else g_x3p_grid = v; }
 
 void launch_linear_x3p(const ConvGemmDev& e_in, hipStream_t s) {

@@ -13,13 +13,14 @@
 // argument: it is captured once and replayed.  A decode step is a chain of weight-streaming GEMVs (HBM-bound:
 // every weight byte is read once per token), so the GEMV kernel is a plain coalesced 16-byte-per-lane dot product,
 // not an MFMA tile; the prompt pass (ids_len rows at once) goes through the MFMA implicit-GEMM kernel instead.
+#include <atomic>
 #include "gpt.h"
 #include "mfma.h"
 #include <cstdlib>
 
 namespace mi {
 
-static long g_gpt_mfma_min = 9;
+static std::atomic<long> g_gpt_mfma_min = 9;
 bool gpt_set_option(const char* key, long v) {
     if (std::string(key) == "gpt_mfma_min") { g_gpt_mfma_min = v; return true; }
     return false;
