@@ -469,6 +469,14 @@ __global__ __launch_bounds__(256, 2) void attn_x3f_kernel(const float* __restric
         f1 = __builtin_bit_cast(Frag, x3_u4{h[0], h[1], h[2], h[3]});
         f2 = __builtin_bit_cast(Frag, x3_u4{l[0], l[1], l[2], l[3]});
     };
+    // the probabilities: in [0, 1] by construction, no range clamp
+    auto split8p = [&](const float4 a, const float4 b, Frag& f1, Frag& f2) __attribute__((always_inline)) {
+        unsigned h[4], l[4];
+        x2_split_pair_raw(a.x, a.y, h[0], l[0]); x2_split_pair_raw(a.z, a.w, h[1], l[1]);
+        x2_split_pair_raw(b.x, b.y, h[2], l[2]); x2_split_pair_raw(b.z, b.w, h[3], l[3]);
+        f1 = __builtin_bit_cast(Frag, x3_u4{h[0], h[1], h[2], h[3]});
+        f2 = __builtin_bit_cast(Frag, x3_u4{l[0], l[1], l[2], l[3]});
+    };
 
     // ---- Q: the NP pieces of log2(e) * Q[q0 + lr][16 ks + 8 hi .. +8] ------------------------------------------------
     Frag qf3[4][NP];
@@ -652,7 +660,7 @@ __global__ __launch_bounds__(256, 2) void attn_x3f_kernel(const float* __restric
                     split8(float4{p[8 * s2], p[8 * s2 + 1], p[8 * s2 + 2], p[8 * s2 + 3]},
                            float4{p[8 * s2 + 4], p[8 * s2 + 5], p[8 * s2 + 6], p[8 * s2 + 7]}, pf[0], pf[1], pf[2]);
                 else
-                    split8h(float4{p[8 * s2], p[8 * s2 + 1], p[8 * s2 + 2], p[8 * s2 + 3]},
+                    split8p(float4{p[8 * s2], p[8 * s2 + 1], p[8 * s2 + 2], p[8 * s2 + 3]},
                             float4{p[8 * s2 + 4], p[8 * s2 + 5], p[8 * s2 + 6], p[8 * s2 + 7]}, pf[0], pf[1]);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {

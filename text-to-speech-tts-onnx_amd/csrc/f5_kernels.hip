@@ -9,17 +9,13 @@
 //   Vocos head       exp/clip magnitude, phase -> re/im           vocos/heads.py:55-59, STFT_Process.py:160-163
 //   ISTFT OLA        overlap-add + envelope + clamp + int16       STFT_Process.py:164-166, Export_F5.py:203
 //   CFG/Euler        x += (p + (p - p1)*cfg) * dt[k]              Export_F5.py:179-180
+#include "wave_reduce.h"
 #include "common.h"
 #include "f5_kernels.h"
 #include "x3_split.h"
 
 namespace mi {
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
 
 // -----------------------------------------------------------------------------------------------
 // row norm: one 64-lane wave per row, row cached in registers (D <= 64*4*MAXV), two-pass statistics

@@ -23,17 +23,21 @@ __device__ __forceinline__ void x3_split_pair(float x, float y, unsigned& p1, un
 
 // Two-way fp16 split: a ~= hi + lo * 2^-11 with hi = fp16(a), lo = fp16((a - hi) * 2^11) — 22 significant bits, the low
 // part stored scaled so that it lives in the same exponent range as the high part (no fp16 underflow of the residual: the
-// absolute error floor is 2^-36, the relative error 2^-23).  |a| is clamped to the fp16 range (65504) first: a linear
-// layer operand beyond it would turn into inf - inf.  Two fp32 values -> packed pairs (low half = x, high half = y).
+// absolute error floor is 2^-36, the relative error 2^-23).  Finite |a| beyond the fp16 range saturates at 65504 (it would
+// otherwise turn into inf - inf); the clamp is a compare-select, so a NaN stays a NaN (fminf / fmaxf would hide it).
+// Two fp32 values -> packed pairs (low half = x, high half = y).
 typedef _Float16 x2_h2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void x2_split_pair(float x, float y, unsigned& ph, unsigned& pl) {
-    x = __builtin_fminf(__builtin_fmaxf(x, -65504.f), 65504.f);
-    y = __builtin_fminf(__builtin_fmaxf(y, -65504.f), 65504.f);
+__device__ __forceinline__ void x2_split_pair_raw(float x, float y, unsigned& ph, unsigned& pl) {
     const x2_h2 h = __builtin_convertvector(x3_f2{x, y}, x2_h2);
     ph = __builtin_bit_cast(unsigned, h);
     const float rx = (x - (float)h.x) * 2048.f, ry = (y - (float)h.y) * 2048.f;       // exact
     const x2_h2 l = __builtin_convertvector(x3_f2{rx, ry}, x2_h2);
     pl = __builtin_bit_cast(unsigned, l);
+}
+__device__ __forceinline__ void x2_split_pair(float x, float y, unsigned& ph, unsigned& pl) {
+    x = x > 65504.f ? 65504.f : x; x = x < -65504.f ? -65504.f : x;
+    y = y > 65504.f ? 65504.f : y; y = y < -65504.f ? -65504.f : y;
+    x2_split_pair_raw(x, y, ph, pl);
 }
 // eight consecutive values -> the 16-byte slot of each plane
 template <int NP> __device__ __forceinline__ void xnp_split8(const float (&v)[8], x3_u4 (&pl)[NP]) {
