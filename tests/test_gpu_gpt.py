@@ -157,11 +157,14 @@ def test_penalty_carries_across_sentences(small, g):
     e.close()
 
 
+@pytest.mark.parametrize("hidden,inner", [(256, 1024), (320, 1352), (704, 2816)])
 @pytest.mark.parametrize("dtype,tol", [("f32", 3e-4), ("f16", 4e-2), ("bf16", 2.5e-1)])
-def test_medium_model_vs_oracle(dtype, tol):
-    """hidden 256 / 4 heads / 3 layers, 75-row prompt (MFMA GEMM path with a ragged tile), then teacher-forced single
-    steps (GEMV path) against the oracle."""
-    cfg = IndexGPTConfig(hidden=256, layers=3, heads=4, inner=1024, mel_codes=301, text_tokens=64, max_mel_pos=80,
+def test_medium_model_vs_oracle(dtype, tol, hidden, inner):
+    """3 layers, 75-row prompt (MFMA GEMM path with a ragged tile), then teacher-forced single steps (the decode-step GEMV
+    kernel) against the oracle.  The widths walk the GEMV's compile-time K iterations and its padded lanes: hidden 256 (one
+    iteration at 16 bits, none padded), 320 (lanes 40-63 padded; inner 1352 = 2.64 iterations), 704 / 2816 (1.4 / 5.5
+    iterations at 16 bits, 2.75 / 11 in fp32); 301 lm_head rows end inside a block."""
+    cfg = IndexGPTConfig(hidden=hidden, layers=3, heads=hidden // 64, inner=inner, mel_codes=301, text_tokens=64, max_mel_pos=80,
                          max_text_pos=80, max_seq=160, start_mel_token=299, stop_mel_token=300, max_generate_length=120)
     st = W.synth_state(W.gpt_spec(cfg), 77)
     e = IndexGPT(cfg, st, dtype=dtype)
