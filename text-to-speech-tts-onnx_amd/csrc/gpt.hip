@@ -945,7 +945,13 @@ static void gemv_d_dispatch(const Gpt::GLin& l, const void* x, const float* ln_w
 #define GD(RR, KK, LNN, QK) gemv_d_launch<T, RR, KK, LNN, QK>(l, x, ln_w, ln_b, pre_w, pre_b, pre_out, res, out, of, act, kcl, vcl, st, max_seq, s)
     if (ln_w) {
         MI_REQUIRE(ki <= 8, "gemv: the fused LayerNorm supports K <= 2048");
-        const bool r2 = l.n >= 2048;
+        // rows per wave: the fewest (most waves in flight) for which the launch is one round of 512-thread blocks, one per CU
+        // (5120 rows at R = 2 are 320 blocks on 256 CUs: the 64 CUs that get two set the time — 6.1 us against 4.7 for the
+        // 3840-row layer; R = 3: 214 blocks, 5.4 us)
+        static int cus = 0;
+        if (!cus) { int dev = 0; hipDeviceProp_t pr; MI_HIP(hipGetDevice(&dev)); MI_HIP(hipGetDeviceProperties(&pr, dev)); cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
+        int r = 1;
+        while (r < (kcl ? 2 : 4) && (l.n + 8 * r - 1) / (8 * r) > cus) ++r;
 #define GD_K(RR, QK)                                                                              \
     do {                                                                                          \
         if (ki <= 1) GD(RR, 1, true, QK); else if (ki == 2) GD(RR, 2, true, QK);                   \
@@ -953,8 +959,8 @@ static void gemv_d_dispatch(const Gpt::GLin& l, const void* x, const float* ln_w
         else if (ki == 5) GD(RR, 5, true, QK); else if (ki == 6) GD(RR, 6, true, QK);              \
         else GD(RR, 8, true, QK);                                                                 \
     } while (0)
-        if (kcl) { if (r2) GD_K(2, true); else GD_K(1, true); }
-        else { if (r2) GD_K(2, false); else GD_K(1, false); }
+        if (kcl) { if (r == 2) GD_K(2, true); else GD_K(1, true); }
+        else { if (r == 1) GD_K(1, false); else if (r == 2) GD_K(2, false); else if (r == 3) GD_K(3, false); else GD_K(4, false); }
 #undef GD_K
     } else {
         MI_REQUIRE(ki <= 32, "gemv: K <= 8192");
