@@ -923,7 +923,8 @@ void launch_attention(const void* q, const void* k, const void* v, void* o, int 
     const int zmax = g_attn_zmax;
     // key slices for the SPLIT2 form (see attn_kernel): makespan(Z) = ceil(units * Z / CUs) / Z in units of one unsliced
     // workgroup, + 6 % per extra slice for the prologue and the merge (measured, fp32, one utterance = 576 units:
-    // Z = 1 / 2 / 3 / 4 -> 135 / 122 / 121 / 126 us)
+    // Z = 1 / 2 / 3 / 4 -> 135 / 122 / 121 / 126 us in round 2; 62.1 / 58.8 / 60.8 / 60.7 us with the fp16-pair kernel of
+    // round 3, whose slices are shorter against the same merge: + 9 % for fp32)
     auto pick_z = [&](int zlimit16) -> int {
         const long units = (long)((N + 63) / 64) * BH;
         const int nstage = (N + 63) / 64;
@@ -941,7 +942,7 @@ void launch_attention(const void* q, const void* k, const void* v, void* o, int 
         const int zm = dtype == MI_F32 ? zmax : std::min(zmax, zlimit16);
         for (int z = 1; z <= zm; ++z) {
             if (z > 1 && (!ws || !cnt || units * z * (2 * 32 * 64 + 2 * 64 * 2) > ws_floats || units > cnt_n || nstage < 2 * z)) break;
-            const double cost = (double)((units * z + cus - 1) / cus) / z * (1.0 + 0.06 * (z - 1));
+            const double cost = (double)((units * z + cus - 1) / cus) / z * (1.0 + (dtype == MI_F32 ? 0.09 : 0.06) * (z - 1));
             if (cost < best - 1e-9) { best = cost; Z = z; }
         }
         return Z;
