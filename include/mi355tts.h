@@ -235,7 +235,9 @@ int         mi_indextts_cond_run(mi_cond* h, const int16_t* audio, int64_t L, fl
  *       partial products per fp32 product on two accumulator sets; measured error against float64 below the native fp32
  *       MFMA's.  3: three bf16 planes (exact split), six partial products.
  *   "attn_f32_x3" (default 2): attention with both products formed that way (V is then kept transposed, like in the 16-bit
- *       engines); 1: q.k only; 0: native fp32 MFMA.
+ *       engines); 1: q.k only; 0: native fp32 MFMA.  "attn_f32_planes" (default 2): the operand format of that path — 2: fp16
+ *       {hi, lo} pairs with the low part unscaled (three partial products into one accumulator; attention's operands are of
+ *       order one); 3: three bf16 planes (exact split, six partial products).
  * Further tuning keys (defaults are the measured best): "gemm_ph8", "gemm_ph8_min_tiles", "gemm_ph8_order",
  * "gemm_ph8_split_max", "gemm_ph8_split_min_nk" (256x256 16-bit kernel); "gemm_sk_qkv32";
  * "gemm_f32_x3p" (0: the round-2 kernel gemm_x3.hip instead of the panel-plane kernel gemm_x3p.hip), "gemm_x3p_grid" (XCD bands:

@@ -419,11 +419,12 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const T* __restrict__ q, c
 // LDS as they are, instead of 8 float4 loads + 176 VALU of splitting per thread and stage — work that every one of the
 // N / 64 query tiles of a head repeated on the same K / V values (with the key-split 64-query workgroups a wave multiplies
 // ONE 32x32 tile per stage: the stage split was as many VALU cycles as the tile's softmax and P split together).
-// NP = 2 (only with KVP): K / V^T arrive as fp16 {hi, lo * 2^11} pairs (x3_split.h) and Q / P are split the same way: three
-// partial products per block on two accumulator sets (hi*hi ; hi*lo + lo*hi) for S and for O, combined as A + 2^-11 B —
-// half the MFMAs of the three-plane form, 4 instead of 6 bytes per K / V element.
+// NP = 2 (only with KVP): K / V^T arrive as fp16 {hi, lo} pairs with the low part UNSCALED (x3_split.h: x2u_split_pair — the
+// operands of attention are of order one, their residuals stay above fp16's subnormal floor where it matters) and Q / P are
+// split the same way: three partial products per block, small terms first, into the one accumulator — half the MFMAs of the
+// three-plane form, 4 instead of 6 bytes per K / V element, no second accumulator set.
 template <bool SPLIT2, bool KVP = false, int NP = 3>
-__global__ __launch_bounds__(256, 2) void attn_x3f_kernel(const float* __restrict__ q, const float* __restrict__ k,
+__global__ __launch_bounds__(256, NP == 2 ? 3 : 2) void attn_x3f_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                        const float* __restrict__ v, float* __restrict__ o, int H, int N,
                                                        float* __restrict__ ws, int* __restrict__ cnt,
                                                        unsigned char* __restrict__ o_planes, int o_np) {
@@ -464,16 +465,16 @@ __global__ __launch_bounds__(256, 2) void attn_x3f_kernel(const float* __restric
 
     auto split8h = [&](const float4 a, const float4 b, Frag& f1, Frag& f2) __attribute__((always_inline)) {
         unsigned h[4], l[4];
-        x2_split_pair(a.x, a.y, h[0], l[0]); x2_split_pair(a.z, a.w, h[1], l[1]);
-        x2_split_pair(b.x, b.y, h[2], l[2]); x2_split_pair(b.z, b.w, h[3], l[3]);
+        x2u_split_pair(a.x, a.y, h[0], l[0]); x2u_split_pair(a.z, a.w, h[1], l[1]);
+        x2u_split_pair(b.x, b.y, h[2], l[2]); x2u_split_pair(b.z, b.w, h[3], l[3]);
         f1 = __builtin_bit_cast(Frag, x3_u4{h[0], h[1], h[2], h[3]});
         f2 = __builtin_bit_cast(Frag, x3_u4{l[0], l[1], l[2], l[3]});
     };
     // the probabilities: in [0, 1] by construction, no range clamp
     auto split8p = [&](const float4 a, const float4 b, Frag& f1, Frag& f2) __attribute__((always_inline)) {
         unsigned h[4], l[4];
-        x2_split_pair_raw(a.x, a.y, h[0], l[0]); x2_split_pair_raw(a.z, a.w, h[1], l[1]);
-        x2_split_pair_raw(b.x, b.y, h[2], l[2]); x2_split_pair_raw(b.z, b.w, h[3], l[3]);
+        x2u_split_pair_raw(a.x, a.y, h[0], l[0]); x2u_split_pair_raw(a.z, a.w, h[1], l[1]);
+        x2u_split_pair_raw(b.x, b.y, h[2], l[2]); x2u_split_pair_raw(b.z, b.w, h[3], l[3]);
         f1 = __builtin_bit_cast(Frag, x3_u4{h[0], h[1], h[2], h[3]});
         f2 = __builtin_bit_cast(Frag, x3_u4{l[0], l[1], l[2], l[3]});
     };
@@ -565,13 +566,8 @@ __global__ __launch_bounds__(256, 2) void attn_x3f_kernel(const float* __restric
     };
 
     f32x16 oacc[2];
-    f32x16 oaccb[NP == 2 ? 2 : 1];                          // NP = 2: the 2^11-scaled cross terms of O
 #pragma unroll
     for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.f; oacc[1][r] = 0.f; }
-    if constexpr (NP == 2) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { oaccb[0][r] = 0.f; oaccb[1][r] = 0.f; }
-    }
     float m_run = -INFINITY, l_run = 0.f;
 
     const int nstage_all = (N + KT - 1) / KT;
@@ -591,11 +587,6 @@ __global__ __launch_bounds__(256, 2) void attn_x3f_kernel(const float* __restric
             f32x16 sacc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
-            f32x16 saccb;
-            if constexpr (NP == 2) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) saccb[r] = 0.f;
-            }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 Frag kf[NP];
@@ -605,15 +596,11 @@ __global__ __launch_bounds__(256, 2) void attn_x3f_kernel(const float* __restric
                 if constexpr (NP == 3) {
 #pragma unroll
                     for (int t = 0; t < 6; ++t) sacc = MF::mma(kf[TA[t]], qf3[ks][TB[t]], sacc);
-                } else {
-                    saccb = MF::mma(kf[1], qf3[ks][0], saccb);
-                    saccb = MF::mma(kf[0], qf3[ks][1], saccb);
+                } else {                          // small terms first, one accumulator (unscaled low parts)
+                    sacc = MF::mma(kf[1], qf3[ks][0], sacc);
+                    sacc = MF::mma(kf[0], qf3[ks][1], sacc);
                     sacc = MF::mma(kf[0], qf3[ks][0], sacc);
                 }
-            }
-            if constexpr (NP == 2) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sacc[r] = __builtin_fmaf(saccb[r], 0x1p-11f, sacc[r]);
             }
             if (key0 + 32 > N) {
 #pragma unroll
@@ -633,10 +620,6 @@ __global__ __launch_bounds__(256, 2) void attn_x3f_kernel(const float* __restric
                 m_run = m_new;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
-                if constexpr (NP == 2) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) { oaccb[0][r] *= alpha; oaccb[1][r] *= alpha; }
-                }
             }
             typedef float f2 __attribute__((ext_vector_type(2)));
             float p[16];
@@ -677,8 +660,8 @@ __global__ __launch_bounds__(256, 2) void attn_x3f_kernel(const float* __restric
 #pragma unroll
                         for (int t = 0; t < 6; ++t) oacc[dt] = MF::mma(vf[TA[t]], pf[TB[t]], oacc[dt]);
                     } else {
-                        oaccb[dt] = MF::mma(vf[1], pf[0], oaccb[dt]);
-                        oaccb[dt] = MF::mma(vf[0], pf[1], oaccb[dt]);
+                        oacc[dt] = MF::mma(vf[1], pf[0], oacc[dt]);
+                        oacc[dt] = MF::mma(vf[0], pf[1], oacc[dt]);
                         oacc[dt] = MF::mma(vf[0], pf[0], oacc[dt]);
                     }
                 }
@@ -698,12 +681,6 @@ __global__ __launch_bounds__(256, 2) void attn_x3f_kernel(const float* __restric
             store_lds();
             __syncthreads();
         }
-    }
-    if constexpr (NP == 2) {
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[dt][r] = __builtin_fmaf(oaccb[dt][r], 0x1p-11f, oacc[dt][r]);
     }
     bool owner = true;                                              // this wave holds a finished 32-query result
     if constexpr (SPLIT2) {

@@ -41,7 +41,7 @@ struct ConvGemmDev {
     const void* w3;                              // gemm_x3.hip: weight planes [3][N][K] bf16 (null: not available)
     const void* xp; const void* w3p; int np;     // gemm_x3p.hip: A and B as panel planes (null: not available), np planes each (3 bf16 | 2 fp16)
     void* out_planes;                            // gemm_x3p.hip: output as panel planes of an [M][N] matrix (null: rows in `out`)
-    int kv_planes; long k_ld;                    // EPI_QKV_ROPE, fp32: K and V^T leave pre-split (attention.hip KVP), np = kv_planes planes (3 bf16 | 2 fp16 pairs; 1 = 3): out2 = [bh][np][k_ld][64], out3 = [bh][np][64][v_ld]
+    int kv_planes; long k_ld;                    // EPI_QKV_ROPE, fp32: K and V^T leave pre-split (attention.hip KVP), np = kv_planes planes (3 bf16 | 2 fp16 pairs with the low part unscaled, x2u_split_pair; 1 = 3): out2 = [bh][np][k_ld][64], out3 = [bh][np][64][v_ld]
     int tail_tiles, tail_split;                  // gemm_ph8.hip: the last tail_tiles tiles are cut into tail_split K slices (0 / 1: none)
 };
 
@@ -379,8 +379,13 @@ __device__ __forceinline__ void gemm_epilogue_qkv_lds(f32x16 (&acc)[TMQ][2], con
                     // K for the fp32 attention kernel with pre-split operands: the three bf16 pieces of the row's eight values,
                     // one 16-byte store per plane ([bh][plane][key][64])
                     if (p.kv_planes == 2) {          // fp16 {hi, lo} pairs: [bh][2][key][64]
-                        x3_u4 pl[2];
-                        xnp_split8<2>(x, pl);
+                        x3_u4 pl[2];                  // unscaled low part: the attention kernel sums both parts into one accumulator
+                        {
+                            unsigned wh[4], wl[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) x2u_split_pair(x[2 * q], x[2 * q + 1], wh[q], wl[q]);
+                            pl[0] = x3_u4{wh[0], wh[1], wh[2], wh[3]}; pl[1] = x3_u4{wl[0], wl[1], wl[2], wl[3]};
+                        }
                         bf16* kp = (bf16*)p.out2 + ((((long)b + biv[gi]) * p.heads + hh) * 2 * p.k_ld + mv[gi]) * 64 + c8;
                         if (okv[gi]) {
                             *reinterpret_cast<x3_u4*>(kp) = pl[0];
@@ -434,7 +439,7 @@ __device__ __forceinline__ void gemm_epilogue_qkv_lds(f32x16 (&acc)[TMQ][2], con
                     for (int d = 0; d < 32; ++d) {
                         const int dd = dh * 32 + d;
                         unsigned ph, pl;
-                        x2_split_pair(stage[row * 65 + dd], 0.f, ph, pl);
+                        x2u_split_pair(stage[row * 65 + dd], 0.f, ph, pl);
                         if (ok) {
                             vp[(long)dd * p.v_ld] = (unsigned short)ph;
                             vp[pstride + (long)dd * p.v_ld] = (unsigned short)pl;

@@ -39,6 +39,21 @@ __device__ __forceinline__ void x2_split_pair(float x, float y, unsigned& ph, un
     y = y > 65504.f ? 65504.f : y; y = y < -65504.f ? -65504.f : y;
     x2_split_pair_raw(x, y, ph, pl);
 }
+// The same pair with the low part UNSCALED: lo = fp16(a - hi).  Both parts then multiply into ONE accumulator (no 2^-11 fold),
+// at the price of fp16's subnormal spacing for the residual: absolute operand error 2^-25 instead of 2^-36.  For operands of
+// order one whose products are summed into a softmax argument or a probability-weighted mean (attention: q, k, v, p) that is
+// below the fp32 rounding of the sum; the linear layers keep the scaled form (arbitrary operand magnitudes).
+__device__ __forceinline__ void x2u_split_pair_raw(float x, float y, unsigned& ph, unsigned& pl) {
+    const x2_h2 h = __builtin_convertvector(x3_f2{x, y}, x2_h2);
+    ph = __builtin_bit_cast(unsigned, h);
+    const x2_h2 l = __builtin_convertvector(x3_f2{x - (float)h.x, y - (float)h.y}, x2_h2);
+    pl = __builtin_bit_cast(unsigned, l);
+}
+__device__ __forceinline__ void x2u_split_pair(float x, float y, unsigned& ph, unsigned& pl) {
+    x = x > 65504.f ? 65504.f : x; x = x < -65504.f ? -65504.f : x;
+    y = y > 65504.f ? 65504.f : y; y = y < -65504.f ? -65504.f : y;
+    x2u_split_pair_raw(x, y, ph, pl);
+}
 // eight consecutive values -> the 16-byte slot of each plane
 template <int NP> __device__ __forceinline__ void xnp_split8(const float (&v)[8], x3_u4 (&pl)[NP]) {
     unsigned w[NP][4];
