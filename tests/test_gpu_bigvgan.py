@@ -311,7 +311,7 @@ def test_bad_inputs_raise(small_voc):
 # ---------------------------------------------------------------------------------------------
 _DEFAULTS = {"gemm_big_tile_min": 160, "gemm_n192_min": 160, "gemm_mid_tile_min": 160, "gemm_dma3_k_min": 2048,
              "gemm_use_dma3": 1, "gemm_use_dma": 1, "gemm_big_tiles": 1, "gemm_n192": 1, "gemm_f32_dma": 1, "gemm_ring4": 1, "gemm_ring4_max": 256, "gemm_buf": 1, "gemm_f32_small": 1, "gemm_f32_small_max": 1024, "gemm_small16_max": 256, "gemm_sk": 1, "gemm_sk_stages": 0, "gemm_ph8": 1, "gemm_ph8_min_tiles": 200, "gemm_ph8_order": 1, "gemm_ph8_split_max": 2, "gemm_ph8_split_min_nk": 24, "gemm_f32_x3": 1,
-             "gemm_f32_x3p": 1, "gemm_x3p_grid": 0, "gemm_x3p_noalign": 0, "gemm_f32_planes": 2}
+             "gemm_f32_x3p": 1, "gemm_x3p_grid": 0, "gemm_x3p_noalign": 0, "gemm_f32_planes": 2, "gemm_f32_n64_pairs": 1}
 
 
 @pytest.fixture
@@ -505,6 +505,37 @@ def test_f32_linear_fp16_pairs_over_the_operand_range(gemm_options, scale):
         assert rel["pairs"] < 1.5 * rel["native"] and rel["pairs"] < 1.5 * rel["bf16x3"] and rel["pairs"] < 1e-6, rel
     else:       # sum over K of w * (2^-36 operand error): sqrt(K) * rms(w) = 1 here
         assert err["pairs"] < 4 * 2.0 ** -36, err
+
+
+@pytest.mark.parametrize("C,groups,k,T,B", [(1024, 16, 31, 1126, 2), (512, 8, 31, 300, 1), (256, 4, 9, 515, 3)])
+def test_f32_grouped_conv_fp16_pairs_in_registers(gemm_options, C, groups, k, T, B):
+    """The DiT's position convolution (Conv1d k = 31, 16 groups of 64 channels) in fp32: conv_gemm_dma_kernel splits both
+    operands into fp16 {hi, lo} pairs in registers (three 16-bit MFMAs per k-step on two accumulator sets instead of eight
+    fp32 MFMAs; option gemm_f32_n64_pairs).  Against the oracle, against the native fp32 MFMA form of the same kernel, and
+    against float64: no further from it than native."""
+    x = W.synth_normal(41, f"gx{C}{T}", (B, C, T))
+    w = W.synth_normal(42, f"gw{C}{k}", (C, C // groups, k), std=1.0 / np.sqrt(C // groups * k))
+    b = W.synth_normal(43, "gb", (C,), std=0.1)
+    cgo = C // groups
+    ref = np.concatenate([O.conv1d(x[:, gi * cgo:(gi + 1) * cgo], w[gi * cgo:(gi + 1) * cgo], b[gi * cgo:(gi + 1) * cgo], padding=k // 2)
+                          for gi in range(groups)], axis=1)
+    gemm_options("gemm_f32_n64_pairs", 1)
+    y = BV.conv1d(x, w, b, padding=k // 2, groups=groups, dtype="f32")
+    assert np.array_equal(y, BV.conv1d(x, w, b, padding=k // 2, groups=groups, dtype="f32"))
+    gemm_options("gemm_f32_n64_pairs", 0)
+    y0 = BV.conv1d(x, w, b, padding=k // 2, groups=groups, dtype="f32")
+    np.testing.assert_allclose(y, ref, atol=3e-5, rtol=1e-5)
+    assert np.abs(y - y0).max() < 3e-5 and not np.array_equal(y, y0)        # K = 1984: two fp32 summation orders
+    xp = np.pad(x.astype(np.float64), ((0, 0), (0, 0), (k // 2, k // 2)))
+    cg = C // groups
+    ref64 = np.zeros((B, C, T))
+    for gi in range(groups):
+        win = np.lib.stride_tricks.sliding_window_view(xp[:, gi * cg:(gi + 1) * cg], k, axis=2)       # (B, cg, T, k)
+        ref64[:, gi * cg:(gi + 1) * cg] = np.einsum("bctk,ock->bot", win, w[gi * cg:(gi + 1) * cg].astype(np.float64))
+    ref64 += b.astype(np.float64)[None, :, None]
+    e_pairs, e_native = rms(y - ref64), rms(y0 - ref64)
+    print(f"grouped conv C={C} k={k}: rms error against float64: pairs {e_pairs:.3e}, native fp32 MFMA {e_native:.3e}")
+    assert e_pairs < 1.5 * e_native + 1e-9, (e_pairs, e_native)
 
 
 @pytest.mark.parametrize("f32_dma,small,buf", [(1, 1, 1), (1, 0, 1), (1, 1, 0), (1, 0, 0), (0, 1, 1)])

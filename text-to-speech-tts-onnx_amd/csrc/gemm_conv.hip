@@ -165,9 +165,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmDev p) 
 //     the same XOR.  Every ds_read_b128 lane group then covers all 64 banks exactly once (conflict-free).
 //   * the loads of chunk c+1 are in flight while the 16 MFMAs per wave of chunk c run.
 // ---------------------------------------------------------------------------------------------------
-template <typename T, typename TO, bool LEPI, int NST = 2, int BT = 128>
+// PAIRS (fp32 only): the operands are split into fp16 {hi, lo * 2^11} pairs IN REGISTERS in front of the matrix cores (x3_split.h)
+// and every 16-deep k-step is three v_mfma_f32_32x32x16_f16 on two accumulator sets instead of eight v_mfma_f32_32x32x2_f32 —
+// the arithmetic of gemm_x3p.hip for shapes its panel planes do not cover (the grouped k = 31 position convolution of the
+// DiT, N = 64 per group): 512 matrix-core cycles per chunk become 96, the split costs ~290 VALU cycles.
+template <typename T, typename TO, bool LEPI, int NST = 2, int BT = 128, bool PAIRS = false>
 __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvGemmDev p) {
     using MF = Mfma<T>;
+    static_assert(!PAIRS || (sizeof(T) == 4 && NST == 2), "PAIRS: the fp32 two-buffer loop");
     // a tile row is always 128 bytes = eight 16-byte k-vectors: 64 halfs / bf16s or 32 floats per K chunk
     constexpr int VEC = 16 / (int)sizeof(T), KC = 8 * VEC;
     // BT = 128: the 128x128 tile (64x64 per wave).  BT = 64: 64x64 tiles (32x32 per wave) for fp32 problems with too few
@@ -273,11 +278,63 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvGemmDev
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    f32x16 accb[PAIRS ? TM : 1][PAIRS ? TN : 1];          // PAIRS: the 2^11-scaled cross terms
+    if constexpr (PAIRS) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accb[i][j][r] = 0.f;
+    }
     int tap = 0, c0 = 0;
     const int ntaps = p.K / p.Cin;
     auto compute = [&](int buf) {
         const T* As = smem + buf * TILE;
         const T* Bs = As + BM * KC;
+        if constexpr (PAIRS) {
+            using MH = Mfma<f16>;
+            using FH = typename MH::Frag;
+            // k-step s of the 32-float chunk: lane half lk holds k = 16 s + 8 lk .. + 8 = the k-vectors 4 s + 2 lk and + 1 of its row
+            // (A and B alike, so the contraction pairs up); finite values beyond the fp16 range saturate
+            auto split8 = [&](const float4 u, const float4 w, FH& fh, FH& fl, bool clamp) __attribute__((always_inline)) {
+                float v[8] = {u.x, u.y, u.z, u.w, w.x, w.y, w.z, w.w};
+                unsigned h[4], l[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float a = v[2 * q], b2 = v[2 * q + 1];
+                    if (clamp) { a = __builtin_amdgcn_fmed3f(a, -65504.f, 65504.f); b2 = __builtin_amdgcn_fmed3f(b2, -65504.f, 65504.f); }
+                    x2_split_pair_raw(a, b2, h[q], l[q]);
+                }
+                fh = __builtin_bit_cast(FH, x3_u4{h[0], h[1], h[2], h[3]});
+                fl = __builtin_bit_cast(FH, x3_u4{l[0], l[1], l[2], l[3]});
+            };
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                FH ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int row = wm * WM + i * 32 + lr, sw = (row >> 1) & 7, kv = 4 * st + 2 * lk;
+                    split8(*reinterpret_cast<const float4*>(As + row * KC + ((kv ^ sw) * VEC)),
+                           *reinterpret_cast<const float4*>(As + row * KC + (((kv + 1) ^ sw) * VEC)), ah[i], al[i], true);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int row = wn * WN + j * 32 + lr, sw = (row >> 1) & 7, kv = 4 * st + 2 * lk;
+                    split8(*reinterpret_cast<const float4*>(Bs + row * KC + ((kv ^ sw) * VEC)),
+                           *reinterpret_cast<const float4*>(Bs + row * KC + (((kv + 1) ^ sw) * VEC)), bh[j], bl[j], false);     // weights: finite, in range
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        accb[i][j] = MH::mma(al[i], bh[j], accb[i][j]);
+                        accb[i][j] = MH::mma(ah[i], bl[j], accb[i][j]);
+                        acc[i][j] = MH::mma(ah[i], bh[j], acc[i][j]);
+                    }
+            }
+            return;
+        }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             if constexpr (sizeof(T) == 2) {
@@ -416,6 +473,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvGemmDev
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the trailing zero-page chunks must not land on the epilogue's staging
         __builtin_amdgcn_s_barrier();
     }
+    if constexpr (PAIRS) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = __builtin_fmaf(accb[i][j][r], 0x1p-11f, acc[i][j][r]);
+    }
     if constexpr (LEPI) {
         constexpr int ERT = (WN <= 64 && TM % 2 == 0) ? 2 : 1;
         float* stage = reinterpret_cast<float*>(smem) + wave * (ERT * 32 * WN);
@@ -443,6 +508,7 @@ static std::atomic<long> g_x3 = 1;
 bool gemm_x3_enabled() { return g_x3 != 0; }
 // ... with both operands as panel planes (gemm_x3p.hip, round 3) when the caller supplies them
 static std::atomic<long> g_x3p = 1;
+static std::atomic<long> g_f32_n64_pairs = 1;     // fp32 N = 64 convolutions with >= 8 taps: fp16 pairs split in registers (conv_gemm_dma_kernel PAIRS)
 // number format of the panel planes built from now on: 3 = three bf16 planes (six products), 2 = fp16 {hi, lo} planes (three products)
 static std::atomic<long> g_x3p_np = 0;          // 0: not set by mi_set_option -> MI355TTS_F32_PLANES, else 2
 int x3p_planes() {
@@ -483,6 +549,15 @@ static void dispatch_tiles(const ConvGemmDev& d, int B, hipStream_t s) {
                 e.Tm = (d.M + 63) / 64; e.Tn = 1; e.RT = B * e.Tm; e.RC = 0;
                 e.use_buf = buf_ok(d, (int)sizeof(T));
                 dim3 g2(e.RT * e.Tn, d.G);
+                if constexpr (sizeof(T) == 4) {
+                    // fp32 with many taps (the DiT's grouped k = 31 position convolution): operands as fp16 pairs split in registers
+                    if (g_x3 != 0 && g_f32_n64_pairs != 0 && d.K / d.Cin >= 8 && d.Cin % 32 == 0) {
+                        if (e.lds_epi) { prof_set_kernel("conv_gemm_dma_kernel<float, float, true, 2, 64, fp16 pairs>", "", ""); hipLaunchKernelGGL((conv_gemm_dma_kernel<T, TO, true, 2, 64, true>), g2, blk, 0, s, e); }
+                        else { prof_set_kernel("conv_gemm_dma_kernel<float, float, false, 2, 64, fp16 pairs>", "", ""); hipLaunchKernelGGL((conv_gemm_dma_kernel<T, TO, false, 2, 64, true>), g2, blk, 0, s, e); }
+                        MI_HIP(hipGetLastError());
+                        return;
+                    }
+                }
                 if (e.lds_epi) MI_LAUNCH((conv_gemm_dma_kernel<T, TO, true, 2, 64>), T, TO, g2, blk, 0, s, e);
                 else MI_LAUNCH((conv_gemm_dma_kernel<T, TO, false, 2, 64>), T, TO, g2, blk, 0, s, e);
                 MI_HIP(hipGetLastError());
@@ -660,6 +735,7 @@ bool gemm_set_option(const char* key, long v) {
     else if (k == "gemm_sk_qkv32") g_sk_qkv32 = v;
     else if (k == "gemm_f32_x3") g_x3 = v;
     else if (k == "gemm_f32_x3p") g_x3p = v;
+    else if (k == "gemm_f32_n64_pairs") g_f32_n64_pairs = v;
     else if (k == "gemm_f32_planes") { if (v != 2 && v != 3) return false; g_x3p_np = v; }
     else if (k == "gemm_x3p_noalign") x3p_set_option(0, v);
     else if (k == "gemm_x3p_grid") x3p_set_option(1, v);
