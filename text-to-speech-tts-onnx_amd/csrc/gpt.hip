@@ -756,6 +756,25 @@ __global__ __launch_bounds__(1024) void gpt_pick_kernel(const float* __restrict_
         hid += sl * (size_t)max_tok * hidden;
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ int next_id, next_gen;
+    // everything that does not depend on the argmax is requested first (the kernel is a chain of dependent round trips: 8.4 us
+    // for 33 KB of logits): the state words, the penalty scalar, the oldest penalised token, the last_hidden_state row
+    int w[GS_WORDS];
+    float repv = 0.f;
+    int tok_r = 0;
+    if (tid == 0) {
+#pragma unroll
+        for (int q = 0; q < GS_WORDS; q += 4) {
+            const int4 v = *reinterpret_cast<const int4*>(st + q);
+            w[q] = v.x; w[q + 1] = v.y; w[q + 2] = v.z; w[q + 3] = v.w;
+        }
+        repv = rep_dev[0];
+        const int r = w[GS_RESET];
+        tok_r = (r >= 0 && r < max_tok) ? toks[r] : 0;
+    }
+    float lastv[2];                                        // hidden <= 2048
+#pragma unroll
+    for (int q = 0; q < 2; ++q) lastv[q] = tid + q * 1024 < hidden ? last[tid + q * 1024] : 0.f;
     float best = -INFINITY;
     int idx = 0x7fffffff;
     for (int c = tid; c < codes; c += 1024) {
@@ -771,34 +790,44 @@ __global__ __launch_bounds__(1024) void gpt_pick_kernel(const float* __restrict_
     if (lane == 0) { bv[wave] = best; bi[wave] = idx; }
     __syncthreads();
     if (tid == 0) {
-        for (int w = 1; w < 16; ++w)
-            if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+        for (int q = 1; q < 16; ++q)
+            if (bv[q] > best || (bv[q] == best && bi[q] < idx)) { best = bv[q]; idx = bi[q]; }
         if (idx == 0x7fffffff) idx = 0;
         slot = -1;
-        if (!st[GS_DONE]) {
-            const int t = idx, n = st[GS_NDEC];
-            st[GS_TOKEN] = t;
+        if (!w[GS_DONE]) {
+            const int t = idx, n = w[GS_NDEC];
+            w[GS_TOKEN] = t;
             if (n < max_tok) { toks[n] = t; slot = n; }
-            st[GS_NDEC] = n + 1;
+            w[GS_NDEC] = n + 1;
             bool stop = false;
-            for (int s = 0; s < st[GS_NSTOP]; ++s) stop |= (st[GS_STOP0 + s] == t);
-            if (stop) st[GS_DONE] = 1;
-            else if (st[GS_UPDATE_PEN]) {                     // Inference_IndexTTS_ONNX.py:768-772
-                pen[t] = rep_dev[0];      // device scalar: the captured decode graphs must see a changed REPEAT_PENALITY
-                const int r = st[GS_RESET];
-                if (n + 1 > st[GS_RANGE] && r < max_tok && toks[r] != t) { pen[toks[r]] = 1.f; st[GS_RESET] = r + 1; }
+#pragma unroll
+            for (int q = 0; q < GS_WORDS - GS_STOP0; ++q) stop |= (q < w[GS_NSTOP] && w[GS_STOP0 + q] == t);
+            if (stop) w[GS_DONE] = 1;
+            else if (w[GS_UPDATE_PEN]) {                      // Inference_IndexTTS_ONNX.py:768-772
+                pen[t] = repv;            // device scalar: the captured decode graphs must see a changed REPEAT_PENALITY
+                const int r = w[GS_RESET];
+                // toks[r] was fetched before toks[n] = t above: the same element only if r == n
+                const int tr = (r == n && n < max_tok) ? t : tok_r;
+                if (n + 1 > w[GS_RANGE] && r < max_tok && tr != t) { pen[tr] = 1.f; w[GS_RESET] = r + 1; }
             }
-            st[GS_HIST] += rows;
-            st[GS_GEN_LEN] += 1;
-            if (st[GS_LIMIT] > 0 && n + 1 >= st[GS_LIMIT]) st[GS_DONE] = 1;   // `while num_decode < generate_limit`
+            w[GS_HIST] += rows;
+            w[GS_GEN_LEN] += 1;
+            if (w[GS_LIMIT] > 0 && n + 1 >= w[GS_LIMIT]) w[GS_DONE] = 1;      // `while num_decode < generate_limit`
+#pragma unroll
+            for (int q = 0; q < GS_STOP0; q += 4) *reinterpret_cast<int4*>(st + q) = make_int4(w[q], w[q + 1], w[q + 2], w[q + 3]);
+            if (GS_STOP0 % 4) { for (int q = GS_STOP0 / 4 * 4; q < GS_STOP0; ++q) st[q] = w[q]; }
         }
+        next_id = w[GS_TOKEN]; next_gen = w[GS_GEN_LEN];
     }
     __syncthreads();
-    if (slot >= 0)
-        for (int c = tid; c < hidden; c += 1024) hid[(size_t)slot * hidden + c] = last[c];
+    if (slot >= 0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            if (tid + q * 1024 < hidden) hid[(size_t)slot * hidden + tid + q * 1024] = lastv[q];
+    }
     // graph C for the next decode step (IndexTTS_C.forward, Export_IndexTTS.py:222-225) from the state just written:
     // the step's input row, so that a decode step does not start with a launch of its own for it
-    const int id = min(max(st[GS_TOKEN], 0), codes - 1), g = min(max(st[GS_GEN_LEN], 0), max_pos - 1);
+    const int id = min(max(next_id, 0), codes - 1), g = min(max(next_gen, 0), max_pos - 1);
     for (int c = tid; c < hidden; c += 1024) {
         const float v = emb[(size_t)id * hidden + c] + pos[(size_t)g * hidden + c];
         if (xa) xa[c] = v;
@@ -951,7 +980,7 @@ static void gemv_d_dispatch(const Gpt::GLin& l, const void* x, const float* ln_w
         static int cus = 0;
         if (!cus) { int dev = 0; hipDeviceProp_t pr; MI_HIP(hipGetDevice(&dev)); MI_HIP(hipGetDeviceProperties(&pr, dev)); cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
         int r = 1;
-        while (r < (kcl ? 2 : 4) && (l.n + 8 * r - 1) / (8 * r) > cus) ++r;
+        while (r < (kcl ? 2 : 5) && (l.n + 8 * r - 1) / (8 * r) > cus) ++r;
 #define GD_K(RR, QK)                                                                              \
     do {                                                                                          \
         if (ki <= 1) GD(RR, 1, true, QK); else if (ki == 2) GD(RR, 2, true, QK);                   \
@@ -960,7 +989,7 @@ static void gemv_d_dispatch(const Gpt::GLin& l, const void* x, const float* ln_w
         else GD(RR, 8, true, QK);                                                                 \
     } while (0)
         if (kcl) { if (r == 2) GD_K(2, true); else GD_K(1, true); }
-        else { if (r == 1) GD_K(1, false); else if (r == 2) GD_K(2, false); else if (r == 3) GD_K(3, false); else GD_K(4, false); }
+        else { if (r == 1) GD_K(1, false); else if (r == 2) GD_K(2, false); else if (r == 3) GD_K(3, false); else if (r == 4) GD_K(4, false); else GD_K(5, false); }
 #undef GD_K
     } else {
         MI_REQUIRE(ki <= 32, "gemv: K <= 8192");
