@@ -28,14 +28,22 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ 
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float* xr = x + row * D;
-    float4 v[MAXV];
+    float4 v[MAXV], av[MAXV], bv[MAXV];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int c = (i * 64 + lane) * 4;
         v[i] = c < D ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0, 0, 0, 0);
-        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
+    // the affine / modulation vectors are requested with the row, not after its statistics (one L2 round trip less per wave)
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * 4, cc = c < D ? c : 0;
+        av[i] = *reinterpret_cast<const float4*>(a + cc);
+        bv[i] = *reinterpret_cast<const float4*>(b + cc);
+    }
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     float mean = 0.f, inv;
     if (mode == NORM_L2) {
         float q = 0.f;
@@ -60,10 +68,8 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ 
     for (int i = 0; i < MAXV; ++i) {
         const int c = (i * 64 + lane) * 4;
         if (c < D) {
-            const float4 av = *reinterpret_cast<const float4*>(a + c);
-            const float4 bv = *reinterpret_cast<const float4*>(b + c);
             float o[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
-            const float aa[4] = {av.x, av.y, av.z, av.w}, bb[4] = {bv.x, bv.y, bv.z, bv.w};
+            const float aa[4] = {av[i].x, av[i].y, av[i].z, av[i].w}, bb[4] = {bv[i].x, bv[i].y, bv[i].z, bv[i].w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float n = (o[k] - mean) * inv;
@@ -90,7 +96,7 @@ __global__ __launch_bounds__(256) void rownorm_x3p_kernel(const float* __restric
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float* xr = x + row * D;
-    float4 v[MAXP][2];
+    float4 v[MAXP][2], av[MAXP][2], bv[MAXP][2];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) {
@@ -98,8 +104,17 @@ __global__ __launch_bounds__(256) void rownorm_x3p_kernel(const float* __restric
         const bool in = c < D;
         v[i][0] = in ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0, 0, 0, 0);
         v[i][1] = in ? *reinterpret_cast<const float4*>(xr + c + 4) : make_float4(0, 0, 0, 0);
-        s += ((v[i][0].x + v[i][0].y) + (v[i][0].z + v[i][0].w)) + ((v[i][1].x + v[i][1].y) + (v[i][1].z + v[i][1].w));
     }
+    // scale / shift requested with the row, not after its statistics (one L2 round trip less per wave)
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+        const int c = (i * 64 + lane) * 8, cc = c < D ? c : 0;
+        av[i][0] = *reinterpret_cast<const float4*>(a + cc); av[i][1] = *reinterpret_cast<const float4*>(a + cc + 4);
+        bv[i][0] = *reinterpret_cast<const float4*>(b + cc); bv[i][1] = *reinterpret_cast<const float4*>(b + cc + 4);
+    }
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i)
+        s += ((v[i][0].x + v[i][0].y) + (v[i][0].z + v[i][0].w)) + ((v[i][1].x + v[i][1].y) + (v[i][1].z + v[i][1].w));
     const float mean = wave_sum(s) / (float)D;
     float q = 0.f;
 #pragma unroll
@@ -120,8 +135,7 @@ __global__ __launch_bounds__(256) void rownorm_x3p_kernel(const float* __restric
         const int s8 = i * 64 + lane, c = s8 * 8;
         if (c < D) {
             float o[8] = {v[i][0].x, v[i][0].y, v[i][0].z, v[i][0].w, v[i][1].x, v[i][1].y, v[i][1].z, v[i][1].w};
-            const float4 a0 = *reinterpret_cast<const float4*>(a + c), a1 = *reinterpret_cast<const float4*>(a + c + 4);
-            const float4 b0 = *reinterpret_cast<const float4*>(b + c), b1 = *reinterpret_cast<const float4*>(b + c + 4);
+            const float4 a0 = av[i][0], a1 = av[i][1], b0 = bv[i][0], b1 = bv[i][1];
             const float aa[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
             for (int k = 0; k < 8; ++k) o[k] = (o[k] - mean) * inv * (1.f + aa[k]) + bb[k];
