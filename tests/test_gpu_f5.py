@@ -414,6 +414,33 @@ def test_full_size_fp32_fused_producers_are_bit_neutral(full):
         eng.close()
 
 
+@pytest.mark.parametrize("N", [701, 1015, 1280])
+def test_full_size_fp32_other_lengths_default_forms_against_native(full, N):
+    """The full-width DiT at frame counts other than the bench's 1126 — odd ones (K / V^T plane rows, the second batch item's
+    rows and the last 128-row panel all start at odd offsets), one that fills whole panels — default arithmetic (fp16-pair
+    linear layers, pre-split K / V^T, fp16-pair attention, pair-split position convolution) against the native fp32 MFMA
+    forms of the same engine, one evaluation and two utterances."""
+    from mi355tts import _lib
+    cfg, raw, audio, ids, _, _ = full
+    noise = np.stack([W.synth_normal(77 + u, "noise_n", (N, cfg.mel_dim)) for u in range(2)])
+    eng = F5Engine(cfg, raw, dtype="f32")
+    try:
+        o = [eng.preprocess(audio[u].reshape(1, 1, -1), ids[u].reshape(1, -1), np.array([N]), noise=noise[u]) for u in range(2)]
+        cmt = np.concatenate([x["cat_mel_text"] for x in o]); cmtd = np.concatenate([x["cat_mel_text_drop"] for x in o])
+        a = eng.dit_eval(noise, cmt, cmtd, 3)
+        a1 = eng.dit_eval(noise[:1], cmt[:1], cmtd[:1], 3)
+        _lib.set_option("gemm_f32_x3", 0); _lib.set_option("attn_f32_x3", 0); _lib.set_option("gemm_f32_n64_pairs", 0)
+        b = eng.dit_eval(noise, cmt, cmtd, 3)
+    finally:
+        _lib.set_option("gemm_f32_x3", 1); _lib.set_option("attn_f32_x3", 2); _lib.set_option("gemm_f32_n64_pairs", 1)
+        eng.close()
+    assert a.shape == (4, N, cfg.mel_dim) and np.isfinite(a).all()
+    e = rms(a - b) / rms(b)
+    print(f"N = {N}: default forms against native fp32 MFMA, DiT evaluation: rel rms {e:.2e}")
+    assert e < 3e-6, e
+    assert rms(a[:2] - a1) / rms(a1) < 3e-6                    # one utterance alone: other tile counts, same values
+
+
 @pytest.mark.parametrize("dtype,gate", [("bf16", 3e-2), ("f16", 1e-2)])
 def test_full_size_lowp_u8_against_reference_fixture(full, gfull, dtype, gate):
     """configs[3] shard: 8 utterances per GPU in one batch, 16-bit DiT operands.  Utterance 0 is the reference fixture's
