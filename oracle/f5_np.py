@@ -365,6 +365,8 @@ def attention(cfg, st, p, u, cos, sin):
         bi, h = divmod(j, H)
         qh, kh = rope_apply(q[bi, h], cos, sin), rope_apply(k[bi, h], cos, sin)
         s = qh @ kh.T                                                   # (N, N) fp32
+        if getattr(cfg, "ref_fp16_attn", False):                        # fp16/modules.py:467: fp16 scores, .float() * 100.0
+            s = s.astype(np.float16).astype(F32) * F32(100.0)
         s -= s.max(axis=-1, keepdims=True)
         np.exp(s, out=s)
         s /= s.sum(axis=-1, keepdims=True)

@@ -133,8 +133,10 @@ def melscale_fbanks(n_freqs, f_min, f_max, n_mels, sample_rate, norm=None, mel_s
     return torch.max(zero, torch.min(down_slopes, up_slopes))
 
 
-def load_f5_ref():
-    """Returns (modules, dit, vocos_models, vocos_heads, STFT_Process) from the reference files."""
+def load_f5_ref(fp16: bool = False):
+    """Returns (modules, dit, vocos_models, vocos_heads, STFT_Process) from the reference files.  ``fp16``: the
+    reference's fp16-transformer variant of modules.py (F5/fp16/modules.py, which Export_F5.py:88-89 installs over
+    f5_tts/model/modules.py when use_fp16_transformer is set)."""
     ort = types.ModuleType("onnxruntime")
     sys.modules["onnxruntime"] = ort
     ta = _pkg("torchaudio")
@@ -160,7 +162,7 @@ def load_f5_ref():
     _pkg("f5_tts.model")
     _pkg("f5_tts.model.backbones")
     d = REF + "/F5_TTS/modeling_modified/"
-    modules = _load("f5_tts.model.modules", d + "F5/modules.py")
+    modules = _load("f5_tts.model.modules", d + ("F5/fp16/modules.py" if fp16 else "F5/modules.py"))
     dit = _load("f5_tts.model.backbones.dit", d + "F5/dit.py")
     _pkg("vocos")
     so = _pkg("vocos.spectral_ops")

@@ -34,9 +34,9 @@ def synth_audio(n, seed=SEED):
     return np.clip(np.round(a), -32768, 32767).astype(np.int16)
 
 
-def build_ref_f5(cfg: F5Config, state):
+def build_ref_f5(cfg: F5Config, state, fp16: bool = False):
     import math
-    modules, dit, vmodels, vheads, stft = R.load_f5_ref()
+    modules, dit, vmodels, vheads, stft = R.load_f5_ref(fp16)
     model = dit.DiT(dim=cfg.dim, depth=cfg.depth, heads=cfg.heads, dim_head=cfg.dim_head, ff_mult=cfg.ff_mult,
                     mel_dim=cfg.mel_dim, text_num_embeds=cfg.text_num_embeds, text_dim=cfg.text_dim,
                     conv_layers=cfg.conv_layers).eval()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Full-size golden fixtures (BASELINE.json shapes) from the REFERENCE's own PyTorch module code.
 
-    python tests/golden/make_golden_full.py [f5] [bigvgan] [zh]      (build container only; ~3 min of torch-CPU)
+    python tests/golden/make_golden_full.py [f5] [f5fp16] [bigvgan] [zh]      (build container only; ~3 min of torch-CPU each)
 
 * ``f5_full.npz``      F5Config() (dim 1024, 16 heads, depth 22, N = 1126, NFE grid 32): the reference chain
                        F5Preprocess -> 31 x F5Transformer -> F5Decode (wrappers exec'ed from F5_TTS/Export_F5.py:98-203
@@ -9,6 +9,11 @@
                        ``weights.f5_synthetic_inputs`` (utterance 0).  Holds one DiT evaluation, the final sampler state
                        and the int16 waveform; inputs and weights are regenerable from seeds (splitmix64, platform
                        independent), so only the reference's OUTPUTS are stored.
+* ``f5_full_fp16.npz`` the same chain as the reference's fp16-transformer export runs it (``use_fp16_transformer``,
+                       Export_F5.py:20,88-89,139-140,198-199,321-326,348-349): F5/fp16/modules.py in place of modules.py
+                       (q k scores as an fp16 matmul, ``.float() * 100``, fp32 softmax, ``.half()`` probabilities, :467), the
+                       extra x0.1 on the q / k projections, F5Preprocess / F5Decode with use_fp16, the whole F5Transformer
+                       ``.half()`` (fp16 weights, activations, residual stream and sampler state) — on torch-CPU fp16.
 * ``bigvgan_full.npz`` BigVGANConfig() at mel (1,100,512) (BASELINE configs[0]; item 0 of the configs[1] batch) through
                        the reference generator + the int16 wrapper (BigVGAN/Export_BigVGAN.py:37-49).
 * ``zh_prompt.npz``    G1 of SURVEY.md §8c: the reference's STFT_Process (stft_B) + the F5Preprocess mel on the first second of
@@ -95,6 +100,62 @@ def gen_f5_full():
                                                                           np.sqrt((w ** 2).mean()), np.abs(w).max()))
 
 
+def gen_f5_full_fp16():
+    """The reference's fp16-transformer export semantics at the BASELINE shapes (same inputs / weights as f5_full.npz)."""
+    import math
+    from make_golden_f5 import build_ref_f5
+    cfg = F5Config()
+    state = W.synth_state(W.f5_spec(cfg), SEED)
+    modules, model, f5_model, vocos, stft, ns = build_ref_f5(cfg, state, fp16=True)
+    audio, ids, N, noise = W.f5_synthetic_inputs(cfg, 1, 0)
+    custom_stft = stft.STFT_Process(model_type="stft_B", n_fft=cfg.n_fft, win_length=cfg.n_fft, hop_len=cfg.hop_length,
+                                    max_frames=0, window_type="hann").eval()
+    custom_istft = stft.STFT_Process(model_type="istft_A", n_fft=cfg.n_fft, win_length=cfg.n_fft,
+                                     hop_len=cfg.hop_length, max_frames=cfg.max_signal_length, window_type="hann").eval()
+    pre = ns["F5Preprocess"](f5_model, custom_stft, nfft=cfg.n_fft, n_mels=cfg.mel_dim, sample_rate=cfg.sample_rate,
+                             num_head=cfg.heads, head_dim=cfg.dim_head, target_rms=0.15, use_fp16=True)
+    o = pre(t(audio[0]).view(1, 1, -1), t(ids[0]).view(1, -1), torch.tensor([N], dtype=torch.long))
+    _, cq, sq, ck, sk, cmt, cmtd, rsl = o
+    assert cmt.dtype == torch.float16 and cq.dtype == torch.float16
+    R_len = int(rsl)
+    ns2 = {"torch": torch, "math": math, "f5_model": f5_model, "HEAD_DIM": cfg.dim_head, "use_fp16_transformer": True}
+    R.exec_lines(R.REF + "/F5_TTS/Export_F5.py", 321, 333, ns2)          # q/k pre-scale fold incl. the fp16 x0.1
+    assert ns2["dtype"] == torch.float16 and abs(ns2["scale_factor"] - 0.1 * cfg.dim_head ** -0.25) < 1e-9
+    tr = ns["F5Transformer"](f5_model, cfg=cfg.cfg_strength, steps=cfg.nfe_step, sway_coef=cfg.sway_coef,
+                             dtype=torch.float16, fuse_step=1)
+    tr = tr.half()                                                        # Export_F5.py:348-349
+    out = {"N": np.int64(N), "ref_signal_len": np.int64(R_len)}
+    x0 = t(noise[:1]).half()                                              # Export_F5.py:139-140 (noise.half())
+    t1 = time.time()
+    pred = model(x=x0, cond=cmt, cond_drop=cmtd, time=tr.time_expand[:, torch.tensor([7])], rope_cos_q=cq, rope_sin_q=sq,
+                 rope_cos_k=ck, rope_sin_k=sk)
+    assert pred.dtype == torch.float16
+    print(f"one fp16 DiT evaluation: {time.time() - t1:.1f} s")
+    out["dit_pred_t7"] = pred.numpy()
+    x = x0.clone()
+    ts = torch.tensor([0], dtype=torch.int32)
+    for i in range(cfg.nfe_step - 1):
+        x, ts = tr(x, cq, sq, ck, sk, cmt, cmtd, ts)
+        if i == 0:
+            out["loop_step1"] = x[0].numpy().copy()
+    assert x.dtype == torch.float16 and int(ts) == cfg.nfe_step - 1
+    out["loop_final"] = x[0].numpy().copy()
+    print(f"31 fp16 evaluations: {time.time() - t1:.0f} s")
+    ns3 = {"torch": torch, "vocos": vocos}
+    R.exec_lines(R.REF + "/F5_TTS/Export_F5.py", 390, 402, ns3)           # Vocos norm / gamma folds
+    dec = ns["F5Decode"](vocos, custom_istft, target_rms=0.15, use_fp16=True)
+    out["e2e_i16"] = dec(x.clone(), torch.tensor(R_len, dtype=torch.long))[0, 0].numpy()
+    np.savez_compressed(os.path.join(HERE, "f5_full_fp16.npz"), **out)
+    print("f5_full_fp16.npz:", {k: (np.asarray(v).shape, np.asarray(v).dtype) for k, v in out.items()})
+    g = np.load(os.path.join(HERE, "f5_full.npz"))                        # the reference's own fp16-vs-fp32 distance
+    def rel(a, b):
+        a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+        return float(np.sqrt(((a - b) ** 2).mean() / (b ** 2).mean()))
+    print("   reference fp16 vs reference fp32: dit_pred_t7 rel rms %.3e  loop_final rel rms %.3e  waveform rms %.3e (of full scale)"
+          % (rel(out["dit_pred_t7"], g["dit_pred_t7"]), rel(out["loop_final"], g["loop_final"]),
+             float(np.sqrt((((out["e2e_i16"].astype(np.float64) - g["e2e_i16"]) / 32767.0) ** 2).mean()))))
+
+
 def gen_bigvgan_full():
     from make_golden import build_ref_bigvgan
     cfg = BigVGANConfig()
@@ -143,3 +204,5 @@ if __name__ == "__main__":
         gen_bigvgan_full()
     if "f5" in what:
         gen_f5_full()
+    if "f5fp16" in what:
+        gen_f5_full_fp16()

@@ -462,6 +462,58 @@ def test_full_size_lowp_u8_against_reference_fixture(full, gfull, dtype, gate):
     print(f"F5 full size {dtype} U=8 vs reference: waveform rms {err:.2e} (gate {gate}), item 5 batch vs alone {e5:.2e}")
 
 
+@pytest.fixture(scope="module")
+def gfull16(golden_dir):
+    return np.load(os.path.join(golden_dir, "f5_full_fp16.npz"))
+
+
+def test_full_size_reference_fp16_transformer_fixture(full, gfull, gfull16):
+    """SURVEY 8 a7, fp16 variant: the reference's fp16-transformer export (use_fp16_transformer, Export_F5.py:20,88-89,139-140,
+    198-199,321-326,348-349; F5/fp16/modules.py:467) run on torch-CPU fp16 at the BASELINE shapes -> tests/golden/f5_full_fp16.npz.
+    Two f16 engines against it: the engine's own f16 form, and `ref_fp16_attn` (the export's attention rounding points: q / k
+    with the extra x0.1 folded in before the fp16 rounding, q k scores rounded to fp16, x100 in fp32, fp32 softmax, fp16
+    probabilities).  The reference chain rounds EVERY tensor to fp16 (residual stream and sampler state included), the engine
+    keeps those in fp32, so the comparison is a distance, not an identity:
+      * each engine is within 5e-4 waveform rms (of full scale) of the reference-fp16 waveform and its single DiT evaluation
+        within 4e-3 relative rms of the reference-fp16 one (the reference's own fp16-vs-fp32 distances, measured when the
+        fixture was written: 1.4e-4 and 1.6e-3);
+      * each engine is no farther from the reference's FP32 chain than the reference's own fp16 chain is (x1.25 slack)."""
+    import dataclasses
+    cfg, raw, audio, ids, N, noise = full
+    assert int(gfull16["N"]) == N and int(gfull16["ref_signal_len"]) == 563
+    assert gfull16["dit_pred_t7"].dtype == np.float16 and gfull16["loop_final"].dtype == np.float16
+    w16 = gfull16["e2e_i16"].astype(np.float64)
+    w32 = gfull["e2e_i16"].astype(np.float64)
+    ref_gap = rms((w16 - w32) / 32767.0)                               # the reference's own fp16-vs-fp32 distance
+    ref_gap_pred = rms(gfull16["dit_pred_t7"].astype(np.float64) - gfull["dit_pred_t7"]) / rms(gfull["dit_pred_t7"])
+    assert 5e-5 < ref_gap < 5e-4 and 5e-4 < ref_gap_pred < 5e-3, (ref_gap, ref_gap_pred)
+    p16 = gfull16["dit_pred_t7"].astype(np.float64)
+    for mode in (False, True):
+        c = dataclasses.replace(cfg, ref_fp16_attn=mode)
+        eng = F5Engine(c, raw, dtype="f16")
+        o = eng.preprocess(audio[0].reshape(1, 1, -1), ids[0].reshape(1, -1), np.array([N]), noise=noise[0])
+        pred = eng.dit_eval(noise[:1], o["cat_mel_text"], o["cat_mel_text_drop"], 7)
+        e_pred16 = rms(pred - p16) / rms(p16)
+        e_pred32 = rms(pred - gfull["dit_pred_t7"]) / rms(gfull["dit_pred_t7"])
+        w = eng.synthesize(audio[:1], ids[:1], N, noise=noise[:1])[0, 0].astype(np.float64)
+        e16 = rms((w - w16) / 32767.0)
+        e32 = rms((w - w32) / 32767.0)
+        eng.close()
+        print(f"F5 full size f16 engine (ref_fp16_attn={mode}) vs reference fp16 export: DiT eval rel {e_pred16:.2e}, waveform rms "
+              f"{e16:.2e}; vs reference fp32: DiT eval rel {e_pred32:.2e}, waveform rms {e32:.2e}  "
+              f"[reference fp16 vs its fp32: {ref_gap_pred:.2e} / {ref_gap:.2e}]")
+        assert e_pred16 < 4e-3 and e16 < 5e-4, (mode, e_pred16, e16)
+        assert e_pred32 < 1.25 * ref_gap_pred and e32 < 1.25 * ref_gap, (mode, e_pred32, e32, ref_gap_pred, ref_gap)
+
+
+def test_ref_fp16_attn_is_an_f16_only_form():
+    import dataclasses
+    cfg = dataclasses.replace(F5Config.small(), ref_fp16_attn=True)
+    raw = W.synth_state(W.f5_spec(cfg), 9527)
+    with pytest.raises(Exception, match="f16"):
+        F5Engine(cfg, raw, dtype="f32")
+
+
 def test_real_prompt_stft_and_mel(golden_dir, small):
     """G1: the first second of the real prompt IndexTTS/example/zh.wav through the engine's front end against
     the reference's STFT_Process (stft_B, STFT_Process.py:153-157) and the F5Preprocess mel (Export_F5.py:122-125)."""

@@ -127,6 +127,26 @@ def test_host_text_helpers():
     assert O.max_duration(144000, "a" * 80, "b" * 80) == 563 + 563
 
 
+def test_ref_fp16_attention_fold_is_consistent(g, small):
+    """use_fp16_transformer (Export_F5.py:321-326, fp16/modules.py:467): x0.1 on q and on k, scores rounded to fp16, x100.  With
+    the fold and the score scale taken from the same config the oracle stays on the reference's fp32 DiT evaluation up to the
+    fp16 rounding of the scores (11 bits of a score of order one -> ~1e-3 relative in the prediction); the fold alone, without
+    the x100, is a different function."""
+    import dataclasses
+    cfg, st = small
+    cfg16 = dataclasses.replace(cfg, ref_fp16_attn=True)
+    assert cfg16.to_float_array() == [cfg.cfg_strength, cfg.sway_coef, 100.0] and len(cfg.to_float_array()) == 2
+    st16 = W.fold_f5(cfg16, W.synth_state(W.f5_spec(cfg16), 9527))
+    k = "transformer.transformer_blocks.0.attn.to_q.weight"
+    np.testing.assert_allclose(st16[k], st[k] * np.float32(0.1), rtol=3e-7)
+    _, _, texp = O.time_tables(cfg, st)
+    args = (g["dit_noise"], g["pre_cat_mel_text"], g["pre_cat_mel_text_drop"], texp[2], g["pre_rope_cos_q"], g["pre_rope_sin_q"])
+    p16 = O.dit_forward(cfg16, st16, *args)
+    ref = g["dit_pred_t2"]
+    assert rms(p16 - ref) / rms(ref) < 5e-3
+    assert rms(O.dit_forward(cfg, st16, *args) - ref) / rms(ref) > 2e-2        # fold without the x100: not the same function
+
+
 def test_oracle_full_size_dit_evaluation_against_reference_fixture(golden_dir):
     """ONE DiT evaluation at the BASELINE shape (dim 1024, 16 heads, depth 22, N = 1126, CFG batch 2) through the oracle
     against the reference's DiT.forward run in the build container (tests/golden/make_golden_full.py -> f5_full.npz):

@@ -39,10 +39,16 @@ namespace mi {
 //                 arithmetic): 24 v_mfma_f32_32x32x16_bf16 (768 cycles) instead of 32 v_mfma_f32_32x32x2_f32 (2048) per 32x32
 //                 tile; Q is split once per workgroup, the K fragments on their way from LDS (176 VALU instructions per
 //                 tile, overlapped by the co-resident waves).  P V stays on the native fp32 MFMA (it wants V transposed).
-template <typename T, bool SPLIT2 = false, bool X3S = false>
+// REFH (f16 only): the rounding points of the reference's fp16-transformer export (F5/fp16/modules.py:467, Export_F5.py:321-326):
+//                 q / k carry an extra x0.1 each (folded into the projections before they are rounded to fp16), the scores
+//                 leave the q k product as fp16 values, are widened and multiplied by `sscale` (= 100) in fp32, softmax in fp32,
+//                 probabilities rounded to fp16 for P V.  Q is therefore NOT pre-multiplied by log2(e) (that would re-round
+//                 it): log2(e) rides on `sscale`.
+template <typename T, bool SPLIT2 = false, bool X3S = false, bool REFH = false>
 __global__ __launch_bounds__(256, 3) void attn_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                    const T* __restrict__ v, T* __restrict__ o, int H, int N,
-                                                   float* __restrict__ ws, int* __restrict__ cnt) {
+                                                   float* __restrict__ ws, int* __restrict__ cnt, float sscale = 1.f) {
+    static_assert(!REFH || (sizeof(T) == 2 && !X3S), "REFH is the fp16 form");
     using MF = Mfma<T>;
     constexpr int KP = MF::KP;
     constexpr int D = 64, KT = 64;
@@ -100,7 +106,7 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const T* __restrict__ q, c
                 if (ok) raw = *reinterpret_cast<const uint4*>(qb + (long)qr * D + ks * 16 + hi * 8);
                 T* e = reinterpret_cast<T*>(&raw);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) e[j] = from_f32<T>(to_f32(e[j]) * 1.4426950408889634f);
+                for (int j = 0; j < 8; ++j) if constexpr (!REFH) e[j] = from_f32<T>(to_f32(e[j]) * 1.4426950408889634f);
                 qf[ks] = *reinterpret_cast<const typename MF::Frag*>(&raw);
             }
         }
@@ -194,6 +200,12 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const T* __restrict__ q, c
                         *reinterpret_cast<const typename MF::Frag*>(Ks + (kt * 32 + lr) * LDK + ks * 2 * KP + hi * KP);
                     sacc = MF::mma(a, qf[ks], sacc);
                 }
+            }
+            if constexpr (REFH) {
+                // torch.matmul(query, key) is an fp16 tensor; `.float() * 100.0` follows (fp16/modules.py:467)
+                const float c = sscale * 1.4426950408889634f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[r] = to_f32(from_f32<T>(sacc[r])) * c;
             }
             // ---- online softmax (per lane = per query) -----------------------------------------
             // only the tile that straddles N needs the key >= N select (2 VALU issues per score, a third of the
@@ -883,7 +895,8 @@ bool attention_can_write_planes(int N, int BH, int dtype) {
 }
 
 void launch_attention(const void* q, const void* k, const void* v, void* o, int BH, int H, int N, int dtype, hipStream_t s,
-                      float* ws, long ws_floats, int* cnt, long cnt_n, void* o_planes, int kv_planes, int o_np) {
+                      float* ws, long ws_floats, int* cnt, long cnt_n, void* o_planes, int kv_planes, int o_np, float ref_fp16_scale) {
+    MI_REQUIRE(ref_fp16_scale == 0.f || (dtype == MI_F16 && ref_fp16_scale > 0.f), "attention: the reference-fp16 score form needs f16 operands");
     MI_REQUIRE(o_np == 2 || o_np == 3, "attention: 2 or 3 output planes");
     MI_REQUIRE(!o_planes || attention_can_write_planes(N, BH, dtype), "attention: panel-plane output needs the fp32 split kernel");
     MI_REQUIRE(!kv_planes || attention_can_write_planes(N, BH, dtype), "attention: pre-split K / V need the fp32 split kernel");
@@ -967,7 +980,11 @@ void launch_attention(const void* q, const void* k, const void* v, void* o, int 
         // 576 workgroups, the 128-query form is already balanced and shares each K / V stage among more waves)
         const bool sp = g_attn_split && (long)((N + 127) / 128) * BH < 512 && N >= 64;
         const dim3 grid(sp ? (N + 63) / 64 : (N + 127) / 128, BH, sp ? pick_z(z16) : 1);
-        if (dtype == MI_F16) {
+        if (dtype == MI_F16 && ref_fp16_scale != 0.f) {
+            prof_set_kernel(sp ? "attn_kernel<T, true, reference-fp16 scores>" : "attn_kernel<T, false, reference-fp16 scores>", type_label<f16>());
+            if (sp) hipLaunchKernelGGL((attn_kernel<f16, true, false, true>), grid, dim3(256), 0, s, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)o, H, N, ws, cnt, ref_fp16_scale);
+            else hipLaunchKernelGGL((attn_kernel<f16, false, false, true>), grid, dim3(256), 0, s, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)o, H, N, ws, cnt, ref_fp16_scale);
+        } else if (dtype == MI_F16) {
             if (sp) ATTN_LAUNCH(f16, true, grid, dim3(256), 0, s, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)o, H, N, ws, cnt);
             else ATTN_LAUNCH(f16, false, grid, dim3(256), 0, s, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)o, H, N, ws, cnt);
         } else {

@@ -9,6 +9,7 @@ struct F5Cfg {
     int dim, depth, heads, dim_head, ff_mult, mel, text_dim, vocab, conv_layers, conv_mult, pos_k, pos_g, freq_dim,
         nfe, max_len, n_fft, hop, sr, vd, vi, vlayers;
     float cfg_strength, sway;
+    float score_scale = 1.f;   // != 1 (f16 engines only): the reference's fp16-transformer score form, see launch_attention(ref_fp16_scale)
     int ff() const { return dim * ff_mult; }
     int nb() const { return n_fft / 2 + 1; }
     int cat_dim() const { return 2 * mel + text_dim; }     // x | mel | text

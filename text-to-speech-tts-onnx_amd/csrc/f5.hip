@@ -19,7 +19,7 @@ namespace mi {
 static int rup(int a, int b) { return (a + b - 1) / b * b; }
 
 F5Cfg parse_f5_cfg(const int32_t* ci, int ni, const float* cf, int nf) {
-    MI_REQUIRE(ci && ni == 21 && cf && nf == 2, "f5 cfg: expected 21 ints + 2 floats");
+    MI_REQUIRE(ci && ni == 21 && cf && (nf == 2 || nf == 3), "f5 cfg: expected 21 ints + 2 floats (+ the optional attention score scale)");
     F5Cfg c;
     int i = 0;
     c.dim = ci[i++]; c.depth = ci[i++]; c.heads = ci[i++]; c.dim_head = ci[i++]; c.ff_mult = ci[i++]; c.mel = ci[i++];
@@ -27,6 +27,7 @@ F5Cfg parse_f5_cfg(const int32_t* ci, int ni, const float* cf, int nf) {
     c.pos_g = ci[i++]; c.freq_dim = ci[i++]; c.nfe = ci[i++]; c.max_len = ci[i++]; c.n_fft = ci[i++]; c.hop = ci[i++];
     c.sr = ci[i++]; c.vd = ci[i++]; c.vi = ci[i++]; c.vlayers = ci[i++];
     c.cfg_strength = cf[0]; c.sway = cf[1];
+    if (nf == 3) { c.score_scale = cf[2]; MI_REQUIRE(c.score_scale > 0.f && c.score_scale <= 1e4f, "f5 cfg: attention score scale"); }
     MI_REQUIRE(c.dim == c.heads * c.dim_head, "f5 cfg: dim != heads*dim_head");
     MI_REQUIRE(c.dim_head == 64, "f5: the attention kernel is built for head_dim 64");
     MI_REQUIRE(c.dim % 32 == 0 && c.dim <= 2048 && c.text_dim % 8 == 0 && c.mel % 4 == 0, "f5 cfg: widths");
@@ -76,6 +77,7 @@ static inline float round_f16(float v) { return (float)(f16)v; }
 F5::F5(const F5Cfg& c, const float* w, int64_t nw, int dt, int dev, int mem) : cfg(c), dtype(dt), device(dev) {
     np = x3p_planes();
     MI_REQUIRE(dt == MI_F32 || dt == MI_F16 || dt == MI_BF16, "f5: bad dtype");
+    MI_REQUIRE(c.score_scale == 1.f || dt == MI_F16, "f5: the attention score scale (reference fp16-transformer form) needs an f16 engine");
     MI_REQUIRE(nw == f5_param_count(c), "f5: weight blob size does not match the config");
     MI_HIP(hipSetDevice(dev));
     MI_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
@@ -613,7 +615,7 @@ void F5::dit_eval(int U, int N, int k) {
                 fused = gemm_x3p_would_run(g);
             }
             launch_attention(qb.p, kb.p, vb.p, Ob.p, B * H, H, N, dtype, s, attn_ws.as<float>(), attn_ws_floats, attn_cnt.as<int>(), attn_cnt_n,
-                             fused ? Ap.p : nullptr, kvp ? kvp_fmt : 0, np);
+                             fused ? Ap.p : nullptr, kvp ? kvp_fmt : 0, np, cfg.score_scale != 1.f ? cfg.score_scale : 0.f);
             gemm(dtype, Ob.p, (long)N * d, d, d, bk.o, X.p, MI_F32, (long)N * d, d, B, N, ACT_NONE, X.p, m + 2 * d, fused, Ap.p);
         }
         {

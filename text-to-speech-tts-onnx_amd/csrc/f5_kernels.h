@@ -35,7 +35,9 @@ void launch_cfg_update(float* noise, const float* pred, int U, int N, int M, flo
 // counter per tile); without them every query tile is one workgroup
 void launch_attention(const void* q, const void* k, const void* v, void* o, int BH, int H, int N, int dtype, hipStream_t s,
                       float* ws = nullptr, long ws_floats = 0, int* cnt = nullptr, long cnt_n = 0, void* o_planes = nullptr,
-                      int kv_planes = 0, int o_np = 3);
+                      int kv_planes = 0, int o_np = 3, float ref_fp16_scale = 0.f);
+// ref_fp16_scale (f16 engines; 0 = off): the score rounding points of the reference's fp16-transformer export — q k scores
+// rounded to fp16, then x ref_fp16_scale (= 100, undoing the extra x0.1 folded into q and k) in fp32 (F5/fp16/modules.py:467)
 // kv_planes (fp32 engines, both products split): k and v are the pre-split bf16 planes the QKV epilogue wrote (ConvGemm::kv_planes:
 // k [BH][3][ld][64], v [BH][3][64][ld], ld = N rounded up to 64, pad keys of v zero) — ask attention_takes_kv_planes() first
 bool attention_takes_kv_planes(int N, int BH, int dtype);

@@ -118,6 +118,9 @@ class F5Config:
     sway_coef: float = -1.0
     max_signal_length: int = 4096
     fuse_step: int = 1                   # FUSE_NFE: Euler steps per F5_Transformer.run (Export_F5.py:167-182, host-side only)
+    # use_fp16_transformer (Export_F5.py:20,321-326; F5/fp16/modules.py:467): q / k projections carry an extra x0.1 each, the
+    # q k scores are rounded to fp16 and multiplied by 100 in fp32 before the fp32 softmax.  f16 engines only.
+    ref_fp16_attn: bool = False
     # STFT / mel
     n_fft: int = 1024
     hop_length: int = 256
@@ -142,8 +145,12 @@ class F5Config:
                 self.n_fft, self.hop_length, self.sample_rate, self.vocos_dim, self.vocos_intermediate,
                 self.vocos_layers]
 
+    @property
+    def attn_score_scale(self) -> float:
+        return 100.0 if self.ref_fp16_attn else 1.0
+
     def to_float_array(self) -> List[float]:
-        return [self.cfg_strength, self.sway_coef]
+        return [self.cfg_strength, self.sway_coef] + ([self.attn_score_scale] if self.ref_fp16_attn else [])
 
     @staticmethod
     def small() -> "F5Config":

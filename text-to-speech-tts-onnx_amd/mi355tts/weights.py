@@ -262,7 +262,10 @@ def fold_f5(cfg: F5Config, state: Dict[str, np.ndarray]) -> "OrderedDict[str, np
     """Apply the export-time folds (see module docstring) and return a new dict whose
     keys are those of ``f5_packed_spec``."""
     st = OrderedDict((k, np.array(v, dtype=np.float32, copy=True)) for k, v in state.items())
-    sf = np.float32(math.pow(cfg.dim_head, -0.25))
+    sf = math.pow(cfg.dim_head, -0.25)
+    if getattr(cfg, "ref_fp16_attn", False):
+        sf *= 0.1                                 # Export_F5.py:322-324 ("To avoid overflow in float16 format")
+    sf = np.float32(sf)
     for i in range(cfg.depth):
         p = f"transformer.transformer_blocks.{i}.attn."
         for nm in ("to_q", "to_k"):
