@@ -99,7 +99,11 @@ int         mi_conv_transpose1d(const float* x, int B, int Cin, int T, const flo
  * cfg_i = F5Config.to_int_array() (21 ints: dim, depth, heads, dim_head, ff_mult, mel_dim, text_dim,
  *   text_num_embeds, conv_layers, conv_mult, pos_conv_kernel, pos_conv_groups, freq_embed_dim, nfe_step,
  *   max_signal_length, n_fft, hop_length, sample_rate, vocos_dim, vocos_intermediate, vocos_layers);
- * cfg_f = [cfg_strength, sway_coef].  `dtype` selects the DiT operand type (fp32 residual stream and
+ * cfg_f = [cfg_strength, sway_coef] or [cfg_strength, sway_coef, attn_score_scale].  The third value (MI_F16 engines
+ * only; absent = 1) selects the attention rounding points of the reference's fp16-transformer export
+ * (use_fp16_transformer, F5_TTS/Export_F5.py:20,321-326; F5/fp16/modules.py:467): the caller folds head_dim^-0.25 * 0.1
+ * into the q / k projections of the blob (mi355tts.weights.fold_f5 does, from F5Config.ref_fp16_attn), the kernel rounds
+ * the q k scores to fp16 and multiplies them by attn_score_scale (= 100) in fp32 before the fp32 softmax.  `dtype` selects the DiT operand type (fp32 residual stream and
  * fp32 softmax/norm statistics always); the front end and the vocoder always run in fp32, like the
  * reference's CPU-pinned graphs A and C (F5-TTS-ONNX-Inference.py:173,214).
  * Batching extension: U utterances of equal max_duration N; tensors gain a leading U axis.        */

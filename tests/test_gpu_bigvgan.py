@@ -259,7 +259,7 @@ def test_full_size_reference_fixture(full_state, golden_dir):
     (tests/golden/make_golden_full.py: BigVGAN/modeling_modified/bigvgan.py:384-410 through Export_BigVGAN.py:37-49 on
     mel (1,100,512)).  fp32: the north-star gate (1e-3 RMS) with headroom + int16 within the truncation boundary;
     fp16 B=8 (configs[1]): item 0 of the bench batch is the fixture's mel, the same mel tiled 8 times must give 8 equal
-    waveforms, gate 2e-2 RMS (stated, storage rounded to fp16 after every layer)."""
+    waveforms, gate 4e-3 RMS (achieved 6.3e-4; storage rounded to fp16 after every layer)."""
     cfg, st = full_state
     gf = np.load(os.path.join(golden_dir, "bigvgan_full.npz"))
     ref = gf["wav_i16"].astype(np.float64)
@@ -278,7 +278,7 @@ def test_full_size_reference_fixture(full_state, golden_dir):
     w8 = v.run(mel8)
     assert w8.shape == (8, 1, 131102)
     err16 = rms((w8[0, 0] - ref) / 32767.0)
-    assert err16 < 2e-2, err16
+    assert err16 < 4e-3, err16                                       # achieved 6.3e-4 (profiles/r3); stated bound of the fp16 form 2e-2
     # batch position does not change an item's result, and neither does running it again: bit-identical in the DEFAULT
     # policy (two workgroups of the fused AA+conv kernel per CU).  Round 2 tolerated <= 64 LSB here; the cause was one
     # sample per channel read through `v_pk_fma_f32 ... op_sel:[0,1,0]` next to another workgroup's MFMAs (aa_math.h,

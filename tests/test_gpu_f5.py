@@ -441,7 +441,7 @@ def test_full_size_fp32_other_lengths_default_forms_against_native(full, N):
     assert rms(a[:2] - a1) / rms(a1) < 3e-6                    # one utterance alone: other tile counts, same values
 
 
-@pytest.mark.parametrize("dtype,gate", [("bf16", 3e-2), ("f16", 1e-2)])
+@pytest.mark.parametrize("dtype,gate", [("bf16", 1.5e-3), ("f16", 3e-4)])        # achieved (profiles/r3): 2.5e-4 / 3.4e-5
 def test_full_size_lowp_u8_against_reference_fixture(full, gfull, dtype, gate):
     """configs[3] shard: 8 utterances per GPU in one batch, 16-bit DiT operands.  Utterance 0 is the reference fixture's
     utterance: waveform inside the stated low-precision gate of the REFERENCE waveform; every utterance equals its own
