@@ -508,6 +508,8 @@ static std::atomic<long> g_x3 = 1;
 bool gemm_x3_enabled() { return g_x3 != 0; }
 // ... with both operands as panel planes (gemm_x3p.hip, round 3) when the caller supplies them
 static std::atomic<long> g_x3p = 1;
+static std::atomic<long> g_f32_gconv = 1;         // ... and, when the shape allows, with each operand split once per workgroup (gconv_pairs.hip)
+bool launch_gconv_pairs(const ConvGemm& p, hipStream_t s);
 static std::atomic<long> g_f32_n64_pairs = 1;     // fp32 N = 64 convolutions with >= 8 taps: fp16 pairs split in registers (conv_gemm_dma_kernel PAIRS)
 // number format of the panel planes built from now on: 3 = three bf16 planes (six products), 2 = fp16 {hi, lo} planes (three products)
 static std::atomic<long> g_x3p_np = 0;          // 0: not set by mi_set_option -> MI355TTS_F32_PLANES, else 2
@@ -736,6 +738,7 @@ bool gemm_set_option(const char* key, long v) {
     else if (k == "gemm_f32_x3") g_x3 = v;
     else if (k == "gemm_f32_x3p") g_x3p = v;
     else if (k == "gemm_f32_n64_pairs") g_f32_n64_pairs = v;
+    else if (k == "gemm_f32_gconv") g_f32_gconv = v;
     else if (k == "gemm_f32_planes") { if (v != 2 && v != 3) return false; g_x3p_np = v; }
     else if (k == "gemm_x3p_noalign") x3p_set_option(0, v);
     else if (k == "gemm_x3p_grid") x3p_set_option(1, v);
@@ -889,6 +892,8 @@ void launch_conv_gemm(const ConvGemm& p_in, hipStream_t s) {
     double flops = 2.0 * p.B * p.G * (double)p.M * p.N * d.K;
     ProfScope ps(FAM_CONV_GEMM, s, bytes, flops);
 
+    // fp32 grouped convolutions with 64 channels per group and >= 8 taps (the DiT's position convolution): gconv_pairs.hip
+    if (p.dtype == MI_F32 && g_x3 != 0 && g_f32_n64_pairs != 0 && g_f32_gconv != 0 && g_use_dma && launch_gconv_pairs(p, s)) return;
     if (p.dtype == MI_F32) {
         dispatch_tiles<float, float>(d, p.B, s);
     } else if (p.dtype == MI_F16) {
