@@ -246,7 +246,13 @@ int         mi_indextts_cond_run(mi_cond* h, const int16_t* audio, int64_t L, fl
  * "gemm_ph8_split_max", "gemm_ph8_split_min_nk" (256x256 16-bit kernel); "gemm_sk_qkv32";
  * "gemm_f32_x3p" (0: the round-2 kernel gemm_x3.hip instead of the panel-plane kernel gemm_x3p.hip), "gemm_x3p_grid" (XCD bands:
  * 0 automatic, else 1 / 2 / 4 / 8 row bands), "gemm_x3p_noalign"; "attn_kv_planes" (0: the fp32 attention kernel splits K / V itself);
- * "gemm_f32_n64_dma", "gemm_n64_dma16"; "attn_z_max", "attn_z16_max", "attn_z_force" (key slices).
+ * "gemm_f32_n64_dma", "gemm_n64_dma16"; "attn_z_max", "attn_z16_max", "attn_z_force" (key slices);
+ * "gemm_f32_n64_pairs" (fp32 convolutions with 64 channels per group and >= 8 taps — the DiT position convolution — on fp16
+ * pairs; 0: native fp32 MFMA) and "gemm_f32_gconv" (default 1: gconv_pairs.hip, each operand split once per workgroup; 0: the
+ * LDS-DMA kernel that splits in registers per k-step);
+ * "bigvgan_streams" (default 3): the AMP blocks of a BigVGAN stage (one per resblock kernel size) on side streams of the
+ * handle — 1: everything on the handle's one stream; 2: only the stages whose AMP halves are separate AA and conv launches
+ * (C > 96); 3: every stage.  The waveform is bit-identical in all three.
  * Changing an option invalidates the hipGraphs captured by existing handles.   */
 int         mi_set_option(const char* key, int64_t value);
 

@@ -254,6 +254,28 @@ def test_full_size_properties(full_state):
     v.close()
 
 
+@pytest.mark.parametrize("dtype,B,F", [("f32", 2, 24), ("f16", 3, 40), ("bf16", 1, 33)])
+def test_amp_blocks_on_side_streams_are_bit_identical(full_state, dtype, B, F):
+    """The three AMP blocks of a stage (resblock kernels 3 / 7 / 11, bigvgan.py:384-398) only meet in their input and in the
+    accumulation of their outputs; by default (bigvgan_streams = 3) blocks 1 and 2 run on side streams of the handle with
+    scratch of their own and the accumulation keeps its block order through events.  Same kernels, same order of every
+    rounding: the waveform must equal the one-stream forward bit for bit, in every stream mode, run after run."""
+    from mi355tts import _lib
+    cfg, st = full_state
+    v = BV.BigVGANVocoder(cfg, st, dtype=dtype)
+    mel = _mel(B, F, seed=23)
+    try:
+        _lib.set_option("bigvgan_streams", 1)
+        ref = v.run(mel)
+        assert rms(ref) > 100
+        for ns in (2, 3, 3, 1):
+            _lib.set_option("bigvgan_streams", ns)
+            assert np.array_equal(v.run(mel), ref), ns
+    finally:
+        _lib.set_option("bigvgan_streams", 3)
+        v.close()
+
+
 def test_full_size_reference_fixture(full_state, golden_dir):
     """BASELINE configs[0] / [1] against the REFERENCE generator + int16 wrapper run at the real shape
     (tests/golden/make_golden_full.py: BigVGAN/modeling_modified/bigvgan.py:384-410 through Export_BigVGAN.py:37-49 on

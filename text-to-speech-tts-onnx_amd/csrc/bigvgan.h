@@ -32,6 +32,14 @@ struct BigVGAN {
     // workspace
     int ws_B = 0, ws_F = 0;
     DevBuf bIN, bX, bT1, bT2, bP, bQ, d_mel, d_out_f32, d_out_i16;
+    // the AMP blocks of a stage (one per resblock kernel size) only share their input X and the accumulation into IN: blocks
+    // 1.. run on side streams with scratch buffers of their own (option "bigvgan_streams", bigvgan.hip body())
+    static constexpr int MAX_SIDE = 3;
+    hipStream_t side[MAX_SIDE] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_x = nullptr, ev_last[MAX_SIDE + 1] = {nullptr, nullptr, nullptr, nullptr};
+    DevBuf sT1[MAX_SIDE], sT2[MAX_SIDE], sP[MAX_SIDE], sQ[MAX_SIDE];
+    hipStream_t ls = nullptr;      // launch stream of conv / aa / aa_conv (null: `stream`)
+    void ensure_side(int n);
 
     BigVGAN(const BigVGANCfg& g, const float* w, int64_t nw, int dt, int dev);
     ~BigVGAN();
@@ -59,6 +67,8 @@ void unit_conv1d(const float* x, int B, int Cin, int T, const float* w, const fl
                  int padding, int groups, int dtype, float* y);
 void unit_conv_transpose1d(const float* x, int B, int Cin, int T, const float* w, const float* bias, int Cout, int k,
                            int stride, int padding, int dtype, float* y);
+
+bool bigvgan_set_option(const char* key, long v);   // "bigvgan_streams"
 
 // runtime.hip
 const std::string& last_error();

@@ -13,6 +13,7 @@
 #include "common.h"
 #include "bigvgan.h"
 #include "f5_kernels.h"
+#include <atomic>
 #include <cstdlib>
 
 namespace mi {
@@ -167,7 +168,31 @@ BigVGAN::BigVGAN(const BigVGANCfg& g, const float* w, int64_t nw, int dt, int de
 }
 
 BigVGAN::~BigVGAN() {
+    for (hipStream_t& q : side) if (q) (void)hipStreamDestroy(q);
+    if (ev_x) (void)hipEventDestroy(ev_x);
+    for (hipEvent_t& e : ev_last) if (e) (void)hipEventDestroy(e);
     if (stream) (void)hipStreamDestroy(stream);
+}
+
+// Streams for the AMP blocks of a stage.  bigvgan_streams: 1 = everything on the engine's stream (rounds 1-3); 2 = blocks 1.. of
+// the stages whose AMP halves are separate AA and conv launches (C > 96) on side streams; 3 = every stage.
+// fp16, mel (8,100,512), same box (tools/r3/bigvgan_streams_ab.py, profiles/r3/s6_bigvgan_streams_ab.txt): 16.8 / 16.2 / 16.07 ms per
+// forward for 1 / 2 / 3, waveforms identical bit for bit.
+static std::atomic<long> g_bigvgan_streams = 3;
+bool bigvgan_set_option(const char* key, long v) {
+    if (std::string(key) != "bigvgan_streams") return false;
+    g_bigvgan_streams = std::max(1L, std::min(3L, v));
+    return true;
+}
+
+void BigVGAN::ensure_side(int n) {
+    MI_REQUIRE(n <= MAX_SIDE, "bigvgan: more resblock kernels than side streams");
+    if (!ev_x) MI_HIP(hipEventCreateWithFlags(&ev_x, hipEventDisableTiming));
+    for (int j = 0; j <= n; ++j) if (!ev_last[j]) MI_HIP(hipEventCreateWithFlags(&ev_last[j], hipEventDisableTiming));
+    for (int j = 0; j < n; ++j) {
+        if (!side[j]) MI_HIP(hipStreamCreateWithFlags(&side[j], hipStreamNonBlocking));
+        for (DevBuf* b : {&sT1[j], &sT2[j], &sP[j], &sQ[j]}) b->ensure(bT1.bytes);
+    }
 }
 
 void BigVGAN::ensure_workspace(int B, int F) {
@@ -193,7 +218,7 @@ void BigVGAN::conv(const ConvW& cw, const void* x, void* out, int B, int T, int 
     p.B = B; p.T_in = T; p.M = T; p.N = Cout; p.Cin = Cin; p.taps = k; p.dil = dil; p.pad = (k * dil - dil) / 2;
     p.x_bstride = (long)T * Cin; p.x_rstride = Cin; p.out_bstride = (long)T * Cout; p.out_rstride = Cout;
     p.alpha = alpha; p.accumulate = accumulate;
-    launch_conv_gemm(p, stream);
+    launch_conv_gemm(p, ls ? ls : stream);
 }
 
 void BigVGAN::aa_conv(const SnakeP& sp, const ConvW& cw, const void* x, void* out, int B, int T, int C, int k, int dil,
@@ -202,14 +227,14 @@ void BigVGAN::aa_conv(const SnakeP& sp, const ConvW& cw, const void* x, void* ou
     a.dtype = dtype; a.x = x; a.w = cw.w.p; a.bias = cw.b.as<float>(); a.snake_alpha = sp.alpha.as<float>();
     a.snake_inv_beta = sp.inv_beta.as<float>(); a.out = out; a.res = res; a.B = B; a.T = T; a.C = C; a.k = k; a.dil = dil;
     a.alpha = alpha; a.accumulate = accumulate;
-    launch_aa_conv(a, stream);
+    launch_aa_conv(a, ls ? ls : stream);
 }
 
 void BigVGAN::aa(const SnakeP& sp, const void* x, void* y, int B, int T, int C, int post) {
     AAAct a;
     a.dtype = dtype; a.x = x; a.y = y; a.alpha = sp.alpha.as<float>(); a.inv_beta = sp.inv_beta.as<float>();
     a.B = B; a.T = T; a.C = C; a.post = post;
-    launch_aa_act(a, stream);
+    launch_aa_act(a, ls ? ls : stream);
 }
 
 long BigVGAN::total_cond() const {
@@ -275,6 +300,7 @@ static void eff_bias(ConvW& cw, const float* cond, hipStream_t s) {
 // x0: channels-last (B, F, mel_pad) in the engine dtype, held in bT1
 void BigVGAN::body(const void* x0, int B, int F, const float* const* cond, float* out_f32, int16_t* out_i16, int mem) {
     const long Tout = (long)F * cfg.hop + 30;
+    ls = nullptr;
     DevBuf* IN = &bIN;     // holds the running stage input/output
     DevBuf* X = &bX;
     {
@@ -302,26 +328,59 @@ void BigVGAN::body(const void* x0, int B, int F, const float* const* cond, float
             p.epi = EPI_CONVT; p.u = st.u; p.Cout = C; p.padT = (st.k - st.u) / 2; p.T_out = Tn;
             launch_conv_gemm(p, stream);
         }
-        // AMP blocks: XS(=IN) = 1/3 * sum_j block_j(X)
-        for (int j = 0; j < cfg.n_kernels; ++j) {
-            AmpBlock& bk = st.blocks[j];
-            const void* cur = X->p;
-            for (int l = 0; l < cfg.n_dil; ++l) {
-                const bool last = l == cfg.n_dil - 1;
-                void* dst = last ? IN->p : ((l & 1) ? bQ.p : bP.p);
-                if (use_fused && C <= fused_max_c) {
+        // AMP blocks: XS(=IN) = 1/3 * sum_j block_j(X).  The blocks only meet in X (read) and in IN (block 0 writes it, blocks
+        // 1.. accumulate, in block order: 16-bit storage rounds after every accumulate).  With side streams block j runs on its
+        // own stream with its own scratch, launches issued dilation-major so that all blocks are in flight from the start; the
+        // LAST conv of block j waits for the last conv of block j - 1 (events), so the values are those of the one-stream order,
+        // bit for bit.  What it buys: the AA launches (VALU / HBM) of one block run beside the conv GEMM (matrix cores, one
+        // workgroup per CU with LDS and registers to spare) of another.
+        const bool fused = use_fused && C <= fused_max_c;
+        const long ns = g_bigvgan_streams;
+        const int nside = (cfg.n_kernels > 1 && cfg.n_kernels - 1 <= MAX_SIDE && (ns >= 3 || (ns == 2 && !fused))) ? cfg.n_kernels - 1 : 0;
+        if (nside) {
+            ensure_side(nside);
+            MI_HIP(hipEventRecord(ev_x, stream));
+            for (int j = 0; j < nside; ++j) MI_HIP(hipStreamWaitEvent(side[j], ev_x, 0));
+        }
+        std::vector<const void*> curs(cfg.n_kernels, X->p);
+        static const bool dbg_sync = [] { const char* e = std::getenv("MI355TTS_BV_SYNC"); return e && e[0] == '1'; }();
+        // issue order: dilation-major with side streams (every block has its own scratch), block-major on one stream (the
+        // blocks share T1 / T2 / P / Q there)
+        const int n_it = cfg.n_dil * cfg.n_kernels;
+        for (int it = 0; it < n_it; ++it) {
+            const int l = nside ? it / cfg.n_kernels : it % cfg.n_dil;
+            const int j = nside ? it % cfg.n_kernels : it / cfg.n_dil;
+            const bool last = l == cfg.n_dil - 1;
+            {
+                AmpBlock& bk = st.blocks[j];
+                const bool sidej = nside && j > 0;
+                hipStream_t sj = sidej ? side[j - 1] : stream;
+                ls = sj;
+                void* t1 = sidej ? sT1[j - 1].p : bT1.p;
+                void* t2 = sidej ? sT2[j - 1].p : bT2.p;
+                void* pp = sidej ? sP[j - 1].p : bP.p;
+                void* qq = sidej ? sQ[j - 1].p : bQ.p;
+                const void* cur = curs[j];
+                void* dst = last ? IN->p : ((l & 1) ? qq : pp);
+                if (fused) {
                     // HBM-bound stages: AA folded into the conv's operand staging (5 tensor passes instead of 9)
-                    aa_conv(bk.acts[2 * l], bk.c1[l], cur, bT2.p, B, Tn, C, bk.k, cfg.dil[j][l], nullptr, 1.f, 0);
-                    aa_conv(bk.acts[2 * l + 1], bk.c2[l], bT2.p, dst, B, Tn, C, bk.k, 1, cur, last ? inv_nk : 1.f, last && j > 0);
+                    aa_conv(bk.acts[2 * l], bk.c1[l], cur, t2, B, Tn, C, bk.k, cfg.dil[j][l], nullptr, 1.f, 0);
+                    if (nside && last && j > 0) MI_HIP(hipStreamWaitEvent(sj, ev_last[j - 1], 0));
+                    aa_conv(bk.acts[2 * l + 1], bk.c2[l], t2, dst, B, Tn, C, bk.k, 1, cur, last ? inv_nk : 1.f, last && j > 0);
                 } else {
-                    aa(bk.acts[2 * l], cur, bT1.p, B, Tn, C, 0);
-                    conv(bk.c1[l], bT1.p, bT2.p, B, Tn, C, C, bk.k, cfg.dil[j][l], nullptr, 1.f, 0);
-                    aa(bk.acts[2 * l + 1], bT2.p, bT1.p, B, Tn, C, 0);
-                    conv(bk.c2[l], bT1.p, dst, B, Tn, C, C, bk.k, 1, cur, last ? inv_nk : 1.f, last && j > 0);
+                    aa(bk.acts[2 * l], cur, t1, B, Tn, C, 0);
+                    conv(bk.c1[l], t1, t2, B, Tn, C, C, bk.k, cfg.dil[j][l], nullptr, 1.f, 0);
+                    aa(bk.acts[2 * l + 1], t2, t1, B, Tn, C, 0);
+                    if (nside && last && j > 0) MI_HIP(hipStreamWaitEvent(sj, ev_last[j - 1], 0));
+                    conv(bk.c2[l], t1, dst, B, Tn, C, C, bk.k, 1, cur, last ? inv_nk : 1.f, last && j > 0);
                 }
-                cur = dst;
+                if (nside && last) MI_HIP(hipEventRecord(ev_last[j], sj));
+                if (dbg_sync) MI_HIP(hipDeviceSynchronize());
+                curs[j] = dst;
             }
         }
+        ls = nullptr;
+        if (nside) MI_HIP(hipStreamWaitEvent(stream, ev_last[cfg.n_kernels - 1], 0));
         T = Tn;
     }
     const int cl = cfg.c0 >> cfg.n_up;

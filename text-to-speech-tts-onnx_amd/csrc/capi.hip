@@ -765,7 +765,7 @@ int mi_set_option(const char* key, int64_t value) {
     return guard([&] {
         MI_REQUIRE(key != nullptr, "mi_set_option: null key");
         MI_REQUIRE(gemm_set_option(key, (long)value) || gpt_set_option(key, (long)value) || aa_conv_set_option(key, (long)value) ||
-                       attn_set_option(key, (long)value), "mi_set_option: unknown key");
+                       attn_set_option(key, (long)value) || bigvgan_set_option(key, (long)value), "mi_set_option: unknown key");
         option_epoch_bump();
     });
 }
