@@ -735,6 +735,8 @@ def main():
     ap.add_argument("--dtype", default=None, help="f5: f32 on one GPU (configs[2]), bf16 with --gpus > 1 (configs[3]) | f16 ; "
                                                   "bigvgan: f16 (default) | f32 | bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE",
+                    help="mi_set_option(KEY, VALUE) before anything runs (A/B measurements); repeatable")
     ap.add_argument("--no-pmc", action="store_true", help="f5 on one GPU: skip the two rocprofv3 --pmc passes that fill roofline.traffic")
     ap.add_argument("--no-secondary", action="store_true", help="f5 on one GPU: skip the configs[1] / configs[3]-shard blocks")
     ap.add_argument("--cpu-frames", type=int, default=128)
@@ -768,6 +770,11 @@ def main():
                          "(MI355TTS_BENCH_ONE_GPU=1 MI355TTS_BENCH_BACKEND=gloo maps every rank to device 0 for plumbing tests)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if args.option:
+        from mi355tts import _lib
+        for kv in args.option:
+            k, v = kv.split("=", 1)
+            _lib.set_option(k, int(v))
 
     if args.workload == "f5":
         # one GPU: configs[2] (fp32, one utterance) — the config parity is gated on; N > 1: the configs[3] shard

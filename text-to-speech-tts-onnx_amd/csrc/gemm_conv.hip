@@ -524,6 +524,7 @@ bool gemm_x3p_enabled() { return g_x3 != 0 && g_x3p != 0; }
 static std::atomic<long> g_sk_qkv32 = 0;
 // 256x256 eight-phase kernel (gemm_ph8.hip) for 16-bit linear layers with at least g_ph8_min_tiles tiles of 256x256
 static std::atomic<long> g_ph8 = 1, g_ph8_min_tiles = 200, g_ph8_order = 1;
+static std::atomic<long> g_row_split = 1;          // rows beyond the last whole round of 256x256 tiles as a second launch (launch_conv_gemm)
 static DevBuf g_zero_page[16];
 
 // buffer-descriptor DMA (BUF kernels): whole 64-deep chunks only, and every byte offset must fit the 32-bit range check
@@ -744,6 +745,7 @@ bool gemm_set_option(const char* key, long v) {
     else if (k == "gemm_x3p_grid") x3p_set_option(1, v);
     else if (k == "gemm_ph8") g_ph8 = v;
     else if (k == "gemm_ph8_min_tiles") g_ph8_min_tiles = v;
+    else if (k == "gemm_row_split") g_row_split = v;
     else if (k == "gemm_ph8_order") g_ph8_order = v;
     else if (k == "gemm_ph8_split_max") ph8_set_split_max(v);
     else if (k == "gemm_ph8_split_min_nk") ph8_set_split_min_nk(v);
@@ -784,6 +786,39 @@ void launch_conv_gemm(const ConvGemm& p_in, hipStream_t s) {
         p.T_in = p.M = p.B * p.M; p.B = 1;          // one-tap GEMM over contiguous batch items: a single M axis
     }
     const int odt = p.out_dtype < 0 ? p.dtype : p.out_dtype;
+    // Row split of a 16-bit linear layer whose 256x256 tiles spill into a nearly empty last round.  A batch of 8 utterances is
+    // M = 18016 rows = 70.4 row tiles: N = 1024 gives 284 tiles on 256 CUs — a full round and then 28 tiles with 228 CUs idle for
+    // as long again (O / FF2 ran at 312 TFLOP/s against ~600 for QKV / FF1); N = 2048: 568 = two rounds + 56.  The rows of whole
+    // rounds (M1 = a multiple of 256 * CUs / column tiles) go to the eight-phase kernel as before, the remaining rows (1632
+    // here) are a second launch that the dispatch below hands to the 128x128 kernels: 104 / 208 small tiles instead of a round
+    // of big ones.  Rows are independent in every EPI_PLAIN epilogue (bias, activation, gate per column, residual per element).
+    if (g_row_split != 0 && g_ph8 != 0 && dtype_size(p.dtype) == 2 && p.B == 1 && p.G == 1 && p.taps == 1 && p.pad == 0 && p.epi == EPI_PLAIN &&
+        p.M == p.T_in && p.N % 256 == 0 && p.gate_bstride == 0 && !p.out_planes && !p.xp && !p.accumulate) {
+        int dev = 0, cus = 256;
+        MI_HIP(hipGetDevice(&dev));
+        {
+            static int cu_count[16] = {0};
+            if (!cu_count[dev & 15]) { hipDeviceProp_t pr; MI_HIP(hipGetDeviceProperties(&pr, dev)); cu_count[dev & 15] = pr.multiProcessorCount; }
+            cus = cu_count[dev & 15];
+        }
+        const long ntn = p.N / 256;
+        if (cus % ntn == 0) {
+            const long block = 256L * (cus / ntn);            // rows of one full round
+            const long k = p.M / block, rem = p.M - k * block;
+            const long rem_tiles = (rem + 255) / 256 * ntn;
+            if (k >= 1 && rem > 0 && rem_tiles * 2 < cus && k * cus >= g_ph8_min_tiles) {
+                ConvGemm a = p, b = p;
+                a.M = a.T_in = (int)(k * block);
+                b.M = b.T_in = (int)rem;
+                b.x = (const char*)p.x + (size_t)(k * block) * p.x_rstride * dtype_size(p.dtype);
+                b.out = (char*)p.out + (size_t)(k * block) * p.out_rstride * dtype_size(odt);
+                if (p.res) b.res = (const char*)p.res + (size_t)(k * block) * p.out_rstride * dtype_size(odt);
+                launch_conv_gemm(a, s);
+                launch_conv_gemm(b, s);
+                return;
+            }
+        }
+    }
     const int vec = 16 / (int)dtype_size(p.dtype);
     MI_REQUIRE(p.Cin % vec == 0, "conv_gemm: Cin must be a multiple of the 16-byte vector");
     MI_REQUIRE(p.x_rstride % vec == 0 && p.x_bstride % vec == 0 && p.x_goff % vec == 0, "conv_gemm: x strides");
