@@ -158,6 +158,7 @@ struct ConvGemm {
     const void* rope_pack = nullptr;   // optional: (cos, sin) half pairs [token][head_dim / 2] (values must equal the fp32 tables)
     void* out2 = nullptr; void* out3 = nullptr;
     int rows_per_item = 0;        // EPI_QKV_ROPE with the batch flattened into M: tokens per batch item (0: M)
+    int m_off = 0;                // ... and the flattened row this launch's row 0 stands for (row split inside launch_conv_gemm)
     long v_ld = 0;                // > 0: V is written transposed, [b*H + h][head_dim][v_ld] (keys contiguous)
     // fp32 + LDS-staged QKV epilogue only: K and V^T leave as the three bf16 planes of x3_split.h (the attention kernel then
     // stages them without splitting): out2 = [b*H + h][3][k_ld][64], out3 = [b*H + h][3][64][v_ld]; q stays fp32

@@ -792,8 +792,11 @@ void launch_conv_gemm(const ConvGemm& p_in, hipStream_t s) {
     // rounds (M1 = a multiple of 256 * CUs / column tiles) go to the eight-phase kernel as before, the remaining rows (1632
     // here) are a second launch that the dispatch below hands to the 128x128 kernels: 104 / 208 small tiles instead of a round
     // of big ones.  Rows are independent in every EPI_PLAIN epilogue (bias, activation, gate per column, residual per element).
-    if (g_row_split != 0 && g_ph8 != 0 && dtype_size(p.dtype) == 2 && p.B == 1 && p.G == 1 && p.taps == 1 && p.pad == 0 && p.epi == EPI_PLAIN &&
-        p.M == p.T_in && p.N % 256 == 0 && p.gate_bstride == 0 && !p.out_planes && !p.xp && !p.accumulate) {
+    const bool split_plain = p.epi == EPI_PLAIN && p.gate_bstride == 0 && !p.out_planes && !p.accumulate;
+    const bool split_qkv = p.epi == EPI_QKV_ROPE && p.rows_per_item >= 32 && !p.kv_planes && p.m_off == 0;   // the epilogue indexes
+                                                      // tokens from the flattened row: the second launch carries its row offset (m_off)
+    if (g_row_split != 0 && g_ph8 != 0 && dtype_size(p.dtype) == 2 && p.B == 1 && p.G == 1 && p.taps == 1 && p.pad == 0 &&
+        (split_plain || split_qkv) && p.M == p.T_in && p.N % 256 == 0 && !p.xp) {
         int dev = 0, cus = 256;
         MI_HIP(hipGetDevice(&dev));
         {
@@ -802,21 +805,25 @@ void launch_conv_gemm(const ConvGemm& p_in, hipStream_t s) {
             cus = cu_count[dev & 15];
         }
         const long ntn = p.N / 256;
-        if (cus % ntn == 0) {
-            const long block = 256L * (cus / ntn);            // rows of one full round
-            const long k = p.M / block, rem = p.M - k * block;
-            const long rem_tiles = (rem + 255) / 256 * ntn;
-            if (k >= 1 && rem > 0 && rem_tiles * 2 < cus && k * cus >= g_ph8_min_tiles) {
-                ConvGemm a = p, b = p;
-                a.M = a.T_in = (int)(k * block);
-                b.M = b.T_in = (int)rem;
-                b.x = (const char*)p.x + (size_t)(k * block) * p.x_rstride * dtype_size(p.dtype);
-                b.out = (char*)p.out + (size_t)(k * block) * p.out_rstride * dtype_size(odt);
-                if (p.res) b.res = (const char*)p.res + (size_t)(k * block) * p.out_rstride * dtype_size(odt);
-                launch_conv_gemm(a, s);
-                launch_conv_gemm(b, s);
-                return;
+        long gc = cus, t = ntn;
+        while (t) { const long u = gc % t; gc = t; t = u; }       // gcd(cus, ntn)
+        const long rstep = cus / gc;                              // row tiles that make a whole number of rounds
+        const long r = (p.M / 256) / rstep * rstep;               // N = 1024 / 2048 / 3072 on 256 CUs: multiples of 64 / 32 / 64
+        const long rem = p.M - 256 * r;
+        const long rem_tiles = (rem + 255) / 256 * ntn;
+        if (r >= 1 && rem > 0 && rem_tiles * 2 < cus && r * ntn >= g_ph8_min_tiles) {
+            ConvGemm a = p, b = p;
+            a.M = a.T_in = (int)(256 * r);
+            b.M = b.T_in = (int)rem;
+            b.x = (const char*)p.x + (size_t)(256 * r) * p.x_rstride * dtype_size(p.dtype);
+            if (split_qkv) b.m_off = (int)(256 * r);
+            else {
+                b.out = (char*)p.out + (size_t)(256 * r) * p.out_rstride * dtype_size(odt);
+                if (p.res) b.res = (const char*)p.res + (size_t)(256 * r) * p.out_rstride * dtype_size(odt);
             }
+            launch_conv_gemm(a, s);
+            launch_conv_gemm(b, s);
+            return;
         }
     }
     const int vec = 16 / (int)dtype_size(p.dtype);
@@ -834,7 +841,8 @@ void launch_conv_gemm(const ConvGemm& p_in, hipStream_t s) {
     d.act = p.act; d.alpha = p.alpha; d.accumulate = p.accumulate; d.epi = p.epi;
     d.u = p.u; d.Cout = p.Cout; d.padT = p.padT; d.T_out = p.T_out;
     d.rope_cos = p.rope_cos; d.rope_sin = p.rope_sin; d.rope_pack = p.rope_pack; d.heads = p.heads; d.head_dim = p.head_dim;
-    d.out2 = p.out2; d.out3 = p.out3; d.v_ld = p.v_ld; d.Mb = p.rows_per_item;
+    d.out2 = p.out2; d.out3 = p.out3; d.v_ld = p.v_ld; d.Mb = p.rows_per_item; d.m_off = p.m_off;
+    MI_REQUIRE(p.m_off == 0 || (p.epi == EPI_QKV_ROPE && p.rows_per_item >= 32), "conv_gemm: a row offset needs the flattened QKV epilogue");
     d.kv_planes = p.kv_planes; d.k_ld = p.k_ld;
     d.sk_ws = p.sk_ws; d.sk_flags = p.sk_flags; d.sk_slots = p.sk_slots;
     const bool use_x3p = x3p_eligible(p);

@@ -32,6 +32,7 @@ struct ConvGemmDev {
     int u, Cout, padT, T_out;
     const float* rope_cos; const float* rope_sin; const void* rope_pack; int heads, head_dim; void* out2; void* out3;
     long v_ld; int Mb;
+    int m_off = 0;   // EPI_QKV_ROPE: this launch's row 0 is row m_off of the flattened [batch item][token] axis (launch_conv_gemm's row split)
     const void* zero;      // >= 16 bytes of zeros: source for out-of-range / K-tail vectors of the LDS-DMA path
     int dbg;               // tuning only: 1 = no DMA in the main loop, 2 = no ds_read/MFMA in the main loop
     int lds_epi;           // 1: outputs leave through the LDS-staged, 16-byte-store epilogue (alignment checked on the host)
@@ -102,7 +103,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], const ConvG
             const long head_off = vt ? ((long)hh * p.head_dim + dd) * p.v_ld : (long)hh * Mb * p.head_dim + dd;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const int mb = m0 + wm * WM + i * 32 + 4 * lk;
+                const int mb = p.m_off + m0 + wm * WM + i * 32 + 4 * lk;
                 const int bi0 = p.Mb > 0 ? mb / Mb : 0;                    // one division per 32-row tile (Mb >= 32)
                 const int mloc0 = mb - bi0 * Mb;
                 TO* dst0 = base + ((long)b + bi0) * item_stride + head_off;        // this tile touches at most two items
@@ -115,11 +116,11 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], const ConvG
                     const float partner = __shfl_xor(v, 1);
                     int m = mloc0 + off, bi = bi0;                         // token position inside its batch item
                     if (m >= Mb) { m -= Mb; ++bi; }
-                    if (mg >= p.M) { m = 0; bi = 0; }
+                    if (mg - p.m_off >= p.M) { m = 0; bi = 0; }
                     const float c = which < 2 ? p.rope_cos[(long)m * p.head_dim + dd] : 1.f;
                     const float sn = which < 2 ? p.rope_sin[(long)m * p.head_dim + dd] : 0.f;
                     v = v * c + sgn * partner * sn;
-                    if (mg < p.M) (bi == bi0 ? dst0 : dst1)[(long)m * mstride] = from_f32<TO>(v);
+                    if (mg - p.m_off < p.M) (bi == bi0 ? dst0 : dst1)[(long)m * mstride] = from_f32<TO>(v);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -301,7 +302,8 @@ __device__ __forceinline__ void gemm_epilogue_qkv_lds(f32x16 (&acc)[TMQ][2], con
     const int nbase = n0 + wn * 64;
     const int which = nbase / dm, hh = (nbase - which * dm) >> 6;           // wave-uniform
     const int Mb = p.Mb > 0 ? p.Mb : p.M;
-    const int mbase = m0 + wm * (32 * TMQ);
+    const int mrow = m0 + wm * (32 * TMQ);                                   // row of this launch
+    const int mbase = mrow + p.m_off;                                        // ... of the flattened [batch item][token] axis
     const int bi0 = mbase / Mb, mloc0 = mbase - bi0 * Mb;
     const bool vt = which == 2 && p.v_ld > 0;
     TO* base = (TO*)(which == 0 ? p.out : which == 1 ? p.out2 : p.out3);
@@ -331,7 +333,7 @@ __device__ __forceinline__ void gemm_epilogue_qkv_lds(f32x16 (&acc)[TMQ][2], con
 #pragma unroll
             for (int gi = 0; gi < GRP; ++gi) {
                 const int rr = (lane >> 3) + (it0 + gi) * 8;
-                okv[gi] = mbase + rr < p.M;
+                okv[gi] = mrow + rr < p.M;
                 int m = mloc0 + rr, bi = bi0;
                 if (m >= Mb) { m -= Mb; ++bi; }
                 if (!okv[gi]) { m = 0; bi = bi0; }
@@ -426,7 +428,7 @@ __device__ __forceinline__ void gemm_epilogue_qkv_lds(f32x16 (&acc)[TMQ][2], con
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             const int rr = i * 32 + row;
-            const bool ok = mbase + rr < p.M;
+            const bool ok = mrow + rr < p.M;
             int m = mloc0 + rr, bi = bi0;
             if (m >= Mb) { m -= Mb; ++bi; }
             TO* dst = base + (((long)b + bi) * p.heads + hh) * 64 * p.v_ld + m;
