@@ -53,6 +53,48 @@ def test_f5_driver_sequence_through_facade(tmp_path, golden_dir):
     assert np.array_equal(w2, wav)
 
 
+def test_f5_fp16_transformer_export_through_facade(tmp_path, golden_dir):
+    """The reference's use_fp16_transformer export (Export_F5.py:20): graphs A / B / C exchange noise, RoPE tables,
+    cat_mel_text(_drop) and denoised as float16 (:139-140, :198-199, :348-349), q / k carry the extra x0.1 and the scores the
+    x100 (:321-326, fp16/modules.py:467).  The façade's sessions for F5Config(ref_fp16_attn=True) declare and exchange float16,
+    refuse float32 feeds like ORT would, and land inside the f16 gate of the reference chain's fp32 waveform."""
+    import dataclasses
+    g = np.load(os.path.join(golden_dir, "f5_small.npz"))
+    cfg = dataclasses.replace(F5Config.small(), ref_fp16_attn=True)
+    wfile = tmp_path / "f5_weights_fp16_export.npy"
+    np.save(wfile, W.pack_f5(cfg, W.synth_state(W.f5_spec(cfg), 9527)))
+    paths = {k: onnxruntime.save_model(str(tmp_path / f"{k}.mi355.json"), k, cfg, str(wfile), "f16")
+             for k in ("F5_Preprocess", "F5_Transformer", "F5_Decode")}
+    A = onnxruntime.InferenceSession(paths["F5_Preprocess"])
+    B = onnxruntime.InferenceSession(paths["F5_Transformer"])
+    Cc = onnxruntime.InferenceSession(paths["F5_Decode"])
+    assert {a.name: a.type for a in A.get_outputs()}["cat_mel_text"] == "tensor(float16)"
+    assert {a.name: a.type for a in B.get_inputs()}["rope_cos_q"] == "tensor(float16)"
+    assert B.get_outputs()[0].type == "tensor(float16)" and Cc.get_inputs()[0].type == "tensor(float16)"
+    in_A, out_A = [a.name for a in A.get_inputs()], [a.name for a in A.get_outputs()]
+    in_B, out_B = [a.name for a in B.get_inputs()], [a.name for a in B.get_outputs()]
+    N = int(g["pre_N"])
+    noise, cq, sq, ck, sk, cmt, cmtd, rsl = A.run(out_A, {in_A[0]: g["pre_audio"].reshape(1, 1, -1), in_A[1]: g["pre_text_ids"].reshape(1, -1),
+                                                          in_A[2]: np.array([N], dtype=np.int64)})
+    for a in (noise, cq, sq, ck, sk, cmt, cmtd):
+        assert a.dtype == np.float16
+    assert np.array_equal(cq.astype(np.float32)[0, 0], g["pre_rope_cos_q"])              # the tables are fp16 values in both exports
+    noise = g["dit_noise"][None].astype(np.float16)                                     # Export_F5.py:140: noise.half()
+    time_step = np.array([0], dtype=np.int32)
+    for i in range(cfg.nfe_step - 1):
+        noise, time_step = B.run([out_B[0], out_B[1]], {in_B[0]: noise, in_B[1]: cq, in_B[2]: sq, in_B[3]: ck, in_B[4]: sk,
+                                                      in_B[5]: cmt, in_B[6]: cmtd, in_B[7]: time_step})
+        assert noise.dtype == np.float16
+    wav = Cc.run(None, {Cc.get_inputs()[0].name: noise, Cc.get_inputs()[1].name: rsl})[0]
+    assert wav.dtype == np.int16 and wav.shape == (1, 1, g["e2e_i16"].shape[0])
+    err = np.sqrt(np.mean(((wav[0, 0].astype(np.float64) - g["e2e_i16"]) / 32767.0) ** 2))
+    print(f"fp16-transformer export through the facade (float16 graph I/O, fp16 sampler state between runs): waveform rms {err:.2e}")
+    assert err < 5e-4, err                                                              # achieved 5.8e-5
+    with pytest.raises(onnxruntime.InvalidArgument):
+        B.run(None, {in_B[0]: noise.astype(np.float32), in_B[1]: cq, in_B[2]: sq, in_B[3]: ck, in_B[4]: sk, in_B[5]: cmt, in_B[6]: cmtd,
+                     in_B[7]: time_step})
+
+
 def test_f5_facade_fuse_nfe_seed_and_rope_inputs(tmp_path, golden_dir):
     """FUSE_NFE > 1 (`for i in range(0, NFE_STEP - 1, FUSE_NFE)`, F5-TTS-ONNX-Inference.py:291): the transformer graph advances
     fuse_step Euler steps per run; repeated preprocess runs draw fresh noise like ORT's generator; RoPE feeds that are not

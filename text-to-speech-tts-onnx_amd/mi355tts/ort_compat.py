@@ -137,7 +137,7 @@ _ENGINES: Dict[tuple, object] = {}
 
 
 def _engine(kind: str, cfg, wfile: str, dtype: str, device: int):
-    key = (kind, os.path.abspath(wfile), dtype, device)
+    key = (kind, os.path.abspath(wfile), dtype, device, bool(getattr(cfg, "ref_fp16_attn", False)))
     if key not in _ENGINES:
         blob = np.load(wfile, mmap_mode="r")
         if kind == "f5":
@@ -199,7 +199,11 @@ def _graph_io(graph: str, cfg, dtype: str):
                  NodeArg("max_logit_id", "tensor(int32)", [1, 1])]
         return ins, outs
     H, D, M, cd = cfg.heads, cfg.dim_head, cfg.mel_dim, cfg.mel_dim + cfg.text_dim
-    ft = "tensor(float)"          # the engine keeps graph I/O in fp32 whatever the DiT operand dtype
+    # the engine keeps graph I/O in fp32 whatever the DiT operand dtype — except for the reference's fp16-transformer export
+    # (cfg.ref_fp16_attn; Export_F5.py:139-140,198-199,348-349), whose graphs exchange noise / RoPE tables / cat_mel_text /
+    # denoised as float16: the sessions then declare, produce and accept float16 (values rounded exactly where that export
+    # rounds them: at the graph boundaries)
+    ft = "tensor(float16)" if getattr(cfg, "ref_fp16_attn", False) else "tensor(float)"
     cond = [NodeArg("noise", ft, [1, "max_duration", M]), NodeArg("rope_cos_q", ft, [2, H, "max_duration", D]),
             NodeArg("rope_sin_q", ft, [2, H, "max_duration", D]), NodeArg("rope_cos_k", ft, [2, H, D, "max_duration"]),
             NodeArg("rope_sin_k", ft, [2, H, D, "max_duration"]), NodeArg("cat_mel_text", ft, [1, "max_duration", cd]),
@@ -420,17 +424,23 @@ class InferenceSession:
             conds = [self._chk(feed, a.name, np.float32, 3) for a in self._inputs[:-1]]
             lat = self._chk(feed, "save_hidden_state", np.float32, 2)
             return {"generated_wav": e.run_latent(lat, conds)}
+        h16 = bool(getattr(self._cfg, "ref_fp16_attn", False))       # the fp16-transformer export's float16 graph I/O
+        fdt = np.float16 if h16 else np.float32
         if g == "F5_Preprocess":
             audio = self._chk(feed, "audio", np.int16, 3)
             ids = self._chk(feed, "text_ids", np.int32, 2)
             md = self._chk(feed, "max_duration", np.int64, 1)
             seed = _SEED[0] + _SEED_DRAWS[0]              # ORT's generator advances: repeated runs draw fresh noise
             _SEED_DRAWS[0] += 1
-            return e.preprocess(audio, ids, md, noise=None, seed=seed)
+            o = e.preprocess(audio, ids, md, noise=None, seed=seed)
+            if h16:
+                o = {k: (np.ascontiguousarray(v).astype(np.float16) if isinstance(v, np.ndarray) and v.dtype == np.float32 else v)
+                     for k, v in o.items()}
+            return o
         if g == "F5_Transformer":
-            noise = self._chk(feed, "noise", np.float32, 3)
-            cmt = self._chk(feed, "cat_mel_text", np.float32, 3)
-            cmtd = self._chk(feed, "cat_mel_text_drop", np.float32, 3)
+            noise = self._chk(feed, "noise", fdt, 3).astype(np.float32)
+            cmt = self._chk(feed, "cat_mel_text", fdt, 3).astype(np.float32)
+            cmtd = self._chk(feed, "cat_mel_text_drop", fdt, 3).astype(np.float32)
             ts = self._chk(feed, "time_step", np.int32, 1)
             # the engine keeps the RoPE tables on the device (the reference re-feeds 37 MB of them per call); a feed that is
             # not graph A's table (Export_F5.py:107-112: cos/sin of n * 10000^(-2j/64), rounded through fp16) is rejected
@@ -445,9 +455,9 @@ class InferenceSession:
                     raise InvalidArgument(f"{n}: not the RoPE table of F5_Preprocess (this engine regenerates the tables on "
                                           f"the device and cannot honour modified ones)")
             x, t = e.transformer_step(noise, cmt, cmtd, ts, fuse=max(1, int(getattr(self._cfg, "fuse_step", 1))))
-            return {"denoised": x, "time_step": t}
+            return {"denoised": x.astype(fdt) if h16 else x, "time_step": t}
         if g == "F5_Decode":
-            den = self._chk(feed, "denoised", np.float32, 3)
+            den = self._chk(feed, "denoised", fdt, 3).astype(np.float32)
             rsl = int(np.asarray(feed["ref_signal_len"]))
             return {"output_audio": e.decode(den, rsl)}
         raise Fail(g)
