@@ -23,7 +23,7 @@ namespace mi {
 extern __constant__ float c_h_fused[12];
 __constant__ float c_h_fused[12];
 
-static std::atomic<long> g_aa_lds_min = -1;        // > 80 KB: one workgroup per CU (bit-reproducible 16-bit tiles), see launch_t
+static std::atomic<long> g_aa_lds_min = -1;        // > 80 KB: one workgroup per CU (a diagnostic since round 3), see launch_t
 bool aa_conv_set_option(const char* key, long v) {
     if (std::string(key) != "aa_conv_deterministic") return false;
     g_aa_lds_min = v ? 82 * 1024 : 0;
@@ -286,13 +286,13 @@ static void launch_t(const AAConv& q, hipStream_t s) {
             lds = std::max(lds, ((off + ring) * sizeof(T) + 15) / 16 * 16);
         }
     }
-    // Run-to-run identity.  The 16-bit kernels fit two workgroups per CU (188 VGPRs + accumulators, <= 66 KB of LDS), and
-    // with two co-resident workgroups the activated tile is not bit-reproducible on gfx950: while another workgroup's waves
-    // on the same SIMD issue their MFMA phase, a handful of the ~10^7 outputs of a launch come out ONE ulp of the 16-bit
-    // storage type different (tools/ubench/aa_race.hip: same binary, 25-40 of 119 runs differ with two workgroups per CU,
-    // 0 of 119 with one; 0 of 199 with the MFMA loop skipped at run time; staged tile, parameters and re-read inputs
-    // verified identical).  One workgroup per CU removes it at +19 % forward time, so it is opt-in:
-    // mi_set_option("aa_conv_deterministic", 1) or MI355TTS_AACONV_LDS_MIN=83968.
+    // Run-to-run identity.  The 16-bit kernels fit two workgroups per CU (<= 66 KB of LDS) and that is the default.  Rounds 1-2
+    // were not bit-reproducible in that mode: one sample per channel was read through `v_pk_fma_f32 ... op_sel:[0,1,0]`, and
+    // next to a co-resident workgroup's MFMAs that read came back one ulp off in a handful of the ~10^7 outputs of a launch
+    // (profiles/r3/aa_conv_opsel_rootcause.txt / _ab.txt).  aa_math.h no longer produces that encoding (channel pairs, every VGPR
+    // source a whole aligned pair): 0 of 119 runs differ with two workgroups per CU, and tests/test_gpu_bigvgan.py asserts
+    // array_equal across batch items and runs in the default mode.  The one-workgroup-per-CU policy stays as a diagnostic:
+    // mi_set_option("aa_conv_deterministic", 1) or MI355TTS_AACONV_LDS_MIN=83968 (+19 % forward time).
     {
         if (g_aa_lds_min < 0) { const char* e = std::getenv("MI355TTS_AACONV_LDS_MIN"); g_aa_lds_min = e ? std::atol(e) : 0; }
         if (sizeof(T) == 2) lds = std::max(lds, (size_t)g_aa_lds_min);

@@ -1,7 +1,9 @@
 // aa_race.hip — standalone determinism stress of the fused AA+conv kernel (tools only; compiled on the GPU box):
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I csrc tools/ubench/aa_race.hip csrc/aa_conv.hip csrc/aa_act.hip csrc/runtime.hip -o aa_race
-//   MI355TTS_AACONV_LDS_MIN=0 ./aa_race 64 32768 120      two workgroups per CU: a few elements differ in 20-35 % of the runs
-//   ./aa_race 64 32768 120                                 one workgroup per CU (the product default): 0 runs differ
+//   ./aa_race 64 32768 120                                 two workgroups per CU (the product default): round 2 — a few elements
+//                                                          differed in 20-35 % of the runs; round 3 (channel-pair AA math, no op_sel
+//                                                          broadcast reads): 0 of 119 runs differ
+//   MI355TTS_AACONV_LDS_MIN=83968 ./aa_race 64 32768 120   one workgroup per CU (diagnostic policy): 0 runs differ in either round
 // identity 1-tap conv => the output IS the activated tile; N runs must be bit-identical.
 #include "common.h"
 #include <vector>
