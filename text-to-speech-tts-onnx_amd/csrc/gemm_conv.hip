@@ -501,6 +501,7 @@ static std::atomic<long> g_ring4_max = 256;
 // stream-K (gemm_sk.hip): 0 off ; 1 fp32 linear layers ; 2 also 16-bit ; g_sk_stages: ring depth override (0 = automatic) ;
 // g_sk_max_tiles: only launches with at most this many 128x128 tiles (beyond that one tile per workgroup balances by itself)
 static std::atomic<long> g_sk = 1, g_sk_stages = 0, g_sk_max_tiles = 2048, g_sk_order = -1;
+static std::atomic<long> g_sk_min_tiles = 64;      // plain stream-K linear layers: at least this many 128x128 tiles ("gemm_sk_min_tiles")
 // whole tiles first, stream-K for the remainder only: measured SLOWER on the fp32 DiT layers (FF1 / FF2, 288 tiles: 87.0 vs
 // 83.7 us per launch — the remainder's eight-piece fix-ups cost more than the aligned K walk of the first phase gains): opt-in
 // fp32 linear layers as six exact bf16 x bf16 partial products (gemm_x3.hip) when the caller supplies the weight planes
@@ -604,7 +605,7 @@ static void dispatch_tiles(const ConvGemmDev& d, int B, hipStream_t s) {
             constexpr int KCB = 128 / (int)sizeof(T);
             const long tiles = (long)((d.M + 127) / 128) * ((d.N + 127) / 128);
             if (g_sk >= (sizeof(T) == 4 ? 1 : 2) && d.sk_ws && d.sk_slots >= 256 && B == 1 && d.G == 1 && d.K == d.Cin && d.Cin % KCB == 0 &&
-                (d.epi == EPI_PLAIN || (d.epi == EPI_QKV_ROPE && (sizeof(T) == 2 || g_sk_qkv32))) && buf_ok(d, (int)sizeof(T)) && d.M > 128 && tiles >= 64 && tiles <= g_sk_max_tiles && d.pad == 0) {
+                (d.epi == EPI_PLAIN || (d.epi == EPI_QKV_ROPE && (sizeof(T) == 2 || g_sk_qkv32))) && buf_ok(d, (int)sizeof(T)) && d.M > 128 && tiles >= g_sk_min_tiles && tiles <= g_sk_max_tiles && d.pad == 0) {
                 ConvGemmDev e = d;
                 e.Tm = (d.M + 127) / 128; e.Tn = (d.N + 127) / 128; e.RT = e.Tm;
                 e.RC = d.M <= d.N ? 0 : 1;      // per-XCD groups: whole weight panels (x re-read 8x) when x is the smaller operand, else whole row tiles
@@ -735,6 +736,7 @@ bool gemm_set_option(const char* key, long v) {
     else if (k == "gemm_sk") g_sk = v;
     else if (k == "gemm_sk_stages") g_sk_stages = v;
     else if (k == "gemm_sk_max_tiles") g_sk_max_tiles = v;
+    else if (k == "gemm_sk_min_tiles") g_sk_min_tiles = std::max(1L, v);
     else if (k == "gemm_sk_qkv32") g_sk_qkv32 = v;
     else if (k == "gemm_f32_x3") g_x3 = v;
     else if (k == "gemm_f32_x3p") g_x3p = v;
