@@ -17,7 +17,6 @@
 //      accB += a_lo b_hi + a_hi b_lo ; result accA + 2^-11 accB (lo lo ~ 2^-22 of the product is dropped) — the
 //      arithmetic of gemm_x3p.hip NP = 2 and of the kernel it replaces;
 //   4. accumulators -> LDS -> coalesced epilogue: + bias, Mish, + residual, 16-byte fp32 row stores.
-#include <cstdlib>
 #include "common.h"
 #include "gemm_epilogue.h"
 #include "mfma.h"
@@ -30,10 +29,6 @@ struct GConvPairsDev {
     int T_in, M, taps, pad, act;
     long x_bstride, x_rstride, x_goff, out_bstride, out_rstride;
     int K;          // taps * 64
-    int ntile, G, B;   // row tiles per (group, batch item), groups, batch items
-    int xcd_map;       // 1: workgroup id -> (tile, group, item) so that the workgroups of one XCD share few groups' weights
-    int dbg;           // tuning (MI355TTS_GCONV_DBG): bit0 skip the tap loop, bit1 skip the epilogue's global traffic, bit2 skip the
-                       // activation loads, bit3 skip the MFMAs only (weights still stream), bit4 skip the weight stream only
 };
 
 constexpr int GCP_C = 64;                 // channels per group (in and out)
@@ -79,83 +74,52 @@ __global__ __launch_bounds__(256, BM <= 128 ? 2 : 1) void gconv_pairs_kernel(con
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, hi = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
-    // Workgroup -> (row tile, group, batch item).  Consecutive workgroup ids go to consecutive XCDs (8 of them, each with its own
-    // 4 MB L2); a group's weights are 64 x taps x 64 fp32 = 508 KB at k = 31 and every workgroup streams all of them once.  Plain
-    // (tile, group, item) order spreads all 16 groups over every XCD — 8 MB of weights per L2, refetched from the fabric tap after
-    // tap.  With the map, XCD x only sees groups x, x + 8, ...: two groups = 1 MB per L2.
-    int tile, g, b;
-    {
-        const int id = blockIdx.x;
-        if (p.xcd_map) {
-            const int gpx = p.G >> 3;                               // groups per XCD (G % 8 == 0)
-            const int xcd = id & 7, slot = id >> 3;
-            g = xcd + 8 * (slot % gpx);
-            const int rest = slot / gpx;
-            tile = rest % p.ntile; b = rest / p.ntile;
-        } else {
-            tile = id % p.ntile; g = (id / p.ntile) % p.G; b = id / (p.ntile * p.G);
-        }
-    }
-    const int m0 = tile * BM;
+    const int m0 = blockIdx.x * BM, g = blockIdx.y, b = blockIdx.z;
     const float* xb = p.x + (long)b * p.x_bstride + (long)g * p.x_goff;
     const float* wg = p.w + (long)g * GCP_C * p.K;
 
-    // ---- weights of tap t: thread -> (co = v / 8, ci = 8 (v % 8) .. + 8), two of those per thread; TWO taps in flight (the
-    // load of tap t + 2 is issued before tap t is multiplied: an L2 / fabric round trip is longer than one tap's MFMAs) ---------
-    struct WRegs { float4 r[2][2]; };
-    WRegs wA, wB;
-    auto wload = [&](int t, WRegs& w) {
+    // ---- weights of tap t: thread -> (co = v / 8, ci = 8 (v % 8) .. + 8), two of those per thread -----------------
+    float4 wreg[2][2];
+    auto wload = [&](int t) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int v = tid + q * 256, co = v >> 3, c8 = v & 7;
             const float* src = wg + (long)co * p.K + t * GCP_C + c8 * 8;
-            w.r[q][0] = *reinterpret_cast<const float4*>(src);
-            w.r[q][1] = *reinterpret_cast<const float4*>(src + 4);
+            wreg[q][0] = *reinterpret_cast<const float4*>(src);
+            wreg[q][1] = *reinterpret_cast<const float4*>(src + 4);
         }
     };
-    auto wstore = [&](const WRegs& w) {
+    auto wstore = [&]() {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int v = tid + q * 256, co = v >> 3, c8 = v & 7;
             x3_u4 h, l;
-            gcp_split8(w.r[q][0], w.r[q][1], h, l, false);
+            gcp_split8(wreg[q][0], wreg[q][1], h, l, false);
             *reinterpret_cast<x3_u4*>(WH + co * S + c8 * 8) = h;
             *reinterpret_cast<x3_u4*>(WL + co * S + c8 * 8) = l;
         }
     };
-    wload(0, wA);
-    if (p.taps > 1) wload(1, wB);
-    // ---- 1. activations: rows m0 - pad .. , split once.  Four 32-byte items per thread are requested before the first is
-    // used: one item per loop trip exposed a global round trip per trip (7 trips at BM = 192: a quarter of the kernel) ----------
+    wload(0);
+    // ---- 1. activations: rows m0 - pad .. , split once ---------------------------------------------------------------
     {
         const int t_base = m0 - p.pad;
         const int nitem = rows_a * 8;
-        constexpr int DEPTH = 4;
-        for (int v0 = tid; v0 < nitem; v0 += 256 * DEPTH) {
-            float4 u[DEPTH], w2[DEPTH];
-#pragma unroll
-            for (int q = 0; q < DEPTH; ++q) {
-                const int v = v0 + q * 256, row = v >> 3, c8 = v & 7, t = t_base + row;
-                u[q] = float4{0.f, 0.f, 0.f, 0.f}; w2[q] = u[q];
-                if (v < nitem && t >= 0 && t < p.T_in && !(p.dbg & 4)) {
-                    const float* src = xb + (long)t * p.x_rstride + c8 * 8;
-                    u[q] = *reinterpret_cast<const float4*>(src);
-                    w2[q] = *reinterpret_cast<const float4*>(src + 4);
-                }
+        for (int v = tid; v < nitem; v += 256) {
+            const int row = v >> 3, c8 = v & 7;
+            const int t = t_base + row;
+            float4 u = float4{0.f, 0.f, 0.f, 0.f}, w2 = u;
+            if (t >= 0 && t < p.T_in) {
+                const float* src = xb + (long)t * p.x_rstride + c8 * 8;
+                u = *reinterpret_cast<const float4*>(src);
+                w2 = *reinterpret_cast<const float4*>(src + 4);
             }
-#pragma unroll
-            for (int q = 0; q < DEPTH; ++q) {
-                const int v = v0 + q * 256, row = v >> 3, c8 = v & 7;
-                if (v < nitem) {
-                    x3_u4 h, l;
-                    gcp_split8(u[q], w2[q], h, l, true);
-                    *reinterpret_cast<x3_u4*>(AH + row * S + c8 * 8) = h;
-                    *reinterpret_cast<x3_u4*>(AL + row * S + c8 * 8) = l;
-                }
-            }
+            x3_u4 h, l;
+            gcp_split8(u, w2, h, l, true);
+            *reinterpret_cast<x3_u4*>(AH + row * S + c8 * 8) = h;
+            *reinterpret_cast<x3_u4*>(AL + row * S + c8 * 8) = l;
         }
     }
-    wstore(wA);
+    wstore();
     __syncthreads();
 
     // ---- 2. main loop: one tap (64 k = four 16-deep steps) per iteration ---------------------------------------------
@@ -166,52 +130,32 @@ __global__ __launch_bounds__(256, BM <= 128 ? 2 : 1) void gconv_pairs_kernel(con
         for (int r = 0; r < 16; ++r) { acc[i][r] = 0.f; accb[i][r] = 0.f; }
     const f16* bh_row = WH + (wn * 32 + lr) * S + hi * 8;
     const f16* bl_row = WL + (wn * 32 + lr) * S + hi * 8;
-    // one tap: `ld` receives the weights of tap t + 2 (it held tap t, already in LDS), `st` holds tap t + 1 and goes to LDS
-    // once every wave is done with tap t.  The weight fragments of the whole tap are read up front, the activation fragments
-    // of k-step ks + 1 while k-step ks is multiplied.
-    auto tap = [&](int t, WRegs& ld, const WRegs& st) __attribute__((always_inline)) {
-        if (t + 2 < p.taps && !(p.dbg & 16)) wload(t + 2, ld);
+    for (int t = 0; t < p.taps; ++t) {
+        if (t + 1 < p.taps) wload(t + 1);
         const f16* ah_row = AH + (wm * WM + lr + t) * S + hi * 8;
         const f16* al_row = AL + (wm * WM + lr + t) * S + hi * 8;
-        FH bh[4], bl[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            bh[ks] = *reinterpret_cast<const FH*>(bh_row + ks * 16);
-            bl[ks] = *reinterpret_cast<const FH*>(bl_row + ks * 16);
-        }
-        FH ah[2][TM], al[2][TM];
+            const FH bh = *reinterpret_cast<const FH*>(bh_row + ks * 16);
+            const FH bl = *reinterpret_cast<const FH*>(bl_row + ks * 16);
+            FH ah[TM], al[TM];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            ah[0][i] = *reinterpret_cast<const FH*>(ah_row + i * 32 * S);
-            al[0][i] = *reinterpret_cast<const FH*>(al_row + i * 32 * S);
-        }
-        if (!(p.dbg & 8))
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            if (ks + 1 < 4) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    ah[(ks + 1) & 1][i] = *reinterpret_cast<const FH*>(ah_row + i * 32 * S + (ks + 1) * 16);
-                    al[(ks + 1) & 1][i] = *reinterpret_cast<const FH*>(al_row + i * 32 * S + (ks + 1) * 16);
-                }
+            for (int i = 0; i < TM; ++i) {
+                ah[i] = *reinterpret_cast<const FH*>(ah_row + i * 32 * S + ks * 16);
+                al[i] = *reinterpret_cast<const FH*>(al_row + i * 32 * S + ks * 16);
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                accb[i] = MH::mma(al[ks & 1][i], bh[ks], accb[i]);
-                accb[i] = MH::mma(ah[ks & 1][i], bl[ks], accb[i]);
-                acc[i] = MH::mma(ah[ks & 1][i], bh[ks], acc[i]);
+                accb[i] = MH::mma(al[i], bh, accb[i]);
+                accb[i] = MH::mma(ah[i], bl, accb[i]);
+                acc[i] = MH::mma(ah[i], bh, acc[i]);
             }
         }
-        if (t + 1 < p.taps && !(p.dbg & 16)) {
+        if (t + 1 < p.taps) {
             __syncthreads();                  // every wave is done with this tap's weights
-            wstore(st);
+            wstore();
             __syncthreads();
         }
-    };
-    if (!(p.dbg & 1))
-    for (int t = 0; t < p.taps; t += 2) {
-        tap(t, wA, wB);
-        if (t + 1 < p.taps) tap(t + 1, wB, wA);
     }
     __syncthreads();                          // ... and with the activation planes, before OUT overwrites them
     // ---- 3. accumulators -> LDS -> coalesced epilogue ------------------------------------------------------------------
@@ -225,26 +169,16 @@ __global__ __launch_bounds__(256, BM <= 128 ? 2 : 1) void gconv_pairs_kernel(con
         float* ob = p.out + (long)b * p.out_bstride + (long)g * GCP_C;
         const float* rb = p.res ? p.res + (long)b * p.out_bstride + (long)g * GCP_C : nullptr;
         const float* bias = p.bias ? p.bias + g * GCP_C : nullptr;
-        constexpr int DEPTH = 4;                  // residual rows requested four trips ahead (same reason as in the prologue)
-        static_assert((BM * 16) % (256 * DEPTH) == 0, "whole batches");
-        for (int v0 = tid; v0 < BM * 16; v0 += 256 * DEPTH) {
-            float4 rv[DEPTH];
-#pragma unroll
-            for (int q = 0; q < DEPTH; ++q) {
-                const int v = v0 + q * 256, row = v >> 4, c4 = v & 15, m = m0 + row;
-                rv[q] = float4{0.f, 0.f, 0.f, 0.f};
-                if (rb && m < p.M && !(p.dbg & 2)) rv[q] = *reinterpret_cast<const float4*>(rb + (long)m * p.out_rstride + c4 * 4);
-            }
-#pragma unroll
-            for (int q = 0; q < DEPTH; ++q) {
-                const int v = v0 + q * 256, row = v >> 4, c4 = v & 15, m = m0 + row;
-                if (m >= p.M || (p.dbg & 2)) continue;
-                float4 o = *reinterpret_cast<const float4*>(OUT + row * GCP_C + c4 * 4);
-                if (bias) { const float4 bv = *reinterpret_cast<const float4*>(bias + c4 * 4); o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w; }
-                if (p.act != ACT_NONE) { o.x = gcp_act(o.x, p.act); o.y = gcp_act(o.y, p.act); o.z = gcp_act(o.z, p.act); o.w = gcp_act(o.w, p.act); }
-                o.x += rv[q].x; o.y += rv[q].y; o.z += rv[q].z; o.w += rv[q].w;
-                *reinterpret_cast<float4*>(ob + (long)m * p.out_rstride + c4 * 4) = o;
-            }
+        for (int v = tid; v < BM * 16; v += 256) {
+            const int row = v >> 4, c4 = v & 15;
+            const int m = m0 + row;
+            if (m >= p.M) continue;
+            float4 o = *reinterpret_cast<const float4*>(OUT + row * GCP_C + c4 * 4);
+            if (bias) { const float4 bv = *reinterpret_cast<const float4*>(bias + c4 * 4); o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w; }
+            if (p.act != ACT_NONE) { o.x = gcp_act(o.x, p.act); o.y = gcp_act(o.y, p.act); o.z = gcp_act(o.z, p.act); o.w = gcp_act(o.w, p.act); }
+            const long gi = (long)m * p.out_rstride + c4 * 4;
+            if (rb) { const float4 rv = *reinterpret_cast<const float4*>(rb + gi); o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w; }
+            *reinterpret_cast<float4*>(ob + gi) = o;
         }
     }
 }
@@ -262,7 +196,6 @@ bool launch_gconv_pairs(const ConvGemm& p, hipStream_t s) {
     d.T_in = p.T_in; d.M = p.M; d.taps = p.taps; d.pad = p.pad; d.act = p.act;
     d.x_bstride = p.x_bstride; d.x_rstride = p.x_rstride; d.x_goff = p.x_goff; d.out_bstride = p.out_bstride; d.out_rstride = p.out_rstride;
     d.K = p.taps * GCP_C;
-    { static const int dbg = [] { const char* e = std::getenv("MI355TTS_GCONV_DBG"); return e ? std::atoi(e) : 0; }(); d.dbg = dbg; }
     // rows per workgroup: 128 (two workgroups per CU) or 192 (one), whichever puts fewer rows on the busiest CU — one
     // utterance (B = 2, M = 1126, 16 groups) is 288 workgroups of 128 rows (32 CUs get two: 256 rows) or 192 of 192 rows
     int cus = 256;
@@ -280,11 +213,7 @@ bool launch_gconv_pairs(const ConvGemm& p, hipStream_t s) {
     lds = std::max(lds, (size_t)BM * GCP_C * 4);
     lds = (lds + 15) / 16 * 16;
     if (lds > 160 * 1024) return false;
-    d.ntile = (p.M + BM - 1) / BM; d.G = p.G; d.B = p.B;
-    const long nwg = (long)d.ntile * p.G * p.B;
-    d.xcd_map = (p.G % 8 == 0 && nwg % 8 == 0) ? 1 : 0;
-    if (nwg > 0x7fffffffL) return false;
-    const dim3 grid((unsigned)nwg);
+    const dim3 grid((p.M + BM - 1) / BM, p.G, p.B);
 #define GCP_LAUNCH(BMv)                                                                                                       \
     do {                                                                                                                      \
         auto kfn = gconv_pairs_kernel<BMv>;                                                                                   \
