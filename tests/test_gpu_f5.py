@@ -178,6 +178,30 @@ def test_attention_against_oracle_ragged_lengths(small):
     eng.close()
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
+def test_attention_xcd_aware_workgroup_map_is_bit_neutral(dtype):
+    """attn_xcd_map = 1 (off by default: measured -1.6 % on the bf16 attention launch, nothing in fp32) re-reads the workgroup
+    ids so that the query tiles of a head share one XCD's L2.  Only WHICH workgroup computes a tile changes: the DiT evaluation
+    must be bit-identical — 128-query and 64-query forms, key slices (N = 700 in fp32), batches of 1 and 2 utterances."""
+    from mi355tts import _lib
+    cfg = F5Config(dim=256, depth=1, heads=4, dim_head=64, text_dim=64, text_num_embeds=40, conv_layers=1,
+                   pos_conv_groups=4, vocos_dim=64, vocos_intermediate=128, vocos_layers=1, nfe_step=4)
+    eng = F5Engine(cfg, W.synth_state(W.f5_spec(cfg), 7), dtype=dtype)
+    try:
+        for U, N in ((1, 130), (2, 257), (1, 700)):
+            noise = W.synth_normal(3, f"n{N}", (U, N, cfg.mel_dim))
+            cmt = W.synth_normal(4, f"c{N}", (U, N, cfg.mel_dim + cfg.text_dim), std=0.7)
+            cmtd = W.synth_normal(5, f"d{N}", (U, N, cfg.mel_dim + cfg.text_dim), std=0.7)
+            _lib.set_option("attn_xcd_map", 0)
+            ref = eng.dit_eval(noise, cmt, cmtd, 1)
+            _lib.set_option("attn_xcd_map", 1)
+            got = eng.dit_eval(noise, cmt, cmtd, 1)
+            assert np.isfinite(ref).all() and np.array_equal(got, ref), (dtype, U, N)
+    finally:
+        _lib.set_option("attn_xcd_map", 0)
+        eng.close()
+
+
 def test_fp32_attention_split_products_match_native():
     """attn_f32_x3 = 1: q.k as exact three-way bf16 splits on the bf16 pipes; = 2: p.v as well (K / V^T split once per stage
     into bf16 planes in LDS, V transposed by the QKV epilogue); = 0: native fp32 MFMA.  All inside the DiT gate against the

@@ -44,11 +44,24 @@ namespace mi {
 //                 leave the q k product as fp16 values, are widened and multiplied by `sscale` (= 100) in fp32, softmax in fp32,
 //                 probabilities rounded to fp16 for P V.  Q is therefore NOT pre-multiplied by log2(e) (that would re-round
 //                 it): log2(e) rides on `sscale`.
+// Workgroup -> (query tile, head).  Consecutive workgroup ids (x fastest) go to consecutive XCDs, so the query tiles of one head
+// — which all stream that head's K and V — land on up to eight different L2s and each fetches K / V from the fabric for itself.
+// With `xmap` (heads a multiple of 8) the ids are re-read so that XCD x serves heads x, x + 8, ...: a head's query tiles share
+// one L2.  Each z plane (key slice) starts at XCD 0 because gridDim.x * gridDim.y is then a multiple of 8.
+#define ATTN_XCD_MAP                                                                          \
+    int bx_ = (int)blockIdx.x, by_ = (int)blockIdx.y;                                         \
+    if (xmap) {                                                                               \
+        const int l2 = bx_ + (int)gridDim.x * by_, slot = l2 >> 3;                            \
+        by_ = (l2 & 7) + 8 * (slot / (int)gridDim.x);                                         \
+        bx_ = slot % (int)gridDim.x;                                                          \
+    }
+
 template <typename T, bool SPLIT2 = false, bool X3S = false, bool REFH = false>
 __global__ __launch_bounds__(256, 3) void attn_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                    const T* __restrict__ v, T* __restrict__ o, int H, int N,
-                                                   float* __restrict__ ws, int* __restrict__ cnt, float sscale = 1.f) {
+                                                   float* __restrict__ ws, int* __restrict__ cnt, float sscale = 1.f, int xmap = 0) {
     static_assert(!REFH || (sizeof(T) == 2 && !X3S), "REFH is the fp16 form");
+    ATTN_XCD_MAP
     using MF = Mfma<T>;
     constexpr int KP = MF::KP;
     constexpr int D = 64, KT = 64;
@@ -63,8 +76,8 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const T* __restrict__ q, c
     T* Vs = smem + KT * LDK;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, hi = lane >> 5;
-    const int bh = blockIdx.y;
-    const int q0 = SPLIT2 ? blockIdx.x * 64 + (wave >> 1) * 32 : blockIdx.x * 128 + wave * 32;
+    const int bh = by_;
+    const int q0 = SPLIT2 ? bx_ * 64 + (wave >> 1) * 32 : bx_ * 128 + wave * 32;
     const T* qb = q + (long)bh * N * D;
     const T* kb = k + (long)bh * N * D;
     const long vld = sizeof(T) == 4 ? 0 : (long)((N + 7) / 8 * 8);
@@ -328,7 +341,7 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const T* __restrict__ q, c
         const int Z = (int)gridDim.z;
         if (Z > 1) {
             const int z = (int)blockIdx.z;
-            const int unit = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+            const int unit = (int)(by_ * gridDim.x + bx_);
             constexpr int SLOT = 2 * 32 * 64 + 2 * 64 * 2;           // floats per (unit, slice)
             // write-through (sc1) stores / sc1 loads through a buffer descriptor, as in gemm_sk.hip: no L2-wide write-back fence
             typedef unsigned int u4 __attribute__((ext_vector_type(4)));
@@ -439,7 +452,8 @@ template <bool SPLIT2, bool KVP = false, int NP = 3>
 __global__ __launch_bounds__(256, NP == 2 ? 3 : 2) void attn_x3f_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                        const float* __restrict__ v, float* __restrict__ o, int H, int N,
                                                        float* __restrict__ ws, int* __restrict__ cnt,
-                                                       unsigned char* __restrict__ o_planes, int o_np) {
+                                                       unsigned char* __restrict__ o_planes, int o_np, int xmap = 0) {
+    ATTN_XCD_MAP
     // o_planes != null: the output leaves as gemm_x3p.hip panel planes of the [B * N][H * 64] matrix (the A operand of the O
     // projection), split here (o_np = 3 bf16 planes | 2 fp16 planes), instead of fp32 rows in o
     static_assert(NP == 3 || (NP == 2 && KVP), "attn_x3f: the two-plane form reads pre-split K / V");
@@ -454,8 +468,8 @@ __global__ __launch_bounds__(256, NP == 2 ? 3 : 2) void attn_x3f_kernel(const fl
     bf16* Vs = smem + NP * KPL;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, hi = lane >> 5;
-    const int bh = blockIdx.y;
-    const int q0 = SPLIT2 ? blockIdx.x * 64 + (wave >> 1) * 32 : blockIdx.x * 128 + wave * 32;
+    const int bh = by_;
+    const int q0 = SPLIT2 ? bx_ * 64 + (wave >> 1) * 32 : bx_ * 128 + wave * 32;
     const float* qb = q + (long)bh * N * D;
     const float* kb = k + (long)bh * N * D;
     const long vld = KVP ? (long)((N + 63) / 64 * 64) : (long)((N + 7) / 8 * 8);
@@ -733,7 +747,7 @@ __global__ __launch_bounds__(256, NP == 2 ? 3 : 2) void attn_x3f_kernel(const fl
         const int Z = (int)gridDim.z;
         if (Z > 1) {
             const int z = (int)blockIdx.z;
-            const int unit = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+            const int unit = (int)(by_ * gridDim.x + bx_);
             constexpr int SLOT = 2 * 32 * 64 + 2 * 64 * 2;           // floats per (unit, slice)
             // write-through (sc1) stores / sc1 loads through a buffer descriptor, as in gemm_sk.hip: no L2-wide write-back fence
             typedef unsigned int u4 __attribute__((ext_vector_type(4)));
@@ -846,6 +860,7 @@ static std::atomic<int> g_attn_x3 = 2;
 static std::atomic<int> g_attn_np = 2;                                // format of the pre-split K / V^T (and of Q / P inside the kernel): 2 fp16 pairs | 3 bf16 planes
 static std::atomic<int> g_attn_split = 1;                             // 64-query workgroups with the keys split between wave pairs when the grid is small
 static std::atomic<int> g_attn_zmax = 4, g_attn_z16 = 1, g_attn_zforce = 0;      // zforce (tests): exactly that many slices, even empty ones
+static std::atomic<int> g_attn_xmap = 0;                              // XCD-aware (query tile, head) map of the workgroup ids (A/B: attn_xcd_map)
 static std::atomic<int> g_attn_kvp = 1;                               // fp32, both products split: K / V^T pre-split by the QKV epilogue (A/B: attn_kv_planes)
 // The MI355TTS_ATTN_* environment overrides are read ONCE, before the first use of any of the globals above by ANY of the
 // three entry points: F5::dit_eval asks attention_v_ld() for the V layout of the QKV epilogue before the first
@@ -873,6 +888,7 @@ bool attn_set_option(const char* key, long v) {
     else if (k == "attn_z16_max") g_attn_z16 = (int)std::max(1L, std::min(4L, v));
     else if (k == "attn_f32_x3") g_attn_x3 = (int)std::max(0L, std::min(2L, v));
     else if (k == "attn_split") g_attn_split = v != 0;
+    else if (k == "attn_xcd_map") g_attn_xmap = v != 0;
     else if (k == "attn_kv_planes") g_attn_kvp = v != 0;
     else if (k == "attn_f32_planes") { if (v != 2 && v != 3) return false; g_attn_np = (int)v; }
     else if (k == "attn_z_force") g_attn_zforce = (int)std::max(0L, std::min(4L, v));
@@ -910,6 +926,7 @@ void launch_attention(const void* q, const void* k, const void* v, void* o, int 
         hipLaunchKernelGGL((attn_kernel<TT, SP>), __VA_ARGS__);                 \
     } while (0)
     attn_env_once();
+    const int xm = (g_attn_xmap != 0 && BH % 8 == 0) ? 1 : 0;
     const int zmax = g_attn_zmax;
     // key slices for the SPLIT2 form (see attn_kernel): makespan(Z) = ceil(units * Z / CUs) / Z in units of one unsliced
     // workgroup, + 6 % per extra slice for the prologue and the merge (measured, fp32, one utterance = 576 units:
@@ -946,7 +963,7 @@ void launch_attention(const void* q, const void* k, const void* v, void* o, int 
             if (g_attn_x3 == 2) {
                 if (kv_planes == 2) {
                     prof_set_kernel("attn_x3f_kernel<true, pre-split K V, fp16 pairs>", "", "");
-                    hipLaunchKernelGGL((attn_x3f_kernel<true, true, 2>), dim3((N + 63) / 64, BH, Z), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt, (unsigned char*)o_planes, o_np);
+                    hipLaunchKernelGGL((attn_x3f_kernel<true, true, 2>), dim3((N + 63) / 64, BH, Z), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt, (unsigned char*)o_planes, o_np, xm);
                 } else if (kv_planes) {
                     prof_set_kernel("attn_x3f_kernel<true, pre-split K V>", "", "");
                     hipLaunchKernelGGL((attn_x3f_kernel<true, true>), dim3((N + 63) / 64, BH, Z), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt, (unsigned char*)o_planes, o_np);
@@ -962,7 +979,7 @@ void launch_attention(const void* q, const void* k, const void* v, void* o, int 
         } else if (g_attn_x3 == 2) {
             if (kv_planes == 2) {
                 prof_set_kernel("attn_x3f_kernel<false, pre-split K V, fp16 pairs>", "", "");
-                hipLaunchKernelGGL((attn_x3f_kernel<false, true, 2>), dim3((N + 127) / 128, BH), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt, (unsigned char*)o_planes, o_np);
+                hipLaunchKernelGGL((attn_x3f_kernel<false, true, 2>), dim3((N + 127) / 128, BH), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt, (unsigned char*)o_planes, o_np, xm);
             } else if (kv_planes) {
                 prof_set_kernel("attn_x3f_kernel<false, pre-split K V>", "", "");
                 hipLaunchKernelGGL((attn_x3f_kernel<false, true>), dim3((N + 127) / 128, BH), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt, (unsigned char*)o_planes, o_np);
@@ -985,11 +1002,11 @@ void launch_attention(const void* q, const void* k, const void* v, void* o, int 
             if (sp) hipLaunchKernelGGL((attn_kernel<f16, true, false, true>), grid, dim3(256), 0, s, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)o, H, N, ws, cnt, ref_fp16_scale);
             else hipLaunchKernelGGL((attn_kernel<f16, false, false, true>), grid, dim3(256), 0, s, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)o, H, N, ws, cnt, ref_fp16_scale);
         } else if (dtype == MI_F16) {
-            if (sp) ATTN_LAUNCH(f16, true, grid, dim3(256), 0, s, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)o, H, N, ws, cnt);
-            else ATTN_LAUNCH(f16, false, grid, dim3(256), 0, s, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)o, H, N, ws, cnt);
+            if (sp) ATTN_LAUNCH(f16, true, grid, dim3(256), 0, s, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)o, H, N, ws, cnt, 1.f, xm);
+            else ATTN_LAUNCH(f16, false, grid, dim3(256), 0, s, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)o, H, N, ws, cnt, 1.f, xm);
         } else {
-            if (sp) ATTN_LAUNCH(bf16, true, grid, dim3(256), 0, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, H, N, ws, cnt);
-            else ATTN_LAUNCH(bf16, false, grid, dim3(256), 0, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, H, N, ws, cnt);
+            if (sp) ATTN_LAUNCH(bf16, true, grid, dim3(256), 0, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, H, N, ws, cnt, 1.f, xm);
+            else ATTN_LAUNCH(bf16, false, grid, dim3(256), 0, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, H, N, ws, cnt, 1.f, xm);
         }
     }
 #undef ATTN_LAUNCH
