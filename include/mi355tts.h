@@ -250,8 +250,8 @@ int         mi_indextts_cond_run(mi_cond* h, const int16_t* audio, int64_t L, fl
  * "gemm_f32_n64_pairs" (fp32 convolutions with 64 channels per group and >= 8 taps — the DiT position convolution — on fp16
  * pairs; 0: native fp32 MFMA) and "gemm_f32_gconv" (default 1: gconv_pairs.hip, each operand split once per workgroup; 0: the
  * LDS-DMA kernel that splits in registers per k-step);
- * "attn_xcd_map" (default 0; 1: the attention kernels re-read their workgroup ids so that the query tiles of a head run on one
- * XCD — bit-identical results, measured within 2 % either way);
+ * "attn_xcd_map" (default 1: the attention kernels re-read their workgroup ids so that the query tiles of a head run on one
+ * XCD and share its L2 — bit-identical results, about 1 % per launch; 0: plain (tile, head) order);
  * "bigvgan_streams" (default 3): the AMP blocks of a BigVGAN stage (one per resblock kernel size) on side streams of the
  * handle — 1: everything on the handle's one stream; 2: only the stages whose AMP halves are separate AA and conv launches
  * (C > 96); 3: every stage.  The waveform is bit-identical in all three.

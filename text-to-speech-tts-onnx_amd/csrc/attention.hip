@@ -860,7 +860,7 @@ static std::atomic<int> g_attn_x3 = 2;
 static std::atomic<int> g_attn_np = 2;                                // format of the pre-split K / V^T (and of Q / P inside the kernel): 2 fp16 pairs | 3 bf16 planes
 static std::atomic<int> g_attn_split = 1;                             // 64-query workgroups with the keys split between wave pairs when the grid is small
 static std::atomic<int> g_attn_zmax = 4, g_attn_z16 = 1, g_attn_zforce = 0;      // zforce (tests): exactly that many slices, even empty ones
-static std::atomic<int> g_attn_xmap = 0;                              // XCD-aware (query tile, head) map of the workgroup ids (A/B: attn_xcd_map)
+static std::atomic<int> g_attn_xmap = 1;                              // XCD-aware (query tile, head) map of the workgroup ids (A/B: attn_xcd_map; -1 % per launch, bit-neutral)
 static std::atomic<int> g_attn_kvp = 1;                               // fp32, both products split: K / V^T pre-split by the QKV epilogue (A/B: attn_kv_planes)
 // The MI355TTS_ATTN_* environment overrides are read ONCE, before the first use of any of the globals above by ANY of the
 // three entry points: F5::dit_eval asks attention_v_ld() for the V layout of the QKV epilogue before the first
