@@ -433,8 +433,9 @@ def run_f5(args, world, rank, local, dev, dist, torch):
                    "collective_backend": dist.get_backend() if world > 1 else None,
                    "arithmetic": ("fp32 values, fp32 accumulation; the DiT linear layers form each fp32 product as three fp16 x fp16 partial products "
                                   "(operands as fp16 {hi, lo * 2^11} pairs = 22 significant bits, gemm_x3p.hip: measured error against float64 "
-                                  "BELOW the native fp32 MFMA's), both products of attention as six exact bf16 x bf16 partial products (3-way "
-                                  "split) — same fp32 parity gates as the native fp32 MFMA path, which is timed in secondary.f5_f32_native_mfma") if args.dtype == "f32" else "16-bit operands, fp32 accumulation, fp32 residual stream",
+                                  "BELOW the native fp32 MFMA's), both products of attention and the grouped position convolution the same way "
+                                  "(attention with the low parts unscaled: its operands are of order one) — same fp32 parity gates as the "
+                                  "native fp32 MFMA path, which is timed in secondary.f5_f32_native_mfma") if args.dtype == "f32" else "16-bit operands, fp32 accumulation, fp32 residual stream",
                    "end_to_end_TFLOP_per_step": res["end_to_end_TFLOP_per_step"],
                    "end_to_end_TFLOP_per_s": res["end_to_end_TFLOP_per_s"],
                    "inputs": "audio / text ids / injected noise resident in HBM, int16 waveform left in HBM",
