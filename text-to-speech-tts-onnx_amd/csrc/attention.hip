@@ -56,6 +56,19 @@ namespace mi {
         bx_ = slot % (int)gridDim.x;                                                          \
     }
 
+// lane <-> lane ^ 32 exchange of the online softmax (row max, row sum: a query column lives in lanes l and l + 32) on
+// v_permlane32_swap instead of ds_bpermute (no LDS-crossbar round trip on the S -> max -> exp chain).  Two copies of the value
+// go in; the instruction leaves {own low | low} in one register and {high | own high} in the other, so their max / sum is the
+// pair's in every lane, and a + b == b + a bit for bit: both halves still agree and the values are those of the shuffle form.
+// Inline asm: on this toolchain the builtin returns the first register twice (tools/ubench/permlane32b.hip); the s_nop covers
+// the VALU-write -> permlane-read hazard (two wait states).
+__device__ __forceinline__ void xor32_pair(float v, float& a, float& b) {
+    a = v; b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float xor32_max(float v) { float a, b; xor32_pair(v, a, b); return fmaxf(a, b); }
+__device__ __forceinline__ float xor32_sum(float v) { float a, b; xor32_pair(v, a, b); return a + b; }
+
 template <typename T, bool SPLIT2 = false, bool X3S = false, bool REFH = false>
 __global__ __launch_bounds__(256, 3) void attn_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                    const T* __restrict__ v, T* __restrict__ o, int H, int N,
@@ -233,7 +246,7 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const T* __restrict__ q, c
             float mloc = -INFINITY;
 #pragma unroll
             for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, sacc[r]);
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32));         // (v_permlane32_swap measured 1 % SLOWER in this kernel, 3.5 % faster in attn_x3f_kernel)
             // lazy rescale: keep the old reference max while it is within 2^8 of the new one (P <= 256, exact in
             // fp32 accumulation); rescale O and l only when some query of the wave needs it (wave-uniform branch)
             float alpha = 1.f;
@@ -638,7 +651,7 @@ __global__ __launch_bounds__(256, NP == 2 ? 3 : 2) void attn_x3f_kernel(const fl
             float mloc = -INFINITY;
 #pragma unroll
             for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, sacc[r]);
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+            mloc = xor32_max(mloc);
             float alpha = 1.f;
             if (!__all(mloc - m_run <= 8.0f)) {
                 const float m_new = fmaxf(m_run, mloc);
@@ -659,7 +672,7 @@ __global__ __launch_bounds__(256, NP == 2 ? 3 : 2) void attn_x3f_kernel(const fl
                 ls2 += e;
             }
             float lsum = ls2.x + ls2.y;
-            lsum += __shfl_xor(lsum, 32);
+            lsum = xor32_sum(lsum);
             l_run = l_run * alpha + lsum;
             // ---- O^T += V^T P^T: the probabilities a lane holds are the B operand (keys in accumulator-row order) ------------
 #pragma unroll
