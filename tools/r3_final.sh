@@ -5,7 +5,7 @@
 #   the BigVGAN / IndexTTS workloads; bench.py --gpus 2 started WITHOUT a launcher (both ranks on this box's one GPU, gloo)
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-O=$ROOT/gpurun_out/r3final8; mkdir -p $O
+O=$ROOT/gpurun_out/r3final9; mkdir -p $O
 cd $ROOT
 timeout 2400 python -m pytest tests -m gpu -q -x -rA --timeout 900 > $O/tests_gpu_rA.log 2>&1; tail -3 $O/tests_gpu_rA.log
 timeout 1200 python bench.py --steps 10 --warmup 2 > $O/bench_default_final.json 2> $O/bench_default_final.err
