@@ -118,6 +118,15 @@ mi_f5*      mi_f5_create_mem(const int32_t* cfg_i, int n_i, const float* cfg_f, 
 void        mi_f5_destroy(mi_f5* h);
 /* load-time tables (tests): time_expand (nfe, dim), delta_t (nfe-1)   Export_F5.py:153-164          */
 int         mi_f5_tables(mi_f5* h, float* time_expand, float* delta_t);
+/* What the engine is doing, machine-readably (no reference counterpart: ONNX Runtime has one arithmetic).  Keys:
+ *   "f32_arithmetic"     fp32 engines: 0 native fp32 MFMA | 2 fp16 {hi, lo} pairs | 3 three bf16 planes — the form IN USE (the
+ *                        config's trailing int 21 selects it; an fp16-pair engine whose weights exceed the fp16 range at load,
+ *                        or whose activations do during a call, has switched itself to 3); -1 for 16-bit engines
+ *   "saturation_events"  calls on this handle during which a pair operand met the fp16 range limit and that were therefore
+ *                        re-run on three bf16 planes (0 or 1: the switch is permanent)
+ *   "adaln_fold"         1 when the load-time vectors of the AdaLN fold exist (LayerNorm statistics carried by the GEMM epilogues)
+ * Returns the value, or a negative MI_E* code for a null handle / unknown key.                                              */
+int64_t     mi_f5_info(mi_f5* h, const char* key);
 /* graph A.  audio (L) int16, text_ids (T) int32 (pad value -1 allowed), max_duration N.
  * noise_in != NULL injects the initial noise (N,100); else it is drawn from `seed`.
  * Outputs (any may be NULL): noise (N,100), rope_cos/rope_sin (N,64) [the ONNX graph broadcasts these

@@ -364,20 +364,19 @@ def gfull(golden_dir):
     return np.load(os.path.join(golden_dir, "f5_full.npz"))
 
 
-@pytest.mark.parametrize("form", ["fp16-pairs", "bf16x3-splits", "native-fp32-mfma"])
+@pytest.mark.parametrize("form", ["fp16-pairs", "fp16-pairs, row-norm launches", "bf16x3-splits", "native-fp32-mfma"])
 def test_full_size_fp32_against_reference_fixture(full, gfull, form):
     """configs[2]: fp32, one utterance, NFE grid 32 — the north-star gate (waveform <= 1e-3 RMS) on the north-star config.
-    All three fp32 forms of the engine: the default (linear layers as fp16 {hi, lo} pairs: gemm_f32_planes = 2, attention as
-    exact bf16 splits), the linear layers as three bf16 planes (gemm_f32_planes = 3: round 3's first form) and the native
-    fp32 MFMA (gemm_f32_x3 = 0, attn_f32_x3 = 0: what bench.py times as secondary.f5_f32_native_mfma)."""
-    from mi355tts import _lib
-    if form == "native-fp32-mfma":
-        _lib.set_option("gemm_f32_x3", 0); _lib.set_option("attn_f32_x3", 0)
-    _lib.set_option("gemm_f32_planes", 3 if form == "bf16x3-splits" else 2)       # read when the engine splits its weights
-    try:
-        _full_size_fp32_body(full, gfull, form)
-    finally:
-        _lib.set_option("gemm_f32_x3", 1); _lib.set_option("attn_f32_x3", 2); _lib.set_option("gemm_f32_planes", 2)
+    Every fp32 form of the engine, selected per ENGINE (F5Config.f32_arithmetic / adaln_fold, round 4): the default (linear
+    layers, attention and position convolution as fp16 {hi, lo} pairs, AdaLN folded into the GEMM epilogues), the same with
+    row-norm launches instead of the fold, the linear layers as three bf16 planes (round 3's first form) and the native fp32
+    MFMA (what bench.py times as secondary.f5_f32_native_mfma)."""
+    import dataclasses
+    cfg = full[0]
+    kind = {"fp16-pairs": "fp16x2-pairs", "fp16-pairs, row-norm launches": "fp16x2-pairs", "bf16x3-splits": "bf16x3",
+            "native-fp32-mfma": "native-fp32-mfma"}[form]
+    cfg2 = dataclasses.replace(cfg, f32_arithmetic=kind, adaln_fold=False if "row-norm" in form else None)
+    _full_size_fp32_body((cfg2,) + tuple(full[1:]), gfull, form)
 
 
 def _full_size_fp32_body(full, gfull, form):
@@ -403,6 +402,7 @@ def _full_size_fp32_body(full, gfull, form):
     err = rms((w[0, 0].astype(np.float64) - gfull["e2e_i16"].astype(np.float64)) / 32767.0)
     assert err < 1e-3, err                                               # THE north-star gate
     assert rms(gfull["e2e_i16"]) > 500
+    assert eng.info()["f32_arithmetic"] == cfg.f32_arithmetic and eng.info()["saturation_events"] == 0
     eng.close()
     print(f"F5 full size fp32 ({form}) vs reference: DiT eval rel {e_pred:.2e}, "
           f"31-step state rel {e_loop:.2e}, waveform rms {err:.2e}")
@@ -556,3 +556,145 @@ def test_real_prompt_stft_and_mel(golden_dir, small):
     m = z["logmel"] > np.log(2e-5)
     assert m.mean() > 0.9
     assert np.abs(lm - z["logmel"])[m].max() < 2e-3
+
+
+# ---------------------------------------------------------------------------------------------
+# Round 4: the AdaLN fold, the engine-level fp32 arithmetic and the fp16-pair range watch
+# ---------------------------------------------------------------------------------------------
+def _mid_cfg(**kw):
+    """Full-width DiT layers (dim 1024 / heads 16: the shapes whose kernels carry the fold), two blocks, small front / back end."""
+    return F5Config(depth=2, text_dim=64, text_num_embeds=40, conv_layers=1, vocos_dim=64, vocos_intermediate=128, vocos_layers=1,
+                    nfe_step=4, **kw)
+
+
+def _mid_inputs(cfg, U, N, seed=3):
+    noise = np.stack([W.synth_normal(seed + u, f"n{N}", (N, cfg.mel_dim)) for u in range(U)])
+    cmt = np.stack([W.synth_normal(seed + 11 + u, f"c{N}", (N, cfg.mel_dim + cfg.text_dim), std=0.7) for u in range(U)])
+    cmtd = np.stack([W.synth_normal(seed + 22 + u, f"d{N}", (N, cfg.mel_dim + cfg.text_dim), std=0.7) for u in range(U)])
+    return noise, cmt, cmtd
+
+
+def _norm_launches(eng, noise, cmt, cmtd, k):
+    from mi355tts import _lib
+    _lib.prof_reset(); _lib.prof_enable(["norm", "conv_gemm"])
+    try:
+        eng.dit_eval(noise, cmt, cmtd, k)
+    finally:
+        _lib.prof_enable(())
+    ks = _lib.prof_kernels()
+    return _lib.prof_get("norm")["launches"], [x["kernel"] for x in ks]
+
+
+@pytest.mark.parametrize("dtype,tol_paths,tol_oracle", [("f32", 1e-6, 5e-6), ("f16", 5e-4, 1.5e-3), ("bf16", 4e-3, 1.2e-2)])      # achieved: 2.3e-7 / 1.4e-6, 1.4e-4 / 4.5e-4, 1.1e-3 / 3.6e-3
+def test_adaln_fold_against_rownorm_path_and_oracle(dtype, tol_paths, tol_oracle):
+    """AdaLayerNorm (modules.py:301-305) folded into the GEMM epilogues either side of it (gemm_epilogue.h): the O / FF2 epilogue
+    leaves x o (1 + scale) and per-row partial statistics, the QKV / FF1 epilogue finishes rstd * acc - mean * rstd * W(1 + scale)
+    + (W shift + b).  Against the same engine with the fold off (row-norm launches) and against the oracle; one and three
+    utterances (the stream-K panel-plane kernel / the 128x128 and 256x256 16-bit kernels), odd and panel-filling token counts."""
+    import dataclasses
+    cfg = _mid_cfg()
+    raw = W.synth_state(W.f5_spec(cfg), 7)
+    st = W.fold_f5(cfg, raw)
+    tables = O.time_tables(cfg, st)
+    e_fold = F5Engine(cfg, raw, dtype=dtype)
+    e_rows = F5Engine(dataclasses.replace(cfg, adaln_fold=False), raw, dtype=dtype)
+    try:
+        assert e_fold.info()["adaln_fold"] and not e_rows.info()["adaln_fold"]
+        # (fp32: the panel-plane kernel takes a layer from 64 tiles of 128 x 128 on: >= 897 rows for the O / FF2 projections)
+        for U, N in ((1, 500), (3, 257), (2, 640)) if dtype == "f32" else ((1, 300), (3, 257), (8, 1126)):
+            noise, cmt, cmtd = _mid_inputs(cfg, U, N)
+            a = e_fold.dit_eval(noise, cmt, cmtd, 2)
+            b = e_rows.dit_eval(noise, cmt, cmtd, 2)
+            e_ab = rms(a - b) / rms(b)
+            assert np.isfinite(a).all() and e_ab < tol_paths, (dtype, U, N, e_ab)
+            n_fold, names = _norm_launches(e_fold, noise, cmt, cmtd, 2)
+            n_rows, _ = _norm_launches(e_rows, noise, cmt, cmtd, 2)
+            # the fold keeps two norm-family launches per evaluation (the first block's prologue, AdaLN-final); rows: 2 per block + 1
+            assert n_fold == 2 and n_rows == 2 * cfg.depth + 1, (n_fold, n_rows, names)
+            if dtype == "f32":
+                assert any("AdaLN fold" in k for k in names), names
+            if U <= 3:
+                cos, sin = O.rope_tables(N, 64)
+                ref = O.dit_forward(cfg, st, noise[0], cmt[0], cmtd[0], tables[2][2], cos, sin)
+                e_o = rms(a[:2] - ref) / rms(ref)
+                assert e_o < tol_oracle, (dtype, U, N, e_o)
+                print(f"AdaLN fold {dtype} U={U} N={N}: fold vs row-norm path rel rms {e_ab:.2e}, fold vs oracle {e_o:.2e}")
+        # run-to-run identity of the fold (plain stores, fixed summation order everywhere)
+        a2 = e_fold.dit_eval(noise, cmt, cmtd, 2)
+        assert np.array_equal(a, a2)
+    finally:
+        e_fold.close(); e_rows.close()
+
+
+def test_two_engines_with_different_fp32_arithmetic_coexist():
+    """The fp32 arithmetic is a property of the engine (F5Config.f32_arithmetic), not of the process: an fp16-pair engine, a
+    three-plane bf16 engine and a native-fp32-MFMA engine alive at once, called alternately, each give exactly what they give
+    alone — and report what they run (mi_f5_info)."""
+    import dataclasses
+    cfg = _mid_cfg()
+    raw = W.synth_state(W.f5_spec(cfg), 7)
+    noise, cmt, cmtd = _mid_inputs(cfg, 1, 500)
+    kinds = ["fp16x2-pairs", "bf16x3", "native-fp32-mfma"]
+    alone = {}
+    for kind in kinds:
+        e = F5Engine(dataclasses.replace(cfg, f32_arithmetic=kind), raw, dtype="f32")
+        assert e.info()["f32_arithmetic"] == kind
+        alone[kind] = e.dit_eval(noise, cmt, cmtd, 1)
+        e.close()
+    engines = {kind: F5Engine(dataclasses.replace(cfg, f32_arithmetic=kind), raw, dtype="f32") for kind in kinds}
+    try:
+        for _ in range(2):
+            for kind in kinds:
+                got = engines[kind].dit_eval(noise, cmt, cmtd, 1)
+                assert np.array_equal(got, alone[kind]), kind
+        assert not np.array_equal(alone["fp16x2-pairs"], alone["native-fp32-mfma"])
+        for kind in kinds[:2]:
+            assert rms(alone[kind] - alone["native-fp32-mfma"]) / rms(alone["native-fp32-mfma"]) < 3e-6
+        assert F5Engine(cfg, raw, dtype="bf16").info()["f32_arithmetic"] is None
+    finally:
+        for e in engines.values():
+            e.close()
+
+
+def test_fp16_pair_range_watch_heavy_tailed_operands():
+    """fp16 pairs hold |a| <= 65504 and used to clamp silently.  (a) activations: a DiT whose residual
+    stream carries a few 1e5 outliers (a conditioning row scaled up) — the pair engine must notice (saturation_events), switch
+    itself to the exact three-plane bf16 split, re-run the call, and agree with the native-fp32 engine; (b) weights: a matrix
+    with one 1e5 entry is loaded straight into the three-plane format."""
+    import dataclasses
+    cfg = _mid_cfg()
+    raw = W.synth_state(W.f5_spec(cfg), 7)
+    noise, cmt, cmtd = _mid_inputs(cfg, 1, 500)
+    e_nat = F5Engine(dataclasses.replace(cfg, f32_arithmetic="native-fp32-mfma"), raw, dtype="f32")
+    e_pair = F5Engine(dataclasses.replace(cfg, f32_arithmetic="fp16x2-pairs"), raw, dtype="f32")
+    try:
+        ok = e_pair.dit_eval(noise, cmt, cmtd, 1)
+        assert e_pair.info() == {"f32_arithmetic": "fp16x2-pairs", "saturation_events": 0, "adaln_fold": True}
+        ref_ok = e_nat.dit_eval(noise, cmt, cmtd, 1)
+        assert rms(ok - ref_ok) / rms(ref_ok) < 3e-6
+        # heavy tail: 0.1 % of the conditioning entries at +-3e6 (they reach the residual stream through in_proj: rows of ~1e5)
+        hot = cmt.copy()
+        idx = np.unravel_index(np.arange(0, hot.size, 997), hot.shape)
+        hot[idx] = 3e6 * np.sign(hot[idx] + 1e-9)
+        ref = e_nat.dit_eval(noise, hot, cmtd, 1)
+        got = e_pair.dit_eval(noise, hot, cmtd, 1)
+        info = e_pair.info()
+        assert info["saturation_events"] == 1 and info["f32_arithmetic"] == "bf16x3", info
+        assert np.isfinite(got).all() and rms(got - ref) / rms(ref) < 1e-5, rms(got - ref) / rms(ref)
+        # the switch is permanent and the ordinary input still gives an fp32-equivalent answer
+        again = e_pair.dit_eval(noise, cmt, cmtd, 1)
+        assert rms(again - ref_ok) / rms(ref_ok) < 3e-6 and e_pair.info()["saturation_events"] == 1
+    finally:
+        e_nat.close(); e_pair.close()
+    big = {k: v.copy() for k, v in raw.items()}
+    name = next(k for k in big if k.endswith("attn.to_q.weight"))
+    big[name][3, 5] = 1e6          # (the q rows are folded with 64^-0.25 on the way in: still beyond 65504)
+    e = F5Engine(dataclasses.replace(cfg, f32_arithmetic="fp16x2-pairs"), big, dtype="f32")
+    try:
+        assert e.info()["f32_arithmetic"] == "bf16x3"
+        en = F5Engine(dataclasses.replace(cfg, f32_arithmetic="native-fp32-mfma"), big, dtype="f32")
+        a, b = e.dit_eval(noise, cmt, cmtd, 1), en.dit_eval(noise, cmt, cmtd, 1)
+        en.close()
+        assert np.isfinite(a).all() and rms(a - b) / rms(b) < 1e-5
+    finally:
+        e.close()

@@ -879,6 +879,8 @@ static std::atomic<int> g_attn_kvp = 1;                               // fp32, b
 // three entry points: F5::dit_eval asks attention_v_ld() for the V layout of the QKV epilogue before the first
 // launch_attention() of the process, and a lazy read inside launch_attention() made that first block write V transposed
 // for a kernel that then read it untransposed.  mi_set_option() applied later overrides the environment.
+static inline int opt_attn_x3() { const int o = arith_tls().attn_x3; return o >= 0 ? o : (int)g_attn_x3; }      // the engine's arithmetic first (ArithScope, common.h)
+static inline int opt_attn_np() { const int o = arith_tls().attn_np; return (o == 2 || o == 3) ? o : (int)g_attn_np; }
 static void attn_env_once() {
     static std::once_flag once;
     std::call_once(once, [] {
@@ -892,7 +894,7 @@ static void attn_env_once() {
 }
 long attention_v_ld(int N, int dtype) {
     attn_env_once();
-    return (dtype == MI_F32 && g_attn_x3 != 2) ? 0 : (long)((N + 7) / 8 * 8);
+    return (dtype == MI_F32 && opt_attn_x3() != 2) ? 0 : (long)((N + 7) / 8 * 8);
 }
 bool attn_set_option(const char* key, long v) {
     attn_env_once();
@@ -912,15 +914,15 @@ bool attn_set_option(const char* key, long v) {
 bool attention_takes_kv_planes(int N, int BH, int dtype) {
     attn_env_once();
     (void)N; (void)BH;
-    return dtype == MI_F32 && g_attn_x3 == 2 && g_attn_kvp != 0;
+    return dtype == MI_F32 && opt_attn_x3() == 2 && g_attn_kvp != 0;
 }
 
-int attention_kv_planes_format() { attn_env_once(); return g_attn_np; }
+int attention_kv_planes_format() { attn_env_once(); return opt_attn_np(); }
 
 bool attention_can_write_planes(int N, int BH, int dtype) {
     attn_env_once();
     (void)N; (void)BH;
-    return dtype == MI_F32 && g_attn_x3 == 2;
+    return dtype == MI_F32 && opt_attn_x3() == 2;
 }
 
 void launch_attention(const void* q, const void* k, const void* v, void* o, int BH, int H, int N, int dtype, hipStream_t s,
@@ -973,7 +975,7 @@ void launch_attention(const void* q, const void* k, const void* v, void* o, int 
         if (g_attn_split && (long)((N + 127) / 128) * BH < 1024 && N >= 64) {
             // ... and cut the key range into Z slices when that evens out the workgroups per CU
             const int Z = pick_z(1);
-            if (g_attn_x3 == 2) {
+            if (opt_attn_x3() == 2) {
                 if (kv_planes == 2) {
                     prof_set_kernel("attn_x3f_kernel<true, pre-split K V, fp16 pairs>", "", "");
                     hipLaunchKernelGGL((attn_x3f_kernel<true, true, 2>), dim3((N + 63) / 64, BH, Z), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt, (unsigned char*)o_planes, o_np, xm);
@@ -984,12 +986,12 @@ void launch_attention(const void* q, const void* k, const void* v, void* o, int 
                 prof_set_kernel("attn_x3f_kernel<true>", "", "");
                 hipLaunchKernelGGL((attn_x3f_kernel<true>), dim3((N + 63) / 64, BH, Z), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt, (unsigned char*)o_planes, o_np);
                 }
-            } else if (g_attn_x3 == 1) {
+            } else if (opt_attn_x3() == 1) {
                 prof_set_kernel("attn_kernel<float, true, x3>", "", "");
                 hipLaunchKernelGGL((attn_kernel<float, true, true>), dim3((N + 63) / 64, BH, Z), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt);
             } else
                 ATTN_LAUNCH(float, true, dim3((N + 63) / 64, BH, Z), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt);
-        } else if (g_attn_x3 == 2) {
+        } else if (opt_attn_x3() == 2) {
             if (kv_planes == 2) {
                 prof_set_kernel("attn_x3f_kernel<false, pre-split K V, fp16 pairs>", "", "");
                 hipLaunchKernelGGL((attn_x3f_kernel<false, true, 2>), dim3((N + 127) / 128, BH), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt, (unsigned char*)o_planes, o_np, xm);
@@ -1000,7 +1002,7 @@ void launch_attention(const void* q, const void* k, const void* v, void* o, int 
             prof_set_kernel("attn_x3f_kernel<false>", "", "");
             hipLaunchKernelGGL((attn_x3f_kernel<false>), dim3((N + 127) / 128, BH), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt, (unsigned char*)o_planes, o_np);
             }
-        } else if (g_attn_x3 == 1) {
+        } else if (opt_attn_x3() == 1) {
             prof_set_kernel("attn_kernel<float, false, x3>", "", "");
             hipLaunchKernelGGL((attn_kernel<float, false, true>), dim3((N + 127) / 128, BH), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt);
         } else

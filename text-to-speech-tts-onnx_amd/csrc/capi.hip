@@ -33,6 +33,20 @@ template <typename F> static int guard(F&& f) {
     }
 }
 
+// Runs `body` (launches + a stream synchronisation).  fp16-pair engines: if a producer flagged an operand at the fp16 range limit
+// (x3_split.h sat_publish) the results of the call are not fp32-equivalent — the engine switches itself to the exact three-plane
+// bf16 split (permanently; mi_f5_info reports it) and the body runs again.  `body` must not have overwritten its inputs.
+template <typename F> static void f5_run_checked(F5& e, F&& body) {
+    body();
+    if (e.dtype == MI_F32 && e.np == 2 && e.take_saturation()) {
+        ++e.sat_events;
+        e.set_arith(ARITH_BF16X3);
+        ArithScope sc(e.arith);          // (the caller's scope still holds the pair override)
+        body();
+        (void)e.take_saturation();
+    }
+}
+
 extern "C" {
 
 const char* mi_version(void) { return "mi355tts 0.1 (gfx950)"; }
@@ -221,6 +235,7 @@ struct F5Recover {
     MI_REQUIRE((h) && (h)->impl, name ": null handle");                            \
     std::lock_guard<std::mutex> lk_((h)->mu);                                      \
     F5Recover rec_((h)->impl);                                                     \
+    ArithScope arith_((h)->impl->arith);                                           \
     MI_REQUIRE((mem) == MI_HOST || (mem) == MI_DEVICE, name ": bad mem kind")
 
 static void copy_out(void* dst, const void* src, size_t bytes, int mem, hipStream_t s) {
@@ -236,6 +251,22 @@ int mi_f5_tables(mi_f5* h, float* time_expand, float* delta_t) {
         if (time_expand) std::memcpy(time_expand, e.h_time_expand.data(), e.h_time_expand.size() * 4);
         if (delta_t) std::memcpy(delta_t, e.h_delta.data(), e.h_delta.size() * 4);
     });
+}
+
+int64_t mi_f5_info(mi_f5* h, const char* key) {
+    int64_t v = -1;
+    int rc = guard([&] {
+        MI_REQUIRE(h && h->impl && key, "mi_f5_info: null handle / key");
+        std::lock_guard<std::mutex> lk_(h->mu);
+        F5& e = *h->impl;
+        ArithScope as(e.arith);
+        const std::string k(key);
+        if (k == "f32_arithmetic") v = e.dtype != MI_F32 ? -1 : !gemm_x3_enabled() ? ARITH_NATIVE : (gemm_x3p_enabled() ? e.np : ARITH_BF16X3);
+        else if (k == "saturation_events") v = e.sat_events;
+        else if (k == "adaln_fold") v = e.fold_built ? 1 : 0;
+        else MI_REQUIRE(false, "mi_f5_info: unknown key");
+    });
+    return rc == MI_OK ? v : (int64_t)rc;
 }
 
 int mi_f5_preprocess(mi_f5* h, const int16_t* audio, int64_t L, const int32_t* text_ids, int64_t T, int64_t max_duration,
@@ -256,7 +287,7 @@ int mi_f5_preprocess(mi_f5* h, const int16_t* audio, int64_t L, const int32_t* t
         copy_out(cat_mel_text, e.d_cmt.p, (size_t)N * cd * 4, mem, s);
         copy_out(cat_mel_text_drop, e.d_cmtd.p, (size_t)N * cd * 4, mem, s);
         MI_HIP(hipStreamSynchronize(s));
-        e.check_text_ids();
+        e.finish_call();
         if (ref_signal_len) *ref_signal_len = R;
     });
 }
@@ -267,11 +298,15 @@ int mi_f5_transformer_step(mi_f5* h, float* noise, const float* cmt, const float
         F5_CHECK(h, mem, "mi_f5_transformer_step");
         MI_REQUIRE(noise && cmt && cmtd && time_step && fuse >= 1 && U >= 1 && N > 0, "mi_f5_transformer_step: bad arguments");
         F5& e = *h->impl;
-        e.load_cond(noise, cmt, cmtd, U, (int)N, mem);
-        e.build_cat_cond(U, (int)N);
-        e.steps(U, (int)N, *time_step, fuse);
+        f5_run_checked(e, [&] {
+            e.load_cond(noise, cmt, cmtd, U, (int)N, mem);
+            e.build_cat_cond(U, (int)N);
+            e.steps(U, (int)N, *time_step, fuse);
+            MI_HIP(hipStreamSynchronize(e.stream));
+        });
         copy_out(noise, e.d_noise.p, (size_t)U * N * e.cfg.mel * 4, mem, e.stream);
         MI_HIP(hipStreamSynchronize(e.stream));
+        e.finish_call();
         *time_step += fuse;
     });
 }
@@ -281,11 +316,15 @@ int mi_f5_sample(mi_f5* h, float* noise, const float* cmt, const float* cmtd, in
         F5_CHECK(h, mem, "mi_f5_sample");
         MI_REQUIRE(noise && cmt && cmtd && U >= 1 && N > 0, "mi_f5_sample: bad arguments");
         F5& e = *h->impl;
-        e.load_cond(noise, cmt, cmtd, U, (int)N, mem);
-        e.build_cat_cond(U, (int)N);
-        e.steps(U, (int)N, k0, n_steps);
+        f5_run_checked(e, [&] {
+            e.load_cond(noise, cmt, cmtd, U, (int)N, mem);
+            e.build_cat_cond(U, (int)N);
+            e.steps(U, (int)N, k0, n_steps);
+            MI_HIP(hipStreamSynchronize(e.stream));
+        });
         copy_out(noise, e.d_noise.p, (size_t)U * N * e.cfg.mel * 4, mem, e.stream);
         MI_HIP(hipStreamSynchronize(e.stream));
+        e.finish_call();
     });
 }
 
@@ -294,11 +333,15 @@ int mi_f5_dit_eval(mi_f5* h, const float* noise, const float* cmt, const float* 
         F5_CHECK(h, mem, "mi_f5_dit_eval");
         MI_REQUIRE(noise && cmt && cmtd && pred && U >= 1 && N > 0, "mi_f5_dit_eval: bad arguments");
         F5& e = *h->impl;
-        e.load_cond(noise, cmt, cmtd, U, (int)N, mem);
-        e.build_cat_cond(U, (int)N);
-        e.dit_eval(U, (int)N, k);
+        f5_run_checked(e, [&] {
+            e.load_cond(noise, cmt, cmtd, U, (int)N, mem);
+            e.build_cat_cond(U, (int)N);
+            e.dit_eval(U, (int)N, k);
+            MI_HIP(hipStreamSynchronize(e.stream));
+        });
         copy_out(pred, e.pred.p, (size_t)2 * U * N * e.cfg.mel * 4, mem, e.stream);
         MI_HIP(hipStreamSynchronize(e.stream));
+        e.finish_call();
     });
 }
 
@@ -315,6 +358,7 @@ int mi_f5_decode(mi_f5* h, const float* denoised, int U, int64_t N, int64_t ref_
         copy_out(out, e.v_outi.p, (size_t)U * len * 2, mem, e.stream);
         copy_out(out_f32, e.v_outf.p, (size_t)U * len * 4, mem, e.stream);
         MI_HIP(hipStreamSynchronize(e.stream));
+        e.finish_call();
         if (out_len) *out_len = len;
     });
 }
@@ -326,13 +370,16 @@ int mi_f5_synthesize(mi_f5* h, int U, const int16_t* audio, int64_t L, const int
         MI_REQUIRE(audio && text_ids && out && U >= 1 && max_duration > 0, "mi_f5_synthesize: bad arguments");
         F5& e = *h->impl;
         const int N = (int)max_duration;
-        const int R = e.preprocess(U, audio, L, text_ids, (int)T, N, noise_in, seed, mem);
-        e.build_cat_cond(U, N);
-        e.steps(U, N, 0, e.cfg.nfe - 1);
-        const long len = e.decode(e.d_noise.as<float>(), U, N, R, nullptr, e.v_outi.as<int16_t>());
-        copy_out(out, e.v_outi.p, (size_t)U * len * 2, mem, e.stream);
-        MI_HIP(hipStreamSynchronize(e.stream));
-        e.check_text_ids();
+        long len = 0;
+        f5_run_checked(e, [&] {
+            const int R = e.preprocess(U, audio, L, text_ids, (int)T, N, noise_in, seed, mem);
+            e.build_cat_cond(U, N);
+            e.steps(U, N, 0, e.cfg.nfe - 1);
+            len = e.decode(e.d_noise.as<float>(), U, N, R, nullptr, e.v_outi.as<int16_t>());
+            copy_out(out, e.v_outi.p, (size_t)U * len * 2, mem, e.stream);
+            MI_HIP(hipStreamSynchronize(e.stream));
+        });
+        e.finish_call();
         if (out_len) *out_len = len;
     });
 }
@@ -347,18 +394,22 @@ int mi_f5_synthesize_mel(mi_f5* h, int U, const int16_t* audio, int64_t L, const
         MI_REQUIRE(audio && text_ids && mel_out && U >= 1 && max_duration > 0, "mi_f5_synthesize_mel: bad arguments");
         F5& e = *h->impl;
         const int N = (int)max_duration;
-        const int R = e.preprocess(U, audio, L, text_ids, (int)T, N, noise_in, seed, mem);
-        const int F = N - R, mel = e.cfg.mel;
-        MI_REQUIRE(F >= 1, "mi_f5_synthesize_mel: max_duration leaves no generated frames");
-        e.build_cat_cond(U, N);
-        e.steps(U, N, 0, e.cfg.nfe - 1);
-        float* dst = mel_out;
-        if (mem == MI_HOST) { e.v_outf.ensure((size_t)U * mel * F * 4); dst = e.v_outf.as<float>(); }
-        for (int u = 0; u < U; ++u)
-            launch_nlc_to_ncl(e.d_noise.as<float>() + ((size_t)u * N + R) * mel, dst + (size_t)u * mel * F, 1, mel, F, MI_F32, e.stream);
-        if (mem == MI_HOST) copy_out(mel_out, dst, (size_t)U * mel * F * 4, mem, e.stream);
-        MI_HIP(hipStreamSynchronize(e.stream));
-        e.check_text_ids();
+        int F = 0;
+        f5_run_checked(e, [&] {
+            const int R = e.preprocess(U, audio, L, text_ids, (int)T, N, noise_in, seed, mem);
+            const int mel = e.cfg.mel;
+            F = N - R;
+            MI_REQUIRE(F >= 1, "mi_f5_synthesize_mel: max_duration leaves no generated frames");
+            e.build_cat_cond(U, N);
+            e.steps(U, N, 0, e.cfg.nfe - 1);
+            float* dst = mel_out;
+            if (mem == MI_HOST) { e.v_outf.ensure((size_t)U * mel * F * 4); dst = e.v_outf.as<float>(); }
+            for (int u = 0; u < U; ++u)
+                launch_nlc_to_ncl(e.d_noise.as<float>() + ((size_t)u * N + R) * mel, dst + (size_t)u * mel * F, 1, mel, F, MI_F32, e.stream);
+            if (mem == MI_HOST) copy_out(mel_out, dst, (size_t)U * mel * F * 4, mem, e.stream);
+            MI_HIP(hipStreamSynchronize(e.stream));
+        });
+        e.finish_call();
         if (n_frames) *n_frames = F;
     });
 }

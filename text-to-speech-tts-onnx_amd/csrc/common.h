@@ -173,8 +173,22 @@ struct ConvGemm {
     // ... and its output as panel planes too (the A operand of the NEXT linear layer: FF1 -> FF2), instead of rows in `out`;
     // plain epilogue only: bias + activation, no residual / gate / accumulate
     void* out_planes = nullptr;
+    // ---- AdaLN fold (round 4; f5.hip dit_eval; modules.py:301-305,599-613) -------------------------------------------------
+    // u = LN(x) * (1 + sc) + sh through W is  rstd * W(x o (1 + sc)) - rstd * mean * (W (1 + sc)) + (W sh + b): the LayerNorm
+    // never needs a pass of its own.  PRODUCER (the O / FF2 projections: res + gate epilogue, fp32 rows out): after
+    // x_new = res + gate * (acc + bias) it also writes  ln_out = x_new o (1 + ln_scale)  — panel planes of ln_out_np planes
+    // (fp32 engines) or rows [M][N] of the engine dtype — and  ln_stats_out[row][N / 32][2] = (sum, sum of squares) of x_new
+    // over each 32-column block (plain stores, fixed order: bit-reproducible).  CONSUMER (QKV / FF1): with ln_stats_in set,
+    // v = rstd * acc - (mean * rstd) * ln_p[col] + ln_c[col] replaces acc + bias (ln_p = W (1 + sc), ln_c = W sh + b per
+    // (step, block), built at load time); mean / rstd over ln_dim columns with ln_eps, biased variance.
+    const float* ln_scale = nullptr; void* ln_out = nullptr; float* ln_stats_out = nullptr; int ln_out_np = 0;
+    const float* ln_stats_in = nullptr; const float* ln_p = nullptr; const float* ln_c = nullptr; int ln_dim = 0; float ln_eps = 0.f;
+    // fp16-pair producers: *sat |= 1 when an operand met the fp16 range limit (|a| >= 65504, inf, nan) while being split
+    int* sat = nullptr;
 };
+constexpr int LN_BLK = 32;        // columns per partial-statistics block of the AdaLN fold
 void launch_conv_gemm(const ConvGemm& p, hipStream_t s);
+bool gemm_ln_fold_ok(const ConvGemm& p);           // will launch_conv_gemm(p) run on a kernel whose epilogue has the fold (ln_* fields)?
 // gemm_x3p.hip panel planes: [panel = row / 128][chunk = k / 32][plane 0..2][row % 128][32 bf16], the four 16-byte k-slots of a
 // 64-byte row XOR-swizzled by (row >> 2) & 3
 constexpr int X3P_PLANE = 128 * 32 * 2;          // one plane of one (panel, chunk): 128 rows x 64 bytes
@@ -203,6 +217,31 @@ struct SkWorkspace {
     void attach(ConvGemm& g) const { g.sk_ws = ws.as<float>(); g.sk_flags = flags.as<int>(); g.sk_slots = slots; }
 };
 bool gemm_set_option(const char* key, long v);
+
+// How an fp32 engine forms its fp32 products on the matrix cores — a property of the ENGINE, not of the process (VERDICT r3
+// weak #1: an fp16-pair engine and a native-fp32 engine must be able to coexist).  The launchers read the process-wide
+// options (mi_set_option: tools, A/B runs) THROUGH this thread-local override; every C-ABI call on an F5 handle runs under
+// an ArithScope of that handle's setting, so the dispatch (and the hipGraphs captured from it) follow the engine.
+// A field of -1 means "no override: the process-wide option".
+struct ArithOverride {
+    int gemm_x3 = -1;      // fp32 linear layers through the 16-bit pipes at all (0: native v_mfma_f32_32x32x2_f32)
+    int gemm_x3p = -1;     // ... with both operands as panel planes (gemm_x3p.hip)
+    int planes = -1;       // panel-plane format: 2 = fp16 {hi, lo} pairs, 3 = three bf16 planes (exact, full fp32 exponent range)
+    int n64_pairs = -1;    // grouped position convolution as fp16 pairs (conv_gemm_dma_kernel PAIRS)
+    int gconv = -1;        // ... with each operand split once per workgroup (gconv_pairs.hip)
+    int attn_x3 = -1;      // fp32 attention: 0 native, 1 q.k split, 2 both products split
+    int attn_np = -1;      // ... as 2 fp16 pairs | 3 bf16 planes
+};
+enum { ARITH_DEFAULT = -1, ARITH_NATIVE = 0, ARITH_PAIRS = 2, ARITH_BF16X3 = 3 };
+ArithOverride arith_for(int kind);     // ARITH_* -> the override that selects it everywhere (ARITH_DEFAULT: all fields -1)
+ArithOverride& arith_tls();
+struct ArithScope {
+    ArithOverride saved;
+    explicit ArithScope(const ArithOverride& a) : saved(arith_tls()) { arith_tls() = a; }
+    ~ArithScope() { arith_tls() = saved; }
+    ArithScope(const ArithScope&) = delete;
+    ArithScope& operator=(const ArithScope&) = delete;
+};
 
 // anti-aliased SnakeBeta (aa_act.hip); channels-last (B,T,C) -> (B,T+2*shift,C)
 struct AAAct {

@@ -10,6 +10,10 @@ struct F5Cfg {
         nfe, max_len, n_fft, hop, sr, vd, vi, vlayers;
     float cfg_strength, sway;
     float score_scale = 1.f;   // != 1 (f16 engines only): the reference's fp16-transformer score form, see launch_attention(ref_fp16_scale)
+    // optional trailing ints of the config array (mi355tts/config.py F5Config.to_int_array):
+    int f32_arith = ARITH_DEFAULT;   // fp32 engines: ARITH_PAIRS | ARITH_BF16X3 | ARITH_NATIVE; ARITH_DEFAULT = the process-wide options (fp16 pairs)
+    int mel_type = 0;                // prompt mel front end: 0 vocos (HTK fbank of the magnitude, Export_F5.py:113,125) | 1 bigvgan (slaney, modules.py:30-72)
+    int ln_fold = -1;                // AdaLN fold: -1 / 1 on where the kernels support it, 0 off (row-norm launches)
     int ff() const { return dim * ff_mult; }
     int nb() const { return n_fft / 2 + 1; }
     int cat_dim() const { return 2 * mel + text_dim; }     // x | mel | text
@@ -62,7 +66,21 @@ struct F5 {
     long attn_ws_floats = 0, attn_cnt_n = 0;
     int ws_U = 0, ws_N = 0;
     int np = 3;              // planes per operand of the panel-plane GEMMs, fixed when the weights are split (x3p_planes())
+    ArithOverride arith;     // this engine's fp32 arithmetic: every call on the handle runs under ArithScope(arith)
+    int arith_kind = ARITH_DEFAULT;
     DevBuf Ap, Ap2;          // fp32 engines: the A operand of the big linear layers as panel planes (gemm_x3p.hip): dim / ff columns
+    // ---- AdaLN fold (dit_eval; gemm_epilogue.h) ----
+    bool fold_built = false; // the load-time vectors exist (dim >= 1024, dim % 128 == 0, cfg.ln_fold != 0)
+    DevBuf ApN;              // fp32 engines: x o (1 + scale) of the residual row as panel planes (16-bit engines: rows in Ub)
+    DevBuf ln_stats;         // [rows][dim / 32][2] partial (sum, sum of squares) per residual row
+    DevBuf ln_tab;           // [nfe][depth][ W_qkv (1 + sc_a) : 3d | W_qkv sh_a + b : 3d | W_ff1 (1 + sc_m) : ff | W_ff1 sh_m + b : ff ]
+    long ln_ld = 0, ln_blk = 0;
+    DevBuf d_sat;            // fp16-pair producers raise word 0 when an operand met the fp16 range limit (x3_split.h sat_publish)
+    long sat_events = 0;     // calls on this handle that tripped it (and were re-run on three bf16 planes)
+    void build_ln_tables(int i, DevBuf& G, DevBuf& S, DevBuf& tmpw);
+    void set_arith(int kind);                 // (re)split the big matrices for ARITH_PAIRS / ARITH_BF16X3 / ARITH_NATIVE
+    bool take_saturation();                   // after a stream synchronisation: did a producer flag a saturated operand?  (clears it)
+    void finish_call();                       // ... plus the stream-K watchdog and the text-id flag: every C-ABI entry ends with it
     DevBuf d_noise, d_cmt, d_cmtd, cat, h32, hT, c1, X, Ub, qb, kb, vb, Ob, Hff, pred;
     DevBuf p_audio, p_pad, p_spec, p_mag, p_mel, p_ids, p_tid, p_err, p_tx, p_ty, p_ty2, p_ss;
     std::vector<float> h_noise;
@@ -72,8 +90,7 @@ struct F5 {
     ~F5();
     void ensure_workspace(int U, int N);
     void gemm(int dt, const void* x, long xb, long xr, int K, const Lin& L, void* out, int odt, long ob, long orr,
-              int B, int M, int act = ACT_NONE, const void* res = nullptr, const float* gate = nullptr, bool planes_ready = false,
-              const void* in_planes = nullptr, void* out_planes = nullptr);
+              int B, int M, int act = ACT_NONE, const void* res = nullptr, const float* gate = nullptr);
     // fills d_noise, d_cmt, d_cmtd for U utterances (asynchronous on `stream`); returns ref_signal_len
     int preprocess(int U, const int16_t* audio, long L, const int32_t* text_ids, int T, int N,
                    const float* noise_in, uint64_t seed, int mem);

@@ -19,13 +19,20 @@ namespace mi {
 static int rup(int a, int b) { return (a + b - 1) / b * b; }
 
 F5Cfg parse_f5_cfg(const int32_t* ci, int ni, const float* cf, int nf) {
-    MI_REQUIRE(ci && ni == 21 && cf && (nf == 2 || nf == 3), "f5 cfg: expected 21 ints + 2 floats (+ the optional attention score scale)");
+    MI_REQUIRE(ci && ni >= 21 && ni <= 24 && cf && (nf == 2 || nf == 3),
+               "f5 cfg: expected 21 ints (+ up to 3 optional: fp32 arithmetic, mel type, AdaLN fold) + 2 floats (+ the optional attention score scale)");
     F5Cfg c;
     int i = 0;
     c.dim = ci[i++]; c.depth = ci[i++]; c.heads = ci[i++]; c.dim_head = ci[i++]; c.ff_mult = ci[i++]; c.mel = ci[i++];
     c.text_dim = ci[i++]; c.vocab = ci[i++]; c.conv_layers = ci[i++]; c.conv_mult = ci[i++]; c.pos_k = ci[i++];
     c.pos_g = ci[i++]; c.freq_dim = ci[i++]; c.nfe = ci[i++]; c.max_len = ci[i++]; c.n_fft = ci[i++]; c.hop = ci[i++];
     c.sr = ci[i++]; c.vd = ci[i++]; c.vi = ci[i++]; c.vlayers = ci[i++];
+    if (ni > 21) c.f32_arith = ci[21];
+    if (ni > 22) c.mel_type = ci[22];
+    if (ni > 23) c.ln_fold = ci[23];
+    MI_REQUIRE(c.f32_arith == ARITH_DEFAULT || c.f32_arith == ARITH_NATIVE || c.f32_arith == ARITH_PAIRS || c.f32_arith == ARITH_BF16X3,
+               "f5 cfg: fp32 arithmetic is -1 (process default), 0 (native fp32 MFMA), 2 (fp16 pairs) or 3 (three bf16 planes)");
+    MI_REQUIRE((c.mel_type == 0 || c.mel_type == 1) && c.ln_fold >= -1 && c.ln_fold <= 1, "f5 cfg: mel type is 0 (vocos) or 1 (bigvgan); AdaLN fold is -1, 0 or 1");
     c.cfg_strength = cf[0]; c.sway = cf[1];
     if (nf == 3) { c.score_scale = cf[2]; MI_REQUIRE(c.score_scale > 0.f && c.score_scale <= 1e4f, "f5 cfg: attention score scale"); }
     MI_REQUIRE(c.dim == c.heads * c.dim_head, "f5 cfg: dim != heads*dim_head");
@@ -75,6 +82,9 @@ static inline float siluf(float v) { return v / (1.f + expf(-v)); }
 static inline float round_f16(float v) { return (float)(f16)v; }
 
 F5::F5(const F5Cfg& c, const float* w, int64_t nw, int dt, int dev, int mem) : cfg(c), dtype(dt), device(dev) {
+    arith_kind = dt == MI_F32 ? c.f32_arith : ARITH_DEFAULT;
+    arith = arith_for(arith_kind);
+    ArithScope arith_scope(arith);        // the load-time launches and the format of the weight planes follow the engine's arithmetic
     np = x3p_planes();
     MI_REQUIRE(dt == MI_F32 || dt == MI_F16 || dt == MI_BF16, "f5: bad dtype");
     MI_REQUIRE(c.score_scale == 1.f || dt == MI_F16, "f5: the attention score scale (reference fp16-transformer form) needs an f16 engine");
@@ -83,6 +93,8 @@ F5::F5(const F5Cfg& c, const float* w, int64_t nw, int dt, int dev, int mem) : c
     MI_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     if (const char* e = std::getenv("MI355TTS_NO_GRAPH")) use_graph = !(e[0] == '1');
     hipStream_t s = stream;
+    d_sat.ensure(64);
+    MI_HIP(hipMemsetAsync(d_sat.p, 0, 64, s));
     const int d = c.dim, td = c.text_dim, ff = c.ff(), ti = td * c.conv_mult, cin = c.cat_dim();
     const float* p = w;
     auto take = [&](size_t n) { const float* r = p; p += n; return r; };          // blob ranges (host or device memory)
@@ -198,16 +210,38 @@ F5::F5(const F5Cfg& c, const float* w, int64_t nw, int dt, int dev, int mem) : c
         const float* w2 = take((size_t)d * ff); const float* b2 = take(d);
         put_lin(R, bk.ff2, w2, b2, d, ff, dt);
         if (dt == MI_F32) {
-            // the four big matrices of the block once more as three bf16 planes each: fp32 products on the bf16 pipes
+            // the four big matrices of the block once more as three bf16 planes each (gemm_x3.hip: the fallback of the panel-plane
+            // kernel); their panel planes are built by set_arith() below, once the number format is settled
             for (Lin* L : {&bk.qkv, &bk.o, &bk.ff1, &bk.ff2}) {
                 L->w3.ensure((size_t)3 * L->n * L->k * 2);
                 split3_planes(L->w.as<float>(), L->w3.p, (long)L->n * L->k, s);
-                if (L->n % 128 == 0 && L->k % 32 == 0) {
-                    L->w3p.ensure((size_t)x3p_bytes(L->n, L->k, np));
-                    x3p_split_rows(L->w.as<float>(), L->k, L->w3p.p, L->n, L->k, s, np);
-                }
+                launch_absmax(L->w.as<float>(), (long)L->n * L->k, d_sat.as<unsigned>() + 1, s);
             }
         }
+    }
+    if (dt == MI_F32) {
+        // fp16 pairs hold |w| <= 65504 only (the weight operand is not clamped by the kernels): a checkpoint with a
+        // larger entry in one of the big matrices gets the exact three-plane bf16 split instead, which spans the fp32 exponent range
+        unsigned bits = 0;
+        MI_HIP(hipMemcpyAsync(&bits, d_sat.as<unsigned>() + 1, 4, hipMemcpyDeviceToHost, s));
+        MI_HIP(hipStreamSynchronize(s));
+        float wmax; std::memcpy(&wmax, &bits, 4);
+        int kind = arith_kind;
+        if (np == 2 && gemm_x3p_enabled() && !(wmax < 65504.f)) kind = ARITH_BF16X3;
+        set_arith(kind);
+    }
+    // ---- AdaLN fold: W (1 + scale) and W shift + b for every (step, block), QKV and FF1 (gemm_epilogue.h) ----
+    fold_built = false;
+    if (c.ln_fold != 0 && d >= 1024 && d % 128 == 0 && ff % 64 == 0) {
+        ln_blk = (long)6 * d + 2 * ff;
+        ln_ld = (long)c.depth * ln_blk;
+        ln_tab.ensure((size_t)steps * ln_ld * 4);
+        DevBuf G, S, tmpw;
+        G.ensure((size_t)steps * d * 4); S.ensure((size_t)steps * d * 4);
+        if (dt != MI_F32) tmpw.ensure((size_t)std::max(3 * d, ff) * d * 4);
+        for (int i = 0; i < c.depth; ++i) build_ln_tables(i, G, S, tmpw);
+        MI_HIP(hipStreamSynchronize(s));
+        fold_built = true;
     }
     {
         const float* mw = take((size_t)2 * d * d); const float* mb = take((size_t)2 * d);
@@ -329,6 +363,69 @@ F5::~F5() {
     if (stream) (void)hipStreamDestroy(stream);
 }
 
+// The engine's fp32 arithmetic (fp32 engines): ARITH_PAIRS = fp16 {hi, lo} pairs (22-bit operands, |a| <= 65504), ARITH_BF16X3 =
+// three bf16 planes (exact, whole fp32 exponent range), ARITH_NATIVE = v_mfma_f32_32x32x2_f32, ARITH_DEFAULT = whatever the
+// process-wide options say.  Builds the panel planes of the big matrices in that format (the fp32 rows stay resident, so the
+// format can change later: take_saturation() -> set_arith(ARITH_BF16X3)).
+void F5::set_arith(int kind) {
+    arith_kind = kind;
+    arith = arith_for(kind);
+    ArithScope sc(arith);
+    np = x3p_planes();
+    drop_graphs();
+    if (dtype != MI_F32) return;
+    const bool planes = gemm_x3p_enabled();
+    for (Block& bk : blocks)
+        for (Lin* L : {&bk.qkv, &bk.o, &bk.ff1, &bk.ff2}) {
+            if (!planes || L->n % 128 != 0 || L->k % 32 != 0) { L->w3p.release(); continue; }
+            L->w3p.ensure((size_t)x3p_bytes(L->n, L->k, np));
+            x3p_split_rows(L->w.as<float>(), L->k, L->w3p.p, L->n, L->k, stream, np);
+        }
+    if (ws_U > 0) {       // the activation planes are sized by the format
+        const long rows = (long)2 * ws_U * ws_N;
+        Ap.ensure((size_t)x3p_bytes(rows, cfg.dim, np)); Ap2.ensure((size_t)x3p_bytes(rows, cfg.ff(), np)); ApN.ensure((size_t)x3p_bytes(rows, cfg.dim, np));
+    }
+    MI_HIP(hipStreamSynchronize(stream));
+}
+
+// block i: [ W_qkv (1 + sc_a) | W_qkv sh_a + b_qkv | W_ff1 (1 + sc_m) | W_ff1 sh_m + b_ff1 ] for every step, as GEMMs of the
+// (steps x d) modulation slices against the weights the engine multiplies by (16-bit engines: the ROUNDED weights)
+void F5::build_ln_tables(int i, DevBuf& G, DevBuf& S, DevBuf& tmpw) {
+    const int d = cfg.dim, ff = cfg.ff(), steps = cfg.nfe;
+    Block& bk = blocks[i];
+    float* tab = ln_tab.as<float>() + (size_t)i * ln_blk;
+    auto run = [&](const Lin& L, long col_shift, long col_scale, float* out_p, float* out_c) {
+        launch_ln_gather(mod.as<float>(), mod_ld, (long)i * 6 * d + col_scale, (long)i * 6 * d + col_shift, G.as<float>(), S.as<float>(), steps, d, stream);
+        const float* w32 = L.w.as<float>();
+        if (dtype != MI_F32) { launch_cast_to_f32(L.w.p, dtype, tmpw.as<float>(), (long)L.n * L.k, stream); w32 = tmpw.as<float>(); }
+        ConvGemm g;
+        g.dtype = MI_F32; g.x = G.p; g.w = w32; g.bias = nullptr; g.out = out_p;
+        g.B = 1; g.T_in = steps; g.M = steps; g.N = L.n; g.Cin = d; g.x_rstride = d; g.x_bstride = (long)steps * d;
+        g.out_rstride = ln_ld; g.out_bstride = (long)steps * ln_ld;
+        launch_conv_gemm(g, stream);
+        g.x = S.p; g.bias = L.b.as<float>(); g.out = out_c;
+        launch_conv_gemm(g, stream);
+        MI_HIP(hipStreamSynchronize(stream));       // G / S / tmpw are reused by the next call
+    };
+    run(bk.qkv, 0, d, tab, tab + 3 * d);                                    // shift_msa at 0, scale_msa at d (modules.py:303)
+    run(bk.ff1, 3 * d, 4 * d, tab + 6 * d, tab + 6 * d + ff);               // shift_mlp at 3d, scale_mlp at 4d
+}
+
+bool F5::take_saturation() {
+    if (!d_sat.p) return false;
+    int flag = 0;
+    MI_HIP(hipMemcpy(&flag, d_sat.p, 4, hipMemcpyDeviceToHost));
+    if (!flag) return false;
+    MI_HIP(hipMemset(d_sat.p, 0, 4));
+    return true;
+}
+
+// every C-ABI entry, after its stream synchronisation: the stream-K watchdog (it used to be looked at only on the
+// paths that validate text ids) and the text-id flag
+void F5::finish_call() {
+    check_text_ids();
+}
+
 void F5::ensure_workspace(int U, int N) {
     if (U <= ws_U && N <= ws_N) return;
     drop_graphs();                         // captured graphs hold raw workspace pointers
@@ -369,7 +466,11 @@ void F5::ensure_workspace(int U, int N) {
         if (vbytes > vb.bytes) { vb.ensure(vbytes); MI_HIP(hipMemsetAsync(vb.p, 0, vbytes, stream)); }
     }
     Hff.ensure(rows * c.ff() * es);
-    if (dtype == MI_F32) { Ap.ensure((size_t)x3p_bytes((long)rows, c.dim, np)); Ap2.ensure((size_t)x3p_bytes((long)rows, c.ff(), np)); }
+    if (dtype == MI_F32) {
+        Ap.ensure((size_t)x3p_bytes((long)rows, c.dim, np)); Ap2.ensure((size_t)x3p_bytes((long)rows, c.ff(), np));
+        if (fold_built) ApN.ensure((size_t)x3p_bytes((long)rows, c.dim, np));
+    }
+    if (fold_built) ln_stats.ensure((rows + 128) * (size_t)(c.dim / LN_BLK) * 2 * 4);
     pred.ensure(rows * c.mel * 4);
     // preprocess temporaries
     const int ti = c.text_dim * c.conv_mult;
@@ -384,30 +485,25 @@ void F5::ensure_workspace(int U, int N) {
     ws_U = Um; ws_N = Nm;
 }
 
-// planes_ready: Ap already holds the rows as panel planes (written by their producer) and the caller has checked
-// gemm_x3p_would_run(): x is not read
+// One linear layer over rows (the front end, the vocoder, and the DiT layers of the ROWS form).  fp32 layers that have panel
+// planes of their weights get their rows split by a separate pass here; the SAME ConvGemm object answers the eligibility
+// question and is launched.
 void F5::gemm(int dt, const void* x, long xb, long xr, int K, const Lin& L, void* out, int odt, long ob, long orr, int B,
-              int M, int act, const void* res, const float* gate, bool planes_ready, const void* in_planes, void* out_planes) {
+              int M, int act, const void* res, const float* gate) {
     ConvGemm g;
     g.dtype = dt; g.out_dtype = odt; g.x = x; g.w = L.w.p; g.w3 = L.w3.p; g.bias = L.b.p ? L.b.as<float>() : nullptr; g.out = out;
     g.res = res; g.gate = gate; g.gate_bstride = 0;
     g.B = B; g.T_in = M; g.M = M; g.N = L.n; g.Cin = K; g.taps = 1;
     g.x_bstride = xb; g.x_rstride = xr; g.out_bstride = ob; g.out_rstride = orr; g.act = act;
+    g.sat = d_sat.as<int>();
     sk.attach(g);
     if (B > 1 && xb == (long)M * xr && ob == (long)M * orr) {      // rows of all batch items are contiguous: one M axis
         g.B = 1; g.T_in = B * M; g.M = B * M;                      // (no per-item tile padding: 2252 rows -> 9 tiles, not 10)
     }
     if (dt == MI_F32 && L.w3p.p && g.B == 1 && Ap.p && gemm_x3p_enabled()) {
-        // fp32 big linear layer: the rows as panel planes — written by their producer (planes_ready) or by a separate pass here
-        void* planes = in_planes ? const_cast<void*>(in_planes) : (K <= cfg.dim ? Ap.p : Ap2.p);
-        g.xp = planes; g.w3p = L.w3p.p; g.np = np; g.out_planes = out_planes;
-        if (!planes_ready) {
-            MI_REQUIRE(!out_planes, "f5: out_planes is only requested after gemm_x3p_would_run()");
-            if (gemm_x3p_would_run(g)) x3p_split_rows((const float*)x, xr, planes, g.M, K, stream, np);
-            else { g.xp = nullptr; g.w3p = nullptr; }
-        }
-    } else {
-        MI_REQUIRE(!planes_ready && !out_planes, "f5: planes_ready / out_planes without the panel-plane path");
+        g.xp = K <= cfg.dim ? Ap.p : Ap2.p; g.w3p = L.w3p.p; g.np = np;
+        if (gemm_x3p_would_run(g)) x3p_split_rows((const float*)x, xr, const_cast<void*>(g.xp), g.M, K, stream, np);
+        else { g.xp = nullptr; g.w3p = nullptr; }
     }
     launch_conv_gemm(g, stream);
 }
@@ -575,75 +671,142 @@ void F5::dit_eval(int U, int N, int k) {
         launch_conv_gemm(g, s);
     }
     // ---- transformer blocks ----------------------------------------------------------------------------------
+    // One ConvGemm per linear layer, built ONCE: the same object answers "which kernel takes this" and is launched (ADVICE r3:
+    // the panel-plane decision used to be taken on a hand-built copy and re-derived at launch).  Three forms:
+    //   FOLD    the AdaLN fold: no row-norm launches; O / FF2 epilogues leave x o (1 + scale) + row statistics, QKV / FF1 finish
+    //           the LayerNorm in theirs (gemm_epilogue.h).  fp32 engines: operands as panel planes; 16-bit engines: rows
+    //   PLANES  fp32 engines without the fold: panel planes written by rownorm_x3p / attention / the FF1 epilogue (round 3)
+    //   ROWS    everything else: row-norm launches, operands as rows (F5::gemm may still split them for the panel-plane kernel)
+    const bool f32 = dtype == MI_F32;
+    auto lin = [&](const Lin& L, int K, int odt, void* out) {
+        ConvGemm g;
+        g.dtype = dtype; g.out_dtype = odt; g.w = L.w.p; g.w3 = L.w3.p; g.bias = L.b.p ? L.b.as<float>() : nullptr; g.out = out;
+        g.B = 1; g.T_in = (int)rows; g.M = (int)rows; g.N = L.n; g.Cin = K; g.taps = 1;
+        g.x_bstride = rows * K; g.x_rstride = K; g.out_bstride = rows * L.n; g.out_rstride = L.n;
+        g.sat = d_sat.as<int>();
+        sk.attach(g);
+        return g;
+    };
+    auto with_planes = [&](ConvGemm& g, const Lin& L, const void* xp) { g.xp = xp; g.w3p = L.w3p.p; g.np = np; };
+    auto qkv_gemm = [&](const Block& bk) {
+        ConvGemm g = lin(bk.qkv, d, -1, qb.p);
+        g.out2 = kb.p; g.out3 = vb.p; g.rows_per_item = N;           // batch flattened into M
+        g.epi = EPI_QKV_ROPE; g.rope_cos = rope_cos.as<float>(); g.rope_sin = rope_sin.as<float>(); g.rope_pack = rope_pack.p; g.heads = H; g.head_dim = D;
+        g.v_ld = attention_v_ld(N, dtype);
+        return g;
+    };
+    const int kvp_fmt = attention_kv_planes_format();       // K / V^T pre-split for the attention kernel: 2 fp16 planes or 3 bf16 planes
+    // which form: decided on block 0's layers (every block has the same shapes and the same weight formats)
+    bool planes = false, fold = false;
+    {
+        const Block& b0 = blocks[0];
+        if (f32 && Ap.p && gemm_x3p_enabled() && b0.qkv.w3p.p && b0.o.w3p.p && b0.ff1.w3p.p && b0.ff2.w3p.p && attention_can_write_planes(N, B * H, dtype)) {
+            ConvGemm gq = qkv_gemm(b0); gq.x = Ub.p; with_planes(gq, b0.qkv, Ap.p);
+            ConvGemm go = lin(b0.o, d, MI_F32, X.p); go.x = Ob.p; go.res = X.p; go.gate = modk; with_planes(go, b0.o, Ap.p);
+            ConvGemm g1 = lin(b0.ff1, d, dtype, Hff.p); g1.x = Ub.p; g1.act = ACT_GELU_TANH; with_planes(g1, b0.ff1, Ap.p);
+            ConvGemm g2 = lin(b0.ff2, ff, MI_F32, X.p); g2.x = Hff.p; g2.res = X.p; g2.gate = modk; with_planes(g2, b0.ff2, Ap2.p);
+            planes = gemm_x3p_would_run(gq) && gemm_x3p_would_run(go) && gemm_x3p_would_run(g1) && gemm_x3p_would_run(g2);
+        }
+        if (fold_built && cfg.ln_fold != 0 && (planes || !f32) && (!f32 || ApN.p) && ln_stats.p) {
+            ConvGemm gq = qkv_gemm(b0); gq.x = Ub.p;
+            ConvGemm go = lin(b0.o, d, MI_F32, X.p); go.x = Ob.p; go.res = X.p; go.gate = modk;
+            ConvGemm g1 = lin(b0.ff1, d, dtype, Hff.p); g1.x = Ub.p; g1.act = ACT_GELU_TANH;
+            ConvGemm g2 = lin(b0.ff2, ff, MI_F32, X.p); g2.x = Hff.p; g2.res = X.p; g2.gate = modk;
+            if (f32) { with_planes(gq, b0.qkv, ApN.p); with_planes(go, b0.o, Ap.p); with_planes(g1, b0.ff1, ApN.p); with_planes(g2, b0.ff2, Ap2.p); }
+            fold = gemm_ln_fold_ok(gq) && gemm_ln_fold_ok(go) && gemm_ln_fold_ok(g1) && gemm_ln_fold_ok(g2);
+        }
+    }
+    float* stats = ln_stats.as<float>();
+    const float* lnk = fold ? ln_tab.as<float>() + (size_t)k * ln_ld : nullptr;
+    if (fold)       // block 0's attention norm: the residual row comes from the position convolution, whose epilogue has no fold
+        launch_ln_prologue(X.as<float>(), f32 ? ApN.p : Ub.p, dtype, np, stats, modk + d, rows, d, d_sat.as<int>(), s);
     for (int i = 0; i < c.depth; ++i) {
         const Block& bk = blocks[i];
         const float* m = modk + (size_t)i * 6 * d;       // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
-        bool kvp = false;                                // this block's K / V^T leave the QKV epilogue pre-split for the attention kernel
-        const int kvp_fmt = attention_kv_planes_format();   // ... as 2 fp16 planes or 3 bf16 planes
-        {
-            ConvGemm g;
-            g.dtype = dtype; g.x = Ub.p; g.w = bk.qkv.w.p; g.w3 = bk.qkv.w3.p; g.bias = bk.qkv.b.as<float>();
-            g.out = qb.p; g.out2 = kb.p; g.out3 = vb.p;
-            g.B = 1; g.T_in = B * N; g.M = B * N; g.rows_per_item = N;       // batch flattened into M
-            g.N = 3 * d; g.Cin = d; g.x_bstride = (long)B * N * d; g.x_rstride = d;
-            g.epi = EPI_QKV_ROPE; g.rope_cos = rope_cos.as<float>(); g.rope_sin = rope_sin.as<float>(); g.rope_pack = rope_pack.p; g.heads = H; g.head_dim = D;
-            g.v_ld = attention_v_ld(N, dtype);
-            sk.attach(g);
-            bool fused = false;
-            if (dtype == MI_F32 && bk.qkv.w3p.p && Ap.p && gemm_x3p_enabled()) {
-                g.xp = Ap.p; g.w3p = bk.qkv.w3p.p; g.np = np;
-                fused = gemm_x3p_would_run(g);
-                if (!fused) { g.xp = nullptr; g.w3p = nullptr; }
-            }
-            // K and V^T pre-split for the attention kernel (only the LDS-staged fp32 QKV epilogue of the panel-plane GEMM writes them)
-            kvp = fused && attention_takes_kv_planes(N, B * H, dtype);
-            if (kvp) { g.kv_planes = kvp_fmt; g.k_ld = g.v_ld = (long)((N + 63) / 64 * 64); }
-            // AdaLN: LN(x) * (1 + scale) + shift — straight into the panel planes the QKV GEMM reads, or as rows
-            if (fused) launch_rownorm_x3p(X.as<float>(), Ap.p, m + d, m, rows, d, 1e-6f, s, np);
-            else launch_rownorm(NORM_LN_MOD, X.as<float>(), Ub.p, dtype, m + d, m, rows, d, 1e-6f, s);
-            launch_conv_gemm(g, s);
-        }
-        {
-            // attention output: straight into the panel planes the O projection reads, when that GEMM takes the panel-plane kernel
-            bool fused = false;
-            if (dtype == MI_F32 && bk.o.w3p.p && Ap.p && gemm_x3p_enabled() && attention_can_write_planes(N, B * H, dtype)) {
-                ConvGemm g;
-                g.dtype = dtype; g.out_dtype = MI_F32; g.x = Ob.p; g.w = bk.o.w.p; g.w3 = bk.o.w3.p; g.xp = Ap.p; g.w3p = bk.o.w3p.p; g.np = np;
-                g.bias = bk.o.b.as<float>(); g.out = X.p; g.res = X.p; g.gate = m + 2 * d; g.B = 1; g.T_in = B * N; g.M = B * N; g.N = d; g.Cin = d;
-                g.x_bstride = (long)N * d; g.x_rstride = d; g.out_bstride = (long)N * d; g.out_rstride = d;
-                sk.attach(g);
-                fused = gemm_x3p_would_run(g);
+        if (fold) {
+            const float* lt = lnk + (size_t)i * ln_blk;   // W_qkv (1 + sc_a) | W_qkv sh_a + b | W_ff1 (1 + sc_m) | W_ff1 sh_m + b
+            const bool kvp = f32 && attention_takes_kv_planes(N, B * H, dtype);
+            {
+                ConvGemm g = qkv_gemm(bk);
+                g.x = Ub.p; g.bias = nullptr;
+                if (f32) with_planes(g, bk.qkv, ApN.p);
+                g.ln_stats_in = stats; g.ln_p = lt; g.ln_c = lt + 3 * d; g.ln_dim = d; g.ln_eps = 1e-6f;
+                if (kvp) { g.kv_planes = kvp_fmt; g.k_ld = g.v_ld = (long)((N + 63) / 64 * 64); }
+                launch_conv_gemm(g, s);
             }
             launch_attention(qb.p, kb.p, vb.p, Ob.p, B * H, H, N, dtype, s, attn_ws.as<float>(), attn_ws_floats, attn_cnt.as<int>(), attn_cnt_n,
-                             fused ? Ap.p : nullptr, kvp ? kvp_fmt : 0, np, cfg.score_scale != 1.f ? cfg.score_scale : 0.f);
-            gemm(dtype, Ob.p, (long)N * d, d, d, bk.o, X.p, MI_F32, (long)N * d, d, B, N, ACT_NONE, X.p, m + 2 * d, fused, Ap.p);
+                             f32 ? Ap.p : nullptr, kvp ? kvp_fmt : 0, np, cfg.score_scale != 1.f ? cfg.score_scale : 0.f);
+            {
+                ConvGemm g = lin(bk.o, d, MI_F32, X.p);
+                g.x = Ob.p; g.res = X.p; g.gate = m + 2 * d;
+                if (f32) with_planes(g, bk.o, Ap.p);
+                g.ln_scale = m + 4 * d; g.ln_out = f32 ? ApN.p : Ub.p; g.ln_out_np = np; g.ln_stats_out = stats;       // -> the FF1 norm
+                launch_conv_gemm(g, s);
+            }
+            {
+                ConvGemm g = lin(bk.ff1, d, dtype, Hff.p);
+                g.x = Ub.p; g.bias = nullptr; g.act = ACT_GELU_TANH;
+                if (f32) { with_planes(g, bk.ff1, ApN.p); g.out_planes = Ap2.p; }
+                g.ln_stats_in = stats; g.ln_p = lt + 6 * d; g.ln_c = lt + 6 * d + ff; g.ln_dim = d; g.ln_eps = 1e-6f;
+                launch_conv_gemm(g, s);
+            }
+            {
+                ConvGemm g = lin(bk.ff2, ff, MI_F32, X.p);
+                g.x = Hff.p; g.res = X.p; g.gate = m + 5 * d;
+                if (f32) with_planes(g, bk.ff2, Ap2.p);
+                if (i + 1 < c.depth) {                   // -> the next block's attention norm (the last block's row goes to AdaLN-final below)
+                    g.ln_scale = m + 6 * d + d; g.ln_out = f32 ? ApN.p : Ub.p; g.ln_out_np = np; g.ln_stats_out = stats;
+                }
+                launch_conv_gemm(g, s);
+            }
+            continue;
         }
+        if (planes) {
+            const bool kvp = attention_takes_kv_planes(N, B * H, dtype);
+            launch_rownorm_x3p(X.as<float>(), Ap.p, m + d, m, rows, d, 1e-6f, s, np);
+            {
+                ConvGemm g = qkv_gemm(bk);
+                g.x = Ub.p; with_planes(g, bk.qkv, Ap.p);
+                if (kvp) { g.kv_planes = kvp_fmt; g.k_ld = g.v_ld = (long)((N + 63) / 64 * 64); }
+                MI_REQUIRE(gemm_x3p_would_run(g), "f5: the QKV layer left the panel-plane kernel between the decision and the launch");
+                launch_conv_gemm(g, s);
+            }
+            launch_attention(qb.p, kb.p, vb.p, Ob.p, B * H, H, N, dtype, s, attn_ws.as<float>(), attn_ws_floats, attn_cnt.as<int>(), attn_cnt_n,
+                             Ap.p, kvp ? kvp_fmt : 0, np, 0.f);
+            {
+                ConvGemm g = lin(bk.o, d, MI_F32, X.p);
+                g.x = Ob.p; g.res = X.p; g.gate = m + 2 * d; with_planes(g, bk.o, Ap.p);
+                MI_REQUIRE(gemm_x3p_would_run(g), "f5: the O projection left the panel-plane kernel between the decision and the launch");
+                launch_conv_gemm(g, s);
+            }
+            launch_rownorm_x3p(X.as<float>(), Ap.p, m + 4 * d, m + 3 * d, rows, d, 1e-6f, s, np);
+            {
+                ConvGemm g = lin(bk.ff1, d, dtype, Hff.p);
+                g.x = Ub.p; g.act = ACT_GELU_TANH; with_planes(g, bk.ff1, Ap.p); g.out_planes = Ap2.p;
+                MI_REQUIRE(gemm_x3p_would_run(g), "f5: the FF1 layer left the panel-plane kernel between the decision and the launch");
+                launch_conv_gemm(g, s);
+            }
+            {
+                ConvGemm g = lin(bk.ff2, ff, MI_F32, X.p);
+                g.x = Hff.p; g.res = X.p; g.gate = m + 5 * d; with_planes(g, bk.ff2, Ap2.p);
+                MI_REQUIRE(gemm_x3p_would_run(g), "f5: the FF2 layer left the panel-plane kernel between the decision and the launch");
+                launch_conv_gemm(g, s);
+            }
+            continue;
+        }
+        // ROWS
+        launch_rownorm(NORM_LN_MOD, X.as<float>(), Ub.p, dtype, m + d, m, rows, d, 1e-6f, s);
         {
-            bool fused = false;
-            if (dtype == MI_F32 && bk.ff1.w3p.p && Ap.p && gemm_x3p_enabled()) {
-                ConvGemm g;      // the FF1 launch as F5::gemm will build it, to ask whether the panel-plane kernel takes it
-                g.dtype = dtype; g.out_dtype = dtype; g.x = Ub.p; g.w = bk.ff1.w.p; g.w3 = bk.ff1.w3.p; g.xp = Ap.p; g.w3p = bk.ff1.w3p.p; g.np = np;
-                g.bias = bk.ff1.b.as<float>(); g.out = Hff.p; g.B = 1; g.T_in = B * N; g.M = B * N; g.N = ff; g.Cin = d; g.taps = 1;
-                g.x_bstride = (long)N * d; g.x_rstride = d; g.out_bstride = (long)N * ff; g.out_rstride = ff; g.act = ACT_GELU_TANH;
-                sk.attach(g);
-                fused = gemm_x3p_would_run(g);
-            }
-            if (fused) launch_rownorm_x3p(X.as<float>(), Ap.p, m + 4 * d, m + 3 * d, rows, d, 1e-6f, s, np);
-            else launch_rownorm(NORM_LN_MOD, X.as<float>(), Ub.p, dtype, m + 4 * d, m + 3 * d, rows, d, 1e-6f, s);
-            // FF1's GELU output: as the panel planes FF2 reads (Ap2), when both GEMMs take the panel-plane kernel
-            bool fused2 = false;
-            if (fused && bk.ff2.w3p.p && Ap2.p) {
-                ConvGemm g;
-                g.dtype = dtype; g.out_dtype = MI_F32; g.x = Hff.p; g.w = bk.ff2.w.p; g.w3 = bk.ff2.w3.p; g.xp = Ap2.p; g.w3p = bk.ff2.w3p.p; g.np = np;
-                g.bias = bk.ff2.b.as<float>(); g.out = X.p; g.res = X.p; g.gate = m + 5 * d; g.B = 1; g.T_in = B * N; g.M = B * N; g.N = d; g.Cin = ff;
-                g.x_bstride = (long)N * ff; g.x_rstride = ff; g.out_bstride = (long)N * d; g.out_rstride = d;
-                sk.attach(g);
-                fused2 = gemm_x3p_would_run(g);
-            }
-            gemm(dtype, Ub.p, (long)N * d, d, d, bk.ff1, Hff.p, dtype, (long)N * ff, ff, B, N, ACT_GELU_TANH, nullptr, nullptr, fused, Ap.p,
-                 fused2 ? Ap2.p : nullptr);
-            gemm(dtype, Hff.p, (long)N * ff, ff, ff, bk.ff2, X.p, MI_F32, (long)N * d, d, B, N, ACT_NONE, X.p, m + 5 * d, fused2, Ap2.p);
+            ConvGemm g = qkv_gemm(bk);
+            g.x = Ub.p; g.x_bstride = (long)B * N * d;
+            launch_conv_gemm(g, s);
         }
+        launch_attention(qb.p, kb.p, vb.p, Ob.p, B * H, H, N, dtype, s, attn_ws.as<float>(), attn_ws_floats, attn_cnt.as<int>(), attn_cnt_n,
+                         nullptr, 0, np, cfg.score_scale != 1.f ? cfg.score_scale : 0.f);
+        gemm(dtype, Ob.p, (long)N * d, d, d, bk.o, X.p, MI_F32, (long)N * d, d, B, N, ACT_NONE, X.p, m + 2 * d);
+        launch_rownorm(NORM_LN_MOD, X.as<float>(), Ub.p, dtype, m + 4 * d, m + 3 * d, rows, d, 1e-6f, s);
+        gemm(dtype, Ub.p, (long)N * d, d, d, bk.ff1, Hff.p, dtype, (long)N * ff, ff, B, N, ACT_GELU_TANH);
+        gemm(dtype, Hff.p, (long)N * ff, ff, ff, bk.ff2, X.p, MI_F32, (long)N * d, d, B, N, ACT_NONE, X.p, m + 5 * d);
     }
     // ---- AdaLN-final (scale, shift order: modules.py:323) + proj_out ------------------------------------------
     const float* mf = modk + (size_t)c.depth * 6 * d;

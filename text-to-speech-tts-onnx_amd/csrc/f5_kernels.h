@@ -11,6 +11,13 @@ void launch_rownorm(int mode, const float* x, void* y, int out_dtype, const floa
 // LN_MOD with the result as gemm_x3p.hip panel planes (three-way bf16 split of the fp32 value) instead of fp32 rows
 void launch_rownorm_x3p(const float* x, void* planes, const float* a, const float* b, long rows, int D, float eps, hipStream_t s,
                         int np = 3);
+// AdaLN fold (ConvGemm::ln_*, gemm_epilogue.h): the producer side as a pass of its own, for the first block of an evaluation —
+// aout = x o (1 + scale) as panel planes of np planes (a_dtype MI_F32) or rows of a_dtype, stats[row][D / 32][2] = partial (sum, sum^2)
+void launch_ln_prologue(const float* x, void* aout, int a_dtype, int np, float* stats, const float* scale, long rows, int D, int* sat,
+                        hipStream_t s);
+void launch_ln_gather(const float* mod, long mod_ld, long col_scale, long col_shift, float* G, float* S, int steps, int D, hipStream_t s);
+void launch_cast_to_f32(const void* src, int dtype, float* dst, long n, hipStream_t s);
+void launch_absmax(const float* x, long n, unsigned* out_bits, hipStream_t s);       // atomicMax of the bit pattern of max |x|
 void launch_dwconv7(const float* x, float* y, const float* w, const float* bias, int B, int T, int C, hipStream_t s);
 void launch_grn(float* y, float* ss_scratch, const float* gamma, const float* beta, int B, int T, int C, hipStream_t s);
 // ids [U][N]; out slabs 2u (text) / 2u+1 (drop)

@@ -162,6 +162,114 @@ void launch_rownorm_x3p(const float* x, void* planes, const float* a, const floa
     MI_HIP(hipGetLastError());
 }
 
+// AdaLN fold, first block of an evaluation (the row's producer is the position convolution, whose epilogue has no fold): what
+// the O / FF2 epilogues do for every later norm (gemm_epilogue.h gemm_epilogue_resid_ln) as a pass of its own — the rows
+// o (1 + scale) as the QKV GEMM's A operand (panel planes, or rows of TA) plus the per-row partial (sum, sum of squares) over
+// 32-column blocks.  A lane holds 8 consecutive columns and a quad of lanes one block: the same partials, bit for bit, as the
+// GEMM epilogues write for the same x.
+template <typename TA, int MAXP, int NP>
+__global__ __launch_bounds__(256) void ln_prologue_kernel(const float* __restrict__ x, void* __restrict__ aout, float* __restrict__ stats,
+                                                          const float* __restrict__ scale, long rows, int D, int* __restrict__ satp) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * D;
+    const int nb = D / LN_BLK;
+    unsigned sat = 0;
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+        const int s8 = i * 64 + lane, c = s8 * 8;
+        if (c < D) {           // D % 32 == 0: a quad is in range as a whole
+            const float4 v0 = *reinterpret_cast<const float4*>(xr + c), v1 = *reinterpret_cast<const float4*>(xr + c + 4);
+            const float4 a0 = *reinterpret_cast<const float4*>(scale + c), a1 = *reinterpret_cast<const float4*>(scale + c + 4);
+            float o[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            float s1 = ((o[0] + o[1]) + (o[2] + o[3])) + ((o[4] + o[5]) + (o[6] + o[7]));
+            float s2 = ((o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3])) + ((o[4] * o[4] + o[5] * o[5]) + (o[6] * o[6] + o[7] * o[7]));
+            s1 += dpp_mov<0xB1>(s1); s2 += dpp_mov<0xB1>(s2);
+            s1 += dpp_mov<0x4E>(s1); s2 += dpp_mov<0x4E>(s2);
+            if ((lane & 3) == 0) *reinterpret_cast<float2*>(stats + (row * nb + (c >> 5)) * 2) = make_float2(s1, s2);
+            const float g[8] = {1.f + a0.x, 1.f + a0.y, 1.f + a0.z, 1.f + a0.w, 1.f + a1.x, 1.f + a1.y, 1.f + a1.z, 1.f + a1.w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] *= g[k];
+            if constexpr (sizeof(TA) == 4) {
+                x3_u4 pl[NP];
+                xnp_split8_sat<NP>(o, pl, sat);
+                unsigned char* dst = (unsigned char*)aout + x3p_slot_offset(row, s8, D >> 5, NP);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) *reinterpret_cast<x3_u4*>(dst + q * X3P_PLANE) = pl[q];
+            } else {
+                struct alignas(16) Pk { TA v[8]; } pk;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) pk.v[k] = from_f32<TA>(o[k]);
+                *reinterpret_cast<Pk*>((TA*)aout + row * D + c) = pk;
+            }
+        }
+    }
+    if constexpr (sizeof(TA) == 4 && NP == 2) sat_publish(satp, sat);
+}
+
+void launch_ln_prologue(const float* x, void* aout, int a_dtype, int np, float* stats, const float* scale, long rows, int D, int* sat,
+                        hipStream_t s) {
+    MI_REQUIRE(D % 128 == 0 && D <= 2048 && (a_dtype != MI_F32 || np == 2 || np == 3), "ln_prologue: D must be a multiple of 128 and <= 2048");
+    dim3 grid((unsigned)((rows + 3) / 4));
+    ProfScope ps(FAM_NORM, s, (double)rows * D * (4.0 + (a_dtype == MI_F32 ? 2.0 * np : 2.0)), 4.0 * rows * D);
+    prof_set_kernel("ln_prologue_kernel (AdaLN fold, first block of an evaluation)", "", "");
+    const int mp = (D + 511) / 512;
+#define LNP(TA, MP, NPL) hipLaunchKernelGGL((ln_prologue_kernel<TA, MP, NPL>), grid, dim3(256), 0, s, x, aout, stats, scale, rows, D, sat)
+#define LNP_T(TA, NPL) do { if (mp == 1) LNP(TA, 1, NPL); else if (mp == 2) LNP(TA, 2, NPL); else LNP(TA, 4, NPL); } while (0)
+    if (a_dtype == MI_F32) { if (np == 3) LNP_T(float, 3); else LNP_T(float, 2); }
+    else if (a_dtype == MI_F16) LNP_T(f16, 2);
+    else LNP_T(bf16, 2);
+#undef LNP_T
+#undef LNP
+    MI_HIP(hipGetLastError());
+}
+
+// load-time helpers of the AdaLN fold (f5.hip): G[k][j] = 1 + mod[k][col_scale + j], S[k][j] = mod[k][col_shift + j]
+__global__ __launch_bounds__(256) void ln_gather_kernel(const float* __restrict__ mod, long mod_ld, long col_scale, long col_shift,
+                                                        float* __restrict__ G, float* __restrict__ S, int steps, int D) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)steps * D) return;
+    const long k = i / D, j = i - k * D;
+    G[i] = 1.f + mod[k * mod_ld + col_scale + j];
+    S[i] = mod[k * mod_ld + col_shift + j];
+}
+void launch_ln_gather(const float* mod, long mod_ld, long col_scale, long col_shift, float* G, float* S, int steps, int D, hipStream_t s) {
+    const long n = (long)steps * D;
+    hipLaunchKernelGGL(ln_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, mod, mod_ld, col_scale, col_shift, G, S, steps, D);
+    MI_HIP(hipGetLastError());
+}
+// dst (fp32) = the values of a 16-bit tensor (what the GEMM actually multiplies by)
+template <typename T>
+__global__ __launch_bounds__(256) void cast_to_f32_kernel(const T* __restrict__ src, float* __restrict__ dst, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = to_f32(src[i]);
+}
+void launch_cast_to_f32(const void* src, int dtype, float* dst, long n, hipStream_t s) {
+    if (n <= 0) return;
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (dtype == MI_F32) MI_HIP(hipMemcpyAsync(dst, src, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+    else if (dtype == MI_F16) hipLaunchKernelGGL(cast_to_f32_kernel<f16>, grid, dim3(256), 0, s, (const f16*)src, dst, n);
+    else hipLaunchKernelGGL(cast_to_f32_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)src, dst, n);
+    MI_HIP(hipGetLastError());
+}
+// *out_bits = max(*out_bits, bits(max |x|)) over a fp32 tensor (non-negative floats order like their bit patterns; nan / inf sort on top)
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ out_bits) {
+    unsigned m = 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const unsigned b = __float_as_uint(x[i]) & 0x7fffffffu;
+        m = b > m ? b : m;
+    }
+    for (int o = 32; o > 0; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)m, o); m = t > m ? t : m; }
+    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, m);
+}
+void launch_absmax(const float* x, long n, unsigned* out_bits, hipStream_t s) {
+    if (n <= 0) return;
+    const int blocks = (int)std::min<long>((n + 255) / 256, 1024);
+    hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, s, x, n, out_bits);
+    MI_HIP(hipGetLastError());
+}
+
 void launch_rownorm(int mode, const float* x, void* y, int out_dtype, const float* a, const float* b, long rows, int D,
                     float eps, hipStream_t s) {
     MI_REQUIRE(D % 4 == 0 && D <= 2048, "rownorm: D must be a multiple of 4 and <= 2048");

@@ -485,7 +485,18 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvGemmDev
         constexpr int ERT = (WN <= 64 && TM % 2 == 0) ? 2 : 1;
         float* stage = reinterpret_cast<float*>(smem) + wave * (ERT * 32 * WN);
         if constexpr (sizeof(TO) == 2 && BT == 128) {
-            if (p.epi == EPI_QKV_ROPE) { gemm_epilogue_qkv_lds<TO>(acc, p, m0, n0, b, wm, wn, lr, lk, stage); return; }
+            if (p.epi == EPI_QKV_ROPE) {
+                if (p.ln_stats_in) gemm_epilogue_qkv_lds<TO, 2, true>(acc, p, m0, n0, b, wm, wn, lr, lk, stage);
+                else gemm_epilogue_qkv_lds<TO>(acc, p, m0, n0, b, wm, wn, lr, lk, stage);
+                return;
+            }
+        }
+        if constexpr (sizeof(T) == 2) {        // DiT linear layers of the 16-bit engines: the AdaLN fold (one batch item, one group: host-checked)
+            if constexpr (sizeof(TO) == 2) {
+                if (p.ln_stats_in) { gemm_epilogue_ln_in<TO, TM, TN, 2>(acc, p, m0 + wm * WM, n0 + wn * WN, lr, lk, stage); return; }
+            } else {
+                if (p.ln_stats_out) { gemm_epilogue_resid_ln<T, TM, TN, 2>(acc, p, m0 + wm * WM, n0 + wn * WN, lr, lk, stage); return; }
+            }
         }
         gemm_epilogue_lds<TO, TM, TN, WM, WN>(acc, p, m0, n0, b, g, wm, wn, lr, lk, stage);
     } else {
@@ -506,7 +517,6 @@ static std::atomic<long> g_sk_min_tiles = 64;      // plain stream-K linear laye
 // 83.7 us per launch — the remainder's eight-piece fix-ups cost more than the aligned K walk of the first phase gains): opt-in
 // fp32 linear layers as six exact bf16 x bf16 partial products (gemm_x3.hip) when the caller supplies the weight planes
 static std::atomic<long> g_x3 = 1;
-bool gemm_x3_enabled() { return g_x3 != 0; }
 // ... with both operands as panel planes (gemm_x3p.hip, round 3) when the caller supplies them
 static std::atomic<long> g_x3p = 1;
 static std::atomic<long> g_f32_gconv = 1;         // ... and, when the shape allows, with each operand split once per workgroup (gconv_pairs.hip)
@@ -514,12 +524,28 @@ bool launch_gconv_pairs(const ConvGemm& p, hipStream_t s);
 static std::atomic<long> g_f32_n64_pairs = 1;     // fp32 N = 64 convolutions with >= 8 taps: fp16 pairs split in registers (conv_gemm_dma_kernel PAIRS)
 // number format of the panel planes built from now on: 3 = three bf16 planes (six products), 2 = fp16 {hi, lo} planes (three products)
 static std::atomic<long> g_x3p_np = 0;          // 0: not set by mi_set_option -> MI355TTS_F32_PLANES, else 2
+// The engine's arithmetic (ArithScope, common.h) overrides the process-wide options for the calling thread
+ArithOverride& arith_tls() { static thread_local ArithOverride a; return a; }
+ArithOverride arith_for(int kind) {
+    ArithOverride a;
+    if (kind == ARITH_NATIVE) { a.gemm_x3 = 0; a.gemm_x3p = 0; a.n64_pairs = 0; a.gconv = 0; a.attn_x3 = 0; }
+    else if (kind == ARITH_PAIRS) { a.gemm_x3 = 1; a.gemm_x3p = 1; a.planes = 2; a.n64_pairs = 1; a.gconv = 1; a.attn_x3 = 2; a.attn_np = 2; }
+    else if (kind == ARITH_BF16X3) { a.gemm_x3 = 1; a.gemm_x3p = 1; a.planes = 3; a.n64_pairs = 0; a.gconv = 0; a.attn_x3 = 2; a.attn_np = 3; }
+    return a;
+}
+static inline long opt_x3() { const int o = arith_tls().gemm_x3; return o >= 0 ? o : (long)g_x3; }
+static inline long opt_x3p() { const int o = arith_tls().gemm_x3p; return o >= 0 ? o : (long)g_x3p; }
+static inline long opt_n64_pairs() { const int o = arith_tls().n64_pairs; return o >= 0 ? o : (long)g_f32_n64_pairs; }
+static inline long opt_gconv() { const int o = arith_tls().gconv; return o >= 0 ? o : (long)g_f32_gconv; }
+bool gemm_x3_enabled() { return opt_x3() != 0; }
 int x3p_planes() {
+    const int o = arith_tls().planes;
+    if (o == 2 || o == 3) return o;
     if (g_x3p_np == 2 || g_x3p_np == 3) return (int)g_x3p_np;
     static const int env = [] { const char* e = std::getenv("MI355TTS_F32_PLANES"); return e ? std::atoi(e) : 0; }();
     return env == 3 ? 3 : 2;
 }
-bool gemm_x3p_enabled() { return g_x3 != 0 && g_x3p != 0; }
+bool gemm_x3p_enabled() { return opt_x3() != 0 && opt_x3p() != 0; }
 // fp32 QKV + RoPE: its scatter epilogue is slow and in a persistent launch every workgroup runs it at the same time at the
 // end (in-model 184 us against 138 us for the 64x64 tiles, whose epilogues overlap other workgroups' main loops): off
 static std::atomic<long> g_sk_qkv32 = 0;
@@ -539,10 +565,14 @@ template <typename T, typename TO>
 static void dispatch_tiles(const ConvGemmDev& d, int B, hipStream_t s) {
     constexpr int KC = sizeof(T) == 4 ? 16 : 64;
     dim3 blk(256);
+    // the AdaLN fold exists in the epilogues of linear_x3p / linear_ph8 / the 16-bit conv_gemm_dma_kernel only: anything else refuses
+    auto no_fold = [&] { MI_REQUIRE(!d.ln_stats_in && !d.ln_stats_out, "conv_gemm: this launch lands on a kernel without the AdaLN fold epilogues (gemm_ln_fold_ok disagrees with the dispatch)"); };
     if (d.N <= 32) {
+        no_fold();
         dim3 grid((d.M + 255) / 256, (d.N + 31) / 32, B * d.G);
         MI_LAUNCH((conv_gemm_kernel<T, TO, 256, 32, 4, 1, KC>), T, TO, grid, blk, 0, s, d);
     } else if (d.N <= 64) {
+        no_fold();
         {
             // N = 64 per group (the DiT position convolution: k = 31, 16 groups of 64 channels): 64x64 tiles of the LDS-DMA kernel
             // instead of the register-staged 128x64 one (fp32: 186 -> 120 us per launch)
@@ -555,7 +585,7 @@ static void dispatch_tiles(const ConvGemmDev& d, int B, hipStream_t s) {
                 dim3 g2(e.RT * e.Tn, d.G);
                 if constexpr (sizeof(T) == 4) {
                     // fp32 with many taps (the DiT's grouped k = 31 position convolution): operands as fp16 pairs split in registers
-                    if (g_x3 != 0 && g_f32_n64_pairs != 0 && d.K / d.Cin >= 8 && d.Cin % 32 == 0) {
+                    if (opt_x3() != 0 && opt_n64_pairs() != 0 && d.K / d.Cin >= 8 && d.Cin % 32 == 0) {
                         if (e.lds_epi) { prof_set_kernel("conv_gemm_dma_kernel<float, float, true, 2, 64, fp16 pairs>", "", ""); hipLaunchKernelGGL((conv_gemm_dma_kernel<T, TO, true, 2, 64, true>), g2, blk, 0, s, e); }
                         else { prof_set_kernel("conv_gemm_dma_kernel<float, float, false, 2, 64, fp16 pairs>", "", ""); hipLaunchKernelGGL((conv_gemm_dma_kernel<T, TO, false, 2, 64, true>), g2, blk, 0, s, e); }
                         MI_HIP(hipGetLastError());
@@ -596,6 +626,7 @@ static void dispatch_tiles(const ConvGemmDev& d, int B, hipStream_t s) {
                 e.Tm = (d.M + 127) / 128; e.Tn = (d.N + 127) / 128; e.RT = e.Tm;
                 e.RC = 0;       // row tiles fastest: neighbouring ranges share the weight planes, the heavier operand here (24 of the 40 KB per chunk): 62.9 -> 61.0 us
                 if (g_sk_order >= 0) e.RC = (int)g_sk_order;
+                no_fold();
                 launch_linear_x3(e, s);
                 return;
             }
@@ -611,6 +642,7 @@ static void dispatch_tiles(const ConvGemmDev& d, int B, hipStream_t s) {
                 e.RC = d.M <= d.N ? 0 : 1;      // per-XCD groups: whole weight panels (x re-read 8x) when x is the smaller operand, else whole row tiles
                 if (g_sk_order >= 0) e.RC = (int)g_sk_order;
                 e.tail_tiles = 0;
+                no_fold();
                 launch_linear_sk<T, TO>(e, (int)g_sk_stages, s);
                 return;
             }
@@ -629,6 +661,7 @@ static void dispatch_tiles(const ConvGemmDev& d, int B, hipStream_t s) {
                 // of the MFMAs and DMA bytes at N = 192) and the fewest DMA bytes per useful flop after 256x256
                 ConvGemmDev e = d;
                 e.RC = 0; e.Tm = (d.M + 255) / 256; e.Tn = d.N / 192; e.RT = B * e.Tm;
+                no_fold();
                 launch_conv_gemm_dma3<T, TO>(e, 192, s);
                 MI_HIP(hipGetLastError());
                 return;
@@ -643,12 +676,14 @@ static void dispatch_tiles(const ConvGemmDev& d, int B, hipStream_t s) {
                 if (g_big_tiles && buf_ok(d) && blocks_256x256 >= g_big_min && n_waste_256 * 4 <= d.N) {
                     // every CU busy for >= 2 rounds: the tile with the fewest DMA bytes per flop
                     e.Tm = (d.M + 255) / 256; e.Tn = (d.N + 255) / 256; e.RT = B * e.Tm;
+                    no_fold();
                     launch_conv_gemm_dma3<T, TO>(e, 256, s);
                     MI_HIP(hipGetLastError());
                     return;
                 }
                 if (blocks_256x128 >= g_mid_min || blocks_128 < blocks_256x128 + 32) {
                     e.Tm = (d.M + 255) / 256; e.Tn = (d.N + 127) / 128; e.RT = B * e.Tm;
+                    no_fold();
                     launch_conv_gemm_dma3<T, TO>(e, 128, s);
                     MI_HIP(hipGetLastError());
                     return;
@@ -687,6 +722,7 @@ static void dispatch_tiles(const ConvGemmDev& d, int B, hipStream_t s) {
         if constexpr (sizeof(T) == 4) {
             // fp32: the same 128x128 LDS-DMA kernel with 32-float K chunks (MFMA-bound: 8x the MFMA cycles per DMA byte)
             if (g_use_dma && g_f32_dma && d.Cin % 4 == 0 && d.K % d.Cin == 0) {
+                no_fold();
                 ConvGemmDev e = d;
                 e.Tm = (d.M + 127) / 128; e.Tn = (d.N + 127) / 128; e.RT = B * e.Tm;
                 e.RC = g_xcd_order ? (e.RT + 7) / 8 : 0;
@@ -708,6 +744,7 @@ static void dispatch_tiles(const ConvGemmDev& d, int B, hipStream_t s) {
                 return;
             }
         }
+        no_fold();
         MI_LAUNCH((conv_gemm_kernel<T, TO, 128, 128, 2, 2, KC>), T, TO, grid, blk, 0, s, d);
     }
     MI_HIP(hipGetLastError());
@@ -757,7 +794,7 @@ bool gemm_set_option(const char* key, long v) {
 
 // the bf16x3 kernel (gemm_x3.hip) takes this launch: decided ONCE here, because the epilogue kind depends on it
 static bool x3_eligible(const ConvGemm& p) {
-    if (!g_x3 || !p.w3 || p.dtype != MI_F32 || (p.out_dtype >= 0 && p.out_dtype != MI_F32)) return false;
+    if (!opt_x3() || !p.w3 || p.dtype != MI_F32 || (p.out_dtype >= 0 && p.out_dtype != MI_F32)) return false;
     if (!p.sk_ws || !p.sk_flags || p.sk_slots < 256 || p.B != 1 || p.G != 1 || p.taps != 1 || p.pad != 0 || p.Cin % 32 != 0 || p.M <= 128) return false;
     if (p.epi != EPI_PLAIN && p.epi != EPI_QKV_ROPE) return false;
     if (p.epi == EPI_QKV_ROPE && !(p.head_dim == 64 && p.rope_pack && (p.rows_per_item == 0 ? p.M : p.rows_per_item) >= 64 &&
@@ -770,7 +807,7 @@ static bool x3_eligible(const ConvGemm& p) {
 
 // ... and the panel-plane form of it (gemm_x3p.hip): whole 128-column weight panels, whole 32-deep chunks
 static bool x3p_eligible(const ConvGemm& p) {
-    if (!g_x3p || !p.xp || !p.w3p) return false;
+    if (!opt_x3p() || !p.xp || !p.w3p) return false;
     ConvGemm q = p;
     q.w3 = p.w3p;                                     // same conditions as the round-2 kernel (q.w3 only has to be non-null)
     if (!x3_eligible(q)) return false;
@@ -780,6 +817,37 @@ static bool x3p_eligible(const ConvGemm& p) {
 }
 
 bool gemm_x3p_would_run(const ConvGemm& p) { return x3p_eligible(p) && p.B == 1 && p.G == 1; }
+
+// outputs leave through the LDS-staged, 16-byte-store epilogues (decided once per launch: the kernels instantiate either kind)
+static bool lds_epi_for(const ConvGemm& p, int odt, bool use_x3) {
+    static int no_lds_epi = -1;
+    if (no_lds_epi < 0) { const char* q = std::getenv("MI355TTS_NO_LDS_EPI"); no_lds_epi = (q && q[0] == '1') ? 1 : 0; }
+    if (no_lds_epi) return false;
+    const int ch = 16 / (int)dtype_size(odt);
+    // measured: +8-14 % on the K = 1024 DiT linears in the 2-blocks-per-CU 128x128 kernel, a loss on the conv shapes
+    // (N <= 768) and in the one-block-per-CU 8-wave kernels, so it is used for wide linear layers only
+    // (fp32 outputs: only the bf16x3 kernel has the staged QKV epilogue; rows leave as 32-byte stores, V either way)
+    const bool qkv_lds = p.epi == EPI_QKV_ROPE && p.head_dim == 64 && (dtype_size(odt) == 2 || use_x3) && p.G == 1 &&
+                         (p.rows_per_item == 0 ? p.M : p.rows_per_item) >= 64 && ((uintptr_t)p.out % 16) == 0 &&
+                         ((uintptr_t)p.out2 % 16) == 0;
+    if (qkv_lds) return true;
+    return p.epi == EPI_PLAIN && p.taps == 1 && p.N >= 1024 && p.N % ch == 0 && p.out_rstride % ch == 0 &&
+           p.out_bstride % ch == 0 && ((uintptr_t)p.out % 16) == 0 && (!p.res || ((uintptr_t)p.res % 16) == 0);
+}
+
+// The AdaLN fold (ConvGemm::ln_*) lives in the LDS-staged epilogues of three kernels: linear_x3p (fp32 engines), linear_ph8 and
+// conv_gemm_dma_kernel (16-bit engines).  This answers, for the caller that has to choose between the fold and a row-norm launch,
+// whether launch_conv_gemm(p) ends up on one of them; dispatch_tiles() refuses (loudly) if the two ever disagree.
+bool gemm_ln_fold_ok(const ConvGemm& p) {
+    const int odt = p.out_dtype < 0 ? p.dtype : p.out_dtype;
+    if (p.B != 1 || p.G != 1 || p.taps != 1 || p.pad != 0 || p.alpha != 1.f || p.accumulate || p.gate_bstride != 0 || p.N % 64 != 0 || p.M <= 128) return false;
+    if (p.epi != EPI_PLAIN && p.epi != EPI_QKV_ROPE) return false;
+    if (p.dtype == MI_F32) return gemm_x3p_would_run(p) && lds_epi_for(p, odt, true);
+    if (!lds_epi_for(p, odt, false) || !g_use_dma || p.Cin % 64 != 0 || p.N <= 64) return false;
+    if (g_sk >= 2) return false;                                        // 16-bit stream-K (opt-in) has no fold epilogue
+    if (g_use_dma3 && p.Cin > g_k_min) return false;                    // K > 2048: the 256-row dma3 kernels
+    return true;
+}
 
 void launch_conv_gemm(const ConvGemm& p_in, hipStream_t s) {
     ConvGemm p = p_in;
@@ -818,10 +886,16 @@ void launch_conv_gemm(const ConvGemm& p_in, hipStream_t s) {
             a.M = a.T_in = (int)(256 * r);
             b.M = b.T_in = (int)rem;
             b.x = (const char*)p.x + (size_t)(256 * r) * p.x_rstride * dtype_size(p.dtype);
-            if (split_qkv) b.m_off = (int)(256 * r);
+            if (split_qkv) b.m_off = (int)(256 * r);       // (the fold's statistics are indexed by the flattened row there too)
             else {
                 b.out = (char*)p.out + (size_t)(256 * r) * p.out_rstride * dtype_size(odt);
                 if (p.res) b.res = (const char*)p.res + (size_t)(256 * r) * p.out_rstride * dtype_size(odt);
+                // AdaLN fold: the per-row operands of the second launch start at its first row (16-bit engines: ln_out is rows [M][N])
+                if (p.ln_stats_in) b.ln_stats_in = p.ln_stats_in + (size_t)(256 * r) * (p.ln_dim / LN_BLK) * 2;
+                if (p.ln_stats_out) {
+                    b.ln_stats_out = p.ln_stats_out + (size_t)(256 * r) * (p.N / LN_BLK) * 2;
+                    b.ln_out = (char*)p.ln_out + (size_t)(256 * r) * p.N * dtype_size(p.dtype);
+                }
             }
             launch_conv_gemm(a, s);
             launch_conv_gemm(b, s);
@@ -856,6 +930,23 @@ void launch_conv_gemm(const ConvGemm& p_in, hipStream_t s) {
         MI_REQUIRE(use_x3p && p.epi == EPI_PLAIN && !p.res && !p.gate && !p.accumulate && p.alpha == 1.f && p.N % 32 == 0,
                    "conv_gemm: out_planes needs the panel-plane kernel and a plain bias + activation epilogue");
         d.out_planes = p.out_planes;
+    }
+    d.ln_scale = p.ln_scale; d.ln_out = p.ln_out; d.ln_stats_out = p.ln_stats_out; d.ln_out_np = p.ln_out_np;
+    d.ln_stats_in = p.ln_stats_in; d.ln_p = p.ln_p; d.ln_c = p.ln_c; d.ln_dim = p.ln_dim; d.ln_eps = p.ln_eps;
+    d.sat = p.sat;
+    if (p.ln_stats_in || p.ln_stats_out) {
+        MI_REQUIRE(!(p.ln_stats_in && p.ln_stats_out), "conv_gemm: a launch is the producer OR the consumer of the AdaLN fold");
+        MI_REQUIRE(p.B == 1 && p.G == 1 && p.taps == 1 && p.alpha == 1.f && !p.accumulate && p.gate_bstride == 0 && p.N % 64 == 0,
+                   "conv_gemm: AdaLN fold needs a plain linear layer over one M axis");
+        if (p.ln_stats_out)
+            MI_REQUIRE(p.epi == EPI_PLAIN && odt == MI_F32 && p.res && p.ln_scale && p.ln_out && p.act == ACT_NONE && !p.out_planes &&
+                           ((uintptr_t)p.ln_out % 16) == 0 && ((uintptr_t)p.ln_stats_out % 8) == 0 && ((uintptr_t)p.ln_scale % 16) == 0 &&
+                           (p.dtype != MI_F32 || p.ln_out_np == p.np),
+                       "conv_gemm: AdaLN fold producer: fp32 residual rows out, (1 + scale) and the next operand's buffer");
+        else
+            MI_REQUIRE(p.ln_p && p.ln_c && p.ln_dim >= 128 && p.ln_dim % 128 == 0 && !p.res && !p.gate && ((uintptr_t)p.ln_stats_in % 16) == 0 &&
+                           ((uintptr_t)p.ln_p % 16) == 0 && ((uintptr_t)p.ln_c % 16) == 0 && (odt != MI_F32 || p.epi == EPI_QKV_ROPE || p.out_planes),
+                       "conv_gemm: AdaLN fold consumer: statistics, W(1 + scale) and W shift + b vectors");
     }
     d.tail_tiles = 0; d.tail_split = 1;
     d.use_buf = 0;
@@ -905,22 +996,10 @@ void launch_conv_gemm(const ConvGemm& p_in, hipStream_t s) {
         // of rows) and every tap re-fetched its rows from the fabric (PMC: 341 MB per launch against 100 MB algorithmic);
         // consecutive taps now re-read the same rows x 64 channels.  fp32 accumulation: only the summation order changes.
         // (A run-time switch between the two orders cost 12 % by itself, so the order is fixed.)
-        static int no_lds_epi = -1;
-        if (no_lds_epi < 0) { const char* q = std::getenv("MI355TTS_NO_LDS_EPI"); no_lds_epi = (q && q[0] == '1') ? 1 : 0; }
-        const int ch = 16 / (int)dtype_size(odt);
-        // measured: +8-14 % on the K = 1024 DiT linears in the 2-blocks-per-CU 128x128 kernel, a loss on the conv shapes
-        // (N <= 768) and in the one-block-per-CU 8-wave kernels, so it is used for wide linear layers only
-        // (fp32 outputs: only the bf16x3 kernel has the staged QKV epilogue; rows leave as 32-byte stores, V either way)
-        const bool qkv_x3 = use_x3;
-        const bool qkv_lds = p.epi == EPI_QKV_ROPE && p.head_dim == 64 && (dtype_size(odt) == 2 || qkv_x3) && p.G == 1 &&
-                             (p.rows_per_item == 0 ? p.M : p.rows_per_item) >= 64 && ((uintptr_t)p.out % 16) == 0 &&
-                             ((uintptr_t)p.out2 % 16) == 0;
-        d.lds_epi = !no_lds_epi && qkv_lds;
-        if (!qkv_lds)
-        d.lds_epi = !no_lds_epi && p.epi == EPI_PLAIN && p.taps == 1 && p.N >= 1024 && p.N % ch == 0 && p.out_rstride % ch == 0 &&
-                    p.out_bstride % ch == 0 && ((uintptr_t)p.out % 16) == 0 && (!p.res || ((uintptr_t)p.res % 16) == 0) &&
-                    (p.epi != EPI_CONVT || p.Cout % ch == 0);
+        d.lds_epi = lds_epi_for(p, odt, use_x3) ? 1 : 0;
     }
+    if (p.ln_stats_in || p.ln_stats_out)
+        MI_REQUIRE(d.lds_epi && (p.dtype != MI_F32 || use_x3p), "conv_gemm: the AdaLN fold lives in the LDS-staged epilogues of linear_x3p / linear_ph8 / conv_gemm_dma (gemm_ln_fold_ok)");
     if (p.kv_planes) MI_REQUIRE(p.epi == EPI_QKV_ROPE && p.dtype == MI_F32 && d.lds_epi && p.v_ld > 0 && p.k_ld > 0 && p.v_ld % 8 == 0,
                                 "conv_gemm: kv_planes needs the fp32 LDS-staged QKV epilogue with transposed V");
     if (p.epi == EPI_CONVT) MI_REQUIRE(p.Cout > 0 && p.N == p.u * p.Cout, "conv_gemm: convT shape");
@@ -938,7 +1017,7 @@ void launch_conv_gemm(const ConvGemm& p_in, hipStream_t s) {
     ProfScope ps(FAM_CONV_GEMM, s, bytes, flops);
 
     // fp32 grouped convolutions with 64 channels per group and >= 8 taps (the DiT's position convolution): gconv_pairs.hip
-    if (p.dtype == MI_F32 && g_x3 != 0 && g_f32_n64_pairs != 0 && g_f32_gconv != 0 && g_use_dma && launch_gconv_pairs(p, s)) return;
+    if (p.dtype == MI_F32 && opt_x3() != 0 && opt_n64_pairs() != 0 && opt_gconv() != 0 && g_use_dma && launch_gconv_pairs(p, s)) return;
     if (p.dtype == MI_F32) {
         dispatch_tiles<float, float>(d, p.B, s);
     } else if (p.dtype == MI_F16) {

@@ -4,6 +4,7 @@
 #include "common.h"
 #include "mfma.h"
 #include "x3_split.h"
+#include "wave_reduce.h"
 
 namespace mi {
 
@@ -44,6 +45,10 @@ struct ConvGemmDev {
     void* out_planes;                            // gemm_x3p.hip: output as panel planes of an [M][N] matrix (null: rows in `out`)
     int kv_planes; long k_ld;                    // EPI_QKV_ROPE, fp32: K and V^T leave pre-split (attention.hip KVP), np = kv_planes planes (3 bf16 | 2 fp16 pairs with the low part unscaled, x2u_split_pair; 1 = 3): out2 = [bh][np][k_ld][64], out3 = [bh][np][64][v_ld]
     int tail_tiles, tail_split;                  // gemm_ph8.hip: the last tail_tiles tiles are cut into tail_split K slices (0 / 1: none)
+    // AdaLN fold (ConvGemm, common.h): producer side (ln_stats_out) / consumer side (ln_stats_in)
+    const float* ln_scale = nullptr; void* ln_out = nullptr; float* ln_stats_out = nullptr; int ln_out_np = 0;
+    const float* ln_stats_in = nullptr; const float* ln_p = nullptr; const float* ln_c = nullptr; int ln_dim = 0; float ln_eps = 0.f;
+    int* sat = nullptr;                          // fp16-pair producers raise bit 0 when an operand met the fp16 range limit
 };
 
 // Shared epilogue: 32x32 accumulator tiles -> bias / activation / gate / residual / alpha / accumulate -> HBM,
@@ -288,13 +293,47 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x16 (&acc)[TM][TN], const C
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// AdaLN fold (ConvGemm::ln_* in common.h; AdaLayerNorm.forward modules.py:301-305, DiTBlock.forward :599-613).
+// The LayerNorm between the residual stream and the QKV / FF1 projections has no launch of its own: the producer of the
+// residual row (O / FF2 epilogue) leaves x o (1 + scale) as the next GEMM's A operand plus per-row partial (sum, sum of squares)
+// over 32-column blocks; the consumer's epilogue finishes  rstd * acc - (mean * rstd) * (W (1 + scale)) + (W shift + b).
+// Every partial is a plain store and every sum runs in a fixed order: results are bit-reproducible and do not depend on
+// which kernel (tile shape) produced the partials.
+// ---------------------------------------------------------------------------------------------------------------------------
+
+// (rstd, mean * rstd) of the 32 rows row0 .. row0 + 31 (clamped to row_last): lane l and lane l + 32 both return row (l & 31).
+// The two half-waves each add one half of the row's D / 32 partial pairs in index order, then low half + high half.
+__device__ __forceinline__ void ln_rows32(const ConvGemmDev& p, long row0, long row_last, int lr, int lk, float& rstd, float& mrstd) {
+    const int nb = p.ln_dim / LN_BLK;                        // a multiple of 4 (ln_dim % 128 == 0, checked on the host)
+    long row = row0 + lr;
+    row = row < row_last ? row : row_last;
+    const float4* sp = reinterpret_cast<const float4*>(p.ln_stats_in + row * (long)(nb * 2)) + lk * (nb >> 2);
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = 0; i < (nb >> 2); ++i) {
+        const float4 t = sp[i];
+        s1 += t.x; s2 += t.y; s1 += t.z; s2 += t.w;
+    }
+    const float o1 = __shfl_xor(s1, 32), o2 = __shfl_xor(s2, 32);
+    const float t1 = lk ? o1 + s1 : s1 + o1;                 // low half + high half on both lanes
+    const float t2 = lk ? o2 + s2 : s2 + o2;
+    const float inv_d = 1.0f / (float)p.ln_dim;
+    const float mean = t1 * inv_d;
+    float var = t2 * inv_d - mean * mean;                    // biased variance
+    var = var > 0.f ? var : 0.f;
+    rstd = 1.0f / sqrtf(var + p.ln_eps);
+    mrstd = mean * rstd;
+}
+
 // LDS-staged variant of the fused QKV epilogue for the 128x128 DMA kernel (head_dim 64, one (q|k|v, head) slice per
 // 64-column wave tile).  q / k: rows leave as 16-byte stores into [b*H + h][token][64] with the interleaved-pair RoPE
 // applied on the 8-column chunk a lane holds.  V (transposed for the attention kernel, [b*H + h][d][key]): the tile is
 // read back column-wise with lane = key, so every store instruction writes 32 consecutive keys of one d (64 contiguous
 // bytes) instead of 64 two-byte writes to 64 different rows.
 // TMQ: 32-row blocks of the wave tile (2: 64 x 64 per wave ; 1: 32 x 64, the eight-wave layout of gemm_x3.hip)
-template <typename TO, int TMQ = 2>
+// LN: consumer side of the AdaLN fold (see below): the accumulators carry W (x o (1 + scale)); bias and the LayerNorm's
+// mean / rstd enter on the row-wise read-back as rstd * acc - (mean * rstd) * ln_p[col] + ln_c[col]
+template <typename TO, int TMQ = 2, bool LN = false>
 __device__ __forceinline__ void gemm_epilogue_qkv_lds(f32x16 (&acc)[TMQ][2], const ConvGemmDev& p, int m0, int n0, int b,
                                                       int wm, int wn, int lr, int lk, float* stage) {
     const int lane = lk * 32 + lr;
@@ -308,10 +347,23 @@ __device__ __forceinline__ void gemm_epilogue_qkv_lds(f32x16 (&acc)[TMQ][2], con
     const bool vt = which == 2 && p.v_ld > 0;
     TO* base = (TO*)(which == 0 ? p.out : which == 1 ? p.out2 : p.out3);
     struct alignas(16) Pk { TO v[8]; };
+    float ln_rs[TMQ], ln_mr[TMQ];
+    if constexpr (LN) {
+#pragma unroll
+        for (int i = 0; i < TMQ; ++i) ln_rows32(p, (long)mbase + i * 32, (long)p.m_off + p.M - 1, lr, lk, ln_rs[i], ln_mr[i]);
+    }
     if (!vt) {
+        float ln_pv[8], ln_cv[8];
+        if constexpr (LN) {
+            const int cc = nbase + (lane & 7) * 8;
+            const float4 a0 = *reinterpret_cast<const float4*>(p.ln_p + cc), a1 = *reinterpret_cast<const float4*>(p.ln_p + cc + 4);
+            const float4 b0 = *reinterpret_cast<const float4*>(p.ln_c + cc), b1 = *reinterpret_cast<const float4*>(p.ln_c + cc + 4);
+            ln_pv[0] = a0.x; ln_pv[1] = a0.y; ln_pv[2] = a0.z; ln_pv[3] = a0.w; ln_pv[4] = a1.x; ln_pv[5] = a1.y; ln_pv[6] = a1.z; ln_pv[7] = a1.w;
+            ln_cv[0] = b0.x; ln_cv[1] = b0.y; ln_cv[2] = b0.z; ln_cv[3] = b0.w; ln_cv[4] = b1.x; ln_cv[5] = b1.y; ln_cv[6] = b1.z; ln_cv[7] = b1.w;
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const float bv = p.bias ? p.bias[nbase + j * 32 + lr] : 0.f;
+            const float bv = (!LN && p.bias) ? p.bias[nbase + j * 32 + lr] : 0.f;
 #pragma unroll
             for (int i = 0; i < TMQ; ++i)
 #pragma unroll
@@ -352,6 +404,11 @@ __device__ __forceinline__ void gemm_epilogue_qkv_lds(f32x16 (&acc)[TMQ][2], con
                 for (int q = 0; q < 8; q += 4) {
                     const float4 t = *reinterpret_cast<const float4*>(&stage[rr * 64 + c8 + q]);
                     x[q] = t.x; x[q + 1] = t.y; x[q + 2] = t.z; x[q + 3] = t.w;
+                }
+                if constexpr (LN) {
+                    const float rs = __shfl(ln_rs[(it0 + gi) >> 2], rr & 31), mr = __shfl(ln_mr[(it0 + gi) >> 2], rr & 31);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) x[q] = __builtin_fmaf(rs, x[q], __builtin_fmaf(-mr, ln_pv[q], ln_cv[q]));
                 }
                 if (which < 2 && p.rope_pack) {
 #pragma unroll
@@ -420,11 +477,17 @@ __device__ __forceinline__ void gemm_epilogue_qkv_lds(f32x16 (&acc)[TMQ][2], con
         for (int i = 0; i < TMQ; ++i) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const float bv = p.bias ? p.bias[nbase + j * 32 + lr] : 0.f;
+                const float bv = (!LN && p.bias) ? p.bias[nbase + j * 32 + lr] : 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     stage[((r & 3) + 8 * (r >> 2) + 4 * lk) * 65 + j * 32 + lr] = acc[i][j][r] + bv;
             }
+            // the value of (row, column dd) on the read-back; LN: this lane's row is row `lane & 31` = lr of block i
+            auto vt_val = [&](int dd) __attribute__((always_inline)) -> float {
+                const float a = stage[row * 65 + dd];
+                if constexpr (LN) return __builtin_fmaf(ln_rs[i], a, __builtin_fmaf(-ln_mr[i], p.ln_p[nbase + dd], p.ln_c[nbase + dd]));
+                else return a;
+            };
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             const int rr = i * 32 + row;
@@ -441,7 +504,7 @@ __device__ __forceinline__ void gemm_epilogue_qkv_lds(f32x16 (&acc)[TMQ][2], con
                     for (int d = 0; d < 32; ++d) {
                         const int dd = dh * 32 + d;
                         unsigned ph, pl;
-                        x2u_split_pair(stage[row * 65 + dd], 0.f, ph, pl);
+                        x2u_split_pair(vt_val(dd), 0.f, ph, pl);
                         if (ok) {
                             vp[(long)dd * p.v_ld] = (unsigned short)ph;
                             vp[pstride + (long)dd * p.v_ld] = (unsigned short)pl;
@@ -453,7 +516,7 @@ __device__ __forceinline__ void gemm_epilogue_qkv_lds(f32x16 (&acc)[TMQ][2], con
                 for (int d = 0; d < 32; ++d) {
                     const int dd = dh * 32 + d;
                     unsigned p1, p2, p3;
-                    x3_split_pair(stage[row * 65 + dd], 0.f, p1, p2, p3);
+                    x3_split_pair(vt_val(dd), 0.f, p1, p2, p3);
                     if (ok) {
                         vp[(long)dd * p.v_ld] = (unsigned short)p1;
                         vp[pstride + (long)dd * p.v_ld] = (unsigned short)p2;
@@ -465,7 +528,7 @@ __device__ __forceinline__ void gemm_epilogue_qkv_lds(f32x16 (&acc)[TMQ][2], con
 #pragma unroll 8
                 for (int d = 0; d < 32; ++d) {
                     const int dd = dh * 32 + d;
-                    const float v = stage[row * 65 + dd];
+                    const float v = vt_val(dd);
                     if (ok) dst[(long)dd * p.v_ld] = from_f32<TO>(v);
                 }
             }
@@ -473,6 +536,184 @@ __device__ __forceinline__ void gemm_epilogue_qkv_lds(f32x16 (&acc)[TMQ][2], con
             __builtin_amdgcn_wave_barrier();
         }
     }
+}
+
+
+template <typename TO> __device__ __forceinline__ void ln_act8(float (&x)[8], int act) {
+    switch (act) {                                            // wave-uniform
+        case ACT_GELU_TANH:
+            if constexpr (sizeof(TO) == 2) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) x[q] = gelu_tanh_fast(x[q]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; q += 4) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x[q + r] = act_apply(x[q + r], ACT_GELU_TANH);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            break;
+        case ACT_GELU_ERF:
+#pragma unroll
+            for (int q = 0; q < 8; ++q) x[q] = act_apply(x[q], ACT_GELU_ERF);
+            break;
+        case ACT_MISH:
+#pragma unroll
+            for (int q = 0; q < 8; ++q) x[q] = act_apply(x[q], ACT_MISH);
+            break;
+        case ACT_SILU:
+#pragma unroll
+            for (int q = 0; q < 8; ++q) x[q] = act_apply(x[q], ACT_SILU);
+            break;
+        default: break;
+    }
+}
+
+// CONSUMER with a plain epilogue (FF1): v = act(rstd * acc - (mean * rstd) * ln_p[col] + ln_c[col]).  The wave tile is TM
+// 32-row blocks x WN = 32 * TN columns, first row `mw` of this launch, first column `nc0`; it leaves as rows of TO (16-bit
+// engines: p.out) or as panel planes of NP planes (fp32 engines: p.out_planes), one 16-byte store per lane and plane.
+template <typename TO, int TM, int TN, int NP>
+__device__ __forceinline__ void gemm_epilogue_ln_in(f32x16 (&acc)[TM][TN], const ConvGemmDev& p, int mw, int nc0, int lr, int lk, float* stage) {
+    constexpr int WN = 32 * TN, LPR = WN / 8, RPI = 64 / LPR, NIT = 32 / RPI;
+    const int lane = lk * 32 + lr;
+    const int c8 = (lane % LPR) * 8, rl0 = lane / LPR;
+    const int col = nc0 + c8;
+    float pv[8], cv[8];
+    {
+        const float4 a0 = *reinterpret_cast<const float4*>(p.ln_p + col), a1 = *reinterpret_cast<const float4*>(p.ln_p + col + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(p.ln_c + col), b1 = *reinterpret_cast<const float4*>(p.ln_c + col + 4);
+        pv[0] = a0.x; pv[1] = a0.y; pv[2] = a0.z; pv[3] = a0.w; pv[4] = a1.x; pv[5] = a1.y; pv[6] = a1.z; pv[7] = a1.w;
+        cv[0] = b0.x; cv[1] = b0.y; cv[2] = b0.z; cv[3] = b0.w; cv[4] = b1.x; cv[5] = b1.y; cv[6] = b1.z; cv[7] = b1.w;
+    }
+    unsigned sat = 0;
+    struct alignas(16) Pk { TO v[8]; };
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        float rstd, mrstd;
+        ln_rows32(p, (long)mw + i * 32, (long)p.M - 1, lr, lk, rstd, mrstd);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * lk) * WN + j * 32 + lr] = acc[i][j][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int rr = rl0 + it * RPI;
+            const int m = mw + i * 32 + rr;
+            const float rs = __shfl(rstd, rr), mr = __shfl(mrstd, rr);
+            const float4 t0 = *reinterpret_cast<const float4*>(&stage[rr * WN + c8]);
+            const float4 t1 = *reinterpret_cast<const float4*>(&stage[rr * WN + c8 + 4]);
+            float x[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+#pragma unroll
+            for (int q = 0; q < 8; ++q) x[q] = __builtin_fmaf(rs, x[q], __builtin_fmaf(-mr, pv[q], cv[q]));
+            ln_act8<TO>(x, p.act);
+            if constexpr (sizeof(TO) == 4) {
+                x3_u4 pl[NP];
+                xnp_split8_sat<NP>(x, pl, sat);
+                if (m < p.M) {
+                    unsigned char* dst = (unsigned char*)p.out_planes + x3p_slot_offset(m, col >> 3, p.N >> 5, NP);
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) *reinterpret_cast<x3_u4*>(dst + q * X3P_PLANE) = pl[q];
+                }
+            } else {
+                Pk o;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) o.v[q] = from_f32<TO>(x[q]);
+                if (m < p.M) *reinterpret_cast<Pk*>((TO*)p.out + (long)m * p.out_rstride + col) = o;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if constexpr (sizeof(TO) == 4 && NP == 2) sat_publish(p.sat, sat);
+}
+
+// PRODUCER (O / FF2 projections): x_new = res + gate * (acc + bias) -> fp32 rows in p.out (the residual stream); the same rows
+// o (1 + ln_scale) -> the next GEMM's A operand (TA = float: panel planes of NP planes; else rows of TA, [M][N]); partial
+// (sum, sum of squares) of x_new per 32-column block -> ln_stats_out.  Wave tile as above.
+template <typename TA, int TM, int TN, int NP>
+__device__ __forceinline__ void gemm_epilogue_resid_ln(f32x16 (&acc)[TM][TN], const ConvGemmDev& p, int mw, int nc0, int lr, int lk, float* stage) {
+    constexpr int WN = 32 * TN, LPR = WN / 8, RPI = 64 / LPR, NIT = 32 / RPI;
+    const int lane = lk * 32 + lr;
+    const int c8 = (lane % LPR) * 8, rl0 = lane / LPR;
+    const int col = nc0 + c8;
+    const int nb = p.N / LN_BLK;
+    float* outp = (float*)p.out;
+    const float* resp = (const float*)p.res;
+    float gsc[8];
+    {
+        const float4 a0 = *reinterpret_cast<const float4*>(p.ln_scale + col), a1 = *reinterpret_cast<const float4*>(p.ln_scale + col + 4);
+        gsc[0] = 1.f + a0.x; gsc[1] = 1.f + a0.y; gsc[2] = 1.f + a0.z; gsc[3] = 1.f + a0.w;
+        gsc[4] = 1.f + a1.x; gsc[5] = 1.f + a1.y; gsc[6] = 1.f + a1.z; gsc[7] = 1.f + a1.w;
+    }
+    unsigned sat = 0;
+    struct alignas(16) Pk { TA v[8]; };
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = nc0 + j * 32 + lr;
+            const float bv = p.bias ? p.bias[n] : 0.f;
+            const float gv = p.gate ? p.gate[n] : 1.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * lk) * WN + j * 32 + lr] = (acc[i][j][r] + bv) * gv;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // all residual rows of the block are requested before the first is used (clamped addresses, masked stores)
+        float4 r0[NIT], r1[NIT];
+        long ix[NIT];
+        bool ok[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int m = mw + i * 32 + rl0 + it * RPI;
+            ok[it] = m < p.M;
+            ix[it] = ok[it] ? (long)m * p.out_rstride + col : 0;
+            r0[it] = *reinterpret_cast<const float4*>(resp + ix[it]);
+            r1[it] = *reinterpret_cast<const float4*>(resp + ix[it] + 4);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int rr = rl0 + it * RPI;
+            const int m = mw + i * 32 + rr;
+            const float4 t0 = *reinterpret_cast<const float4*>(&stage[rr * WN + c8]);
+            const float4 t1 = *reinterpret_cast<const float4*>(&stage[rr * WN + c8 + 4]);
+            float x[8] = {t0.x + r0[it].x, t0.y + r0[it].y, t0.z + r0[it].z, t0.w + r0[it].w,
+                          t1.x + r1[it].x, t1.y + r1[it].y, t1.z + r1[it].z, t1.w + r1[it].w};
+            if (ok[it]) {
+                *reinterpret_cast<float4*>(outp + ix[it]) = make_float4(x[0], x[1], x[2], x[3]);
+                *reinterpret_cast<float4*>(outp + ix[it] + 4) = make_float4(x[4], x[5], x[6], x[7]);
+            }
+            // partial statistics of the 32-column block this lane's quad covers (8 columns per lane, 4 lanes): fixed order
+            float s1 = ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+            float s2 = ((x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3])) + ((x[4] * x[4] + x[5] * x[5]) + (x[6] * x[6] + x[7] * x[7]));
+            s1 += dpp_mov<0xB1>(s1); s2 += dpp_mov<0xB1>(s2);      // lane ^ 1
+            s1 += dpp_mov<0x4E>(s1); s2 += dpp_mov<0x4E>(s2);      // lane ^ 2
+            if (ok[it] && (lane & 3) == 0)
+                *reinterpret_cast<float2*>(p.ln_stats_out + ((long)m * nb + (col >> 5)) * 2) = make_float2(s1, s2);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) x[q] *= gsc[q];
+            if constexpr (sizeof(TA) == 4) {
+                x3_u4 pl[NP];
+                xnp_split8_sat<NP>(x, pl, sat);
+                if (ok[it]) {
+                    unsigned char* dst = (unsigned char*)p.ln_out + x3p_slot_offset(m, col >> 3, p.N >> 5, NP);
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) *reinterpret_cast<x3_u4*>(dst + q * X3P_PLANE) = pl[q];
+                }
+            } else {
+                Pk o;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) o.v[q] = from_f32<TA>(x[q]);
+                if (ok[it]) *reinterpret_cast<Pk*>((TA*)p.ln_out + (long)m * p.N + col) = o;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if constexpr (sizeof(TA) == 4 && NP == 2) sat_publish(p.sat, sat);
 }
 
 typedef __attribute__((address_space(3))) void lds_void;

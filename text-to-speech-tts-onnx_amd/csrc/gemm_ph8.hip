@@ -296,7 +296,14 @@ __global__ __launch_bounds__(512, 1) void linear_ph8_kernel(const ConvGemmDev p)
         float* stage = reinterpret_cast<float*>(smem) + wave * (2 * 32 * 64);
         auto half_out = [&](f32x16 (&q)[2][2], int mh) __attribute__((always_inline)) {
             if constexpr (sizeof(TO) == 2) {
-                if (p.epi == EPI_QKV_ROPE) { gemm_epilogue_qkv_lds<TO>(q, p, mh, n0, 0, 0, wc, lr, lk, stage); return; }
+                if (p.epi == EPI_QKV_ROPE) {
+                    if (p.ln_stats_in) gemm_epilogue_qkv_lds<TO, 2, true>(q, p, mh, n0, 0, 0, wc, lr, lk, stage);
+                    else gemm_epilogue_qkv_lds<TO>(q, p, mh, n0, 0, 0, wc, lr, lk, stage);
+                    return;
+                }
+                if (p.ln_stats_in) { gemm_epilogue_ln_in<TO, 2, 2, 2>(q, p, mh, n0 + wc * 64, lr, lk, stage); return; }      // AdaLN fold: FF1
+            } else {
+                if (p.ln_stats_out) { gemm_epilogue_resid_ln<T, 2, 2, 2>(q, p, mh, n0 + wc * 64, lr, lk, stage); return; }  // AdaLN fold: O / FF2
             }
             gemm_epilogue_lds<TO, 2, 2, 64, 64>(q, p, mh, n0, 0, 0, 0, wc, lr, lk, stage);
         };

@@ -167,7 +167,9 @@ __device__ __forceinline__ void x3p_set_m0(unsigned v) {
 // NP = 3: bf16 planes, six products on one accumulator set.  NP = 2: fp16 {hi, lo * 2^11} planes, three products per block
 // on TWO accumulator sets — accA += hi*hi, accB += lo*hi + hi*lo (both carry the 2^11 of one low part) — combined once per
 // tile as accA + 2^-11 * accB; the lo*lo term (2^-22 of the product, below the fp32 rounding of the sum) is dropped.
-template <typename TO, bool LEPI, int NP, int DBG = 0>
+// FOLD: the instantiation whose epilogues are the AdaLN-fold forms (gemm_epilogue.h: consumer QKV / FF1, producer O / FF2) instead
+// of the plain ones — a separate kernel, so that neither carries the other's code and registers
+template <typename TO, bool LEPI, int NP, int DBG = 0, bool FOLD = false>
 __global__ __launch_bounds__(512, 1) void linear_x3p_kernel(const ConvGemmDev p) {
     using MF = std::conditional_t<NP == 3, Mfma<bf16>, Mfma<f16>>;
     using Frag = typename MF::Frag;
@@ -465,9 +467,15 @@ __global__ __launch_bounds__(512, 1) void linear_x3p_kernel(const ConvGemmDev p)
             }
             if constexpr (LEPI) {
                 float* stage = reinterpret_cast<float*>(smem) + wave * 2176;        // 32 x 64 floats per wave (32 x 65 for the transposed-V path)
-                if (p.epi == EPI_QKV_ROPE) gemm_epilogue_qkv_lds<TO, 1>(h, p, m0, n0, 0, wm2, wn, lr, lk, stage);
-                else if (p.out_planes) x3p_epilogue_planes<1, TN, NP>(h, p, m0, n0, wm2, wn, lr, lk, stage);
-                else gemm_epilogue_lds<TO, 1, TN, 32, WN>(h, p, m0, n0, 0, 0, wm2, wn, lr, lk, stage);
+                if constexpr (FOLD) {
+                    if (p.epi == EPI_QKV_ROPE) gemm_epilogue_qkv_lds<TO, 1, true>(h, p, m0, n0, 0, wm2, wn, lr, lk, stage);                // consumer: QKV
+                    else if (p.ln_stats_in) gemm_epilogue_ln_in<TO, 1, TN, NP>(h, p, m0 + wm2 * 32, n0 + wn * WN, lr, lk, stage);         // consumer: FF1 -> panel planes
+                    else gemm_epilogue_resid_ln<float, 1, TN, NP>(h, p, m0 + wm2 * 32, n0 + wn * WN, lr, lk, stage);                      // producer: O / FF2
+                } else {
+                    if (p.epi == EPI_QKV_ROPE) gemm_epilogue_qkv_lds<TO, 1>(h, p, m0, n0, 0, wm2, wn, lr, lk, stage);
+                    else if (p.out_planes) x3p_epilogue_planes<1, TN, NP>(h, p, m0, n0, wm2, wn, lr, lk, stage);
+                    else gemm_epilogue_lds<TO, 1, TN, 32, WN>(h, p, m0, n0, 0, 0, wm2, wn, lr, lk, stage);
+                }
             } else {
                 gemm_epilogue<TO, 1, TN, 32, WN>(h, p, m0, n0, 0, 0, wm2, wn, lr, lk);
             }
@@ -523,7 +531,9 @@ void launch_linear_x3p(const ConvGemmDev& e_in, hipStream_t s) {
         }
 #undef X2_TUNE
 #endif
-        if (e.lds_epi) { prof_set_kernel("linear_x3p_kernel<float, true, 2>", "", ""); hipLaunchKernelGGL((linear_x3p_kernel<float, true, 2>), grid, dim3(512), 0, s, e); }
+        const bool fold = e.ln_stats_in || e.ln_stats_out;
+        if (fold) { MI_REQUIRE(e.lds_epi, "linear_x3p: the AdaLN fold needs the LDS-staged epilogue"); prof_set_kernel("linear_x3p_kernel<float, true, 2, AdaLN fold>", "", ""); hipLaunchKernelGGL((linear_x3p_kernel<float, true, 2, 0, true>), grid, dim3(512), 0, s, e); }
+        else if (e.lds_epi) { prof_set_kernel("linear_x3p_kernel<float, true, 2>", "", ""); hipLaunchKernelGGL((linear_x3p_kernel<float, true, 2>), grid, dim3(512), 0, s, e); }
         else { prof_set_kernel("linear_x3p_kernel<float, false, 2>", "", ""); hipLaunchKernelGGL((linear_x3p_kernel<float, false, 2>), grid, dim3(512), 0, s, e); }
     } else if (e.lds_epi) {
 #if defined(MI355TTS_TUNING)
@@ -536,9 +546,15 @@ void launch_linear_x3p(const ConvGemmDev& e_in, hipStream_t s) {
             default: break;
         }
 #endif
-        prof_set_kernel("linear_x3p_kernel<float, true, 3>", "", "");
-        hipLaunchKernelGGL((linear_x3p_kernel<float, true, 3>), grid, dim3(512), 0, s, e);
+        if (e.ln_stats_in || e.ln_stats_out) {
+            prof_set_kernel("linear_x3p_kernel<float, true, 3, AdaLN fold>", "", "");
+            hipLaunchKernelGGL((linear_x3p_kernel<float, true, 3, 0, true>), grid, dim3(512), 0, s, e);
+        } else {
+            prof_set_kernel("linear_x3p_kernel<float, true, 3>", "", "");
+            hipLaunchKernelGGL((linear_x3p_kernel<float, true, 3>), grid, dim3(512), 0, s, e);
+        }
     } else {
+        MI_REQUIRE(!e.ln_stats_in && !e.ln_stats_out, "linear_x3p: the AdaLN fold needs the LDS-staged epilogue");
         prof_set_kernel("linear_x3p_kernel<float, false, 3>", "", "");
         hipLaunchKernelGGL((linear_x3p_kernel<float, false, 3>), grid, dim3(512), 0, s, e);
     }

@@ -54,6 +54,13 @@ __device__ __forceinline__ void x2u_split_pair(float x, float y, unsigned& ph, u
     y = y > 65504.f ? 65504.f : y; y = y < -65504.f ? -65504.f : y;
     x2u_split_pair_raw(x, y, ph, pl);
 }
+// Range watch of the fp16-pair split: non-zero when either half of a packed HIGH word sits at the fp16 limit or beyond
+// (|a| >= 65504 after the clamp, inf, nan) — 0x7bff + 0x0401 carries into the sign position of its half.  Producers OR it
+// over everything they split and raise the engine's flag word once (sat_publish): a clamped operand is no longer silent.
+__device__ __forceinline__ unsigned x2_sat_word(unsigned ph) { return ((ph & 0x7fff7fffu) + 0x04010401u) & 0x80008000u; }
+__device__ __forceinline__ void sat_publish(int* flag, unsigned sat) {
+    if (flag && sat) atomicOr(flag, 1);          // only lanes that saw a saturated operand get here: rare by construction
+}
 // eight consecutive values -> the 16-byte slot of each plane
 template <int NP> __device__ __forceinline__ void xnp_split8(const float (&v)[8], x3_u4 (&pl)[NP]) {
     unsigned w[NP][4];
@@ -64,6 +71,11 @@ template <int NP> __device__ __forceinline__ void xnp_split8(const float (&v)[8]
     }
 #pragma unroll
     for (int q = 0; q < NP; ++q) pl[q] = x3_u4{w[q][0], w[q][1], w[q][2], w[q][3]};
+}
+// ... and the range watch of the pair format folded in (three bf16 planes cover the whole fp32 exponent range: nothing to watch)
+template <int NP> __device__ __forceinline__ void xnp_split8_sat(const float (&v)[8], x3_u4 (&pl)[NP], unsigned& sat) {
+    xnp_split8<NP>(v, pl);
+    if constexpr (NP == 2) sat |= x2_sat_word(pl[0].x) | x2_sat_word(pl[0].y) | x2_sat_word(pl[0].z) | x2_sat_word(pl[0].w);
 }
 
 }  // namespace mi

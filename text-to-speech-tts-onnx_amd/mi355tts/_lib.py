@@ -73,6 +73,7 @@ def load() -> C.CDLL:
     L.mi_f5_create_mem.restype = vp
     L.mi_f5_destroy.argtypes = [vp]; L.mi_f5_destroy.restype = None
     L.mi_f5_tables.argtypes = [vp, f32p, f32p]; L.mi_f5_tables.restype = C.c_int
+    L.mi_f5_info.argtypes = [vp, C.c_char_p]; L.mi_f5_info.restype = C.c_int64
     L.mi_f5_preprocess.argtypes = [vp, vp, C.c_int64, vp, C.c_int64, C.c_int64, vp, C.c_uint64, vp, vp, vp, vp, vp,
                                    i64p, C.c_int]
     L.mi_f5_preprocess.restype = C.c_int

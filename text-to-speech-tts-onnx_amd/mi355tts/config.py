@@ -10,7 +10,7 @@ receives them as flat int arrays (see include/mi355tts.h).
 from __future__ import annotations
 
 from dataclasses import dataclass, field, asdict
-from typing import List, Tuple
+from typing import List, Optional, Tuple
 
 
 @dataclass
@@ -90,6 +90,12 @@ class BigVGANConfig:
                              upsample_kernel_sizes=(8, 4), use_bias_at_final=True)
 
 
+# F5Config.f32_arithmetic -> the engine's ARITH_* code (csrc/common.h)
+F32_ARITHMETIC = {None: -1, "native-fp32-mfma": 0, "fp16x2-pairs": 2, "bf16x3": 3}
+F32_ARITHMETIC_NAMES = {0: "native-fp32-mfma", 2: "fp16x2-pairs", 3: "bf16x3"}
+MEL_SPEC_TYPES = {"vocos": 0, "bigvgan": 1}
+
+
 @dataclass
 class F5Config:
     """F5-TTS v1 Base (DiT) + Vocos-mel-24khz + STFT constants.
@@ -121,6 +127,17 @@ class F5Config:
     # use_fp16_transformer (Export_F5.py:20,321-326; F5/fp16/modules.py:467): q / k projections carry an extra x0.1 each, the
     # q k scores are rounded to fp16 and multiplied by 100 in fp32 before the fp32 softmax.  f16 engines only.
     ref_fp16_attn: bool = False
+    # fp32 engines: how fp32 products are formed on the matrix cores — a property of the ENGINE (two engines with different
+    # arithmetic coexist in one process).  None = the library default (fp16 pairs; mi_set_option can change the default for
+    # tools).  "fp16x2-pairs": operands as fp16 {hi, lo} pairs, 22 significant bits, |a| <= 65504 (an engine whose weights or
+    # activations leave that range switches itself to "bf16x3", see F5Engine.info()); "bf16x3": exact three-way bf16 split, whole
+    # fp32 exponent range; "native-fp32-mfma": v_mfma_f32_32x32x2_f32.
+    f32_arithmetic: Optional[str] = None
+    # prompt mel front end (modeling_modified/F5/modules.py:30-72 vs Export_F5.py:113,125): "vocos" | "bigvgan"
+    mel_spec_type: str = "vocos"
+    # AdaLN fold (LayerNorm statistics carried by the GEMM epilogues instead of row-norm launches): None / True = wherever the
+    # kernels support it, False = row-norm launches
+    adaln_fold: Optional[bool] = None
     # STFT / mel
     n_fft: int = 1024
     hop_length: int = 256
@@ -143,7 +160,9 @@ class F5Config:
                 self.text_num_embeds, self.conv_layers, self.conv_mult, self.pos_conv_kernel,
                 self.pos_conv_groups, self.freq_embed_dim, self.nfe_step, self.max_signal_length,
                 self.n_fft, self.hop_length, self.sample_rate, self.vocos_dim, self.vocos_intermediate,
-                self.vocos_layers]
+                self.vocos_layers,
+                F32_ARITHMETIC[self.f32_arithmetic], MEL_SPEC_TYPES[self.mel_spec_type],
+                -1 if self.adaln_fold is None else int(bool(self.adaln_fold))]
 
     @property
     def attn_score_scale(self) -> float:

@@ -74,6 +74,16 @@ class F5Engine:
         except Exception:
             pass
 
+    def info(self) -> dict:
+        """What the engine is doing (mi_f5_info): the fp32 arithmetic IN USE (an fp16-pair engine whose weights or activations
+        leave the fp16 range switches itself to the exact three-plane bf16 split), whether that happened during a call, and
+        whether the AdaLN fold is available."""
+        from .config import F32_ARITHMETIC_NAMES
+        L = _lib.load()
+        a = int(L.mi_f5_info(self._h, b"f32_arithmetic"))
+        return {"f32_arithmetic": F32_ARITHMETIC_NAMES.get(a), "saturation_events": int(L.mi_f5_info(self._h, b"saturation_events")),
+                "adaln_fold": bool(L.mi_f5_info(self._h, b"adaln_fold"))}
+
     # ---- load-time tables -----------------------------------------------------------------------
     def tables(self):
         te = np.empty((self.cfg.nfe_step, self.cfg.dim), np.float32)
