@@ -213,14 +213,20 @@ def pmc_traffic(kernel_label: str, dtype: str, U: int):
 
 
 def bcast_device_blob(torch, dist, blob_t):
-    """rank 0 -> all.  nccl (= RCCL over xGMI): the device buffer itself; gloo (the one-GPU plumbing test): staged through
-    host memory, because gloo's device-tensor support is not a given on ROCm builds."""
-    if dist.get_backend() == "nccl":
-        dist.broadcast(blob_t, src=0)
-        return blob_t
-    h = blob_t.cpu()
-    dist.broadcast(h, src=0)
-    return h.to(blob_t.device)
+    """rank 0 -> all: the library helper (mi355tts/shard.py broadcast_blob_device — RCCL over xGMI on the device buffer itself;
+    gloo in the one-GPU plumbing test is staged through host memory)."""
+    from mi355tts.shard import broadcast_blob_device
+    return broadcast_blob_device(blob_t, src=0)
+
+
+def per_rank_times(torch, dist, world, dt, dev):
+    """[seconds of the timed region on rank 0, 1, ...] gathered to every rank (the line reports them next to the maximum)."""
+    if world <= 1:
+        return [dt]
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+    out = [torch.zeros_like(tt) for _ in range(world)]
+    dist.all_gather(out, tt)
+    return [float(x.item()) for x in out]
 
 
 def max_over_ranks(torch, dist, world, dt, dev):
@@ -244,6 +250,7 @@ class F5Bench:
         # says so in config.workload and is not a benchmark result)
         self.small = os.environ.get("MI355TTS_BENCH_SMALL") == "1"
         self.cfg = F5Config.small() if self.small else F5Config()
+        self.cfg_over = {}            # F5Config fields set from the command line (--f32-arithmetic, --no-adaln-fold)
         self.L = 24000 if self.small else 144000
         self.W = W
         self.raw = None
@@ -255,6 +262,9 @@ class F5Bench:
             self.blob_t = torch.empty(nparam, dtype=torch.float32, device=dev)
         self.bcast_ms = 0.0
         self.dump_dir = None
+        # one process per GPU: fail loudly if two ranks resolved to the same physical device (the plumbing test on a one-GPU box says so)
+        from mi355tts.shard import assert_one_device_per_rank
+        self.rank_devices = [f"{h}:{b}" for h, b in assert_one_device_per_rank(local, allow_shared=os.environ.get("MI355TTS_BENCH_ONE_GPU") == "1")]
         if world > 1:                       # the one collective of the path: weights rank 0 -> all, RCCL over xGMI
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -267,12 +277,22 @@ class F5Bench:
             self.dist.barrier()
         self.torch.cuda.synchronize()
 
-    def measure(self, dtype: str, U: int, steps: int, warmup: int):
+    def measure(self, dtype: str, U: int, steps: int, warmup: int, f32_arithmetic=None):
+        import dataclasses
         from mi355tts import _lib
         from mi355tts.f5 import F5Engine
-        torch, cfg, dev = self.torch, self.cfg, self.dev
+        torch, dev = self.torch, self.dev
+        over = dict(self.cfg_over)
+        if f32_arithmetic is not None:
+            over["f32_arithmetic"] = f32_arithmetic
+        cfg = dataclasses.replace(self.cfg, **over)
         eng = F5Engine(cfg, blob_device=self.blob_t, dtype=dtype, device=self.local)
-        audio, ids, N, noise = self.W.f5_synthetic_inputs(cfg, U, self.rank, L=self.L)
+        eng_info = eng.info()
+        # the job's utterance list: world * U utterances (configs[3]: 64 on 8 GPUs, seeds 9527 ..), contiguous slices per rank
+        from mi355tts.shard import shard_range
+        lo, hi = shard_range(self.world * U, self.world, self.rank)
+        assert hi - lo == U
+        audio, ids, N, noise = self.W.f5_synthetic_inputs(cfg, U, self.rank, L=self.L, first=lo)
         R = audio.shape[1] // cfg.hop_length + 1
         t_audio, t_ids, t_noise = torch.from_numpy(audio).to(dev), torch.from_numpy(ids).to(dev), torch.from_numpy(noise).to(dev)
         out = torch.empty((U, 1, (N - R - 1) * cfg.hop_length), dtype=torch.int16, device=dev)
@@ -296,6 +316,7 @@ class F5Bench:
         torch.cuda.synchronize()
         _lib.prof_enable(())
         kernels = _lib.prof_kernels()
+        rank_dt = per_rank_times(torch, self.dist, self.world, dt, dev)
         dt = max_over_ranks(torch, self.dist, self.world, dt, dev)
         # the reference's own bracket (F5-TTS-ONNX-Inference.py:246-312: host int16 audio + ids in, int16 waveform on the host):
         # the same steps through the host-pointer form of the C-ABI (H2D of audio / ids / noise, D2H of the waveform inside).
@@ -309,13 +330,14 @@ class F5Bench:
             host_ms = (time.perf_counter() - th) / steps * 1e3
         if self.dump_dir:
             np.save(os.path.join(self.dump_dir, f"f5_{dtype}_u{U}_rank{self.rank}.npy"), out.cpu().numpy())
+        eng_info = eng.info()          # (after the runs: an fp16-pair engine that met its range limit has switched itself to bf16x3)
         eng.close()
         peak = MFMA_F32_PEAK_TF if dtype == "f32" else MFMA_F16_PEAK_TF
         gemm_like = [k for k in kernels if k["family"] in ("conv_gemm", "attn")]
         note = ("HIP events on the engine's stream around every launch, one separate eager pass after the timed region (the timed "
                 "region replays a hipGraph; events cannot be recorded into it); flops = 2*M*N*K of the launch")
         dom = gemm_like[0]["kernel"] if gemm_like else ""
-        if "linear_x3p_kernel<float, true, 2>" in dom or "linear_x3p_kernel<float, false, 2>" in dom:
+        if "linear_x3p_kernel<float, true, 2" in dom or "linear_x3p_kernel<float, false, 2" in dom:
             # fp32 products as THREE fp16 x fp16 partial products (operands as {hi, lo * 2^11} fp16 pairs, two accumulator sets:
             # gemm_x3p.hip NP = 2): the ceiling is the dense fp16 MFMA peak / 3 in fp32-equivalent flops
             peak = MFMA_F16_PEAK_TF / 3.0
@@ -334,7 +356,11 @@ class F5Bench:
                "rtf": dt / steps / audio_s, "utterances_per_gpu": U, "frames": N, "audio_seconds_per_step_per_gpu": audio_s,
                "end_to_end_TFLOP_per_step": alg_flops / 1e12, "end_to_end_TFLOP_per_s": alg_flops / (dt / steps) / 1e12,
                "event_timed_kernel_ms_in_eager_pass": ev_ms, "roofline": roof,
-               "host_io_ms_per_step": host_ms, "host_io_value": (audio_s / (host_ms * 1e-3)) if host_ms else None}
+               "host_io_ms_per_step": host_ms, "host_io_value": (audio_s / (host_ms * 1e-3)) if host_ms else None,
+               "utterances_total": self.world * U, "utterance_seeds": [9527, 9527 + self.world * U - 1],
+               "per_rank_ms": [t / steps * 1e3 for t in rank_dt],
+               "arithmetic_kind": eng_info["f32_arithmetic"] if dtype == "f32" else f"{dtype} operands, fp32 accumulate",
+               "adaln_fold": eng_info["adaln_fold"], "saturation_events": eng_info["saturation_events"]}
         return res, (audio, ids, N, noise)
 
 
@@ -393,6 +419,12 @@ def f5_workload_name(dtype, U, N, small=False):
 def run_f5(args, world, rank, local, dev, dist, torch):
     fb = F5Bench(torch, dist, world, rank, local, dev)
     fb.dump_dir = args.dump_dir
+    if args.f32_arithmetic:
+        fb.cfg_over["f32_arithmetic"] = args.f32_arithmetic
+    if args.no_adaln_fold:
+        fb.cfg_over["adaln_fold"] = False
+    if args.adaln_fold:
+        fb.cfg_over["adaln_fold"] = True
     res, (audio, ids, N, noise) = fb.measure(args.dtype, args.batch, args.steps, args.warmup)
     secondary = {}
     if fb.small:
@@ -405,15 +437,8 @@ def run_f5(args, world, rank, local, dev, dist, torch):
         if args.dtype == "f32":
             # the same fp32 workload with the linear layers on the native fp32 MFMA (v_mfma_f32_32x32x2_f32) instead of the
             # exact bf16x3 products: both pass the same fp32 parity gates; reported so that either can be taken as the fp32 number
-            from mi355tts import _lib
-            _lib.set_option("gemm_f32_x3", 0)
-            _lib.set_option("attn_f32_x3", 0)
-            try:
-                r3, _ = fb.measure("f32", args.batch, 5, 2)
-            finally:
-                _lib.set_option("gemm_f32_x3", 1)
-                _lib.set_option("attn_f32_x3", 2)
-            r3["workload"] = f5_workload_name("f32", args.batch, N) + " — linear layers and attention on the native fp32 MFMA (gemm_f32_x3 = 0, attn_f32_x3 = 0)"
+            r3, _ = fb.measure("f32", args.batch, 5, 2, f32_arithmetic="native-fp32-mfma")
+            r3["workload"] = f5_workload_name("f32", args.batch, N) + " — linear layers, attention and position convolution on the native fp32 MFMA (F5Config.f32_arithmetic = native-fp32-mfma)"
             secondary["f5_f32_native_mfma"] = r3
     if world == 1 and not args.no_secondary and not fb.small:
         secondary["f5_plus_bigvgan"] = measure_f5_plus_bigvgan(torch, fb, args.dtype, "f16", args.batch, 3, 2)
@@ -427,10 +452,12 @@ def run_f5(args, world, rank, local, dev, dist, torch):
         "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f5_workload_name(args.dtype, args.batch, N, fb.small),
-                   "utterances_per_gpu": args.batch, "frames": N,
+                   "utterances_per_gpu": args.batch, "utterances_total": res["utterances_total"], "utterance_seeds": res["utterance_seeds"],
+                   "per_rank_ms": res["per_rank_ms"], "rank_devices": fb.rank_devices, "frames": N,
                    "audio_seconds_per_step_per_gpu": res["audio_seconds_per_step_per_gpu"], "rtf": res["rtf"],
                    "weights": "synthetic seeded (337 M DiT + 13.5 M Vocos params)", "weight_bcast_ms": fb.bcast_ms,
                    "collective_backend": dist.get_backend() if world > 1 else None,
+                   "arithmetic_kind": res["arithmetic_kind"], "adaln_fold": res["adaln_fold"], "saturation_events": res["saturation_events"],
                    "arithmetic": ("fp32 values, fp32 accumulation; the DiT linear layers form each fp32 product as three fp16 x fp16 partial products "
                                   "(operands as fp16 {hi, lo * 2^11} pairs = 22 significant bits, gemm_x3p.hip: measured error against float64 "
                                   "BELOW the native fp32 MFMA's), both products of attention and the grouped position convolution the same way "
@@ -738,6 +765,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE",
                     help="mi_set_option(KEY, VALUE) before anything runs (A/B measurements); repeatable")
+    ap.add_argument("--f32-arithmetic", default=None, choices=["fp16x2-pairs", "bf16x3", "native-fp32-mfma"],
+                    help="f5 fp32: F5Config.f32_arithmetic of the engine (default: the library default, fp16x2-pairs)")
+    ap.add_argument("--adaln-fold", action="store_true", help="f5: F5Config.adaln_fold = True (16-bit engines: the fold is opt-in)")
+    ap.add_argument("--no-adaln-fold", action="store_true", help="f5: F5Config.adaln_fold = False (row-norm launches; A/B of the fold)")
     ap.add_argument("--no-pmc", action="store_true", help="f5 on one GPU: skip the two rocprofv3 --pmc passes that fill roofline.traffic")
     ap.add_argument("--no-secondary", action="store_true", help="f5 on one GPU: skip the configs[1] / configs[3]-shard blocks")
     ap.add_argument("--cpu-frames", type=int, default=128)

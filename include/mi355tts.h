@@ -266,6 +266,9 @@ int         mi_indextts_cond_run(mi_cond* h, const int16_t* audio, int64_t L, fl
  * (C > 96); 3: every stage.  The waveform is bit-identical in all three.
  * Changing an option invalidates the hipGraphs captured by existing handles.   */
 int         mi_set_option(const char* key, int64_t value);
+/* PCI bus id of HIP device `device` ("0000:05:00.0") into buf: multi-rank launchers use it to check that every rank drives its
+ * own GPU (mi355tts/shard.py assert_one_device_per_rank).  No reference counterpart (the reference is single-device).   */
+int         mi_device_pci_bus_id(int device, char* buf, int cap);
 
 /* ---- profiling hooks (bench.py roofline leg) -------------------------------------------------
  * family_mask: bit i enables family i (0 = off, -1 = all).  Every launch of an enabled kernel

@@ -596,7 +596,7 @@ def test_adaln_fold_against_rownorm_path_and_oracle(dtype, tol_paths, tol_oracle
     raw = W.synth_state(W.f5_spec(cfg), 7)
     st = W.fold_f5(cfg, raw)
     tables = O.time_tables(cfg, st)
-    e_fold = F5Engine(cfg, raw, dtype=dtype)
+    e_fold = F5Engine(dataclasses.replace(cfg, adaln_fold=True), raw, dtype=dtype)       # (16-bit engines: the fold is opt-in)
     e_rows = F5Engine(dataclasses.replace(cfg, adaln_fold=False), raw, dtype=dtype)
     try:
         assert e_fold.info()["adaln_fold"] and not e_rows.info()["adaln_fold"]

@@ -821,6 +821,13 @@ int mi_set_option(const char* key, int64_t value) {
     });
 }
 
+int mi_device_pci_bus_id(int device, char* buf, int cap) {
+    return guard([&] {
+        MI_REQUIRE(buf && cap >= 16, "mi_device_pci_bus_id: buffer of at least 16 bytes");
+        MI_HIP(hipDeviceGetPCIBusId(buf, cap, device));
+    });
+}
+
 int mi_prof_enable(int family_mask) { prof_enable((unsigned)family_mask); return MI_OK; }
 int mi_prof_reset(void) { return guard([&] { prof_reset(); }); }
 int mi_prof_kernel_count(void) { return prof_kernel_count(); }

@@ -204,7 +204,7 @@ __host__ __device__ inline long x3p_slot_offset(long row, int s8, int nch, int n
     return ((row >> 7) * nch + (s8 >> 2)) * (long)(np * X3P_PLANE) + r * 64 + (((s8 & 3) ^ ((r >> 2) & 3)) << 4);
 }
 long x3p_bytes(long rows, long K, int np = 3);                                        // bytes of the panel planes of a [rows][K] matrix
-void x3p_split_rows(const float* x, long ld, void* planes, int rows, int K, hipStream_t s, int np = 3);
+void x3p_split_rows(const float* x, long ld, void* planes, int rows, int K, hipStream_t s, int np = 3, int* sat = nullptr);   // sat: range watch (x3_split.h)
 int x3p_planes();                                  // option "gemm_f32_planes": the format new planes are built in (3 or 2)
 bool gemm_x3p_enabled();
 bool gemm_x3p_would_run(const ConvGemm& p);        // p.xp / p.w3p set: will launch_conv_gemm(p) take the panel-plane kernel?

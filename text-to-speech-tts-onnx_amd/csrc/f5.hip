@@ -232,7 +232,11 @@ F5::F5(const F5Cfg& c, const float* w, int64_t nw, int dt, int dev, int mem) : c
     }
     // ---- AdaLN fold: W (1 + scale) and W shift + b for every (step, block), QKV and FF1 (gemm_epilogue.h) ----
     fold_built = false;
-    if (c.ln_fold != 0 && d >= 1024 && d % 128 == 0 && ff % 64 == 0) {
+    // fp32 engines: on unless switched off.  16-bit engines: opt-in (ln_fold = 1) — measured on bf16 x 8 utterances the consumer
+    // epilogues of the 256x256 kernel lose more (+26 us per QKV / FF1 launch re-reading the row statistics in every one of the
+    // 12 / 8 column tiles) than the 1395 row-norm launches cost (profiles/r4/adaln_fold_ab.txt)
+    const bool want_fold = dt == MI_F32 ? c.ln_fold != 0 : c.ln_fold == 1;
+    if (want_fold && d >= 1024 && d % 128 == 0 && ff % 64 == 0) {
         ln_blk = (long)6 * d + 2 * ff;
         ln_ld = (long)c.depth * ln_blk;
         ln_tab.ensure((size_t)steps * ln_ld * 4);
@@ -502,7 +506,7 @@ void F5::gemm(int dt, const void* x, long xb, long xr, int K, const Lin& L, void
     }
     if (dt == MI_F32 && L.w3p.p && g.B == 1 && Ap.p && gemm_x3p_enabled()) {
         g.xp = K <= cfg.dim ? Ap.p : Ap2.p; g.w3p = L.w3p.p; g.np = np;
-        if (gemm_x3p_would_run(g)) x3p_split_rows((const float*)x, xr, const_cast<void*>(g.xp), g.M, K, stream, np);
+        if (gemm_x3p_would_run(g)) x3p_split_rows((const float*)x, xr, const_cast<void*>(g.xp), g.M, K, stream, np, d_sat.as<int>());
         else { g.xp = nullptr; g.w3p = nullptr; }
     }
     launch_conv_gemm(g, stream);
@@ -665,7 +669,7 @@ void F5::dit_eval(int U, int N, int k) {
         g.dtype = dtype; g.x = hin; g.w = gconv1.w.p; g.bias = gconv1.b.as<float>(); g.out = c1.p;
         g.B = B; g.G = c.pos_g; g.T_in = N; g.M = N; g.N = d / c.pos_g; g.Cin = d / c.pos_g; g.taps = c.pos_k; g.pad = c.pos_k / 2;
         g.x_bstride = (long)N * d; g.x_rstride = d; g.x_goff = d / c.pos_g; g.out_bstride = (long)N * d; g.out_rstride = d;
-        g.act = ACT_MISH;
+        g.act = ACT_MISH; g.sat = d_sat.as<int>();
         launch_conv_gemm(g, s);
         g.x = c1.p; g.w = gconv2.w.p; g.bias = gconv2.b.as<float>(); g.out = X.p; g.out_dtype = MI_F32; g.res = h32.p;
         launch_conv_gemm(g, s);
@@ -763,7 +767,7 @@ void F5::dit_eval(int U, int N, int k) {
         }
         if (planes) {
             const bool kvp = attention_takes_kv_planes(N, B * H, dtype);
-            launch_rownorm_x3p(X.as<float>(), Ap.p, m + d, m, rows, d, 1e-6f, s, np);
+            launch_rownorm_x3p(X.as<float>(), Ap.p, m + d, m, rows, d, 1e-6f, s, np, d_sat.as<int>());
             {
                 ConvGemm g = qkv_gemm(bk);
                 g.x = Ub.p; with_planes(g, bk.qkv, Ap.p);
@@ -779,7 +783,7 @@ void F5::dit_eval(int U, int N, int k) {
                 MI_REQUIRE(gemm_x3p_would_run(g), "f5: the O projection left the panel-plane kernel between the decision and the launch");
                 launch_conv_gemm(g, s);
             }
-            launch_rownorm_x3p(X.as<float>(), Ap.p, m + 4 * d, m + 3 * d, rows, d, 1e-6f, s, np);
+            launch_rownorm_x3p(X.as<float>(), Ap.p, m + 4 * d, m + 3 * d, rows, d, 1e-6f, s, np, d_sat.as<int>());
             {
                 ConvGemm g = lin(bk.ff1, d, dtype, Hff.p);
                 g.x = Ub.p; g.act = ACT_GELU_TANH; with_planes(g, bk.ff1, Ap.p); g.out_planes = Ap2.p;

@@ -10,7 +10,7 @@ void launch_rownorm(int mode, const float* x, void* y, int out_dtype, const floa
                     float eps, hipStream_t s);
 // LN_MOD with the result as gemm_x3p.hip panel planes (three-way bf16 split of the fp32 value) instead of fp32 rows
 void launch_rownorm_x3p(const float* x, void* planes, const float* a, const float* b, long rows, int D, float eps, hipStream_t s,
-                        int np = 3);
+                        int np = 3, int* sat = nullptr);       // sat: range watch of the fp16-pair split (x3_split.h)
 // AdaLN fold (ConvGemm::ln_*, gemm_epilogue.h): the producer side as a pass of its own, for the first block of an evaluation —
 // aout = x o (1 + scale) as panel planes of np planes (a_dtype MI_F32) or rows of a_dtype, stats[row][D / 32][2] = partial (sum, sum^2)
 void launch_ln_prologue(const float* x, void* aout, int a_dtype, int np, float* stats, const float* scale, long rows, int D, int* sat,

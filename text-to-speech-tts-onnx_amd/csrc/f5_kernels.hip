@@ -91,11 +91,12 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ 
 template <int MAXP, int NP>
 __global__ __launch_bounds__(256) void rownorm_x3p_kernel(const float* __restrict__ x, unsigned char* __restrict__ planes,
                                                           const float* __restrict__ a, const float* __restrict__ b,
-                                                          long rows, int D, float eps) {
+                                                          long rows, int D, float eps, int* __restrict__ satp) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float* xr = x + row * D;
+    unsigned sat = 0;
     float4 v[MAXP][2], av[MAXP][2], bv[MAXP][2];
     float s = 0.f;
 #pragma unroll
@@ -140,22 +141,23 @@ __global__ __launch_bounds__(256) void rownorm_x3p_kernel(const float* __restric
 #pragma unroll
             for (int k = 0; k < 8; ++k) o[k] = (o[k] - mean) * inv * (1.f + aa[k]) + bb[k];
             x3_u4 pl[NP];
-            xnp_split8<NP>(o, pl);
+            xnp_split8_sat<NP>(o, pl, sat);
             unsigned char* dst = planes + x3p_slot_offset(row, s8, nch, NP);
 #pragma unroll
             for (int q = 0; q < NP; ++q) *reinterpret_cast<x3_u4*>(dst + q * X3P_PLANE) = pl[q];
         }
     }
+    if constexpr (NP == 2) sat_publish(satp, sat);
 }
 
-void launch_rownorm_x3p(const float* x, void* planes, const float* a, const float* b, long rows, int D, float eps, hipStream_t s, int np) {
+void launch_rownorm_x3p(const float* x, void* planes, const float* a, const float* b, long rows, int D, float eps, hipStream_t s, int np, int* sat) {
     MI_REQUIRE(D % 32 == 0 && D <= 2048, "rownorm_x3p: D must be whole 32-deep chunks and <= 2048");
     MI_REQUIRE(np == 2 || np == 3, "rownorm_x3p: 2 or 3 planes");
     dim3 grid((unsigned)((rows + 3) / 4));
     ProfScope ps(FAM_NORM, s, (double)rows * D * (4.0 + 2.0 * np), 8.0 * rows * D);
     prof_set_kernel(np == 3 ? "rownorm_x3p_kernel<3 planes>" : "rownorm_x3p_kernel<2 planes>", "", "");
     const int mp = (D + 511) / 512;
-#define RNP(MP, NPL) hipLaunchKernelGGL((rownorm_x3p_kernel<MP, NPL>), grid, dim3(256), 0, s, x, (unsigned char*)planes, a, b, rows, D, eps)
+#define RNP(MP, NPL) hipLaunchKernelGGL((rownorm_x3p_kernel<MP, NPL>), grid, dim3(256), 0, s, x, (unsigned char*)planes, a, b, rows, D, eps, sat)
     if (np == 3) { if (mp == 1) RNP(1, 3); else if (mp == 2) RNP(2, 3); else RNP(4, 3); }
     else { if (mp == 1) RNP(1, 2); else if (mp == 2) RNP(2, 2); else RNP(4, 2); }
 #undef RNP

@@ -29,6 +29,7 @@ struct GConvPairsDev {
     int T_in, M, taps, pad, act;
     long x_bstride, x_rstride, x_goff, out_bstride, out_rstride;
     int K;          // taps * 64
+    int* sat;       // range watch of the activation split (x3_split.h sat_publish); may be null
 };
 
 constexpr int GCP_C = 64;                 // channels per group (in and out)
@@ -104,6 +105,7 @@ __global__ __launch_bounds__(256, BM <= 128 ? 2 : 1) void gconv_pairs_kernel(con
     {
         const int t_base = m0 - p.pad;
         const int nitem = rows_a * 8;
+        unsigned sat = 0;
         for (int v = tid; v < nitem; v += 256) {
             const int row = v >> 3, c8 = v & 7;
             const int t = t_base + row;
@@ -115,9 +117,11 @@ __global__ __launch_bounds__(256, BM <= 128 ? 2 : 1) void gconv_pairs_kernel(con
             }
             x3_u4 h, l;
             gcp_split8(u, w2, h, l, true);
+            sat |= x2_sat_word(h.x) | x2_sat_word(h.y) | x2_sat_word(h.z) | x2_sat_word(h.w);
             *reinterpret_cast<x3_u4*>(AH + row * S + c8 * 8) = h;
             *reinterpret_cast<x3_u4*>(AL + row * S + c8 * 8) = l;
         }
+        sat_publish(p.sat, sat);
     }
     wstore();
     __syncthreads();
@@ -195,7 +199,7 @@ bool launch_gconv_pairs(const ConvGemm& p, hipStream_t s) {
     d.x = (const float*)p.x; d.w = (const float*)p.w; d.bias = p.bias; d.out = (float*)p.out; d.res = (const float*)p.res;
     d.T_in = p.T_in; d.M = p.M; d.taps = p.taps; d.pad = p.pad; d.act = p.act;
     d.x_bstride = p.x_bstride; d.x_rstride = p.x_rstride; d.x_goff = p.x_goff; d.out_bstride = p.out_bstride; d.out_rstride = p.out_rstride;
-    d.K = p.taps * GCP_C;
+    d.K = p.taps * GCP_C; d.sat = p.sat;
     // rows per workgroup: 128 (two workgroups per CU) or 192 (one), whichever puts fewer rows on the busiest CU — one
     // utterance (B = 2, M = 1126, 16 groups) is 288 workgroups of 128 rows (32 CUs get two: 256 rows) or 192 of 192 rows
     int cus = 256;
@@ -217,8 +221,8 @@ bool launch_gconv_pairs(const ConvGemm& p, hipStream_t s) {
 #define GCP_LAUNCH(BMv)                                                                                                       \
     do {                                                                                                                      \
         auto kfn = gconv_pairs_kernel<BMv>;                                                                                   \
-        static bool big_lds = false;                                                                                          \
-        if (lds > 64 * 1024 && !big_lds) { MI_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); big_lds = true; } \
+        /* the opt-in is per device and cheap: set it whenever it is needed (a process-wide flag skipped device 1) */ \
+        if (lds > 64 * 1024) MI_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
         prof_set_kernel("gconv_pairs_kernel<" #BMv "> (fp32 grouped conv, fp16 pairs split once per workgroup)", "", "");      \
         hipLaunchKernelGGL(kfn, grid, dim3(256), lds, s, d);                                                                  \
     } while (0)

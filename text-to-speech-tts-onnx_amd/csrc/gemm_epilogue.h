@@ -333,9 +333,11 @@ __device__ __forceinline__ void ln_rows32(const ConvGemmDev& p, long row0, long 
 // TMQ: 32-row blocks of the wave tile (2: 64 x 64 per wave ; 1: 32 x 64, the eight-wave layout of gemm_x3.hip)
 // LN: consumer side of the AdaLN fold (see below): the accumulators carry W (x o (1 + scale)); bias and the LayerNorm's
 // mean / rstd enter on the row-wise read-back as rstd * acc - (mean * rstd) * ln_p[col] + ln_c[col]
-template <typename TO, int TMQ = 2, bool LN = false>
+// PRE (with LN): (rstd, mean * rstd) of the wave's rows were fetched by the caller (at the start of the tile, under its main loop)
+template <typename TO, int TMQ = 2, bool LN = false, bool PRE = false>
 __device__ __forceinline__ void gemm_epilogue_qkv_lds(f32x16 (&acc)[TMQ][2], const ConvGemmDev& p, int m0, int n0, int b,
-                                                      int wm, int wn, int lr, int lk, float* stage) {
+                                                      int wm, int wn, int lr, int lk, float* stage,
+                                                      const float* pre_rs = nullptr, const float* pre_mr = nullptr) {
     const int lane = lk * 32 + lr;
     const int dm = p.heads * 64;
     const int nbase = n0 + wn * 64;
@@ -347,10 +349,14 @@ __device__ __forceinline__ void gemm_epilogue_qkv_lds(f32x16 (&acc)[TMQ][2], con
     const bool vt = which == 2 && p.v_ld > 0;
     TO* base = (TO*)(which == 0 ? p.out : which == 1 ? p.out2 : p.out3);
     struct alignas(16) Pk { TO v[8]; };
+    unsigned qkv_sat = 0;            // fp32 engines with fp16-pair attention operands: range watch (x3_split.h)
     float ln_rs[TMQ], ln_mr[TMQ];
     if constexpr (LN) {
 #pragma unroll
-        for (int i = 0; i < TMQ; ++i) ln_rows32(p, (long)mbase + i * 32, (long)p.m_off + p.M - 1, lr, lk, ln_rs[i], ln_mr[i]);
+        for (int i = 0; i < TMQ; ++i) {
+            if constexpr (PRE) { ln_rs[i] = pre_rs[i]; ln_mr[i] = pre_mr[i]; }
+            else ln_rows32(p, (long)mbase + i * 32, (long)p.m_off + p.M - 1, lr, lk, ln_rs[i], ln_mr[i]);
+        }
     }
     if (!vt) {
         float ln_pv[8], ln_cv[8];
@@ -444,6 +450,7 @@ __device__ __forceinline__ void gemm_epilogue_qkv_lds(f32x16 (&acc)[TMQ][2], con
 #pragma unroll
                             for (int q = 0; q < 4; ++q) x2u_split_pair(x[2 * q], x[2 * q + 1], wh[q], wl[q]);
                             pl[0] = x3_u4{wh[0], wh[1], wh[2], wh[3]}; pl[1] = x3_u4{wl[0], wl[1], wl[2], wl[3]};
+                            qkv_sat |= x2_sat_word(wh[0]) | x2_sat_word(wh[1]) | x2_sat_word(wh[2]) | x2_sat_word(wh[3]);
                         }
                         bf16* kp = (bf16*)p.out2 + ((((long)b + biv[gi]) * p.heads + hh) * 2 * p.k_ld + mv[gi]) * 64 + c8;
                         if (okv[gi]) {
@@ -463,6 +470,11 @@ __device__ __forceinline__ void gemm_epilogue_qkv_lds(f32x16 (&acc)[TMQ][2], con
                     }
                     continue;
                 }
+                if constexpr (sizeof(TO) == 4) if (p.kv_planes == 2 && which == 0) {
+                    // q leaves as fp32 rows and is split into fp16 pairs (times log2 e) inside the attention kernel: watch its range here
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) qkv_sat |= (fabsf(x[q]) * 1.4426950408889634f >= 65504.f || x[q] != x[q]) ? 1u : 0u;
+                }
                 Pk o8;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) o8.v[q] = from_f32<TO>(x[q]);
@@ -473,6 +485,10 @@ __device__ __forceinline__ void gemm_epilogue_qkv_lds(f32x16 (&acc)[TMQ][2], con
         __builtin_amdgcn_wave_barrier();
     } else {
         const int row = lane & 31, dh = lane >> 5;
+        // LN: the two per-column vectors of the wave's 64 columns, one column per lane (fetched through a lane shuffle below: a
+        // global load per column inside the read-back loop was a chain of 32 dependent round trips per block)
+        float ln_pl = 0.f, ln_cl = 0.f;
+        if constexpr (LN) { ln_pl = p.ln_p[nbase + lane]; ln_cl = p.ln_c[nbase + lane]; }
 #pragma unroll
         for (int i = 0; i < TMQ; ++i) {
 #pragma unroll
@@ -485,7 +501,7 @@ __device__ __forceinline__ void gemm_epilogue_qkv_lds(f32x16 (&acc)[TMQ][2], con
             // the value of (row, column dd) on the read-back; LN: this lane's row is row `lane & 31` = lr of block i
             auto vt_val = [&](int dd) __attribute__((always_inline)) -> float {
                 const float a = stage[row * 65 + dd];
-                if constexpr (LN) return __builtin_fmaf(ln_rs[i], a, __builtin_fmaf(-ln_mr[i], p.ln_p[nbase + dd], p.ln_c[nbase + dd]));
+                if constexpr (LN) return __builtin_fmaf(ln_rs[i], a, __builtin_fmaf(-ln_mr[i], __shfl(ln_pl, dd), __shfl(ln_cl, dd)));
                 else return a;
             };
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -505,6 +521,7 @@ __device__ __forceinline__ void gemm_epilogue_qkv_lds(f32x16 (&acc)[TMQ][2], con
                         const int dd = dh * 32 + d;
                         unsigned ph, pl;
                         x2u_split_pair(vt_val(dd), 0.f, ph, pl);
+                        qkv_sat |= x2_sat_word(ph);
                         if (ok) {
                             vp[(long)dd * p.v_ld] = (unsigned short)ph;
                             vp[pstride + (long)dd * p.v_ld] = (unsigned short)pl;
@@ -536,6 +553,7 @@ __device__ __forceinline__ void gemm_epilogue_qkv_lds(f32x16 (&acc)[TMQ][2], con
             __builtin_amdgcn_wave_barrier();
         }
     }
+    if constexpr (sizeof(TO) == 4) sat_publish(p.sat, qkv_sat);
 }
 
 
@@ -573,8 +591,9 @@ template <typename TO> __device__ __forceinline__ void ln_act8(float (&x)[8], in
 // CONSUMER with a plain epilogue (FF1): v = act(rstd * acc - (mean * rstd) * ln_p[col] + ln_c[col]).  The wave tile is TM
 // 32-row blocks x WN = 32 * TN columns, first row `mw` of this launch, first column `nc0`; it leaves as rows of TO (16-bit
 // engines: p.out) or as panel planes of NP planes (fp32 engines: p.out_planes), one 16-byte store per lane and plane.
-template <typename TO, int TM, int TN, int NP>
-__device__ __forceinline__ void gemm_epilogue_ln_in(f32x16 (&acc)[TM][TN], const ConvGemmDev& p, int mw, int nc0, int lr, int lk, float* stage) {
+template <typename TO, int TM, int TN, int NP, bool PRE = false>
+__device__ __forceinline__ void gemm_epilogue_ln_in(f32x16 (&acc)[TM][TN], const ConvGemmDev& p, int mw, int nc0, int lr, int lk, float* stage,
+                                                    const float* pre_rs = nullptr, const float* pre_mr = nullptr) {
     constexpr int WN = 32 * TN, LPR = WN / 8, RPI = 64 / LPR, NIT = 32 / RPI;
     const int lane = lk * 32 + lr;
     const int c8 = (lane % LPR) * 8, rl0 = lane / LPR;
@@ -591,7 +610,8 @@ __device__ __forceinline__ void gemm_epilogue_ln_in(f32x16 (&acc)[TM][TN], const
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         float rstd, mrstd;
-        ln_rows32(p, (long)mw + i * 32, (long)p.M - 1, lr, lk, rstd, mrstd);
+        if constexpr (PRE) { rstd = pre_rs[i]; mrstd = pre_mr[i]; }
+        else ln_rows32(p, (long)mw + i * 32, (long)p.M - 1, lr, lk, rstd, mrstd);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll

@@ -44,7 +44,7 @@ long x3p_bytes(long rows, long K, int np) { return ((rows + 127) / 128) * (K / 3
 // [rows, rows_pad) are written as zeros (the last row panel is always whole).
 template <int NP>
 __global__ __launch_bounds__(256) void x3p_split_rows_kernel(const float* __restrict__ x, long ld, unsigned char* __restrict__ out,
-                                                             int rows, int K, long total) {
+                                                             int rows, int K, long total, int* __restrict__ satp) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
     const int s8n = K >> 3;
@@ -56,13 +56,15 @@ __global__ __launch_bounds__(256) void x3p_split_rows_kernel(const float* __rest
     }
     const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
     x3_u4 pl[NP];
-    xnp_split8<NP>(v, pl);
+    unsigned sat = 0;
+    xnp_split8_sat<NP>(v, pl, sat);
     unsigned char* dst = out + x3p_slot_offset(row, s8, K >> 5, NP);
 #pragma unroll
     for (int q = 0; q < NP; ++q) *reinterpret_cast<x3_u4*>(dst + q * X3P_PLANE) = pl[q];
+    if constexpr (NP == 2) sat_publish(satp, sat);
 }
 
-void x3p_split_rows(const float* x, long ld, void* planes, int rows, int K, hipStream_t s, int np) {
+void x3p_split_rows(const float* x, long ld, void* planes, int rows, int K, hipStream_t s, int np, int* sat) {
     MI_REQUIRE(K % 32 == 0 && ld % 4 == 0 && ((uintptr_t)x % 16) == 0, "x3p_split_rows: K must be whole 32-deep chunks, rows 16-byte aligned");
     MI_REQUIRE(np == 2 || np == 3, "x3p_split_rows: 2 or 3 planes");
     const int rows_pad = (rows + 127) / 128 * 128;
@@ -70,10 +72,10 @@ void x3p_split_rows(const float* x, long ld, void* planes, int rows, int K, hipS
     const dim3 grid((unsigned)((total + 255) / 256));
     if (np == 3) {
         prof_set_kernel("x3p_split_rows_kernel<3>", "", "");
-        hipLaunchKernelGGL(x3p_split_rows_kernel<3>, grid, dim3(256), 0, s, x, ld, (unsigned char*)planes, rows, K, total);
+        hipLaunchKernelGGL(x3p_split_rows_kernel<3>, grid, dim3(256), 0, s, x, ld, (unsigned char*)planes, rows, K, total, sat);
     } else {
         prof_set_kernel("x3p_split_rows_kernel<2>", "", "");
-        hipLaunchKernelGGL(x3p_split_rows_kernel<2>, grid, dim3(256), 0, s, x, ld, (unsigned char*)planes, rows, K, total);
+        hipLaunchKernelGGL(x3p_split_rows_kernel<2>, grid, dim3(256), 0, s, x, ld, (unsigned char*)planes, rows, K, total, sat);
     }
     MI_HIP(hipGetLastError());
 }
@@ -119,6 +121,7 @@ __device__ __forceinline__ void x3p_epilogue_planes(f32x16 (&acc)[TM][TN], const
     const int c8 = (lane & 7) * 8;
     const int s8 = (n0 + wn * 64 + c8) >> 3;
     unsigned char* planes = (unsigned char*)p.out_planes;
+    unsigned sat = 0;
 #pragma unroll
     for (int it = 0; it < 4 * TM; ++it) {
         const int rr = (lane >> 3) + it * 8;
@@ -127,7 +130,7 @@ __device__ __forceinline__ void x3p_epilogue_planes(f32x16 (&acc)[TM][TN], const
         const float4 t1 = *reinterpret_cast<const float4*>(&stage[rr * 64 + c8 + 4]);
         const float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
         x3_u4 pl[NP];
-        xnp_split8<NP>(v, pl);
+        xnp_split8_sat<NP>(v, pl, sat);
         if (m < p.M) {
             unsigned char* dst = planes + x3p_slot_offset(m, s8, nch_out, NP);
 #pragma unroll
@@ -136,6 +139,7 @@ __device__ __forceinline__ void x3p_epilogue_planes(f32x16 (&acc)[TM][TN], const
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    if constexpr (NP == 2) sat_publish(p.sat, sat);
 }
 
 // the same with an instruction offset OFF (0 / 1024 / 2048 / 3072): it advances the global address AND the LDS address, and the
@@ -259,6 +263,12 @@ __global__ __launch_bounds__(512, 1) void linear_x3p_kernel(const ConvGemmDev p)
             for (int j = 0; j < PER; ++j) x3p_dma16(rsd, (int)((unsigned)vb[j] + (unsigned)coff), base + (unsigned)(j * 1024));
         };
 
+        // AdaLN fold, consumer side: the LayerNorm statistics of the 32 rows this wave will own in the epilogue (block wm * 2 + kg of the
+        // tile), requested now — their L2 round trip and the 16-partial sum run under the main loop instead of in front of the epilogue
+        float ln_rs[1] = {0.f}, ln_mr[1] = {0.f};
+        if constexpr (FOLD) {
+            if (cb == 0 && p.ln_stats_in) ln_rows32(p, (long)p.m_off + m0 + (wm * 2 + kg) * 32, (long)p.m_off + p.M - 1, lr, lk, ln_rs[0], ln_mr[0]);
+        }
         constexpr int NACC = NP == 3 ? 1 : 2;
         f32x16 accs[NACC][TM][TN];
 #pragma unroll
@@ -468,8 +478,8 @@ __global__ __launch_bounds__(512, 1) void linear_x3p_kernel(const ConvGemmDev p)
             if constexpr (LEPI) {
                 float* stage = reinterpret_cast<float*>(smem) + wave * 2176;        // 32 x 64 floats per wave (32 x 65 for the transposed-V path)
                 if constexpr (FOLD) {
-                    if (p.epi == EPI_QKV_ROPE) gemm_epilogue_qkv_lds<TO, 1, true>(h, p, m0, n0, 0, wm2, wn, lr, lk, stage);                // consumer: QKV
-                    else if (p.ln_stats_in) gemm_epilogue_ln_in<TO, 1, TN, NP>(h, p, m0 + wm2 * 32, n0 + wn * WN, lr, lk, stage);         // consumer: FF1 -> panel planes
+                    if (p.epi == EPI_QKV_ROPE) gemm_epilogue_qkv_lds<TO, 1, true, true>(h, p, m0, n0, 0, wm2, wn, lr, lk, stage, ln_rs, ln_mr);       // consumer: QKV
+                    else if (p.ln_stats_in) gemm_epilogue_ln_in<TO, 1, TN, NP, true>(h, p, m0 + wm2 * 32, n0 + wn * WN, lr, lk, stage, ln_rs, ln_mr); // consumer: FF1 -> panel planes
                     else gemm_epilogue_resid_ln<float, 1, TN, NP>(h, p, m0 + wm2 * 32, n0 + wn * WN, lr, lk, stage);                      // producer: O / FF2
                 } else {
                     if (p.epi == EPI_QKV_ROPE) gemm_epilogue_qkv_lds<TO, 1>(h, p, m0, n0, 0, wm2, wn, lr, lk, stage);

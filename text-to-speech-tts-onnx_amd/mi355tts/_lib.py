@@ -119,6 +119,7 @@ def load() -> C.CDLL:
     L.mi_bench_conv_gemm.argtypes = [C.c_int] * 9 + [C.POINTER(C.c_double)]
     L.mi_bench_conv_gemm.restype = C.c_int
     L.mi_set_option.argtypes = [C.c_char_p, C.c_int64]; L.mi_set_option.restype = C.c_int
+    L.mi_device_pci_bus_id.argtypes = [C.c_int, C.c_char_p, C.c_int]; L.mi_device_pci_bus_id.restype = C.c_int
     L.mi_prof_enable.argtypes = [C.c_int]; L.mi_prof_enable.restype = C.c_int
     L.mi_prof_reset.argtypes = []; L.mi_prof_reset.restype = C.c_int
     L.mi_prof_get.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
@@ -198,6 +199,12 @@ def bench_conv_gemm(dtype: str, B: int, T: int, Cin: int, N: int, taps: int = 1,
     check(load().mi_bench_conv_gemm(DTYPES[dtype], B, T, Cin, N, taps, dil, int(with_res), iters, C.byref(ms)),
           "mi_bench_conv_gemm")
     return ms.value
+
+
+def device_pci_bus_id(device: int) -> str:
+    buf = C.create_string_buffer(64)
+    check(load().mi_device_pci_bus_id(int(device), buf, 64), "mi_device_pci_bus_id")
+    return buf.value.decode()
 
 
 def set_option(key: str, value: int) -> None:

@@ -54,6 +54,41 @@ def broadcast_blob(blob, src: int = 0, device=None):
     return t.cpu().numpy()
 
 
+def broadcast_blob_device(blob_t, src: int = 0):
+    """Device-resident form of broadcast_blob: `blob_t` is a float32 CUDA tensor on every rank (filled on `src`, empty elsewhere);
+    it is broadcast IN PLACE over the process group's backend — "nccl" = RCCL over xGMI, the tensor never visits the host — and
+    handed back for F5Engine(blob_device=...) / BigVGANVocoder(blob_device=...), which build their engines straight from HBM.
+    gloo (the one-GPU plumbing tests) stages through host memory, because its device-tensor support is not a given on ROCm."""
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return blob_t
+    if dist.get_backend() == "nccl":
+        dist.broadcast(blob_t, src=src)
+        return blob_t
+    h = blob_t.cpu()
+    dist.broadcast(h, src=src)
+    blob_t.copy_(h)
+    return blob_t
+
+
+def assert_one_device_per_rank(device_index: int, allow_shared: bool = False):
+    """Every rank of a node must drive its own GPU: gathers (hostname, PCI bus id of this rank's device) and fails loudly on
+    every rank if two ranks resolved to the same physical device (e.g. LOCAL_RANK not honoured, HIP_VISIBLE_DEVICES collapsing
+    the ranks onto device 0) — a scaling line measured that way would be N ranks time-slicing one GPU.  Returns the id list."""
+    import socket
+    import torch.distributed as dist
+    from . import _lib
+    me = (socket.gethostname(), _lib.device_pci_bus_id(device_index))
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [me]
+    ids = [None] * dist.get_world_size()
+    dist.all_gather_object(ids, me)
+    if len(set(ids)) != len(ids) and not allow_shared:
+        raise RuntimeError(f"ranks share a physical GPU: {ids} (one process per GPU is the contract; "
+                           "MI355TTS_BENCH_ONE_GPU=1 allows it for plumbing tests)")
+    return ids
+
+
 def gather_waveforms(local: Sequence[np.ndarray], dst: int = 0):
     """Gather per-rank lists of int16 waveforms to `dst` (returns the concatenated list there, None elsewhere)."""
     import torch.distributed as dist

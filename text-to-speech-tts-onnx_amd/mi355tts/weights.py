@@ -454,11 +454,14 @@ F5_BENCH_REF_TEXT = "Some call me nature, others call me mother nature, I am the
 F5_BENCH_GEN_TEXT = "The quick brown fox jumps over the lazy dog while seven wizards brew a potion"
 
 
-def f5_synthetic_inputs(cfg: F5Config, U: int, rank: int = 0, L: int = 144000):
+def f5_synthetic_inputs(cfg: F5Config, U: int, rank: int = 0, L: int = 144000, first: int = None):
     """BASELINE configs[2]/[3]: 6.0 s reference audio (144000 samples -> 563 frames), equal-length ~15-word ASCII
     ref/gen texts (-> N = 1126 by the duration formula of F5-TTS-ONNX-Inference.py:227-231), char-level ids against
     the synthetic vocab, injected noise.  Returns (audio (U,L) i16, ids (U,T) i32, N, noise (U,N,mel) f32).
-    (`L` other than 144000 is for reduced-size plumbing tests only.)"""
+    (`L` other than 144000 is for reduced-size plumbing tests only.)  Utterance u of the call is utterance `first + u` of the
+    job's list (seed 9527 + first + u: configs[3] is seeds 9527 .. 9590 partitioned over the ranks with shard.shard_range);
+    without `first` it is 64 * rank + u, the numbering the fixtures were generated with."""
+    base = 64 * rank if first is None else int(first)
     ref_text = F5_BENCH_REF_TEXT
     gen_text = (F5_BENCH_GEN_TEXT + " " * len(ref_text))[:len(ref_text)]
     vocab = synth_vocab(cfg.text_num_embeds)
@@ -468,9 +471,9 @@ def f5_synthetic_inputs(cfg: F5Config, U: int, rank: int = 0, L: int = 144000):
     audio = np.empty((U, L), np.int16)
     tt = np.arange(L) / cfg.sample_rate
     for u in range(U):
-        a = 0.1 * 32767 * np.sin(2 * np.pi * 220 * tt) + synth_normal(9527 + 64 * rank + u, "audio", (L,), std=500.0)
+        a = 0.1 * 32767 * np.sin(2 * np.pi * 220 * tt) + synth_normal(9527 + base + u, "audio", (L,), std=500.0)
         audio[u] = np.clip(np.round(a), -32768, 32767).astype(np.int16)
-    noise = np.stack([synth_normal(9527 + 64 * rank + u, "noise", (N, cfg.mel_dim)) for u in range(U)])
+    noise = np.stack([synth_normal(9527 + base + u, "noise", (N, cfg.mel_dim)) for u in range(U)])
     return audio, np.tile(ids[None], (U, 1)), N, noise
 
 
