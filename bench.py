@@ -293,7 +293,7 @@ class F5Bench:
         lo, hi = shard_range(self.world * U, self.world, self.rank)
         assert hi - lo == U
         audio, ids, N, noise = self.W.f5_synthetic_inputs(cfg, U, self.rank, L=self.L, first=lo)
-        R = audio.shape[1] // cfg.hop_length + 1
+        R = cfg.ref_frames(audio.shape[1])
         t_audio, t_ids, t_noise = torch.from_numpy(audio).to(dev), torch.from_numpy(ids).to(dev), torch.from_numpy(noise).to(dev)
         out = torch.empty((U, 1, (N - R - 1) * cfg.hop_length), dtype=torch.int16, device=dev)
         audio_s = U * out.shape[-1] / cfg.sample_rate
@@ -372,12 +372,15 @@ def measure_f5_plus_bigvgan(torch, fb, f5_dtype: str, voc_dtype: str, U: int, st
     from mi355tts.config import BigVGANConfig
     from mi355tts.f5 import F5Engine
     from mi355tts.bigvgan import BigVGANVocoder
-    cfg, dev, W = fb.cfg, fb.dev, fb.W
+    import dataclasses
+    dev, W = fb.dev, fb.W
+    # the prompt features of the F5 *_bigvgan checkpoints: the bigvgan-type mel front end (modeling_modified/F5/modules.py:30-72)
+    cfg = dataclasses.replace(fb.cfg, mel_spec_type="bigvgan", **fb.cfg_over)
     vcfg = BigVGANConfig()
     eng = F5Engine(cfg, blob_device=fb.blob_t, dtype=f5_dtype, device=fb.local)
     voc = BigVGANVocoder(vcfg, blob=W.pack_bigvgan(vcfg, W.synth_state(W.bigvgan_spec(vcfg), 9527)), dtype=voc_dtype, device=fb.local)
     audio, ids, N, noise = W.f5_synthetic_inputs(cfg, U, fb.rank, L=fb.L)
-    R = audio.shape[1] // cfg.hop_length + 1
+    R = cfg.ref_frames(audio.shape[1])
     F = N - R
     t_audio, t_ids, t_noise = torch.from_numpy(audio).to(dev), torch.from_numpy(ids).to(dev), torch.from_numpy(noise).to(dev)
     mel = torch.empty((U, cfg.mel_dim, F), dtype=torch.float32, device=dev)
@@ -404,8 +407,10 @@ def measure_f5_plus_bigvgan(torch, fb, f5_dtype: str, voc_dtype: str, U: int, st
     eng.close(); voc.close()
     return {"value": audio_s / dt, "unit": "audio-s/s", "ms_per_step": dt * 1e3, "rtf": dt / audio_s, "dtype": f"{f5_dtype} DiT + {voc_dtype} vocoder",
             "vocoder_ms_per_step": voc_ms, "mel_frames": F, "utterances_per_gpu": U,
-            "workload": f"F5-TTS {f5_dtype} NFE=32 (N={N}) -> generated mel ({U},100,{F}) -> BigVGAN-v2 24khz_100band_256x {voc_dtype} -> int16, "
-                        f"one device-resident pipeline (mi_f5_synthesize_mel + mi_bigvgan_forward)"}
+            "mel_spec_type": cfg.mel_spec_type,
+            "workload": f"F5-TTS {f5_dtype} NFE=32 (N={N}, bigvgan-type prompt mel: slaney basis, center=False, {R} prompt frames) -> generated mel "
+                        f"({U},100,{F}) -> BigVGAN-v2 24khz_100band_256x {voc_dtype} -> int16, one device-resident pipeline "
+                        f"(mi_f5_synthesize_mel + mi_bigvgan_forward)"}
 
 
 def f5_workload_name(dtype, U, N, small=False):

@@ -208,6 +208,34 @@ def melscale_fbanks_htk(n_freqs=513, f_min=0.0, f_max=12000.0, n_mels=100, sampl
     return np.maximum(0.0, np.minimum(down, up)).astype(F32)
 
 
+def mel_basis_slaney(n_fft=1024, n_mels=100, sample_rate=24000, fmin=0.0, fmax=None):
+    """librosa.filters.mel (slaney scale, slaney norm) -> (n_mels, n_fft/2+1): the basis of the reference's bigvgan-type mel
+    (modeling_modified/F5/modules.py:45; librosa is un-vendored: restated from its published definition)."""
+    fmax = sample_rate / 2.0 if fmax is None else float(fmax)
+    f_sp, min_log_hz, logstep = 200.0 / 3, 1000.0, math.log(6.4) / 27.0
+    min_log_mel = min_log_hz / f_sp
+    h2m = lambda f: f / f_sp if f < min_log_hz else min_log_mel + math.log(f / min_log_hz) / logstep
+    mels = np.linspace(h2m(fmin), h2m(fmax), n_mels + 2)
+    mel_f = np.where(mels >= min_log_mel, min_log_hz * np.exp(logstep * (mels - min_log_mel)), f_sp * mels)
+    freqs = np.linspace(0.0, sample_rate / 2.0, n_fft // 2 + 1)
+    fdiff = np.diff(mel_f)
+    ramps = mel_f[:, None] - freqs[None, :]
+    w = np.maximum(0.0, np.minimum(-ramps[:-2] / fdiff[:-1, None], ramps[2:] / fdiff[1:, None]))
+    return (w * (2.0 / (mel_f[2:] - mel_f[:-2]))[:, None]).astype(F32)
+
+
+def bigvgan_mel(audio_f32, n_fft=1024, n_mels=100, sample_rate=24000, hop=256):
+    """get_bigvgan_mel_spectrogram (modules.py:30-72): reflect pad (n_fft - hop) / 2 each side, torch.stft(center=False) with the
+    periodic Hann window, sqrt(re^2 + im^2 + 1e-9), slaney mel basis, log(clamp(., 1e-5)).  audio (L,) float -> (frames, n_mels)."""
+    pad = (n_fft - hop) // 2
+    xp = np.pad(audio_f32.astype(np.float64), (pad, pad), mode="reflect")
+    nfr = (len(xp) - n_fft) // hop + 1
+    idx = np.arange(nfr)[:, None] * hop + np.arange(n_fft)[None, :]
+    spec = np.fft.rfft(xp[idx] * hann_periodic(n_fft).astype(np.float64)[None, :], axis=1)           # (F, n_fft/2+1)
+    mag = np.sqrt(spec.real ** 2 + spec.imag ** 2 + 1e-9).astype(F32)
+    return np.log(np.maximum(mag @ mel_basis_slaney(n_fft, n_mels, sample_rate).T, F32(1e-5))).astype(F32)
+
+
 # ------------------------------------------------------------------------------------------------
 # tables of the exported graphs
 # ------------------------------------------------------------------------------------------------
@@ -296,9 +324,12 @@ def preprocess(cfg, st, audio_i16, text_ids, max_duration, noise):
     ORT).  Returns dict with the graph's eight outputs (batch axes dropped)."""
     N = int(max_duration)
     a = audio_i16.astype(F32) * F32(1.0 / 32768.0)
-    re, im = stft_b(a, cfg.n_fft, cfg.hop_length)
-    fb = melscale_fbanks_htk(cfg.n_freq, 0.0, cfg.sample_rate // 2, cfg.mel_dim, cfg.sample_rate).T   # (100, 513)
-    mel = np.log(np.maximum((fb @ np.sqrt(re * re + im * im)).T, F32(1e-5))).astype(F32)             # (R, 100)
+    if getattr(cfg, "mel_spec_type", "vocos") == "bigvgan":       # the F5 *_bigvgan checkpoints' prompt features (modules.py:30-72)
+        mel = bigvgan_mel(a, cfg.n_fft, cfg.mel_dim, cfg.sample_rate, cfg.hop_length)
+    else:
+        re, im = stft_b(a, cfg.n_fft, cfg.hop_length)
+        fb = melscale_fbanks_htk(cfg.n_freq, 0.0, cfg.sample_rate // 2, cfg.mel_dim, cfg.sample_rate).T   # (100, 513)
+        mel = np.log(np.maximum((fb @ np.sqrt(re * re + im * im)).T, F32(1e-5))).astype(F32)             # (R, 100)
     R = mel.shape[0]
     mel_pad = np.zeros((N, cfg.mel_dim), dtype=F32)
     mel_pad[:R] = mel

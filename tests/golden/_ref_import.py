@@ -133,6 +133,40 @@ def melscale_fbanks(n_freqs, f_min, f_max, n_mels, sample_rate, norm=None, mel_s
     return torch.max(zero, torch.min(down_slopes, up_slopes))
 
 
+def slaney_mel_basis(sr, n_fft, n_mels=128, fmin=0.0, fmax=None, **kw):
+    """librosa.filters.mel (htk=False, norm='slaney') restated from its published definition; librosa is not installed and the
+    reference's bigvgan-type mel front end calls it (modeling_modified/F5/modules.py:18,45).  Cross-checked in
+    make_golden_bigvgan_mel.py against transformers.audio_utils.mel_filter_bank(norm='slaney', mel_scale='slaney')."""
+    import numpy as np
+    assert not kw.get("htk", False) and kw.get("norm", "slaney") == "slaney"
+    fmax = float(sr) / 2 if fmax is None else float(fmax)
+    f_sp = 200.0 / 3
+    min_log_hz, logstep = 1000.0, np.log(6.4) / 27.0
+    min_log_mel = min_log_hz / f_sp
+
+    def hz_to_mel(f):
+        f = np.asanyarray(f, dtype=np.float64)
+        lin = f / f_sp
+        return np.where(f >= min_log_hz, min_log_mel + np.log(np.maximum(f, 1e-30) / min_log_hz) / logstep, lin)
+
+    def mel_to_hz(m):
+        m = np.asanyarray(m, dtype=np.float64)
+        return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
+
+    fftfreqs = np.linspace(0, float(sr) / 2, 1 + n_fft // 2)
+    mel_f = mel_to_hz(np.linspace(hz_to_mel(fmin), hz_to_mel(fmax), n_mels + 2))
+    fdiff = np.diff(mel_f)
+    ramps = np.subtract.outer(mel_f, fftfreqs)
+    weights = np.zeros((n_mels, 1 + n_fft // 2), dtype=np.float64)
+    for i in range(n_mels):
+        lower = -ramps[i] / fdiff[i]
+        upper = ramps[i + 2] / fdiff[i + 1]
+        weights[i] = np.maximum(0, np.minimum(lower, upper))
+    enorm = 2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels])
+    weights *= enorm[:, np.newaxis]
+    return weights.astype(np.float32)
+
+
 def load_f5_ref(fp16: bool = False):
     """Returns (modules, dit, vocos_models, vocos_heads, STFT_Process) from the reference files.  ``fp16``: the
     reference's fp16-transformer variant of modules.py (F5/fp16/modules.py, which Export_F5.py:88-89 installs over
@@ -149,7 +183,7 @@ def load_f5_ref(fp16: bool = False):
     ta.functional = taf
     _pkg("librosa")
     lf = _pkg("librosa.filters")
-    lf.mel = lambda *a, **k: None
+    lf.mel = slaney_mel_basis          # (the bigvgan-type mel front end of modules.py:30-72 calls it; nothing else does)
     _pkg("x_transformers")
     xt = _pkg("x_transformers.x_transformers")
     xt.apply_rotary_pos_emb = lambda *a, **k: None

@@ -698,3 +698,34 @@ def test_fp16_pair_range_watch_heavy_tailed_operands():
         assert np.isfinite(a).all() and rms(a - b) / rms(b) < 1e-5
     finally:
         e.close()
+
+
+def test_bigvgan_type_mel_front_end_against_reference_fixture(golden_dir):
+    """The prompt features of the F5 *_bigvgan checkpoints (VERDICT r3 missing #1): get_bigvgan_mel_spectrogram
+    (modeling_modified/F5/modules.py:30-72 — librosa/slaney mel basis, reflect pad (n_fft - hop) / 2, center=False,
+    sqrt(re^2 + im^2 + 1e-9), log(clamp(., 1e-5))) selected by F5Config.mel_spec_type = "bigvgan", against the output of the
+    reference function itself (tests/golden/make_golden_bigvgan_mel.py) and against the oracle's restatement."""
+    import dataclasses
+    cfg = dataclasses.replace(F5Config.small(), mel_spec_type="bigvgan")
+    raw = W.synth_state(W.f5_spec(cfg), 9527)
+    eng = F5Engine(cfg, raw, dtype="f32")
+    g = np.load(os.path.join(golden_dir, "f5_bigvgan_mel.npz"))
+    try:
+        for name in ("syn", "zh"):
+            pcm, ref = g[name + "_pcm"], g[name + "_logmel"].T            # (frames, 100)
+            R = cfg.ref_frames(pcm.shape[0])
+            assert R == ref.shape[0]
+            o = eng.preprocess(pcm.reshape(1, 1, -1), np.zeros((1, 4), np.int32), np.array([R + 8]))
+            assert int(o["ref_signal_len"]) == R
+            lm = o["cat_mel_text"][0, :R, :100]
+            assert np.all(o["cat_mel_text"][0, R:, :100] == 0.0)
+            m = ref > np.log(2e-5)                                        # log of a clamped value: compare above the clamp floor
+            assert m.mean() > 0.6
+            err = np.abs(lm - ref)[m].max()
+            orc = O.bigvgan_mel(pcm.astype(np.float32) * np.float32(1.0 / 32768.0))
+            print(f"bigvgan-type mel ({name}): max |log-mel - reference| above the floor {err:.2e}; oracle vs reference {np.abs(orc - ref)[m].max():.2e}")
+            assert err < (1e-4 if name == "syn" else 5e-4), err            # zh.wav: near-silent frames sit close to the floor (oracle: 1.7e-4)
+    finally:
+        eng.close()
+    # the vocos-type default is untouched: other frame count for the same audio
+    assert F5Config().ref_frames(144000) == 563 and dataclasses.replace(F5Config(), mel_spec_type="bigvgan").ref_frames(144000) == 562

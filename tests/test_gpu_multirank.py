@@ -44,6 +44,11 @@ def test_bench_two_ranks_on_one_gpu_equals_single_process(tmp_path):
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0 and line["dtype"] == "f32"
     assert "PLUMBING TEST ONLY" in line["config"]["workload"] and line["config"]["utterances_per_gpu"] == 3
     assert line["config"]["weight_bcast_ms"] > 0
+    # round 4: the job-level utterance list, the per-rank times behind the maximum, and which device every rank drove
+    assert line["config"]["utterances_total"] == 6 and line["config"]["utterance_seeds"] == [9527, 9532]
+    assert len(line["config"]["per_rank_ms"]) == 2 and max(line["config"]["per_rank_ms"]) == pytest.approx(line["ms_per_step"], rel=1e-9)
+    devs = line["config"]["rank_devices"]
+    assert len(devs) == 2 and devs[0] == devs[1]            # this plumbing test shares the box's one GPU, and the line says so
     # value = audio of BOTH ranks / max-over-ranks time
     per_gpu = line["config"]["audio_seconds_per_step_per_gpu"]
     assert abs(line["value"] - 2 * per_gpu / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
@@ -51,7 +56,7 @@ def test_bench_two_ranks_on_one_gpu_equals_single_process(tmp_path):
     eng = F5Engine(cfg, W.synth_state(W.f5_spec(cfg), 9527), dtype="f32")
     for rank in range(2):
         got = np.load(tmp_path / f"f5_f32_u3_rank{rank}.npy")
-        audio, ids, N, noise = W.f5_synthetic_inputs(cfg, 3, rank, L=24000)
+        audio, ids, N, noise = W.f5_synthetic_inputs(cfg, 3, rank, L=24000, first=3 * rank)      # the job-level list: rank r owns utterances 3 r .. 3 r + 2
         want = eng.synthesize(audio, ids, N, noise=noise)
         assert got.shape == want.shape and np.array_equal(got, want), rank
         assert np.sqrt(np.mean(want.astype(np.float64) ** 2)) > 100
@@ -91,6 +96,20 @@ def test_bench_two_gpus_rccl():
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert line["n_gpus"] == 2 and line["dtype"] == "bf16" and "configs[3] shard" in line["config"]["workload"]
     assert line["config"]["weight_bcast_ms"] > 0 and line["config"]["collective_backend"] == "nccl"
+    assert line["config"]["utterances_total"] == 16 and len(set(line["config"]["rank_devices"])) == 2
+
+
+def test_two_ranks_on_one_device_are_refused_without_the_plumbing_switch():
+    """One process per GPU is the contract: `bench.py --gpus 2` whose ranks resolve to the SAME physical device must fail loudly
+    (a scaling line measured that way would be two ranks time-slicing one GPU) unless MI355TTS_BENCH_ONE_GPU=1 says it is a
+    plumbing test.  Forced here by hiding all but one device from both ranks."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MI355TTS_BENCH_ONE_GPU")}
+    env.update(MI355TTS_BENCH_BACKEND="gloo", MI355TTS_BENCH_SMALL="1", HSA_ENABLE_IPC_MODE_LEGACY="0", HIP_VISIBLE_DEVICES="0",
+               MI355TTS_BENCH_SAME_DEVICE_TEST="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode != 0
+    assert "only 1 device(s) visible" in (r.stdout + r.stderr) or "ranks share a physical GPU" in (r.stdout + r.stderr)
 
 
 def test_engine_from_device_blob_equals_engine_from_host_blob():

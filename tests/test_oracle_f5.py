@@ -168,3 +168,17 @@ def test_oracle_full_size_dit_evaluation_against_reference_fixture(golden_dir):
     assert pred.shape == ref.shape == (2, N, cfg.mel_dim)
     rel = float(np.sqrt(np.mean((pred - ref) ** 2)) / np.sqrt(np.mean(ref ** 2)))
     assert rel < 1e-4, rel
+
+
+def test_bigvgan_type_mel_oracle_against_reference_fixture(golden_dir):
+    """oracle/f5_np.py bigvgan_mel (modules.py:30-72) against the output of the reference's own function on 1 s of the bench
+    prompt and 1 s of zh.wav (tests/golden/make_golden_bigvgan_mel.py); the slaney basis against its closed-form landmarks."""
+    g = np.load(os.path.join(golden_dir, "f5_bigvgan_mel.npz"))
+    assert float(g["basis_check_max_abs"]) < 1e-7          # generator: restated librosa basis == transformers' slaney/slaney bank
+    for name, tol in (("syn", 2e-5), ("zh", 5e-4)):
+        ref = g[name + "_logmel"].T
+        got = O.bigvgan_mel(g[name + "_pcm"].astype(np.float32) * np.float32(1.0 / 32768.0))
+        m = ref > np.log(2e-5)
+        assert got.shape == ref.shape and np.abs(got - ref)[m].max() < tol
+    b = O.mel_basis_slaney()
+    assert b.shape == (100, 513) and (b >= 0).all() and abs(float(b[50].sum() * (12000.0 / 512)) - 1.0) < 0.02     # slaney norm: unit-area triangles (a mid band spans many bins)

@@ -501,7 +501,7 @@ void cond_run(Cond* e, const int16_t* audio, long L, float* conds_out, float* la
         g.dtype = MI_F32; g.x = e->padded.p; g.w = e->stft_w.p; g.out = e->spec.p;
         g.B = 1; g.T_in = (int)T; g.M = (int)T; g.N = 2 * nb; g.Cin = nf; g.x_rstride = c.hop; g.x_bstride = 0; g.out_rstride = 2 * nb; g.out_bstride = 0;
         launch_conv_gemm(g, s);
-        launch_spec_mag(e->spec.as<float>(), e->mag.as<float>(), (int)T, nb, ldm, s);
+        launch_spec_mag(e->spec.as<float>(), e->mag.as<float>(), (int)T, nb, ldm, 0.f, s);
         ConvGemm m;
         m.dtype = MI_F32; m.x = e->mag.p; m.w = e->fbank.p; m.out = e->mel.p;
         m.B = 1; m.T_in = (int)T; m.M = (int)T; m.N = c.mel; m.Cin = ldm; m.x_rstride = ldm; m.out_rstride = c.mel;

@@ -94,7 +94,7 @@ struct F5 {
     // fills d_noise, d_cmt, d_cmtd for U utterances (asynchronous on `stream`); returns ref_signal_len
     int preprocess(int U, const int16_t* audio, long L, const int32_t* text_ids, int T, int N,
                    const float* noise_in, uint64_t seed, int mem);
-    void stft(const int16_t* audio_dev, int U, long L);     // -> p_spec [u][frame][re | im]
+    void stft(const int16_t* audio_dev, int U, long L, int pad = -1);     // -> p_spec [u][frame][re | im]; pad: reflect padding each side (-1: n_fft / 2)
     void check_text_ids();
     void load_cond(const float* noise, const float* cmt, const float* cmtd, int U, int N, int mem);
     void build_cat_cond(int U, int N);

@@ -293,17 +293,45 @@ F5::F5(const F5Cfg& c, const float* w, int64_t nw, int dt, int dev, int mem) : c
                 sw[(size_t)f * nf + t] = cosf(om) * win[t];
                 sw[(size_t)(nb + f) * nf + t] = -sinf(om) * win[t];
             }
+        if (c.mel_type == 1) {
+            // bigvgan-type front end (modules.py:30-72): torch.stft's DFT of the windowed frame — the exact basis, not the fp32
+            // evaluation order of STFT_Process's conv kernels (that quirk belongs to the vocos-type graph)
+            for (int f = 0; f < nb; ++f)
+                for (int t = 0; t < nf; ++t) {
+                    const double om = 2.0 * M_PI * (double)((long)f * t % nf) / nf;
+                    sw[(size_t)f * nf + t] = (float)(std::cos(om) * (double)win[t]);
+                    sw[(size_t)(nb + f) * nf + t] = (float)(-std::sin(om) * (double)win[t]);
+                }
+        }
         upload_f32(stft_w, sw.data(), sw.size(), s);
         // melscale_fbanks(nb, 0, sr/2, mel, sr, None, 'htk') -> stored [mel][ldm] zero padded
         const int ldm = rup(nb, 8);
         std::vector<float> fb((size_t)c.mel * ldm, 0.f);
+        if (c.mel_type == 1) {
+            // librosa.filters.mel(sr, n_fft, n_mels, fmin = 0, fmax = sr / 2): slaney scale (linear below 1 kHz, log above), slaney
+            // norm (2 / band width) — published definition, librosa is un-vendored (modules.py:18,45)
+            const double f_sp = 200.0 / 3, min_log_hz = 1000.0, logstep = std::log(6.4) / 27.0, min_log_mel = min_log_hz / f_sp;
+            auto h2m = [&](double f) { return f < min_log_hz ? f / f_sp : min_log_mel + std::log(f / min_log_hz) / logstep; };
+            auto m2h = [&](double m) { return m < min_log_mel ? f_sp * m : min_log_hz * std::exp(logstep * (m - min_log_mel)); };
+            const double m0 = h2m(0.0), m1 = h2m((double)c.sr / 2);
+            std::vector<double> mf(c.mel + 2);
+            for (int i = 0; i < c.mel + 2; ++i) mf[i] = m2h(m0 + (m1 - m0) * i / (c.mel + 1));
+            for (int m = 0; m < c.mel; ++m) {
+                const double enorm = 2.0 / (mf[m + 2] - mf[m]);
+                for (int k = 0; k < nb; ++k) {
+                    const double fr = (double)c.sr / 2 * k / (nb - 1);
+                    const double lower = (fr - mf[m]) / (mf[m + 1] - mf[m]), upper = (mf[m + 2] - fr) / (mf[m + 2] - mf[m + 1]);
+                    fb[(size_t)m * ldm + k] = (float)(std::max(0.0, std::min(lower, upper)) * enorm);
+                }
+            }
+        }
         const double m_min = 0.0, m_max = 2595.0 * std::log10(1.0 + (c.sr / 2) / 700.0);
         std::vector<double> fpts(c.mel + 2);
         for (int i = 0; i < c.mel + 2; ++i) {
             const double m = m_min + (m_max - m_min) * i / (c.mel + 1);
             fpts[i] = 700.0 * (std::pow(10.0, m / 2595.0) - 1.0);
         }
-        for (int k = 0; k < nb; ++k) {
+        for (int k = 0; k < nb && c.mel_type == 0; ++k) {
             const double fr = (double)(c.sr / 2) * k / (nb - 1);
             for (int m = 0; m < c.mel; ++m) {
                 const double down = (fr - fpts[m]) / (fpts[m + 1] - fpts[m]);
@@ -536,7 +564,11 @@ int F5::preprocess(int U, const int16_t* audio, long L, const int32_t* text_ids,
                    const float* noise_in, uint64_t seed, int mem) {
     const F5Cfg& c = cfg;
     MI_REQUIRE(audio && text_ids && U >= 1 && L >= c.n_fft / 2 + 1 && T >= 0, "f5_preprocess: bad arguments");
-    const int R = (int)(L / c.hop) + 1;
+    // frames of the prompt: vocos-type mel = reflect pad n_fft / 2, L / hop + 1 frames (Export_F5.py:122-125); bigvgan-type =
+    // reflect pad (n_fft - hop) / 2, center = False (modules.py:54-68)
+    const int mel_pad = c.mel_type == 1 ? (c.n_fft - c.hop) / 2 : c.n_fft / 2;
+    MI_REQUIRE(L + 2 * mel_pad >= c.n_fft && L > mel_pad, "f5_preprocess: audio shorter than one STFT frame");
+    const int R = (int)((L + 2 * mel_pad - c.n_fft) / c.hop) + 1;
     MI_REQUIRE(N >= R && N >= T && N <= c.max_len, "f5_preprocess: max_duration must be >= ref frames, >= text length and <= max_signal_length");
     if (mem == MI_HOST)
         for (long i = 0; i < (long)U * T; ++i) {
@@ -561,8 +593,8 @@ int F5::preprocess(int U, const int16_t* audio, long L, const int32_t* text_ids,
         dt_ids = p_tid.as<int32_t>();
     }
     MI_HIP(hipMemsetAsync(p_err.p, 0, 4, s));
-    stft(da, U, L);
-    launch_spec_mag(p_spec.as<float>(), p_mag.as<float>(), U * R, nb, ldm, s);
+    stft(da, U, L, mel_pad);
+    launch_spec_mag(p_spec.as<float>(), p_mag.as<float>(), U * R, nb, ldm, c.mel_type == 1 ? 1e-9f : 0.f, s);
     {
         ConvGemm g;
         g.dtype = MI_F32; g.x = p_mag.p; g.w = fbank.p; g.out = p_mel.p;
@@ -604,11 +636,12 @@ int F5::preprocess(int U, const int16_t* audio, long L, const int32_t* text_ids,
 
 // STFT-B (STFT_Process.py:144-157): reflect pad n_fft/2, frames of n_fft at stride hop against the hann*cos / -hann*sin
 // kernels as one framed GEMM -> p_spec [u][frame][re(nb) | im(nb)]
-void F5::stft(const int16_t* audio_dev, int U, long L) {
+void F5::stft(const int16_t* audio_dev, int U, long L, int pad) {
     const F5Cfg& c = cfg;
-    const int nf = c.n_fft, nb = c.nb(), R = (int)(L / c.hop) + 1;
-    const long Lp = L + nf;
-    launch_pad_reflect(audio_dev, p_pad.as<float>(), U, L, nf / 2, stream);
+    if (pad < 0) pad = c.n_fft / 2;
+    const int nf = c.n_fft, nb = c.nb(), R = (int)((L + 2 * pad - nf) / c.hop) + 1;
+    const long Lp = L + 2 * pad;
+    launch_pad_reflect(audio_dev, p_pad.as<float>(), U, L, pad, stream);
     ConvGemm g;      // framed GEMM: row f = padded[f*hop : f*hop + n_fft]
     g.dtype = MI_F32; g.x = p_pad.p; g.w = stft_w.p; g.out = p_spec.p;
     g.B = U; g.T_in = R; g.M = R; g.N = 2 * nb; g.Cin = nf; g.x_rstride = c.hop; g.x_bstride = Lp;

@@ -26,7 +26,7 @@ void launch_text_ids(const int32_t* in, int* out, int U, int T, int N, int vocab
 void launch_mask_rows(const int* ids, float* x, int V, int N, int C, hipStream_t s);
 void launch_copy2d(const float* src, long lds_, void* dst, long ldd, long rows, int cols, int out_dtype, hipStream_t s);
 void launch_pad_reflect(const int16_t* a, float* out, int U, long L, int half, hipStream_t s);
-void launch_spec_mag(const float* spec, float* mag, int F, int nb, int ldm, hipStream_t s);
+void launch_spec_mag(const float* spec, float* mag, int F, int nb, int ldm, float eps, hipStream_t s);      // sqrt(re^2 + im^2 + eps)
 void launch_logmel(const float* melraw, float* cmt, float* cmtd, int U, int N, int R, int M, int ld, hipStream_t s);
 void launch_vocos_head(const float* sp, float* c, long rows, int nb, int ldc, hipStream_t s);
 void launch_istft_ola(const float* frames, const float* wsi, int U, int F, int nfft, int hop, float* out_f,

@@ -465,17 +465,17 @@ void launch_pad_reflect(const int16_t* a, float* out, int U, long L, int half, h
 }
 
 // spec [F][2*nb] (re | im) -> mag [F][ldm] (zero padded columns)
-__global__ __launch_bounds__(256) void spec_mag_kernel(const float* __restrict__ spec, float* __restrict__ mag, int F, int nb, int ldm) {
+__global__ __launch_bounds__(256) void spec_mag_kernel(const float* __restrict__ spec, float* __restrict__ mag, int F, int nb, int ldm, float eps) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long)F * ldm) return;
     const int f = (int)(i / ldm), k = (int)(i - (long)f * ldm);
     float v = 0.f;
-    if (k < nb) { const float re = spec[(long)f * 2 * nb + k], im = spec[(long)f * 2 * nb + nb + k]; v = sqrtf(re * re + im * im); }
+    if (k < nb) { const float re = spec[(long)f * 2 * nb + k], im = spec[(long)f * 2 * nb + nb + k]; v = sqrtf(re * re + im * im + eps); }
     mag[i] = v;
 }
-void launch_spec_mag(const float* spec, float* mag, int F, int nb, int ldm, hipStream_t s) {
+void launch_spec_mag(const float* spec, float* mag, int F, int nb, int ldm, float eps, hipStream_t s) {
     const long n = (long)F * ldm;
-    hipLaunchKernelGGL(spec_mag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, spec, mag, F, nb, ldm);
+    hipLaunchKernelGGL(spec_mag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, spec, mag, F, nb, ldm, eps);
     MI_HIP(hipGetLastError());
 }
 

@@ -155,6 +155,13 @@ class F5Config:
     def n_freq(self) -> int:
         return self.n_fft // 2 + 1
 
+    def ref_frames(self, n_samples: int) -> int:
+        """Mel frames of a prompt of n_samples (= ref_signal_len): vocos-type front end L // hop + 1 (reflect pad n_fft / 2,
+        Export_F5.py:122-125); bigvgan-type (L + (n_fft - hop) - n_fft) // hop + 1 (center=False, modules.py:54-68)."""
+        if self.mel_spec_type == "bigvgan":
+            return (n_samples - self.hop_length) // self.hop_length + 1
+        return n_samples // self.hop_length + 1
+
     def to_int_array(self) -> List[int]:
         return [self.dim, self.depth, self.heads, self.dim_head, self.ff_mult, self.mel_dim, self.text_dim,
                 self.text_num_embeds, self.conv_layers, self.conv_mult, self.pos_conv_kernel,

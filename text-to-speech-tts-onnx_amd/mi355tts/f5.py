@@ -202,7 +202,7 @@ class F5Engine:
         if text_ids.shape[0] != U:
             raise ValueError("audio / text_ids batch mismatch")
         N = int(max_duration)
-        R = Ln // cfg.hop_length + 1
+        R = cfg.ref_frames(Ln)
         n = (N - R - 1) * cfg.hop_length
         if n <= 0:
             raise ValueError("max_duration leaves no generated frames")
@@ -228,7 +228,7 @@ class F5Engine:
         if text_ids.shape[0] != U:
             raise ValueError("audio / text_ids batch mismatch")
         N = int(max_duration)
-        F = N - (Ln // cfg.hop_length + 1)
+        F = N - cfg.ref_frames(Ln)
         if F < 1:
             raise ValueError("max_duration leaves no generated frames")
         if noise is not None:
@@ -247,7 +247,7 @@ class F5Engine:
         cfg = self.cfg
         U, Ln = audio.shape
         N = int(max_duration)
-        F = N - (Ln // cfg.hop_length + 1)
+        F = N - cfg.ref_frames(Ln)
         if out is None:
             out = torch.empty((U, cfg.mel_dim, F), dtype=torch.float32, device=audio.device)
         assert audio.is_cuda and audio.dtype == torch.int16 and audio.is_contiguous()
@@ -268,7 +268,7 @@ class F5Engine:
         cfg = self.cfg
         U, Ln = audio.shape
         N = int(max_duration)
-        R = Ln // cfg.hop_length + 1
+        R = cfg.ref_frames(Ln)
         n = (N - R - 1) * cfg.hop_length
         if out is None:
             out = torch.empty((U, 1, n), dtype=torch.int16, device=audio.device)
