@@ -242,7 +242,11 @@ def bigvgan_mel(audio_f32, n_fft=1024, n_mels=100, sample_rate=24000, hop=256):
 def rope_tables(n, head_dim=64):
     """cos/sin (n, head_dim) with interleaved-pair frequencies, rounded through fp16
     (Export_F5.py:107-112)."""
-    inv_freq = (F32(1.0) / (F32(10000.0) ** (np.arange(0, head_dim, 2, dtype=F32) / F32(head_dim)))).astype(F32)
+    # torch: 1.0 / (10000.0 ** (arange(0, D, 2).float() / D)) — a correctly rounded fp32 pow, then an fp32 division.  numpy's own
+    # float32 power differs from it in the last bit for 2 of the 32 exponents, which at n ~ 4000 moves the angle by more than an
+    # fp16 ulp of the table (found by the N = 4096 limit test, round 4): form the power in float64 and round it to fp32 first.
+    expo = (np.arange(0, head_dim, 2, dtype=F32) / F32(head_dim)).astype(np.float64)
+    inv_freq = (F32(1.0) / np.power(np.float64(10000.0), expo).astype(F32)).astype(F32)
     freqs = np.outer(np.arange(n, dtype=F32), inv_freq).astype(F32)
     freqs = np.repeat(freqs, 2, axis=-1)
     return np.cos(freqs).astype(np.float16).astype(F32), np.sin(freqs).astype(np.float16).astype(F32)

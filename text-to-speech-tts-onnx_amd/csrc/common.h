@@ -208,6 +208,7 @@ void x3p_split_rows(const float* x, long ld, void* planes, int rows, int K, hipS
 int x3p_planes();                                  // option "gemm_f32_planes": the format new planes are built in (3 or 2)
 bool gemm_x3p_enabled();
 bool gemm_x3p_would_run(const ConvGemm& p);        // p.xp / p.w3p set: will launch_conv_gemm(p) take the panel-plane kernel?
+bool gemm_x3p_can_write_planes(const ConvGemm& p); // ... and may it be given out_planes (needs the LDS-staged epilogue: N >= 1024)?
 // owner of a stream-K workspace (one per engine handle / stream)
 struct SkWorkspace {
     DevBuf ws, flags; int slots = 0;

@@ -742,7 +742,7 @@ void F5::dit_eval(int U, int N, int k) {
             ConvGemm go = lin(b0.o, d, MI_F32, X.p); go.x = Ob.p; go.res = X.p; go.gate = modk; with_planes(go, b0.o, Ap.p);
             ConvGemm g1 = lin(b0.ff1, d, dtype, Hff.p); g1.x = Ub.p; g1.act = ACT_GELU_TANH; with_planes(g1, b0.ff1, Ap.p);
             ConvGemm g2 = lin(b0.ff2, ff, MI_F32, X.p); g2.x = Hff.p; g2.res = X.p; g2.gate = modk; with_planes(g2, b0.ff2, Ap2.p);
-            planes = gemm_x3p_would_run(gq) && gemm_x3p_would_run(go) && gemm_x3p_would_run(g1) && gemm_x3p_would_run(g2);
+            planes = gemm_x3p_would_run(gq) && gemm_x3p_would_run(go) && gemm_x3p_can_write_planes(g1) && gemm_x3p_would_run(g2);
         }
         if (fold_built && cfg.ln_fold != 0 && (planes || !f32) && (!f32 || ApN.p) && ln_stats.p) {
             ConvGemm gq = qkv_gemm(b0); gq.x = Ub.p;
@@ -909,7 +909,8 @@ void F5::steps(int U, int N, int k0, int nsteps) {
 long F5::decode(const float* den, int U, int N, int R, float* out_f, int16_t* out_i) {
     const F5Cfg& c = cfg;
     const int F = N - R;
-    MI_REQUIRE(R >= 0 && F >= 2, "f5_decode: need at least 2 generated frames");
+    MI_REQUIRE(R >= 0 && F >= 1, "f5_decode: max_duration leaves no generated frame");
+    if (F == 1) return 0;        // one generated frame: the reference's graph C returns (N - R - 1) * hop = 0 samples (Export_F5.py:414)
     hipStream_t s = stream;
     const int vd = c.vd, vi = c.vi, nf = c.n_fft, nb = c.nb();
     const long rows = (long)U * F;

@@ -835,6 +835,14 @@ static bool lds_epi_for(const ConvGemm& p, int odt, bool use_x3) {
            p.out_bstride % ch == 0 && ((uintptr_t)p.out % 16) == 0 && (!p.res || ((uintptr_t)p.res % 16) == 0);
 }
 
+// ... and can it leave its output as panel planes (ConvGemm::out_planes)?  Only the LDS-staged epilogue writes them, and that one is
+// chosen for wide outputs only (N >= 1024): a narrow model (dim 256: FF1 has N = 512) at a large M is eligible for the kernel but
+// not for plane output — found by the N = 4096 limit tests of round 4 (the launch refused loudly; the caller now asks first)
+bool gemm_x3p_can_write_planes(const ConvGemm& p) {
+    return gemm_x3p_would_run(p) && p.epi == EPI_PLAIN && !p.res && !p.gate && !p.accumulate && p.alpha == 1.f && p.N % 32 == 0 &&
+           lds_epi_for(p, MI_F32, true);
+}
+
 // The AdaLN fold (ConvGemm::ln_*) lives in the LDS-staged epilogues of three kernels: linear_x3p (fp32 engines), linear_ph8 and
 // conv_gemm_dma_kernel (16-bit engines).  This answers, for the caller that has to choose between the fold and a row-norm launch,
 // whether launch_conv_gemm(p) ends up on one of them; dispatch_tiles() refuses (loudly) if the two ever disagree.

@@ -180,8 +180,11 @@ class F5Engine:
         U, N, _ = den.shape
         R = int(ref_signal_len)
         n = (N - R - 1) * cfg.hop_length
-        if n <= 0:
-            raise ValueError("decode needs at least two generated frames")
+        if n < 0:
+            raise ValueError("decode needs at least one generated frame")
+        if n == 0:          # one generated frame: the reference's graph C returns an empty waveform ((N - R - 1) * hop samples)
+            out0 = np.empty((U, 1, 0), np.int16)
+            return (out0, np.empty((U, 1, 0), np.float32)) if return_float else out0
         out = np.empty((U, 1, n), np.int16)
         outf = np.empty((U, 1, n), np.float32) if return_float else None
         ln = C.c_int64(0)
@@ -204,11 +207,11 @@ class F5Engine:
         N = int(max_duration)
         R = cfg.ref_frames(Ln)
         n = (N - R - 1) * cfg.hop_length
-        if n <= 0:
+        if n < 0:
             raise ValueError("max_duration leaves no generated frames")
         if noise is not None:
             noise = np.ascontiguousarray(noise, dtype=np.float32).reshape(U, N, cfg.mel_dim)
-        out = np.empty((U, 1, n), np.int16)
+        out = np.empty((U, 1, max(n, 0)), np.int16)
         ln = C.c_int64(0)
         _lib.check(_lib.load().mi_f5_synthesize(self._h, U, audio.ctypes.data, Ln, text_ids.ctypes.data, text_ids.shape[1],
                                                 N, _p(noise), seed, out.ctypes.data, C.byref(ln), _lib.MI_HOST),
