@@ -87,39 +87,74 @@ def f5_synthetic_inputs(cfg, U: int, rank: int):
     return W.f5_synthetic_inputs(cfg, U, rank)
 
 
-def cpu_baseline_f5(cfg, raw_state, audio, ids, N, noise):
-    """numpy oracle (kind 'port'): preprocess + ONE of the 31 DiT evaluations + decode, extrapolated to the
-    full 31-evaluation utterance (every evaluation costs the same).  Threads: min(nproc, 32) for BLAS and for the oracle's
-    own row / head parallelism (oracle/f5_np.py set_threads); the reference driver's own setting is MAX_THREADS = 8
-    (F5-TTS-ONNX-Inference.py:36) — on an 8-core host the two coincide."""
+def cpu_baseline_f5_run(cfg, st, audio, ids, N, noise, threads: int, evals):
+    """The numpy oracle (kind 'port') through the reference's bracket — preprocess, `evals` of the NFE - 1 DiT evaluations (None: ALL
+    of them, the sampling loop as the reference runs it), decode — on `threads` threads (BLAS and the oracle's own row / head
+    parallelism alike).  Returns measured seconds per stage; nothing is scaled here."""
     from oracle import f5_np as O
-    from mi355tts import weights as W
-    st = W.fold_f5(cfg, raw_state)
-    nproc = os.cpu_count() or 1
-    T = int(os.environ.get("MI355TTS_CPU_THREADS", min(nproc, 32)))
-    O.set_threads(T)
+    O.set_threads(threads)
     try:
         from threadpoolctl import threadpool_limits
-        lim = threadpool_limits(limits=T, user_api="blas")
+        lim = threadpool_limits(limits=threads, user_api="blas")
     except Exception:
         import contextlib
         lim = contextlib.nullcontext()
+    nfe = cfg.nfe_step - 1
+    k_run = nfe if evals is None else min(int(evals), nfe)
     with lim:
         t0 = time.perf_counter()
         pre = O.preprocess(cfg, st, audio, ids, N, noise)
         tables = O.time_tables(cfg, st)
         t1 = time.perf_counter()
-        x = O.transformer_step(cfg, st, tables, pre["noise"], pre, 0)
+        x = pre["noise"]
+        per_eval = []
+        for k in range(k_run):
+            te = time.perf_counter()
+            x = O.transformer_step(cfg, st, tables, x, pre, k)
+            per_eval.append(time.perf_counter() - te)
         t2 = time.perf_counter()
         w = O.decode(cfg, st, x, pre["ref_signal_len"])
         t3 = time.perf_counter()
     O.set_threads(1)
-    total = (t1 - t0) + (t2 - t1) * (cfg.nfe_step - 1) + (t3 - t2)
-    secs = w.shape[-1] / cfg.sample_rate
-    return {"value": secs / total, "unit": "audio-s/s", "cores": T, "kind": "port", "host_nproc": nproc,
-            "sample": f"numpy oracle fp32 on {T} threads of a {nproc}-core host: preprocess {t1 - t0:.1f} s + 1 of {cfg.nfe_step - 1} DiT "
-                      f"evaluations {t2 - t1:.1f} s (x{cfg.nfe_step - 1} extrapolated) + decode {t3 - t2:.1f} s for one {secs:.2f} s utterance "
-                      f"(the reference's own torch modules ran one evaluation in 3.0-3.4 s on 8 threads of the build container)"}
+    return {"threads": threads, "evaluations_run": k_run, "evaluations_of_the_workload": nfe, "preprocess_s": t1 - t0,
+            "evaluations_s": per_eval, "decode_s": t3 - t2, "audio_s": w.shape[-1] / cfg.sample_rate}
+
+
+def cpu_baseline_f5(cfg, raw_state, audio, ids, N, noise, full: bool = False):
+    """`cpu_baseline`: the numpy oracle (kind 'port', im2col + OpenBLAS sgemm) on the SAME utterance, at the reference driver's own
+    thread setting (MAX_THREADS = 8, F5-TTS-ONNX-Inference.py:36) and at min(nproc, 32) threads.
+    Default (the bench contract's bounded sample, 10-30 s of CPU work per thread setting): preprocess + MI355TTS_CPU_EVALS (2) of
+    the 31 DiT evaluations + decode, every stage measured; `value` is the utterance rate with the mean measured evaluation time
+    standing for the ones not run, and `sample` says so.  `--cpu-baseline-full`: ALL 31 evaluations run — no scaling anywhere
+    (minutes per thread setting; profiles/r4/cpu_baseline_full.json is such a run on the GPU box's host)."""
+    from mi355tts import weights as W
+    st = W.fold_f5(cfg, raw_state)
+    nproc = os.cpu_count() or 1
+    tN = int(os.environ.get("MI355TTS_CPU_THREADS", min(nproc, 32)))
+    evals = None if full else int(os.environ.get("MI355TTS_CPU_EVALS", "2"))
+    out = {"unit": "audio-s/s", "kind": "port", "host_nproc": nproc}
+    for key, T in (("tN", tN), ("t8", min(8, nproc))):
+        if key == "t8" and T == tN:          # an 8-core host: one run serves both
+            out[key] = dict(out["tN"])
+            continue
+        r = cpu_baseline_f5_run(cfg, st, audio, ids, N, noise, T, evals)
+        mean_eval = sum(r["evaluations_s"]) / len(r["evaluations_s"])
+        total = r["preprocess_s"] + sum(r["evaluations_s"]) + mean_eval * (r["evaluations_of_the_workload"] - r["evaluations_run"]) + r["decode_s"]
+        r["utterance_s"] = total
+        r["value"] = r["audio_s"] / total
+        r["all_evaluations_measured"] = r["evaluations_run"] == r["evaluations_of_the_workload"]
+        out[key] = r
+    best = "t8" if out["t8"]["value"] >= out["tN"]["value"] else "tN"     # (on the 256-thread GPU-box host 8 threads beat 32: 1.8 s vs 4.1 s per evaluation)
+    out["value"] = out[best]["value"]
+    out["cores"] = out[best]["threads"]
+    tN = out[best]["threads"]
+    ran = out["tN"]["evaluations_run"]
+    out["sample"] = (f"numpy oracle fp32, one {out['tN']['audio_s']:.2f} s utterance: preprocess + {ran} of {cfg.nfe_step - 1} DiT evaluations + decode, each "
+                     f"measured, at {out['tN']['threads']} threads (tN) and at {out['t8']['threads']} threads (t8: the reference driver's MAX_THREADS); value = the faster of the two ({tN} threads); "
+                     + ("every evaluation of the sampling loop ran: nothing is extrapolated" if full else
+                        "the evaluations not run are counted at the mean measured evaluation time (bounded sample; the full run with "
+                        "nothing extrapolated: bench.py --cpu-baseline-full, record in profiles/r4/cpu_baseline_full.json)"))
+    return out
 
 
 def _cores() -> int:
@@ -483,7 +518,7 @@ def run_f5(args, world, rank, local, dev, dist, torch):
         line["roofline"]["traffic"] = tb
         line["roofline"]["traffic_detail"] = detail
     if world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline_f5(fb.cfg, fb.raw, audio[0], ids[0], N, noise[0])
+        line["cpu_baseline"] = cpu_baseline_f5(fb.cfg, fb.raw, audio[0], ids[0], N, noise[0], full=args.cpu_baseline_full)
     print(json.dumps(line), flush=True)
 
 
@@ -768,6 +803,9 @@ def main():
     ap.add_argument("--dtype", default=None, help="f5: f32 on one GPU (configs[2]), bf16 with --gpus > 1 (configs[3]) | f16 ; "
                                                   "bigvgan: f16 (default) | f32 | bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-full", action="store_true",
+                    help="f5: the CPU baseline runs ALL 31 evaluations at both thread settings (minutes), nothing extrapolated")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help="f5: print only the cpu_baseline object (no GPU needed)")
     ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE",
                     help="mi_set_option(KEY, VALUE) before anything runs (A/B measurements); repeatable")
     ap.add_argument("--f32-arithmetic", default=None, choices=["fp16x2-pairs", "bf16x3", "native-fp32-mfma"],
@@ -784,6 +822,15 @@ def main():
         # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, rendezvous on
         # 127.0.0.1) and hand over; under `python -m torch.distributed.run ... bench.py --gpus N` the env is already there
         raise SystemExit(spawn_ranks(args.gpus))
+
+    if args.cpu_baseline_only:
+        from mi355tts.config import F5Config
+        from mi355tts import weights as W
+        cfg = F5Config()
+        audio, ids, N, noise = W.f5_synthetic_inputs(cfg, 1, 0)
+        print(json.dumps({"cpu_baseline": cpu_baseline_f5(cfg, W.synth_state(W.f5_spec(cfg), 9527), audio[0], ids[0], N, noise[0],
+                                                         full=args.cpu_baseline_full)}), flush=True)
+        return
 
     import torch
     import torch.distributed as dist

@@ -235,36 +235,27 @@ void        mi_indextts_cond_destroy(mi_cond* h);
 int         mi_indextts_cond_run(mi_cond* h, const int16_t* audio, int64_t L, float* conds, float* conds_latent, float* mel,
                                  int mem);
 
-/* test / tuning hook: tile-dispatch thresholds of the implicit-GEMM kernel ("gemm_big_tile_min", "gemm_n192_min",
- * "gemm_mid_tile_min", "gemm_dma3_k_min", "gemm_use_dma3", "gemm_use_dma", "gemm_big_tiles", "gemm_n192", "gemm_f32_dma", "gemm_ring4", "gemm_ring4_max", "gemm_buf", "gemm_f32_small", "gemm_f32_small_max", "gemm_small16_max", "gemm_sk" (stream-K linear layers: 0 off, 1 fp32, 2 also 16-bit), "gemm_sk_stages", "gemm_sk_max_tiles"), and
- * "gpt_mfma_min" (sentences from which mi_gpt_generate_batch runs its linears on MFMA; default 9), and
- * "aa_conv_deterministic" (1: one workgroup per CU in the fused AA+conv kernel; a diagnostic since round 3 — the default, two per
- * CU, is bit-identical from run to run now that the AA math no longer uses the op_sel encoding that was not).
- * Arithmetic of fp32 engines (all keep fp32 values and fp32 accumulation, and pass the same parity gates):
- *   "gemm_f32_x3" (default 1): the big linear layers form every fp32 product from 16-bit partial products on the 16-bit matrix
- *       cores with both operands pre-split (gemm_x3p.hip; gemm_x3.hip as its fallback); 0: native v_mfma_f32_32x32x2_f32.
- *   "gemm_f32_planes" (default 2; read when an engine splits its weights, i.e. at mi_f5_create): the operand format of that
- *       path.  2: fp16 pairs {hi = fp16(a), lo = fp16((a - hi) * 2^11)} — 22 significant bits, |a| clamped at 65504 — three
- *       partial products per fp32 product on two accumulator sets; measured error against float64 below the native fp32
- *       MFMA's.  3: three bf16 planes (exact split), six partial products.
- *   "attn_f32_x3" (default 2): attention with both products formed that way (V is then kept transposed, like in the 16-bit
- *       engines); 1: q.k only; 0: native fp32 MFMA.  "attn_f32_planes" (default 2): the operand format of that path — 2: fp16
- *       {hi, lo} pairs with the low part unscaled (three partial products into one accumulator; attention's operands are of
- *       order one); 3: three bf16 planes (exact split, six partial products).
- * Further tuning keys (defaults are the measured best): "gemm_ph8", "gemm_ph8_min_tiles", "gemm_ph8_order",
- * "gemm_ph8_split_max", "gemm_ph8_split_min_nk" (256x256 16-bit kernel); "gemm_sk_qkv32";
- * "gemm_f32_x3p" (0: the round-2 kernel gemm_x3.hip instead of the panel-plane kernel gemm_x3p.hip), "gemm_x3p_grid" (XCD bands:
- * 0 automatic, else 1 / 2 / 4 / 8 row bands), "gemm_x3p_noalign"; "attn_kv_planes" (0: the fp32 attention kernel splits K / V itself);
- * "gemm_f32_n64_dma", "gemm_n64_dma16"; "attn_z_max", "attn_z16_max", "attn_z_force" (key slices);
- * "gemm_f32_n64_pairs" (fp32 convolutions with 64 channels per group and >= 8 taps — the DiT position convolution — on fp16
- * pairs; 0: native fp32 MFMA) and "gemm_f32_gconv" (default 1: gconv_pairs.hip, each operand split once per workgroup; 0: the
- * LDS-DMA kernel that splits in registers per k-step);
- * "attn_xcd_map" (default 1: the attention kernels re-read their workgroup ids so that the query tiles of a head run on one
- * XCD and share its L2 — bit-identical results, about 1 % per launch; 0: plain (tile, head) order);
- * "bigvgan_streams" (default 3): the AMP blocks of a BigVGAN stage (one per resblock kernel size) on side streams of the
- * handle — 1: everything on the handle's one stream; 2: only the stages whose AMP halves are separate AA and conv launches
- * (C > 96); 3: every stage.  The waveform is bit-identical in all three.
- * Changing an option invalidates the hipGraphs captured by existing handles.   */
+/* Process-wide tuning / A-B switches (tools, tests).  The arithmetic of an fp32 F5 engine is NOT one of them any more: it is a
+ * property of the engine (config int 21, F5Config.f32_arithmetic; mi_f5_info reports what runs) — the four arithmetic keys below
+ * only set the default of engines created without one.
+ *   arithmetic defaults: "gemm_f32_x3" (1: fp32 linear layers from 16-bit partial products, 0: native v_mfma_f32_32x32x2_f32),
+ *     "gemm_f32_planes" (2: fp16 {hi, lo * 2^11} pairs, 22-bit operands, |a| <= 65504 — watched, see mi_f5_info; 3: three bf16
+ *     planes, exact), "attn_f32_x3" (2: both attention products split, 1: q.k only, 0: native), "attn_f32_planes" (2 | 3);
+ *     "gemm_f32_x3p" (0: the round-2 kernel gemm_x3.hip instead of the panel-plane kernel), "gemm_f32_n64_pairs" /
+ *     "gemm_f32_gconv" (the position convolution on fp16 pairs / with each operand split once per workgroup)
+ *   dispatch thresholds of the implicit-GEMM launcher: "gemm_big_tile_min", "gemm_n192_min", "gemm_mid_tile_min",
+ *     "gemm_dma3_k_min", "gemm_use_dma3", "gemm_use_dma", "gemm_big_tiles", "gemm_n192", "gemm_f32_dma", "gemm_ring4",
+ *     "gemm_ring4_max", "gemm_buf", "gemm_f32_small", "gemm_f32_small_max", "gemm_small16_max", "gemm_sk" (stream-K: 0 off, 1 fp32,
+ *     2 also 16-bit), "gemm_sk_stages", "gemm_ph8", "gemm_ph8_min_tiles", "gemm_ph8_order", "gemm_ph8_split_max", "gemm_ph8_split_min_nk" (split tail, tests), "gemm_row_split",
+ *     "gemm_x3p_grid" (XCD bands: 0 automatic, else 1 / 2 / 4 / 8 row bands), "gemm_x3p_noalign"
+ *   attention: "attn_split", "attn_kv_planes" (0: the fp32 kernel splits K / V itself), "attn_z_force" (key slices, tests),
+ *     "attn_xcd_map" (1: a head's query tiles on one XCD; bit-identical either way)
+ *   "gpt_mfma_min" (sentences from which mi_gpt_generate_batch runs its linears on MFMA; default 9)
+ *   "bigvgan_streams" (default 3): the AMP blocks of a BigVGAN stage on side streams of the handle — 1: one stream; 2: only
+ *     the stages whose AMP halves are separate AA and conv launches (C > 96); 3: every stage.  Bit-identical in all three.
+ * Removed in round 4 (variants that lost their A/B, nothing used them): "gemm_sk_min_tiles", "gemm_sk_max_tiles", "gemm_sk_qkv32",
+ * "gemm_f32_n64_dma", "gemm_n64_dma16", "attn_z_max", "attn_z16_max",
+ * "aa_conv_deterministic".  Changing an option invalidates the hipGraphs captured by existing handles.   */
 int         mi_set_option(const char* key, int64_t value);
 /* PCI bus id of HIP device `device` ("0000:05:00.0") into buf: multi-rank launchers use it to check that every rank drives its
  * own GPU (mi355tts/shard.py assert_one_device_per_rank).  No reference counterpart (the reference is single-device).   */

@@ -24,6 +24,16 @@ def rms(a):
     return float(np.sqrt(np.mean(np.square(np.asarray(a, dtype=np.float64)))))
 
 
+def assert_logmel_close(got, ref, floor=2e-5, atol=2e-4, rtol=2e-4):
+    """log(clamp(mel, 1e-5)): a difference of 1e-9 in a linear value next to the clamp floor is 1e-4 in its log, so the comparison
+    is made where the reference sits above the floor (a blanket atol of 3e-3 hid everything else) — there the
+    linear mel is a sum of >= 1 fp32 products and agrees to a few 1e-5 relative, i.e. a few 1e-5 absolute in the log."""
+    m = ref > np.log(floor)
+    assert m.mean() > 0.5, m.mean()
+    np.testing.assert_allclose(np.asarray(got)[m], np.asarray(ref)[m], atol=atol, rtol=rtol)
+    assert (np.asarray(got)[~m] < np.log(floor) + 0.7).all()       # below the floor on one side: at or near it on the other
+
+
 @pytest.fixture(scope="module")
 def g(golden_dir):
     return np.load(os.path.join(golden_dir, "f5_small.npz"))
@@ -56,7 +66,9 @@ def test_preprocess_golden(g, small):
     np.testing.assert_allclose(o["rope_cos_q"][1, 1], g["pre_rope_cos_q"], atol=1e-3)    # fp16-rounded tables (1 ulp_fp16)
     np.testing.assert_allclose(o["rope_sin_q"][0, 0], g["pre_rope_sin_q"], atol=1e-3)
     assert np.array_equal(o["noise"][0], noise)
-    np.testing.assert_allclose(o["cat_mel_text"][0, :, :100], g["pre_cat_mel_text"][:, :100], atol=3e-3)
+    R = int(o["ref_signal_len"])
+    assert_logmel_close(o["cat_mel_text"][0, :R, :100], g["pre_cat_mel_text"][:R, :100])
+    assert np.all(o["cat_mel_text"][0, R:, :100] == 0.0)
     np.testing.assert_allclose(o["cat_mel_text"][0, :, 100:], g["pre_cat_mel_text"][:, 100:], atol=5e-5)
     np.testing.assert_allclose(o["cat_mel_text_drop"][0], g["pre_cat_mel_text_drop"], atol=5e-5)
 
@@ -350,7 +362,7 @@ def test_full_size_batch_invariance_determinism_and_lowp_gate(full):
     e16 = F5Engine(cfg, raw, dtype="bf16")
     wb = e16.synthesize(audio[:1], ids[:1], N, noise=noise[:1])
     err = rms((wb.astype(np.float64) - w0.astype(np.float64)) / 32767.0)
-    assert err < 3e-2, err
+    assert err < 1.5e-3, err            # achieved 2.5e-4 (profiles/r3); the stated low-precision gate used to be 3e-2
     e16.close()
 
 
@@ -386,7 +398,7 @@ def _full_size_fp32_body(full, gfull, form):
     o = eng.preprocess(audio[0].reshape(1, 1, -1), ids[0].reshape(1, -1), np.array([N]), noise=noise[0])
     R = int(o["ref_signal_len"])
     assert R == int(gfull["ref_signal_len"]) == 563
-    np.testing.assert_allclose(o["cat_mel_text"][0, :, :100], gfull["pre_cat_mel_text"][:, :100], atol=3e-3)
+    assert_logmel_close(o["cat_mel_text"][0, :R, :100], gfull["pre_cat_mel_text"][:R, :100])
     np.testing.assert_allclose(o["cat_mel_text"][0, :, 100:], gfull["pre_cat_mel_text"][:, 100:], atol=1e-4)
     pred = eng.dit_eval(noise[:1], o["cat_mel_text"], o["cat_mel_text_drop"], 7)
     e_pred = rms(pred - gfull["dit_pred_t7"]) / rms(gfull["dit_pred_t7"])

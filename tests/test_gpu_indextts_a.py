@@ -25,7 +25,10 @@ def test_graph_a_against_reference_fixture(golden_dir, tag):
     eng = IndexCond(cfg, raw)
     conds, lat, mel = eng.run(ga[tag + "audio"], return_mel=True)
     st = W.fold_cond(cfg, raw)
-    np.testing.assert_allclose(mel.T, OA.mel_front_end(cfg, st, ga[tag + "audio"]), atol=2e-3)          # log-mel of tiny magnitudes: loose
+    ref_mel = OA.mel_front_end(cfg, st, ga[tag + "audio"])
+    m = ref_mel > np.log(2e-5)               # log of a clamped value: compared where the reference is above the clamp floor
+    assert m.mean() > 0.5
+    np.testing.assert_allclose(mel.T[m], ref_mel[m], atol=2e-4, rtol=2e-4)
     np.testing.assert_allclose(lat, ga[tag + "conds_latent"], atol=5e-4, rtol=1e-3)
     outs, cond0 = eng.split_conds(conds)
     np.testing.assert_allclose(cond0.reshape(-1), ga[tag + "cond_layer"], atol=2e-4, rtol=1e-3)

@@ -24,11 +24,7 @@ extern __constant__ float c_h_fused[12];
 __constant__ float c_h_fused[12];
 
 static std::atomic<long> g_aa_lds_min = -1;        // > 80 KB: one workgroup per CU (a diagnostic since round 3), see launch_t
-bool aa_conv_set_option(const char* key, long v) {
-    if (std::string(key) != "aa_conv_deterministic") return false;
-    g_aa_lds_min = v ? 82 * 1024 : 0;
-    return true;
-}
+bool aa_conv_set_option(const char*, long) { return false; }      // (round 4: "aa_conv_deterministic" removed — the default has been bit-reproducible since round 3; MI355TTS_AACONV_LDS_MIN stays as the diagnostic)
 
 struct AAConvDev {
     const void* x; const void* w; const float* bias; const float* alpha_s; const float* inv_beta; void* out; const void* res;
@@ -292,7 +288,7 @@ static void launch_t(const AAConv& q, hipStream_t s) {
     // (profiles/r3/aa_conv_opsel_rootcause.txt / _ab.txt).  aa_math.h no longer produces that encoding (channel pairs, every VGPR
     // source a whole aligned pair): 0 of 119 runs differ with two workgroups per CU, and tests/test_gpu_bigvgan.py asserts
     // array_equal across batch items and runs in the default mode.  The one-workgroup-per-CU policy stays as a diagnostic:
-    // mi_set_option("aa_conv_deterministic", 1) or MI355TTS_AACONV_LDS_MIN=83968 (+19 % forward time).
+    // MI355TTS_AACONV_LDS_MIN=83968 (+19 % forward time).
     {
         if (g_aa_lds_min < 0) { const char* e = std::getenv("MI355TTS_AACONV_LDS_MIN"); g_aa_lds_min = e ? std::atol(e) : 0; }
         if (sizeof(T) == 2) lds = std::max(lds, (size_t)g_aa_lds_min);

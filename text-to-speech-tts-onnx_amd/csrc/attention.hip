@@ -899,9 +899,7 @@ long attention_v_ld(int N, int dtype) {
 bool attn_set_option(const char* key, long v) {
     attn_env_once();
     const std::string k(key);
-    if (k == "attn_z_max") g_attn_zmax = (int)std::max(1L, std::min(4L, v));
-    else if (k == "attn_z16_max") g_attn_z16 = (int)std::max(1L, std::min(4L, v));
-    else if (k == "attn_f32_x3") g_attn_x3 = (int)std::max(0L, std::min(2L, v));
+    if (k == "attn_f32_x3") g_attn_x3 = (int)std::max(0L, std::min(2L, v));
     else if (k == "attn_split") g_attn_split = v != 0;
     else if (k == "attn_xcd_map") g_attn_xmap = v != 0;
     else if (k == "attn_kv_planes") g_attn_kvp = v != 0;

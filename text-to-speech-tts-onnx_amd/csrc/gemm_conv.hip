@@ -766,15 +766,10 @@ bool gemm_set_option(const char* key, long v) {
     else if (k == "gemm_buf") g_buf = v != 0;
     else if (k == "gemm_f32_small") g_f32_small = v != 0;
     else if (k == "gemm_f32_small_max") g_f32_small_max = v;
-    else if (k == "gemm_f32_n64_dma") g_f32_n64_dma = v;
-    else if (k == "gemm_n64_dma16") g_n64_dma16 = v;
     else if (k == "gemm_small16_max") g_small16_max = v;
     else if (k == "gemm_ring4_max") g_ring4_max = v;
     else if (k == "gemm_sk") g_sk = v;
     else if (k == "gemm_sk_stages") g_sk_stages = v;
-    else if (k == "gemm_sk_max_tiles") g_sk_max_tiles = v;
-    else if (k == "gemm_sk_min_tiles") g_sk_min_tiles = std::max(1L, v);
-    else if (k == "gemm_sk_qkv32") g_sk_qkv32 = v;
     else if (k == "gemm_f32_x3") g_x3 = v;
     else if (k == "gemm_f32_x3p") g_x3p = v;
     else if (k == "gemm_f32_n64_pairs") g_f32_n64_pairs = v;
@@ -786,7 +781,7 @@ bool gemm_set_option(const char* key, long v) {
     else if (k == "gemm_ph8_min_tiles") g_ph8_min_tiles = v;
     else if (k == "gemm_row_split") g_row_split = v;
     else if (k == "gemm_ph8_order") g_ph8_order = v;
-    else if (k == "gemm_ph8_split_max") ph8_set_split_max(v);
+    else if (k == "gemm_ph8_split_max") ph8_set_split_max(v);               // (test hooks of the split-tail instantiation)
     else if (k == "gemm_ph8_split_min_nk") ph8_set_split_min_nk(v);
     else return false;
     return true;
