@@ -31,6 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "text-to-speech-tts-onnx_amd"))
 sys.path.insert(0, ROOT)
 
+USER_OPTIONS = {}                # mi_set_option keys given with --option (restored after passes that flip them)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F16_PEAK_TF = 2500.0        # dense bf16/f16
 MFMA_F32_PEAK_TF = 157.3
@@ -191,7 +192,7 @@ def dominant_kernel_roofline(kernels, steps: int, peak: float, bound: str, note:
                          "alg_GBps": x["bytes"] / (x["ms"] * 1e-3) / 1e9 if x["ms"] > 0 else 0.0} for x in ks[:8]]}
 
 
-def pmc_traffic(kernel_label: str, dtype: str, U: int):
+def pmc_traffic(kernel_label: str, dtype: str, U: int, child=None):
     """`roofline.traffic` of the dominant kernel: fabric-side bytes per launch from rocprofv3 PMC counters, collected as
     MI355X_MICROARCH.md (HBM section) prescribes — FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes (they do not fit one
     pass), FETCH_SIZE doubled (gfx950 tallies 128-byte requests at 64 B), WRITE_SIZE as reported (uncalibrated), both in KB.
@@ -212,12 +213,12 @@ def pmc_traffic(kernel_label: str, dtype: str, U: int):
     base = kernel_label.split("<")[0].strip()
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env["TMPDIR"] = "/tmp"
-    sums, counts, names = {}, {}, {}
+    sums, counts, names, totals = {}, {}, {}, {}
     with tempfile.TemporaryDirectory(prefix="mi355tts_pmc_", dir="/tmp") as td:
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(td, ctr)
             cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", out, "--", sys.executable,
-                   os.path.join(ROOT, "tools", "pmc_f5_eval.py"), dtype, str(U), "1"]
+                   *(child or [os.path.join(ROOT, "tools", "pmc_f5_eval.py"), dtype, str(U), "1"])]
             try:
                 r = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=600)
             except subprocess.TimeoutExpired:
@@ -229,6 +230,7 @@ def pmc_traffic(kernel_label: str, dtype: str, U: int):
                 for row in csv.DictReader(open(f)):
                     if row.get("Counter_Name") != ctr:
                         continue
+                    totals[ctr] = totals.get(ctr, 0.0) + float(row["Counter_Value"])
                     nm = re.sub(r"\(.*\)$", "", re.sub(r"^void ", "", row["Kernel_Name"])).replace("mi::", "")
                     if not nm.startswith(base):
                         continue
@@ -242,6 +244,7 @@ def pmc_traffic(kernel_label: str, dtype: str, U: int):
     write = sums["WRITE_SIZE"] * 1024.0 / counts["WRITE_SIZE"]
     return fetch + write, {"kernel": names["FETCH_SIZE"], "launches_sampled": counts["FETCH_SIZE"],
                            "fetch_bytes_per_launch_x2_corrected": fetch, "write_bytes_per_launch": write,
+                           "whole_command_bytes": 2.0 * totals.get("FETCH_SIZE", 0.0) * 1024.0 + totals.get("WRITE_SIZE", 0.0) * 1024.0,
                            "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes over tools/pmc_f5_eval.py "
                                      "(one DiT evaluation, same shapes); FETCH_SIZE x2 per the gfx950 note of MI355X_MICROARCH.md; "
                                      "fabric-side bytes (Infinity-Cache hits are counted)"}
@@ -487,6 +490,8 @@ def run_f5(args, world, rank, local, dev, dist, torch):
         return
     if world == 1 and not args.no_secondary:
         secondary["bigvgan_f16_b8"] = measure_bigvgan(torch, dist, 1, 0, local, dev, "f16", 8, 512, 10, 3, False)[0]
+        if not args.no_pmc:
+            bigvgan_pmc(secondary["bigvgan_f16_b8"], "f16", 8)
     line = {
         "metric": "audio_seconds_per_second", "value": res["value"], "unit": "audio-s/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak",
@@ -746,7 +751,7 @@ def measure_bigvgan(torch, dist, world, rank, local, dev, dtype, B, F, steps, wa
     torch.cuda.synchronize()
     _lib.prof_enable(())
     kernels = _lib.prof_kernels()
-    _lib.set_option("bigvgan_streams", 3)
+    _lib.set_option("bigvgan_streams", USER_OPTIONS.get("bigvgan_streams", 3))       # (what the caller asked for with --option, else the default)
     voc.close()
     esz = 4 if dtype == "f32" else 2
     alg = bigvgan_algorithmic_bytes(cfg, B, F, esz)
@@ -770,6 +775,20 @@ def measure_bigvgan(torch, dist, world, rank, local, dev, dtype, B, F, steps, wa
            "whole_forward_algorithmic_GBps": alg / (dt / steps) / 1e9,
            "whole_forward_frac_of_hbm_peak": alg / (dt / steps) / 1e9 / HBM_PEAK_GBS, "roofline": roof}
     return res, (cfg, state)
+
+
+def bigvgan_pmc(res, dtype: str, B: int):
+    """roofline.traffic of the vocoder block: fabric-side bytes per launch of its dominant kernel AND of the whole forward (one
+    forward of the same mel shape under two separate --pmc passes, tools/pmc_bigvgan.py), next to the layer-granular algorithmic
+    bytes — traffic above the algorithmic figure is re-reads, below it is what the fusion saved."""
+    if not res.get("roofline"):
+        return
+    tb, detail = pmc_traffic(res["roofline"]["kernel"], dtype, B, child=[os.path.join(ROOT, "tools", "pmc_bigvgan.py"), dtype, str(B), "1"])
+    res["roofline"]["traffic"] = tb
+    res["roofline"]["traffic_detail"] = detail
+    if isinstance(detail, dict) and detail.get("whole_command_bytes"):
+        res["whole_forward_fabric_GB"] = detail["whole_command_bytes"] / 1e9
+        res["whole_forward_fabric_over_algorithmic"] = detail["whole_command_bytes"] / 1e9 / res["whole_forward_algorithmic_GB"]
 
 
 def spawn_ranks(n: int) -> int:
@@ -859,6 +878,7 @@ def main():
         for kv in args.option:
             k, v = kv.split("=", 1)
             _lib.set_option(k, int(v))
+            USER_OPTIONS[k] = int(v)
 
     if args.workload == "f5":
         # one GPU: configs[2] (fp32, one utterance) — the config parity is gated on; N > 1: the configs[3] shard
@@ -891,6 +911,12 @@ def main():
                     "config": {k: v for k, v in res.items() if k not in ("value", "ms_per_step", "dtype", "roofline")},
                     "roofline": res["roofline"]}
             line["config"]["weights"] = "synthetic seeded (112.4 M params)"
+            if world == 1 and not args.no_pmc and not ixf:
+                bigvgan_pmc(res, args.dtype, B)
+                line["roofline"] = res["roofline"]
+                for k in ("whole_forward_fabric_GB", "whole_forward_fabric_over_algorithmic"):
+                    if k in res:
+                        line["config"][k] = res[k]
             if world == 1 and not args.no_cpu_baseline and not ixf:
                 line["cpu_baseline"] = cpu_baseline_bigvgan(cfg, state, args.cpu_frames)
             print(json.dumps(line), flush=True)
