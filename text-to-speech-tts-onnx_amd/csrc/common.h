@@ -183,6 +183,7 @@ struct ConvGemm {
     // (step, block), built at load time); mean / rstd over ln_dim columns with ln_eps, biased variance.
     const float* ln_scale = nullptr; void* ln_out = nullptr; float* ln_stats_out = nullptr; int ln_out_np = 0;
     const float* ln_stats_in = nullptr; const float* ln_p = nullptr; const float* ln_c = nullptr; int ln_dim = 0; float ln_eps = 0.f;
+    int ln_final = 0;             // consumer: ln_stats_in holds FINISHED (rstd, mean * rstd) per row, [row][2] (launch_ln_finalize), not partials
     // fp16-pair producers: *sat |= 1 when an operand met the fp16 range limit (|a| >= 65504, inf, nan) while being split
     int* sat = nullptr;
 };

@@ -232,10 +232,10 @@ F5::F5(const F5Cfg& c, const float* w, int64_t nw, int dt, int dev, int mem) : c
     }
     // ---- AdaLN fold: W (1 + scale) and W shift + b for every (step, block), QKV and FF1 (gemm_epilogue.h) ----
     fold_built = false;
-    // fp32 engines: on unless switched off.  16-bit engines: opt-in (ln_fold = 1) — measured on bf16 x 8 utterances the consumer
-    // epilogues of the 256x256 kernel lose more (+26 us per QKV / FF1 launch re-reading the row statistics in every one of the
-    // 12 / 8 column tiles) than the 1395 row-norm launches cost (profiles/r4/adaln_fold_ab.txt)
-    const bool want_fold = dt == MI_F32 ? c.ln_fold != 0 : c.ln_fold == 1;
+    // On unless switched off.  16-bit engines finish the row statistics with one tiny launch per norm (ln_finalize_kernel) instead
+    // of in every consumer epilogue: with 12 / 8 column tiles of 256 the consumers re-read 197 MB of partials per QKV launch at 8
+    // utterances (+26 us per launch, profiles/r4/adaln_fold_ab.txt)
+    const bool want_fold = c.ln_fold != 0;
     if (want_fold && d >= 1024 && d % 128 == 0 && ff % 64 == 0) {
         ln_blk = (long)6 * d + 2 * ff;
         ln_ld = (long)c.depth * ln_blk;
@@ -502,7 +502,7 @@ void F5::ensure_workspace(int U, int N) {
         Ap.ensure((size_t)x3p_bytes((long)rows, c.dim, np)); Ap2.ensure((size_t)x3p_bytes((long)rows, c.ff(), np));
         if (fold_built) ApN.ensure((size_t)x3p_bytes((long)rows, c.dim, np));
     }
-    if (fold_built) ln_stats.ensure((rows + 128) * (size_t)(c.dim / LN_BLK) * 2 * 4);
+    if (fold_built) { ln_stats.ensure((rows + 128) * (size_t)(c.dim / LN_BLK) * 2 * 4); if (dtype != MI_F32) ln_fin.ensure((rows + 128) * 8); }
     pred.ensure(rows * c.mel * 4);
     // preprocess temporaries
     const int ti = c.text_dim * c.conv_mult;
@@ -744,7 +744,7 @@ void F5::dit_eval(int U, int N, int k) {
             ConvGemm g2 = lin(b0.ff2, ff, MI_F32, X.p); g2.x = Hff.p; g2.res = X.p; g2.gate = modk; with_planes(g2, b0.ff2, Ap2.p);
             planes = gemm_x3p_would_run(gq) && gemm_x3p_would_run(go) && gemm_x3p_can_write_planes(g1) && gemm_x3p_would_run(g2);
         }
-        if (fold_built && cfg.ln_fold != 0 && (planes || !f32) && (!f32 || ApN.p) && ln_stats.p) {
+        if (fold_built && cfg.ln_fold != 0 && (planes || !f32) && (!f32 || ApN.p) && ln_stats.p && (f32 || ln_fin.p)) {
             ConvGemm gq = qkv_gemm(b0); gq.x = Ub.p;
             ConvGemm go = lin(b0.o, d, MI_F32, X.p); go.x = Ob.p; go.res = X.p; go.gate = modk;
             ConvGemm g1 = lin(b0.ff1, d, dtype, Hff.p); g1.x = Ub.p; g1.act = ACT_GELU_TANH;
@@ -755,8 +755,13 @@ void F5::dit_eval(int U, int N, int k) {
     }
     float* stats = ln_stats.as<float>();
     const float* lnk = fold ? ln_tab.as<float>() + (size_t)k * ln_ld : nullptr;
-    if (fold)       // block 0's attention norm: the residual row comes from the position convolution, whose epilogue has no fold
+    const bool fin = fold && !f32;               // 16-bit engines: the statistics are finished by one tiny launch, not per column tile
+    auto finalize = [&] { if (fin) launch_ln_finalize(stats, ln_fin.as<float>(), rows, d, 1e-6f, s); };
+    auto consume = [&](ConvGemm& g) { g.ln_stats_in = fin ? ln_fin.as<float>() : stats; g.ln_final = fin ? 1 : 0; g.ln_dim = d; g.ln_eps = 1e-6f; };
+    if (fold) {     // block 0's attention norm: the residual row comes from the position convolution, whose epilogue has no fold
         launch_ln_prologue(X.as<float>(), f32 ? ApN.p : Ub.p, dtype, np, stats, modk + d, rows, d, d_sat.as<int>(), s);
+        finalize();
+    }
     for (int i = 0; i < c.depth; ++i) {
         const Block& bk = blocks[i];
         const float* m = modk + (size_t)i * 6 * d;       // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
@@ -767,7 +772,7 @@ void F5::dit_eval(int U, int N, int k) {
                 ConvGemm g = qkv_gemm(bk);
                 g.x = Ub.p; g.bias = nullptr;
                 if (f32) with_planes(g, bk.qkv, ApN.p);
-                g.ln_stats_in = stats; g.ln_p = lt; g.ln_c = lt + 3 * d; g.ln_dim = d; g.ln_eps = 1e-6f;
+                consume(g); g.ln_p = lt; g.ln_c = lt + 3 * d;
                 if (kvp) { g.kv_planes = kvp_fmt; g.k_ld = g.v_ld = (long)((N + 63) / 64 * 64); }
                 launch_conv_gemm(g, s);
             }
@@ -779,12 +784,13 @@ void F5::dit_eval(int U, int N, int k) {
                 if (f32) with_planes(g, bk.o, Ap.p);
                 g.ln_scale = m + 4 * d; g.ln_out = f32 ? ApN.p : Ub.p; g.ln_out_np = np; g.ln_stats_out = stats;       // -> the FF1 norm
                 launch_conv_gemm(g, s);
+                finalize();
             }
             {
                 ConvGemm g = lin(bk.ff1, d, dtype, Hff.p);
                 g.x = Ub.p; g.bias = nullptr; g.act = ACT_GELU_TANH;
                 if (f32) { with_planes(g, bk.ff1, ApN.p); g.out_planes = Ap2.p; }
-                g.ln_stats_in = stats; g.ln_p = lt + 6 * d; g.ln_c = lt + 6 * d + ff; g.ln_dim = d; g.ln_eps = 1e-6f;
+                consume(g); g.ln_p = lt + 6 * d; g.ln_c = lt + 6 * d + ff;
                 launch_conv_gemm(g, s);
             }
             {
@@ -795,6 +801,7 @@ void F5::dit_eval(int U, int N, int k) {
                     g.ln_scale = m + 6 * d + d; g.ln_out = f32 ? ApN.p : Ub.p; g.ln_out_np = np; g.ln_stats_out = stats;
                 }
                 launch_conv_gemm(g, s);
+                if (i + 1 < c.depth) finalize();
             }
             continue;
         }

@@ -15,6 +15,8 @@ void launch_rownorm_x3p(const float* x, void* planes, const float* a, const floa
 // aout = x o (1 + scale) as panel planes of np planes (a_dtype MI_F32) or rows of a_dtype, stats[row][D / 32][2] = partial (sum, sum^2)
 void launch_ln_prologue(const float* x, void* aout, int a_dtype, int np, float* stats, const float* scale, long rows, int D, int* sat,
                         hipStream_t s);
+// ... and, for the 16-bit engines, the partials of every row summed once into fin[row] = (rstd, mean * rstd) (ConvGemm::ln_final)
+void launch_ln_finalize(const float* partials, float* fin, long rows, int D, float eps, hipStream_t s);
 void launch_ln_gather(const float* mod, long mod_ld, long col_scale, long col_shift, float* G, float* S, int steps, int D, hipStream_t s);
 void launch_cast_to_f32(const void* src, int dtype, float* dst, long n, hipStream_t s);
 void launch_absmax(const float* x, long n, unsigned* out_bits, hipStream_t s);       // atomicMax of the bit pattern of max |x|

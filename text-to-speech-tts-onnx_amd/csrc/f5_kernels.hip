@@ -227,6 +227,35 @@ void launch_ln_prologue(const float* x, void* aout, int a_dtype, int np, float* 
     MI_HIP(hipGetLastError());
 }
 
+// AdaLN fold, 16-bit engines: the partial (sum, sum of squares) pairs of every row summed ONCE into (rstd, mean * rstd) — the
+// order of gemm_epilogue.h ln_rows32 (low half of the blocks in index order, then the high half, then low + high), so the result
+// is the one a consumer epilogue would have formed itself.  One thread per row; 4.6 MB in, 144 KB out at 8 utterances.
+__global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restrict__ part, float2* __restrict__ fin, long rows, int nb,
+                                                          float inv_d, float eps) {
+    const long row = (long)blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    const float4* sp = reinterpret_cast<const float4*>(part + row * (long)(nb * 2));
+    float h1[2] = {0.f, 0.f}, h2[2] = {0.f, 0.f};
+    for (int hf = 0; hf < 2; ++hf)
+        for (int i = 0; i < (nb >> 2); ++i) {
+            const float4 t = sp[hf * (nb >> 2) + i];
+            h1[hf] += t.x; h2[hf] += t.y; h1[hf] += t.z; h2[hf] += t.w;
+        }
+    const float mean = (h1[0] + h1[1]) * inv_d;
+    float var = (h2[0] + h2[1]) * inv_d - mean * mean;
+    var = var > 0.f ? var : 0.f;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    fin[row] = make_float2(rstd, mean * rstd);
+}
+void launch_ln_finalize(const float* partials, float* fin, long rows, int D, float eps, hipStream_t s) {
+    MI_REQUIRE(D % 128 == 0, "ln_finalize: D must be a multiple of 128");
+    ProfScope ps(FAM_NORM, s, (double)rows * (D / LN_BLK * 8.0 + 8.0), 2.0 * rows * (D / LN_BLK));
+    prof_set_kernel("ln_finalize_kernel (AdaLN fold: partial row statistics -> rstd, mean * rstd)", "", "");
+    hipLaunchKernelGGL(ln_finalize_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, partials, (float2*)fin, rows, D / LN_BLK,
+                       1.0f / (float)D, eps);
+    MI_HIP(hipGetLastError());
+}
+
 // load-time helpers of the AdaLN fold (f5.hip): G[k][j] = 1 + mod[k][col_scale + j], S[k][j] = mod[k][col_shift + j]
 __global__ __launch_bounds__(256) void ln_gather_kernel(const float* __restrict__ mod, long mod_ld, long col_scale, long col_shift,
                                                         float* __restrict__ G, float* __restrict__ S, int steps, int D) {

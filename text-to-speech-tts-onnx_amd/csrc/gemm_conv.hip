@@ -894,7 +894,7 @@ void launch_conv_gemm(const ConvGemm& p_in, hipStream_t s) {
                 b.out = (char*)p.out + (size_t)(256 * r) * p.out_rstride * dtype_size(odt);
                 if (p.res) b.res = (const char*)p.res + (size_t)(256 * r) * p.out_rstride * dtype_size(odt);
                 // AdaLN fold: the per-row operands of the second launch start at its first row (16-bit engines: ln_out is rows [M][N])
-                if (p.ln_stats_in) b.ln_stats_in = p.ln_stats_in + (size_t)(256 * r) * (p.ln_dim / LN_BLK) * 2;
+                if (p.ln_stats_in) b.ln_stats_in = p.ln_stats_in + (size_t)(256 * r) * (p.ln_final ? 1 : p.ln_dim / LN_BLK) * 2;
                 if (p.ln_stats_out) {
                     b.ln_stats_out = p.ln_stats_out + (size_t)(256 * r) * (p.N / LN_BLK) * 2;
                     b.ln_out = (char*)p.ln_out + (size_t)(256 * r) * p.N * dtype_size(p.dtype);
@@ -935,7 +935,7 @@ void launch_conv_gemm(const ConvGemm& p_in, hipStream_t s) {
         d.out_planes = p.out_planes;
     }
     d.ln_scale = p.ln_scale; d.ln_out = p.ln_out; d.ln_stats_out = p.ln_stats_out; d.ln_out_np = p.ln_out_np;
-    d.ln_stats_in = p.ln_stats_in; d.ln_p = p.ln_p; d.ln_c = p.ln_c; d.ln_dim = p.ln_dim; d.ln_eps = p.ln_eps;
+    d.ln_stats_in = p.ln_stats_in; d.ln_p = p.ln_p; d.ln_c = p.ln_c; d.ln_dim = p.ln_dim; d.ln_eps = p.ln_eps; d.ln_final = p.ln_final;
     d.sat = p.sat;
     if (p.ln_stats_in || p.ln_stats_out) {
         MI_REQUIRE(!(p.ln_stats_in && p.ln_stats_out), "conv_gemm: a launch is the producer OR the consumer of the AdaLN fold");
@@ -947,7 +947,7 @@ void launch_conv_gemm(const ConvGemm& p_in, hipStream_t s) {
                            (p.dtype != MI_F32 || p.ln_out_np == p.np),
                        "conv_gemm: AdaLN fold producer: fp32 residual rows out, (1 + scale) and the next operand's buffer");
         else
-            MI_REQUIRE(p.ln_p && p.ln_c && p.ln_dim >= 128 && p.ln_dim % 128 == 0 && !p.res && !p.gate && ((uintptr_t)p.ln_stats_in % 16) == 0 &&
+            MI_REQUIRE(p.ln_p && p.ln_c && p.ln_dim >= 128 && p.ln_dim % 128 == 0 && !p.res && !p.gate && ((uintptr_t)p.ln_stats_in % 8) == 0 && (p.ln_final || ((uintptr_t)p.ln_stats_in % 16) == 0) &&
                            ((uintptr_t)p.ln_p % 16) == 0 && ((uintptr_t)p.ln_c % 16) == 0 && (odt != MI_F32 || p.epi == EPI_QKV_ROPE || p.out_planes),
                        "conv_gemm: AdaLN fold consumer: statistics, W(1 + scale) and W shift + b vectors");
     }

@@ -48,6 +48,7 @@ struct ConvGemmDev {
     // AdaLN fold (ConvGemm, common.h): producer side (ln_stats_out) / consumer side (ln_stats_in)
     const float* ln_scale = nullptr; void* ln_out = nullptr; float* ln_stats_out = nullptr; int ln_out_np = 0;
     const float* ln_stats_in = nullptr; const float* ln_p = nullptr; const float* ln_c = nullptr; int ln_dim = 0; float ln_eps = 0.f;
+    int ln_final = 0;                            // ln_stats_in = finished (rstd, mean * rstd) per row instead of partial sums
     int* sat = nullptr;                          // fp16-pair producers raise bit 0 when an operand met the fp16 range limit
 };
 
@@ -308,6 +309,11 @@ __device__ __forceinline__ void ln_rows32(const ConvGemmDev& p, long row0, long 
     const int nb = p.ln_dim / LN_BLK;                        // a multiple of 4 (ln_dim % 128 == 0, checked on the host)
     long row = row0 + lr;
     row = row < row_last ? row : row_last;
+    if (p.ln_final) {           // finished by ln_finalize_kernel (16-bit engines: every column tile would otherwise redo the 32-partial sum)
+        const float2 t = reinterpret_cast<const float2*>(p.ln_stats_in)[row];
+        rstd = t.x; mrstd = t.y;
+        return;
+    }
     const float4* sp = reinterpret_cast<const float4*>(p.ln_stats_in + row * (long)(nb * 2)) + lk * (nb >> 2);
     float s1 = 0.f, s2 = 0.f;
     for (int i = 0; i < (nb >> 2); ++i) {
@@ -607,11 +613,17 @@ __device__ __forceinline__ void gemm_epilogue_ln_in(f32x16 (&acc)[TM][TN], const
     }
     unsigned sat = 0;
     struct alignas(16) Pk { TO v[8]; };
+    // the statistics of ALL the tile's row blocks are requested before the first block is staged: one L2 round trip per tile, not
+    // one per 32-row block (measured on the 256x256 kernel: a dependent load in front of each of a wave's four blocks cost ~10 us per launch)
+    float rs_all[TM], mr_all[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        float rstd, mrstd;
-        if constexpr (PRE) { rstd = pre_rs[i]; mrstd = pre_mr[i]; }
-        else ln_rows32(p, (long)mw + i * 32, (long)p.M - 1, lr, lk, rstd, mrstd);
+        if constexpr (PRE) { rs_all[i] = pre_rs[i]; mr_all[i] = pre_mr[i]; }
+        else ln_rows32(p, (long)mw + i * 32, (long)p.M - 1, lr, lk, rs_all[i], mr_all[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const float rstd = rs_all[i], mrstd = mr_all[i];
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll

@@ -294,14 +294,22 @@ __global__ __launch_bounds__(512, 1) void linear_ph8_kernel(const ConvGemmDev p)
         // written out twice rather than looped (the unroller gives up on a loop around bodies this large, and a rolled loop
         // would index the accumulators dynamically, i.e. through scratch)
         float* stage = reinterpret_cast<float*>(smem) + wave * (2 * 32 * 64);
-        auto half_out = [&](f32x16 (&q)[2][2], int mh) __attribute__((always_inline)) {
+        // AdaLN fold, consumer side: the (rstd, mean * rstd) of the wave's four 32-row blocks, all requested up front
+        float lrs[4] = {0.f, 0.f, 0.f, 0.f}, lmr[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (sizeof(TO) == 2) {
+            if (p.ln_stats_in) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ln_rows32(p, (long)p.m_off + m0 + wr * 128 + i * 32, (long)p.m_off + p.M - 1, lr, lk, lrs[i], lmr[i]);
+            }
+        }
+        auto half_out = [&](f32x16 (&q)[2][2], int mh, const float* prs, const float* pmr) __attribute__((always_inline)) {
             if constexpr (sizeof(TO) == 2) {
                 if (p.epi == EPI_QKV_ROPE) {
-                    if (p.ln_stats_in) gemm_epilogue_qkv_lds<TO, 2, true>(q, p, mh, n0, 0, 0, wc, lr, lk, stage);
+                    if (p.ln_stats_in) gemm_epilogue_qkv_lds<TO, 2, true, true>(q, p, mh, n0, 0, 0, wc, lr, lk, stage, prs, pmr);
                     else gemm_epilogue_qkv_lds<TO>(q, p, mh, n0, 0, 0, wc, lr, lk, stage);
                     return;
                 }
-                if (p.ln_stats_in) { gemm_epilogue_ln_in<TO, 2, 2, 2>(q, p, mh, n0 + wc * 64, lr, lk, stage); return; }      // AdaLN fold: FF1
+                if (p.ln_stats_in) { gemm_epilogue_ln_in<TO, 2, 2, 2, true>(q, p, mh, n0 + wc * 64, lr, lk, stage, prs, pmr); return; }      // AdaLN fold: FF1
             } else {
                 if (p.ln_stats_out) { gemm_epilogue_resid_ln<T, 2, 2, 2>(q, p, mh, n0 + wc * 64, lr, lk, stage); return; }  // AdaLN fold: O / FF2
             }
@@ -309,11 +317,11 @@ __global__ __launch_bounds__(512, 1) void linear_ph8_kernel(const ConvGemmDev p)
         };
         {
             f32x16 q[2][2] = {{acc[0][0], acc[0][1]}, {acc[1][0], acc[1][1]}};
-            half_out(q, m0 + wr * 128);
+            half_out(q, m0 + wr * 128, lrs, lmr);
         }
         {
             f32x16 q[2][2] = {{acc[2][0], acc[2][1]}, {acc[3][0], acc[3][1]}};
-            half_out(q, m0 + wr * 128 + 64);
+            half_out(q, m0 + wr * 128 + 64, lrs + 2, lmr + 2);
         }
     }
 #endif

@@ -135,8 +135,8 @@ class F5Config:
     f32_arithmetic: Optional[str] = None
     # prompt mel front end (modeling_modified/F5/modules.py:30-72 vs Export_F5.py:113,125): "vocos" | "bigvgan"
     mel_spec_type: str = "vocos"
-    # AdaLN fold (LayerNorm statistics carried by the GEMM epilogues instead of row-norm launches): None = the default (on for
-    # fp32 engines, off for 16-bit engines, where it measured slower), True = wherever the kernels support it, False = row-norm launches
+    # AdaLN fold (LayerNorm statistics carried by the GEMM epilogues instead of row-norm launches): None / True = wherever the
+    # kernels support it (16-bit engines finish the row statistics with one tiny launch per norm), False = row-norm launches
     adaln_fold: Optional[bool] = None
     # STFT / mel
     n_fft: int = 1024
