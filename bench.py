@@ -232,7 +232,7 @@ def pmc_traffic(kernel_label: str, dtype: str, U: int, child=None):
                         continue
                     totals[ctr] = totals.get(ctr, 0.0) + float(row["Counter_Value"])
                     nm = re.sub(r"\(.*\)$", "", re.sub(r"^void ", "", row["Kernel_Name"])).replace("mi::", "")
-                    if not nm.startswith(base):
+                    if base not in nm:          # (f16 instantiations stay mangled in the CSV — the demangler does not know _Float16 — but carry the name)
                         continue
                     e = per.setdefault(nm, [0.0, 0])
                     e[0] += float(row["Counter_Value"]); e[1] += 1

@@ -306,10 +306,14 @@ static std::vector<float> relay(const float* w, int co, int ci, int k) {
     return o;
 }
 
+void cond_destroy(Cond* e);
+
 Cond* cond_create(const CondCfg& c, const float* w, int64_t nw, int device) {
     MI_REQUIRE(w && nw == cond_param_count(c), "mi_indextts_cond_create: weight count does not match the config");
     MI_HIP(hipSetDevice(device));
-    Cond* e = new Cond; e->cfg = c; e->device = device;
+    // owned until creation has succeeded: an upload or a size check that throws half way must not leak the object and its stream
+    struct Guard { Cond* e; ~Guard() { if (e) cond_destroy(e); } } guard{new Cond};
+    Cond* e = guard.e; e->cfg = c; e->device = device;
     MI_HIP(hipStreamCreateWithFlags(&e->s, hipStreamNonBlocking));
     hipStream_t s = e->s;
     const float* p = w;
@@ -433,6 +437,7 @@ Cond* cond_create(const CondCfg& c, const float* w, int64_t nw, int device) {
         up(e->pe, pe.data(), pe.size(), s);
     }
     MI_HIP(hipStreamSynchronize(s));
+    guard.e = nullptr;
     return e;
 }
 

@@ -73,7 +73,11 @@ def read_safetensors(path: str) -> Dict[str, np.ndarray]:
                 raise ValueError(f"{path}: tensor {name}: negative dimension in shape {shape}")
             if not (0 <= lo <= hi <= dsize):
                 raise ValueError(f"{path}: tensor {name}: data_offsets [{lo}, {hi}) outside the {dsize}-byte data section")
-            want = int(np.prod(shape, dtype=np.int64)) * isz if shape else isz
+            want = isz                      # python integers: a hostile shape cannot wrap the product
+            for d in shape:
+                want *= d
+                if want > (1 << 56):        # absurd long before it could overflow anything downstream
+                    raise ValueError(f"{path}: tensor {name}: shape {shape} x {dt} is larger than any file")
             if hi - lo != want:
                 raise ValueError(f"{path}: tensor {name}: {hi - lo} bytes stored, shape {shape} x {dt} needs {want}")
             plan.append((name, dt, shape, lo, hi))

@@ -291,6 +291,10 @@ class IndexCondConfig:
         return (self.frames(audio_len) - 3) // 2 + 1
 
     def to_int_array(self) -> List[int]:
+        # the device engine computes with the epsilons of the published modules (LayerNorm / BatchNorm1d defaults); they are not
+        # part of the int array, so a config that changes them must be refused rather than silently ignored
+        if self.ln_eps != 1e-5 or self.bn_eps != 1e-5:
+            raise ValueError("IndexCondConfig: the HIP engine is built for ln_eps = bn_eps = 1e-5")
         a = [self.n_fft, self.hop, self.n_mels, self.sample_rate, self.audio_pad, self.max_signal_len, self.enc_dim, self.enc_heads,
              self.enc_linear, self.enc_blocks, self.enc_kernel, self.model_dim, self.latents, self.perc_depth, self.perc_heads,
              self.perc_dim_head, self.perc_mult, self.spk_att, self.spk_res2net_scale, self.spk_se, self.spk_embed, self.voc_initial,
