@@ -451,6 +451,43 @@ def measure_f5_plus_bigvgan(torch, fb, f5_dtype: str, voc_dtype: str, U: int, st
                         f"(mi_f5_synthesize_mel + mi_bigvgan_forward)"}
 
 
+def measure_f5_two_requests(torch, fb, dtype: str, steps: int, warmup: int):
+    """Two single-utterance requests served CONCURRENTLY: two engine handles (two HIP streams, each replaying its own hipGraph) driven
+    from two host threads — the serving form of configs[2].  The launch tails and gaps of one persistent-kernel chain are filled by
+    the other (LOG.md round 4).  Not the headline (that is one utterance at a time): a secondary block."""
+    import dataclasses
+    import threading
+    from mi355tts.f5 import F5Engine
+    cfg = dataclasses.replace(fb.cfg, **fb.cfg_over)
+    dev, W = fb.dev, fb.W
+    engs = [F5Engine(cfg, blob_device=fb.blob_t, dtype=dtype, device=fb.local) for _ in range(2)]
+    ins, outs = [], []
+    for i in range(2):
+        audio, ids, N, noise = W.f5_synthetic_inputs(cfg, 1, fb.rank, L=fb.L, first=i)
+        R = cfg.ref_frames(audio.shape[1])
+        ins.append((torch.from_numpy(audio).to(dev), torch.from_numpy(ids).to(dev), torch.from_numpy(noise).to(dev)))
+        outs.append(torch.empty((1, 1, (N - R - 1) * cfg.hop_length), dtype=torch.int16, device=dev))
+
+    def run(i, n):
+        for _ in range(n):
+            engs[i].synthesize_torch(ins[i][0], ins[i][1], N, noise=ins[i][2], out=outs[i])
+
+    for i in range(2):
+        run(i, max(warmup, 2))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=run, args=(i, steps)) for i in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    audio_s = 2 * outs[0].shape[-1] / cfg.sample_rate
+    for e in engs:
+        e.close()
+    return {"value": audio_s / dt, "unit": "audio-s/s", "ms_per_round_of_two": dt * 1e3, "ms_per_utterance": dt * 5e2, "rtf": dt / audio_s, "dtype": dtype,
+            "workload": f"two concurrent F5-TTS {dtype} NFE=32 requests (one utterance each, N={N}) on two engine handles / HIP streams of one GPU"}
+
+
 def f5_workload_name(dtype, U, N, small=False):
     if small:
         return f"PLUMBING TEST ONLY (MI355TTS_BENCH_SMALL=1): reduced F5 model, {dtype}, {U} utterance(s) per GPU, N={N}"
@@ -485,6 +522,8 @@ def run_f5(args, world, rank, local, dev, dist, torch):
             secondary["f5_f32_native_mfma"] = r3
     if world == 1 and not args.no_secondary and not fb.small:
         secondary["f5_plus_bigvgan"] = measure_f5_plus_bigvgan(torch, fb, args.dtype, "f16", args.batch, 3, 2)
+        if args.dtype == "f32" and args.batch == 1:
+            secondary["f5_f32_two_requests"] = measure_f5_two_requests(torch, fb, "f32", 4, 2)
     del fb.blob_t
     if rank != 0:
         return

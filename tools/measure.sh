@@ -32,7 +32,7 @@ if r:
     for k in r.get("kernels", [])[:8]:
         print(f"     {k['kernel'][:78]:78s} {k['ms_per_step']:8.2f} ms  x{k['launches_per_step']:7.0f}  {k['avg_launch_us']:7.1f} us")
 for n, v in (d.get("secondary") or {}).items():
-    print(f"   secondary {n}: {v['ms_per_step']:.2f} ms  {v['value']:.1f}")
+    print(f"   secondary {n}: {v.get('ms_per_step', v.get('ms_per_round_of_two', 0)):.2f} ms  {v['value']:.1f}")
 c = d.get("cpu_baseline")
 if c:
     print("   cpu_baseline", round(c["value"], 4), "cores", c["cores"], {k: round(c[k]["value"], 4) for k in ("t8", "tN") if k in c})
