@@ -183,7 +183,18 @@ __global__ __launch_bounds__(512, 1) void linear_x3p_kernel(const ConvGemmDev p)
 #endif
     // LDS stages: a chunk is requested NST - 1 chunk times before its barrier.  Three for NP = 3 (a chunk time is ~3000 clk);
     // with half the MFMAs per chunk (NP = 2) the same distance in TIME needs one stage more (32 KB stages: 128 KB)
-    constexpr int NST = NP == 3 ? 3 : X3P_NST2;
+#ifndef X3P_BAR2
+#define X3P_BAR2 1          // -DX3P_BAR2=0: the round-3 loop (four stages, a barrier per chunk) for A/B builds
+#endif
+    // BAR2 (NP = 2, round 4): five stages = the whole 160 KB of LDS, ONE barrier per TWO chunks.  With a barrier per 12 MFMAs both
+    // waves of every SIMD park together (PMC: 42 % of the wave cycles in s_waitcnt / s_barrier); here the boundary after an odd
+    // chunk makes chunks c+2 AND c+3 visible (only the youngest request, chunk c+4, stays in flight), the even chunk runs into the
+    // odd one without a wait, and each body requests chunk c+4 FIRST (under its first MFMAs: two chunk times of lead, like the
+    // three-stage ring that measured the same as four) into the stage of chunk c-1 — read two bodies ago, i.e. always behind a
+    // barrier.  Same MFMAs in the same order on the same fragments: bit-identical results (checked: int16 waveforms array_equal).
+    // Same-box A/B (tools/dbg/ab_bar2.sh, profiles/r4/x3p_bar2_ab.txt): 51.5 -> 50.35 us per launch, step 182.8 -> 178.8 ms.
+    constexpr bool BAR2 = (X3P_BAR2 != 0) && NP == 2 && DBG == 0;
+    constexpr int NST = NP == 3 ? 3 : (BAR2 ? 5 : X3P_NST2);
     constexpr int CHB = NP * X3P_PLANE;                         // bytes of one operand chunk
     constexpr int STAGE = 2 * CHB;                              // 48 | 32 KB: A chunk then B chunk
     constexpr int PER = 2 * NP;                                 // DMA instructions per wave per chunk (1 KB each, 8 waves)
@@ -307,9 +318,10 @@ __global__ __launch_bounds__(512, 1) void linear_x3p_kernel(const ConvGemmDev p)
         };
 #define X3P_SB() __builtin_amdgcn_sched_barrier(0)
         // ---- prologue: chunks cb, cb+1, cb+2 requested; chunk cb's fragments into set 0 ----
+        constexpr int NPRE = BAR2 ? NST - 1 : NST;             // chunks requested by the prologue
 #pragma unroll
-        for (int q = 0; q < NST; ++q) issue(q, cb + q);
-        x3p_wait_vm<(NST - 1) * PER>();
+        for (int q = 0; q < NPRE; ++q) issue(q, cb + q);
+        x3p_wait_vm<(NPRE - 1) * PER>();
         __builtin_amdgcn_s_barrier();
 #pragma unroll
         for (int q = 0; q < NR; ++q) ldfrag1(smem + fa_off, smem + fb_off, std::integral_constant<int, 0>{}, q);
@@ -317,10 +329,10 @@ __global__ __launch_bounds__(512, 1) void linear_x3p_kernel(const ConvGemmDev p)
 #pragma unroll
             for (int q = 0; q < NR; ++q) ldfrag1(smem + fa_off, smem + fb_off, std::integral_constant<int, 1>{}, q);
         }
-        x3p_wait_vm<(NST - 2) * PER>();
+        x3p_wait_vm<(BAR2 ? 1 : NST - 2) * PER>();              // BAR2: chunks cb+1 AND cb+2 landed (cb+3 may be in flight)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                           // chunk cb+1 landed, stage 0 free
-        int st_next = 1, st_free = 0;                           // stage of chunk c+1 ; stage chunk c+NST goes to (= stage of chunk c)
+        int st_next = 1, st_free = BAR2 ? 4 : 0;                // stage of chunk c+1 ; stage the chunk requested in body(c) goes to (chunk c+NST -> stage of chunk c ; BAR2: chunk c+4 -> stage of chunk c-1)
         // One chunk: 24 MFMAs on the fragments of chunk c (register set SET).  Under twelve of them the fragments of chunk c+1
         // are read into the other set (past the piece they are stale LDS, never used), under six this wave's six pieces of
         // chunk c+3 are requested; then the boundary, then the last six MFMAs.  Measured (profiles/r3/x3p_ablation_*.txt,
@@ -334,12 +346,12 @@ __global__ __launch_bounds__(512, 1) void linear_x3p_kernel(const ConvGemmDev p)
             const bool more = c + 1 < n;
             const unsigned char* sa = smem + st_next * STAGE + fa_off;
             const unsigned char* sb = smem + st_next * STAGE + fb_off;
-            const int coff = chunk_off(cb + c + NST);
+            const int coff = chunk_off(cb + c + (BAR2 ? NST - 1 : NST));
             const unsigned ldsd = __builtin_amdgcn_readfirstlane(smem_lds + (unsigned)(st_free * STAGE) + lds_part);
             auto boundary = [&]() __attribute__((always_inline)) {
                 // chunk c+2 has landed (this wave's PER pieces of chunk c+3 may stay in flight), the fragments of chunk c+1 are
                 // in registers (its stage is free); for NP = 3 the last six MFMAs run behind the barrier
-                x3p_wait_vm<(NST - 2) * PER>();
+                x3p_wait_vm<(BAR2 ? 1 : NST - 2) * PER>();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             };
@@ -348,12 +360,14 @@ __global__ __launch_bounds__(512, 1) void linear_x3p_kernel(const ConvGemmDev p)
                 if (k == KB && more) boundary();
                 X3P_SB(); mma1(SET, k); X3P_SB();
                 if constexpr (DBG & 16) continue;
-                if (k < NR) ldfrag1(sa, sb, NSET{}, k);
-                else if (k < KB) {
+                // BAR2: the DMA pieces first (slots 0 .. PER-1), the fragment reads behind them
+                const int kr = BAR2 ? k - PER : k, kd = BAR2 ? k : k - NR;
+                if (kr >= 0 && kr < NR) ldfrag1(sa, sb, NSET{}, kr);
+                else if (kd >= 0 && kd < PER) {
                     if constexpr (!(DBG & 1)) {
                         // pieces 0-3 under one M0 value, pieces 4-5 under the next (instruction offsets 0 / 1 / 2 / 3 KB move the
                         // global and the LDS address together)
-                        const int dj = k - NR;
+                        const int dj = kd;
                         if (dj == 0) x3p_set_m0(ldsd); else if (dj == 4) x3p_set_m0(ldsd + 4096u);
                         const int v0 = (int)((unsigned)vb[dj & 4] + (unsigned)coff);
                         if ((dj & 3) == 0) x3p_dma16_off<0>(rsd, v0); else if ((dj & 3) == 1) x3p_dma16_off<1024>(rsd, v0);
@@ -361,14 +375,19 @@ __global__ __launch_bounds__(512, 1) void linear_x3p_kernel(const ConvGemmDev p)
                     }
                 }
             }
-            if constexpr (KB == NM) { if (more) boundary(); }
+            if constexpr (KB == NM) { if (more && (!BAR2 || (c & 1))) boundary(); }       // BAR2: only behind the odd chunk
+        };
+        auto rotate = [&]() __attribute__((always_inline)) {
+            if constexpr (BAR2) { st_free = st_free + 1 == NST ? 0 : st_free + 1; }
+            else st_free = st_next;
+            st_next = st_next + 1 == NST ? 0 : st_next + 1;
         };
         for (int c = 0; c < n; c += 2) {
             body(c, std::integral_constant<int, 0>{});
-            st_free = st_next; st_next = st_next + 1 == NST ? 0 : st_next + 1;
+            rotate();
             if (c + 1 < n) {
                 body(c + 1, std::integral_constant<int, 1>{});
-                st_free = st_next; st_next = st_next + 1 == NST ? 0 : st_next + 1;
+                rotate();
             }
         }
 #undef X3P_SB
