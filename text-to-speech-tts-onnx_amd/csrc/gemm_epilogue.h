@@ -566,17 +566,12 @@ __device__ __forceinline__ void gemm_epilogue_qkv_lds(f32x16 (&acc)[TMQ][2], con
 template <typename TO> __device__ __forceinline__ void ln_act8(float (&x)[8], int act) {
     switch (act) {                                            // wave-uniform
         case ACT_GELU_TANH:
-            if constexpr (sizeof(TO) == 2) {
+            // x * sigmoid(2t) on v_exp_f32 / v_rcp_f32 for every output type (round 4: fp32 too).  The form has no cancellation
+            // (0.5 x (1 + tanh t) loses the digits of 1 + tanh t for negative t in fp32, libm or not); its error is the ~1 ulp of
+            // each of the two instructions plus the rounding of the exponent, <= 3e-7 |x| — the size of the reference formula's own
+            // fp32 rounding.  The libm tanhf expansion cost ~6 us of the FF1 launch's epilogue (profiles/r4/x3p_epilogue_cost.txt).
 #pragma unroll
-                for (int q = 0; q < 8; ++q) x[q] = gelu_tanh_fast(x[q]);
-            } else {
-#pragma unroll
-                for (int q = 0; q < 8; q += 4) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) x[q + r] = act_apply(x[q + r], ACT_GELU_TANH);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
+            for (int q = 0; q < 8; ++q) x[q] = gelu_tanh_fast(x[q]);
             break;
         case ACT_GELU_ERF:
 #pragma unroll

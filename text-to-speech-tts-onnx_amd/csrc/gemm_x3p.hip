@@ -105,7 +105,7 @@ __device__ __forceinline__ void x3p_epilogue_planes(f32x16 (&acc)[TM][TN], const
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r] + bv;
             switch (p.act) {
-                case ACT_GELU_TANH: act16<ACT_GELU_TANH, false>(v); break;
+                case ACT_GELU_TANH: act16<ACT_GELU_TANH, true>(v); break;      // x * sigmoid(2t): see ln_act8 (gemm_epilogue.h)
                 case ACT_GELU_ERF: act16<ACT_GELU_ERF>(v); break;
                 case ACT_MISH: act16<ACT_MISH>(v); break;
                 case ACT_SILU: act16<ACT_SILU>(v); break;
