@@ -173,7 +173,11 @@ __device__ __forceinline__ void x3p_set_m0(unsigned v) {
 // tile as accA + 2^-11 * accB; the lo*lo term (2^-22 of the product, below the fp32 rounding of the sum) is dropped.
 // FOLD: the instantiation whose epilogues are the AdaLN-fold forms (gemm_epilogue.h: consumer QKV / FF1, producer O / FF2) instead
 // of the plain ones — a separate kernel, so that neither carries the other's code and registers
-template <typename TO, bool LEPI, int NP, int DBG = 0, bool FOLD = false>
+// EPK (round 4): which ONE epilogue the instantiation carries — 0: all of the FOLD / plain set (the round-3 form), 1: the QKV epilogue,
+// 2: the plain-output one (FF1 planes / rows), 3: the residual one (O / FF2).  The kernel sits at the 256-register limit: every
+// epilogue compiled into it costs the main loop spills (adding one store path to the QKV epilogue took the spills from 31 to 81
+// registers and 4 - 11 us from EVERY layer), so each launch gets the instantiation with only its own.
+template <typename TO, bool LEPI, int NP, int DBG = 0, bool FOLD = false, int EPK = 0>
 __global__ __launch_bounds__(512, 1) void linear_x3p_kernel(const ConvGemmDev p) {
     using MF = std::conditional_t<NP == 3, Mfma<bf16>, Mfma<f16>>;
     using Frag = typename MF::Frag;
@@ -497,13 +501,13 @@ __global__ __launch_bounds__(512, 1) void linear_x3p_kernel(const ConvGemmDev p)
             if constexpr (LEPI) {
                 float* stage = reinterpret_cast<float*>(smem) + wave * 2176;        // 32 x 64 floats per wave (32 x 65 for the transposed-V path)
                 if constexpr (FOLD) {
-                    if (p.epi == EPI_QKV_ROPE) gemm_epilogue_qkv_lds<TO, 1, true, true>(h, p, m0, n0, 0, wm2, wn, lr, lk, stage, ln_rs, ln_mr);       // consumer: QKV
-                    else if (p.ln_stats_in) gemm_epilogue_ln_in<TO, 1, TN, NP, true>(h, p, m0 + wm2 * 32, n0 + wn * WN, lr, lk, stage, ln_rs, ln_mr); // consumer: FF1 -> panel planes
-                    else gemm_epilogue_resid_ln<float, 1, TN, NP>(h, p, m0 + wm2 * 32, n0 + wn * WN, lr, lk, stage);                      // producer: O / FF2
+                    if ((EPK == 0 || EPK == 1) && (EPK == 1 || p.epi == EPI_QKV_ROPE)) gemm_epilogue_qkv_lds<TO, 1, true, true>(h, p, m0, n0, 0, wm2, wn, lr, lk, stage, ln_rs, ln_mr);       // consumer: QKV
+                    else if ((EPK == 0 || EPK == 2) && (EPK == 2 || p.ln_stats_in)) gemm_epilogue_ln_in<TO, 1, TN, NP, true>(h, p, m0 + wm2 * 32, n0 + wn * WN, lr, lk, stage, ln_rs, ln_mr); // consumer: FF1 -> panel planes
+                    else if constexpr (EPK == 0 || EPK == 3) gemm_epilogue_resid_ln<float, 1, TN, NP>(h, p, m0 + wm2 * 32, n0 + wn * WN, lr, lk, stage);                      // producer: O / FF2
                 } else {
-                    if (p.epi == EPI_QKV_ROPE) gemm_epilogue_qkv_lds<TO, 1>(h, p, m0, n0, 0, wm2, wn, lr, lk, stage);
-                    else if (p.out_planes) x3p_epilogue_planes<1, TN, NP>(h, p, m0, n0, wm2, wn, lr, lk, stage);
-                    else gemm_epilogue_lds<TO, 1, TN, 32, WN>(h, p, m0, n0, 0, 0, wm2, wn, lr, lk, stage);
+                    if ((EPK == 0 || EPK == 1) && (EPK == 1 || p.epi == EPI_QKV_ROPE)) gemm_epilogue_qkv_lds<TO, 1>(h, p, m0, n0, 0, wm2, wn, lr, lk, stage);
+                    else if ((EPK == 0 || EPK == 2) && (EPK == 2 || p.out_planes)) x3p_epilogue_planes<1, TN, NP>(h, p, m0, n0, wm2, wn, lr, lk, stage);
+                    else if constexpr (EPK == 0 || EPK == 3) gemm_epilogue_lds<TO, 1, TN, 32, WN>(h, p, m0, n0, 0, 0, wm2, wn, lr, lk, stage);
                 }
             } else {
                 gemm_epilogue<TO, 1, TN, 32, WN>(h, p, m0, n0, 0, 0, wm2, wn, lr, lk);
@@ -561,8 +565,19 @@ void launch_linear_x3p(const ConvGemmDev& e_in, hipStream_t s) {
 #undef X2_TUNE
 #endif
         const bool fold = e.ln_stats_in || e.ln_stats_out;
-        if (fold) { MI_REQUIRE(e.lds_epi, "linear_x3p: the AdaLN fold needs the LDS-staged epilogue"); prof_set_kernel("linear_x3p_kernel<float, true, 2, AdaLN fold>", "", ""); hipLaunchKernelGGL((linear_x3p_kernel<float, true, 2, 0, true>), grid, dim3(512), 0, s, e); }
-        else if (e.lds_epi) { prof_set_kernel("linear_x3p_kernel<float, true, 2>", "", ""); hipLaunchKernelGGL((linear_x3p_kernel<float, true, 2>), grid, dim3(512), 0, s, e); }
+        // one epilogue per instantiation (EPK): 1 QKV, 2 plain output (planes), 3 residual
+        const int epk = e.epi == EPI_QKV_ROPE ? 1 : fold ? (e.ln_stats_in ? 2 : 3) : (e.out_planes ? 2 : 3);
+        if (fold) {
+            MI_REQUIRE(e.lds_epi, "linear_x3p: the AdaLN fold needs the LDS-staged epilogue");
+            if (epk == 1) { prof_set_kernel("linear_x3p_kernel<float, true, 2, AdaLN fold, QKV>", "", ""); hipLaunchKernelGGL((linear_x3p_kernel<float, true, 2, 0, true, 1>), grid, dim3(512), 0, s, e); }
+            else if (epk == 2) { prof_set_kernel("linear_x3p_kernel<float, true, 2, AdaLN fold, FF1>", "", ""); hipLaunchKernelGGL((linear_x3p_kernel<float, true, 2, 0, true, 2>), grid, dim3(512), 0, s, e); }
+            else { prof_set_kernel("linear_x3p_kernel<float, true, 2, AdaLN fold, O / FF2>", "", ""); hipLaunchKernelGGL((linear_x3p_kernel<float, true, 2, 0, true, 3>), grid, dim3(512), 0, s, e); }
+        }
+        else if (e.lds_epi) {
+            if (epk == 1) { prof_set_kernel("linear_x3p_kernel<float, true, 2, QKV>", "", ""); hipLaunchKernelGGL((linear_x3p_kernel<float, true, 2, 0, false, 1>), grid, dim3(512), 0, s, e); }
+            else if (epk == 2) { prof_set_kernel("linear_x3p_kernel<float, true, 2, planes out>", "", ""); hipLaunchKernelGGL((linear_x3p_kernel<float, true, 2, 0, false, 2>), grid, dim3(512), 0, s, e); }
+            else { prof_set_kernel("linear_x3p_kernel<float, true, 2>", "", ""); hipLaunchKernelGGL((linear_x3p_kernel<float, true, 2, 0, false, 3>), grid, dim3(512), 0, s, e); }
+        }
         else { prof_set_kernel("linear_x3p_kernel<float, false, 2>", "", ""); hipLaunchKernelGGL((linear_x3p_kernel<float, false, 2>), grid, dim3(512), 0, s, e); }
     } else if (e.lds_epi) {
 #if defined(MI355TTS_TUNING)
