@@ -520,6 +520,12 @@ def run_f5(args, world, rank, local, dev, dist, torch):
             r3, _ = fb.measure("f32", args.batch, 5, 2, f32_arithmetic="native-fp32-mfma")
             r3["workload"] = f5_workload_name("f32", args.batch, N) + " — linear layers, attention and position convolution on the native fp32 MFMA (F5Config.f32_arithmetic = native-fp32-mfma)"
             secondary["f5_f32_native_mfma"] = r3
+            if args.batch == 1:
+                # the same fp32 arithmetic with four utterances per step (8 CFG rows): what one GPU serves when requests
+                # can be batched — the fixed per-launch cost of the DiT linear layers is shared by four times the rows
+                r4, _ = fb.measure("f32", 4, 3, 1)
+                r4["workload"] = f5_workload_name("f32", 4, N)
+                secondary["f5_f32_u4"] = r4
     if world == 1 and not args.no_secondary and not fb.small:
         secondary["f5_plus_bigvgan"] = measure_f5_plus_bigvgan(torch, fb, args.dtype, "f16", args.batch, 3, 2)
         if args.dtype == "f32" and args.batch == 1:

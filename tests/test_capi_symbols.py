@@ -44,3 +44,21 @@ def test_fails_loudly_without_gpu():
         pytest.skip("GPU present")
     with pytest.raises(_lib.MiError):
         _lib.init(0)
+
+
+def test_host_paths_under_the_sanitizer_build():
+    """the library's host code (loader, config parsing, blob validation, error paths) under
+    AddressSanitizer + UBSan.  `build.py --sanitize` makes libmi355tts_asan.so; skipped when it has not been built.
+    (GPU tests cannot run under it: the ROCm ASan runtime intercepts hsa_amd_memory_pool_allocate and needs
+    xnack device builds, profiles/r4/asan_gpu_attempt.log.)"""
+    import subprocess
+    import sys
+    lib = os.path.join(ROOT, "text-to-speech-tts-onnx_amd", "mi355tts", "libmi355tts_asan.so")
+    if not os.path.exists(lib) or os.environ.get("MI355TTS_LIB"):
+        pytest.skip("sanitizer build absent (python text-to-speech-tts-onnx_amd/build.py --sanitize)")
+    r = subprocess.run([os.path.join(ROOT, "tools", "sanitize.sh"), sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider",
+                        os.path.join(ROOT, "tests", "test_capi_symbols.py"), os.path.join(ROOT, "tests", "test_checkpoint.py"),
+                        "-k", "not sanitizer"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    out = r.stdout + r.stderr
+    assert "AddressSanitizer" not in out and "runtime error" not in out, out[-3000:]
+    assert r.returncode == 0, out[-3000:]

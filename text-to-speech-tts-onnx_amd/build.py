@@ -1,7 +1,10 @@
 #!/usr/bin/env python
 """Build libmi355tts.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
 
-    python text-to-speech-tts-onnx_amd/build.py [--force] [-j N]
+    python text-to-speech-tts-onnx_amd/build.py [--force] [-j N] [--variant NAME] [--tuning] [--sanitize]
+
+--sanitize: a second library, libmi355tts_asan.so, whose HOST code is built with AddressSanitizer + UBSan (the kernels are
+the product ones); run anything against it with tools/sanitize.sh (LD_PRELOAD of the clang ASan runtime + MI355TTS_LIB).
 """
 from __future__ import annotations
 
@@ -18,6 +21,10 @@ LIB = os.path.join(HERE, "mi355tts", "libmi355tts.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-result", "-fno-gpu-rdc", "-DNDEBUG"] + os.environ.get("MI355TTS_EXTRA_FLAGS", "").split()
+
+
+LINK_FLAGS: list = []
+SAN_HOST = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-g"]
 
 
 def _sources():
@@ -64,7 +71,7 @@ def build(force: bool = False, jobs: int = 4, variant: str = "") -> str:
         objs = list(ex.map(lambda s: _compile(s, force, hdig), srcs))
     newest = max(os.path.getmtime(o) for o in objs)
     if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < newest:
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *LINK_FLAGS, *objs, "-o", LIB]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
@@ -78,4 +85,9 @@ if __name__ == "__main__":
     v = sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else ""
     if "--tuning" in sys.argv:          # the ablation instantiations of the kernels (MI355TTS_GEMM_DBG): tools/r3/*.sh use a `tune` variant
         FLAGS.append("-DMI355TTS_TUNING")
+    if "--sanitize" in sys.argv:        # host side only: -Xarch_host keeps the device code as shipped
+        v = "asan"
+        for f in SAN_HOST:
+            FLAGS.extend(["-Xarch_host", f])
+        LINK_FLAGS.extend(["-fsanitize=address,undefined", "-shared-libsan"])
     print(build(force="--force" in sys.argv, jobs=j, variant=v))
