@@ -166,6 +166,32 @@ def _cores() -> int:
         return os.cpu_count() or 1
 
 
+X3P_ROLES = ("QKV", "FF1", "O / FF2")
+
+
+def merge_instantiations(kernels):
+    """linear_x3p NP = 2 is one kernel compiled per epilogue (template parameter EPK, gemm_x3p.hip): the roofline row is
+    quoted on the kernel, so the per-epilogue instantiations are pooled (flops, bytes, time, launches summed) and kept
+    beside the pooled row.  Returns (kernels with the pooled row in place, the pooled row or None)."""
+    for tag, fam in (("AdaLN fold", r"linear_x3p_kernel<float, true, 2, 0, true, [123]>"), ("", r"linear_x3p_kernel<float, true, 2, 0, false, [123]>")):
+        pre = "linear_x3p_kernel<float, true, 2, " + (tag + ", " if tag else "")
+        names = [pre + r + ">" for r in X3P_ROLES] if tag else ["linear_x3p_kernel<float, true, 2, QKV>", "linear_x3p_kernel<float, true, 2, planes out>", "linear_x3p_kernel<float, true, 2>"]
+        inst = [k for k in kernels if k["kernel"] in names and k["launches"] > 0]
+        if len(inst) < 2:
+            continue
+        m = dict(inst[0])
+        m["kernel"] = "linear_x3p_kernel<float, true, 2" + (", " + tag if tag else "") + ">"
+        for f in ("ms", "launches", "flops", "bytes"):
+            m[f] = sum(k[f] for k in inst)
+        m["instantiations"] = [{"kernel": k["kernel"], "launches": k["launches"], "avg_launch_us": k["ms"] / k["launches"] * 1e3,
+                                "tflops": k["flops"] / (k["ms"] * 1e-3) / 1e12} for k in inst]
+        m["pmc_family"] = fam
+        rest = [k for k in kernels if k not in inst]
+        out = sorted(rest + [m], key=lambda k: -k["ms"])
+        return out, m
+    return kernels, None
+
+
 def dominant_kernel_roofline(kernels, steps: int, peak: float, bound: str, note: str):
     """`roofline` of ONE kernel instantiation: the one with the largest event-timed total among `kernels`
     (_lib.prof_kernels()).  achieved = its algorithmic flops (or bytes) per launch / its average launch duration."""
@@ -192,13 +218,15 @@ def dominant_kernel_roofline(kernels, steps: int, peak: float, bound: str, note:
                          "alg_GBps": x["bytes"] / (x["ms"] * 1e-3) / 1e9 if x["ms"] > 0 else 0.0} for x in ks[:8]]}
 
 
-def pmc_traffic(kernel_label: str, dtype: str, U: int, child=None):
+def pmc_traffic(kernel_label: str, dtype: str, U: int, child=None, family=None):
     """`roofline.traffic` of the dominant kernel: fabric-side bytes per launch from rocprofv3 PMC counters, collected as
     MI355X_MICROARCH.md (HBM section) prescribes — FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes (they do not fit one
     pass), FETCH_SIZE doubled (gfx950 tallies 128-byte requests at 64 B), WRITE_SIZE as reported (uncalibrated), both in KB.
     The passes run a SHORT child command (tools/pmc_f5_eval.py: one DiT evaluation of the same utterance shape on the same
     engine, ~260 dispatches — a PMC pass costs ~40 ms per dispatch) and the counters of the launches of that kernel are
-    averaged.  Returns (bytes_per_launch, detail) or (None, reason)."""
+    averaged.  `family`: a regular expression over the demangled kernel names — every matching instantiation is pooled
+    (launch-weighted, as the event timing of a merged roofline row is) and listed on its own in the detail.
+    Returns (bytes_per_launch, detail) or (None, reason)."""
     import csv
     import glob
     import re
@@ -213,7 +241,7 @@ def pmc_traffic(kernel_label: str, dtype: str, U: int, child=None):
     base = kernel_label.split("<")[0].strip()
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env["TMPDIR"] = "/tmp"
-    sums, counts, names, totals = {}, {}, {}, {}
+    sums, counts, names, totals, insts = {}, {}, {}, {}, {}
     with tempfile.TemporaryDirectory(prefix="mi355tts_pmc_", dir="/tmp") as td:
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(td, ctr)
@@ -232,12 +260,16 @@ def pmc_traffic(kernel_label: str, dtype: str, U: int, child=None):
                         continue
                     totals[ctr] = totals.get(ctr, 0.0) + float(row["Counter_Value"])
                     nm = re.sub(r"\(.*\)$", "", re.sub(r"^void ", "", row["Kernel_Name"])).replace("mi::", "")
-                    if base not in nm:          # (f16 instantiations stay mangled in the CSV — the demangler does not know _Float16 — but carry the name)
+                    if (not re.search(family, nm)) if family else (base not in nm):   # (f16 instantiations stay mangled in the CSV — the demangler does not know _Float16 — but carry the name)
                         continue
                     e = per.setdefault(nm, [0.0, 0])
                     e[0] += float(row["Counter_Value"]); e[1] += 1
             if not per:
                 return None, f"no {base} dispatch in the {ctr} pass"
+            if family:
+                sums[ctr], counts[ctr], names[ctr] = sum(v[0] for v in per.values()), sum(v[1] for v in per.values()), family
+                insts[ctr] = {k: v[0] * 1024.0 * (2.0 if ctr == "FETCH_SIZE" else 1.0) / v[1] for k, v in per.items()}
+                continue
             nm = max(per, key=lambda k: per[k][1])              # the instantiation with the most launches
             sums[ctr], counts[ctr], names[ctr] = per[nm][0], per[nm][1], nm
     fetch = 2.0 * sums["FETCH_SIZE"] * 1024.0 / counts["FETCH_SIZE"]
@@ -245,6 +277,8 @@ def pmc_traffic(kernel_label: str, dtype: str, U: int, child=None):
     return fetch + write, {"kernel": names["FETCH_SIZE"], "launches_sampled": counts["FETCH_SIZE"],
                            "fetch_bytes_per_launch_x2_corrected": fetch, "write_bytes_per_launch": write,
                            "whole_command_bytes": 2.0 * totals.get("FETCH_SIZE", 0.0) * 1024.0 + totals.get("WRITE_SIZE", 0.0) * 1024.0,
+                           **({"per_instantiation_bytes_per_launch": {k: insts["FETCH_SIZE"][k] + insts["WRITE_SIZE"].get(k, 0.0)
+                                                                       for k in insts["FETCH_SIZE"]}} if family else {}),
                            "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes over tools/pmc_f5_eval.py "
                                      "(one DiT evaluation, same shapes); FETCH_SIZE x2 per the gfx950 note of MI355X_MICROARCH.md; "
                                      "fabric-side bytes (Infinity-Cache hits are counted)"}
@@ -387,7 +421,15 @@ class F5Bench:
             peak = MFMA_F16_PEAK_TF / 6.0
             note += ("; this kernel computes every fp32 product as 6 bf16 MFMA partial products (3-way exact operand split, fp32 "
                      "accumulate): peak = 2500 / 6 TFLOP/s of fp32-equivalent work, achieved counts 2*M*N*K once")
+        gemm_like, merged = merge_instantiations(gemm_like)
+        if merged:
+            note += ("; linear_x3p is compiled once per epilogue (QKV | FF1 | O / FF2: no register spills in the main loop) — the row "
+                     "pools the three instantiations (launch-weighted), `instantiations` lists each, and the rocprofv3 summary "
+                     "carries them as linear_x3p_kernel<float, true, 2, 0, true, 1 | 2 | 3>")
         roof = dominant_kernel_roofline(gemm_like, 1, peak, "mfma", note)
+        if roof and merged and roof["kernel"] == merged["kernel"]:
+            roof["instantiations"] = merged["instantiations"]
+            roof["pmc_family"] = merged["pmc_family"]
         alg_flops = f5_flops_per_eval(cfg, N) * (cfg.nfe_step - 1) * U
         ev_ms = sum(k["ms"] for k in kernels)
         res = {"value": self.world * audio_s * steps / dt, "ms_per_step": dt / steps * 1e3, "dtype": dtype,
@@ -564,7 +606,7 @@ def run_f5(args, world, rank, local, dev, dist, torch):
     if secondary:
         line["secondary"] = secondary
     if world == 1 and not args.no_pmc and not fb.small and line["roofline"]:
-        tb, detail = pmc_traffic(line["roofline"]["kernel"], args.dtype, args.batch)
+        tb, detail = pmc_traffic(line["roofline"]["kernel"], args.dtype, args.batch, family=line["roofline"].get("pmc_family"))
         line["roofline"]["traffic"] = tb
         line["roofline"]["traffic_detail"] = detail
     if world == 1 and not args.no_cpu_baseline:
