@@ -1,8 +1,12 @@
-// gemm_x3p.hip — round 3: the fp32 DiT linear layers (QKV, O, FF1, FF2) as exact three-way bf16 splits with BOTH operands
-// pre-split and pre-tiled ("panel planes"), so that the main loop is nothing but LDS-DMA, ds_read_b128 and MFMA.
+// gemm_x3p.hip — the fp32 DiT linear layers (QKV, O, FF1, FF2) from 16-bit partial products (NP = 2: fp16 {hi, lo} pairs,
+// three MFMAs per block, the default; NP = 3: exact three-way bf16 splits, six) with BOTH operands pre-split and pre-tiled
+// ("panel planes"), so that the main loop is nothing but LDS-DMA, ds_read_b128 and MFMA.
 //
-// Arithmetic: that of gemm_x3.hip (a = a1 + a2 + a3, b = b1 + b2 + b3 in bf16, six partial products per block, fp32
-// accumulate, small terms first) — fp32 products carried by the bf16 matrix cores, 2500 / 6 = 416.7 TFLOP/s ceiling.
+// Arithmetic (x3_split.h).  NP = 2: a = hi + lo with hi = fp16(a), lo = fp16((a - hi) * 2^11) — 22 significant bits; per
+// block hi*hi into one accumulator set and hi*lo + lo*hi into a second, joined as acc0 + 2^-11 acc1 at the end of the tile;
+// 2500 / 3 = 833 TFLOP/s ceiling; operands beyond fp16's range are counted (range watch) and the engine falls back to
+// NP = 3: that of gemm_x3.hip (a = a1 + a2 + a3, b likewise in bf16, six partial products per block, fp32 accumulate,
+// small terms first), 2500 / 6 = 416.7 TFLOP/s ceiling.
 //
 // What round 2's kernel (gemm_x3.hip) paid for, measured (profiles/r2): it staged the activations as
 // fp32 and split them in registers in front of the MFMAs (11 VALU per pair, repeated by each of the 8-24 column tiles that
@@ -13,16 +17,21 @@
 // Here:
 //  * Panel-plane layout, for the weights (once at load) AND for the activations (written by the producer of the rows:
 //    x3p_split_rows, or the fused epilogues of rownorm / attention / FF1):
-//        [panel = row / 128][chunk = k / 32][plane 0..2][row % 128][32 bf16]      = 24 KB per (panel, chunk)
+//        [panel = row / 128][chunk = k / 32][plane 0..NP-1][row % 128][32 x 16 bit]   = 8 NP KB per (panel, chunk)
 //    with the 16-byte k-slots of a 64-byte row XOR-swizzled by (row >> 2) & 3 IN MEMORY.  One K chunk of a tile operand
-//    is 24 KB contiguous: every LDS-DMA instruction moves 1 KB of consecutive bytes (the best fill pattern, fillrate.hip),
+//    is 8 NP KB contiguous: every LDS-DMA instruction moves 1 KB of consecutive bytes (the best fill pattern, fillrate.hip),
 //    needs no per-lane address arithmetic, and lands in LDS already in the conflict-free fragment layout.
 //  * 128x128 tile, eight waves = two groups of four: group g multiplies k16 step g of every chunk on 64x64 per wave
 //    (24 MFMAs per wave per chunk from 12 ds_read_b128: 62 B/clk of LDS reads at full MFMA rate, against 85-94 for the
 //    32x64 wave tiles of round 2); the two groups' accumulators meet once per tile in LDS.  Two waves per SIMD.
-//  * Three LDS stages of 48 KB; the fragments of chunk c+1 are read into a second register set under the MFMAs of chunk
-//    c, so the ring holds chunks c+1 .. c+3: a chunk is requested two full chunk times (~3000 clk) before its barrier.
-//    One barrier per chunk, placed in front of the last six MFMAs; every wait is a counted vmcnt(6).
+//  * LDS-DMA ring.  NP = 3: three stages of 48 KB, one barrier per chunk in front of the last six MFMAs.  NP = 2 (fp16
+//    {hi, lo * 2^11} pairs, the default — three MFMAs per block on two accumulator sets): FIVE stages of 32 KB (all 160 KB)
+//    and ONE barrier per TWO chunks (X3P_BAR2): the DMA of chunk c + 4 is issued first in the body into the stage chunk
+//    c - 1 left, the fragments of chunk c + 1 are read into a second register set under the MFMAs of chunk c, every wait
+//    is a counted vmcnt.
+//  * One epilogue per instantiation (EPK, round 4): the kernel sits at the 256-VGPR limit and each epilogue compiled into
+//    it (QKV + RoPE + V^T | plane output with GELU | gated residual + AdaLN statistics) cost spills that slowed every
+//    layer; the launcher picks the instantiation by the layer's role.
 //  * Stream-K frame of gemm_sk.hip (range-ordered fix-up, flags) with two changes for L2: the 8 XCD groups own 2-D blocks
 //    of tiles (GR x GC bands: A is fetched by GC XCDs and B by GR, instead of A by all 8), and every tile walks K
 //    CYCLICALLY from a per-tile start chunk chosen so that all workgroups of the launch are at the same physical chunk at
