@@ -279,8 +279,8 @@ def pmc_traffic(kernel_label: str, dtype: str, U: int, child=None, family=None):
                            "whole_command_bytes": 2.0 * totals.get("FETCH_SIZE", 0.0) * 1024.0 + totals.get("WRITE_SIZE", 0.0) * 1024.0,
                            **({"per_instantiation_bytes_per_launch": {k: insts["FETCH_SIZE"][k] + insts["WRITE_SIZE"].get(k, 0.0)
                                                                        for k in insts["FETCH_SIZE"]}} if family else {}),
-                           "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes over tools/pmc_f5_eval.py "
-                                     "(one DiT evaluation, same shapes); FETCH_SIZE x2 per the gfx950 note of MI355X_MICROARCH.md; "
+                           "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes over " + (os.path.relpath(child[0], ROOT) + " (one forward, same shapes)" if child else "tools/pmc_f5_eval.py (one DiT evaluation, same shapes)") +
+                                     "; FETCH_SIZE x2 per the gfx950 note of MI355X_MICROARCH.md; "
                                      "fabric-side bytes (Infinity-Cache hits are counted)"}
 
 
