@@ -248,7 +248,8 @@ int         mi_indextts_cond_run(mi_cond* h, const int16_t* audio, int64_t L, fl
  *     "gemm_ring4_max", "gemm_buf", "gemm_f32_small", "gemm_f32_small_max", "gemm_small16_max", "gemm_sk" (stream-K: 0 off, 1 fp32,
  *     2 also 16-bit), "gemm_sk_stages", "gemm_ph8", "gemm_ph8_min_tiles", "gemm_ph8_order", "gemm_ph8_split_max", "gemm_ph8_split_min_nk" (split tail, tests), "gemm_row_split",
  *     "gemm_x3p_grid" (XCD bands: 0 automatic, else 1 / 2 / 4 / 8 row bands), "gemm_x3p_noalign"
- *   attention: "attn_split", "attn_kv_planes" (0: the fp32 kernel splits K / V itself), "attn_z_force" (key slices, tests),
+ *   attention: "attn_split" (small grids: 0 plain 128-query workgroups, 1 64-query workgroups with the keys split between wave
+ *     pairs + key slices, 2 [default] fp32: 128-query workgroups + key slices, 16-bit as 1), "attn_kv_planes" (0: the fp32 kernel splits K / V itself), "attn_z_force" (key slices, tests),
  *     "attn_xcd_map" (1: a head's query tiles on one XCD; bit-identical either way)
  *   "gpt_mfma_min" (sentences from which mi_gpt_generate_batch runs its linears on MFMA; default 9)
  *   "bigvgan_streams" (default 3): the AMP blocks of a BigVGAN stage on side streams of the handle — 1: one stream; 2: only

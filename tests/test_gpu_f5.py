@@ -19,6 +19,8 @@ from oracle import f5_np as O
 
 pytestmark = pytest.mark.gpu
 
+ATTN_SPLIT_DEFAULT = 2          # mi_set_option("attn_split"): the library default (attention.hip g_attn_split)
+
 
 def rms(a):
     return float(np.sqrt(np.mean(np.square(np.asarray(a, dtype=np.float64)))))
@@ -233,7 +235,7 @@ def test_fp32_attention_split_products_match_native():
             cos, sin = O.rope_tables(N, 64)
             ref = O.dit_forward(cfg, st, noise, cmt, cmtd, tables[2][1], cos, sin)
             got = {}
-            for split in (1, 0):                               # 64-query key-split workgroups / the 128-query form of large batches
+            for split in (1, 2, 0):                            # 64-query key-split workgroups / 128-query + key slices / the 128-query form of large batches
                 _lib.set_option("attn_split", split)
                 for x3 in (2, 1, 0):
                     _lib.set_option("attn_f32_x3", x3)
@@ -243,15 +245,18 @@ def test_fp32_attention_split_products_match_native():
                 assert np.abs(got[1] - got[0]).max() < 5e-5 and np.abs(got[2] - got[0]).max() < 5e-5
     finally:
         _lib.set_option("attn_f32_x3", 2)
-        _lib.set_option("attn_split", 1)
+        _lib.set_option("attn_split", ATTN_SPLIT_DEFAULT)
         eng.close()
 
 
-@pytest.mark.parametrize("dtype,tol", [("f32", 3e-4), ("f16", 1.5e-2)])
-def test_attention_key_slices_agree(dtype, tol):
+@pytest.mark.parametrize("dtype,tol,split", [("f32", 3e-4, 1), ("f32", 3e-4, 2), ("f16", 1.5e-2, 1)])
+def test_attention_key_slices_agree(dtype, tol, split):
     """Key-sliced attention (gridDim.z slices of the 64-key stages, last-arriver merge in slice order): every slice count,
-    including slices that get no stage at all, gives the unsliced result within rounding and is identical run to run."""
+    including slices that get no stage at all, gives the unsliced result within rounding and is identical run to run.
+    split = 1: 64-query workgroups whose wave pairs share the keys; 2 (fp32 pairs kernel): 128-query workgroups, four
+    32-query groups per slice."""
     from mi355tts import _lib
+    _lib.set_option("attn_split", split)
     cfg = F5Config(dim=256, depth=1, heads=4, dim_head=64, text_dim=64, text_num_embeds=40, conv_layers=1,
                    pos_conv_groups=4, vocos_dim=64, vocos_intermediate=128, vocos_layers=1, nfe_step=4)
     raw = W.synth_state(W.f5_spec(cfg), 7)
@@ -280,6 +285,7 @@ def test_attention_key_slices_agree(dtype, tol):
                 assert np.abs(a - outs[0]).max() < (1e-4 if dtype == "f32" else 0.1)
     finally:
         _lib.set_option("attn_z_force", 0)
+        _lib.set_option("attn_split", ATTN_SPLIT_DEFAULT)
         eng.close()
 
 

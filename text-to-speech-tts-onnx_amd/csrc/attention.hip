@@ -610,8 +610,8 @@ __global__ __launch_bounds__(256, NP == 2 ? 3 : 2) void attn_x3f_kernel(const fl
     float m_run = -INFINITY, l_run = 0.f;
 
     const int nstage_all = (N + KT - 1) / KT;
-    const int st0 = SPLIT2 ? (int)((long)blockIdx.z * nstage_all / gridDim.z) : 0;
-    const int nstage = SPLIT2 ? (int)((long)(blockIdx.z + 1) * nstage_all / gridDim.z) : nstage_all;
+    const int st0 = (int)((long)blockIdx.z * nstage_all / gridDim.z);            // key slices (gridDim.z > 1): see the merge below
+    const int nstage = (int)((long)(blockIdx.z + 1) * nstage_all / gridDim.z);
     if (st0 < nstage) {
         load_regs(st0 * KT);
         store_lds();
@@ -722,13 +722,14 @@ __global__ __launch_bounds__(256, NP == 2 ? 3 : 2) void attn_x3f_kernel(const fl
         }
     }
     bool owner = true;                                              // this wave holds a finished 32-query result
+    constexpr int NG = SPLIT2 ? 2 : 4;                              // 32-query groups of the workgroup
+    int grp = wave;
+    float* comb = reinterpret_cast<float*>(smem);                   // [2 groups][32 accumulator registers][64 lanes] (SPLIT2 pair merge)
+    float* stats = comb + 2 * 32 * 64;                              // [2 groups][64 lanes][m, l]
     if constexpr (SPLIT2) {
         // ---- merge the two key halves: m = max(m0, m1) ; l = l0 2^(m0-m) + l1 2^(m1-m) ; O likewise ----------------------
         __syncthreads();                                            // every wave is done with the K / V stage
-        float* comb = reinterpret_cast<float*>(smem);               // [2 groups][32 accumulator registers][64 lanes]
-        float* stats = comb + 2 * 32 * 64;                          // [2 groups][64 lanes][m, l]
-        static_assert(sizeof(smem) >= (2 * 32 * 64 + 2 * 64 * 2 + 4) * sizeof(float), "merge buffer fits the stage");
-        const int grp = wave >> 1;
+        grp = wave >> 1;
         owner = !(wave & 1);
         if (!owner) {
             stats[(grp * 64 + lane) * 2] = m_run; stats[(grp * 64 + lane) * 2 + 1] = l_run;
@@ -750,6 +751,8 @@ __global__ __launch_bounds__(256, NP == 2 ? 3 : 2) void attn_x3f_kernel(const fl
 #pragma unroll
                 for (int r = 0; r < 16; ++r) oacc[dt][r] = oacc[dt][r] * s0 + comb[((grp * 2 + dt) * 16 + r) * 64 + lane] * s1;
         }
+    }
+    {
         // ---- key slices (gridDim.z > 1).  One utterance in fp32 is 18 x 32 = 576 of these workgroups on 768 slots (three per
         // CU): 2.25 per CU, so the CUs that got three set the makespan and a quarter of the chip idles.  With Z slices the
         // work comes in pieces of 1 / Z (Z = 4: exactly 9 per CU).  Every slice publishes (m, l, O) of its keys with
@@ -761,7 +764,7 @@ __global__ __launch_bounds__(256, NP == 2 ? 3 : 2) void attn_x3f_kernel(const fl
         if (Z > 1) {
             const int z = (int)blockIdx.z;
             const int unit = (int)(by_ * gridDim.x + bx_);
-            constexpr int SLOT = 2 * 32 * 64 + 2 * 64 * 2;           // floats per (unit, slice)
+            constexpr int SLOT = NG * (32 * 64 + 64 * 2);            // floats per (unit, slice)
             // write-through (sc1) stores / sc1 loads through a buffer descriptor, as in gemm_sk.hip: no L2-wide write-back fence
             typedef unsigned int u4 __attribute__((ext_vector_type(4)));
             typedef unsigned int u2 __attribute__((ext_vector_type(2)));
@@ -777,10 +780,10 @@ __global__ __launch_bounds__(256, NP == 2 ? 3 : 2) void attn_x3f_kernel(const fl
                         __builtin_amdgcn_raw_buffer_store_b128(val, rsw, (z * SLOT + (((grp * 2 + dt) * 4 + g4) * 64 + lane) * 4) * 4, 0, 16);
                     }
                 u2 st2; st2.x = __float_as_uint(m_run); st2.y = __float_as_uint(l_run);
-                __builtin_amdgcn_raw_buffer_store_b64(st2, rsw, (z * SLOT + 2 * 32 * 64 + (grp * 64 + lane) * 2) * 4, 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b64(st2, rsw, (z * SLOT + NG * 32 * 64 + (grp * 64 + lane) * 2) * 4, 0, 16);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            __syncthreads();                                         // (also: every wave is done with the K / V stage the ticket word lies in)
             int* ticket = reinterpret_cast<int*>(stats + 2 * 64 * 2);
             if (tid == 0) *ticket = __hip_atomic_fetch_add(cnt + unit, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
@@ -794,7 +797,7 @@ __global__ __launch_bounds__(256, NP == 2 ? 3 : 2) void attn_x3f_kernel(const fl
                 if (zz < Z) {
                     if (zz == z) { mz[zz] = m_run; lz[zz] = l_run; }
                     else {
-                        const u2 st2 = __builtin_amdgcn_raw_buffer_load_b64(rsw, (zz * SLOT + 2 * 32 * 64 + (grp * 64 + lane) * 2) * 4, 0, 16);
+                        const u2 st2 = __builtin_amdgcn_raw_buffer_load_b64(rsw, (zz * SLOT + NG * 32 * 64 + (grp * 64 + lane) * 2) * 4, 0, 16);
                         mz[zz] = __uint_as_float(st2.x); lz[zz] = __uint_as_float(st2.y);
                     }
                     M = fmaxf(M, mz[zz]);
@@ -871,7 +874,7 @@ __global__ __launch_bounds__(256, NP == 2 ? 3 : 2) void attn_x3f_kernel(const fl
 // V then arrives transposed like in the 16-bit engines: attention_v_ld() tells the QKV epilogue)
 static std::atomic<int> g_attn_x3 = 2;
 static std::atomic<int> g_attn_np = 2;                                // format of the pre-split K / V^T (and of Q / P inside the kernel): 2 fp16 pairs | 3 bf16 planes
-static std::atomic<int> g_attn_split = 1;                             // 64-query workgroups with the keys split between wave pairs when the grid is small
+static std::atomic<int> g_attn_split = 2;                             // small grids: 1 = 64-query workgroups with the keys split between wave pairs (+ key slices) ; 2 = fp32 pairs kernel: 128-query workgroups + key slices
 static std::atomic<int> g_attn_zmax = 4, g_attn_z16 = 1, g_attn_zforce = 0;      // zforce (tests): exactly that many slices, even empty ones
 static std::atomic<int> g_attn_xmap = 1;                              // XCD-aware (query tile, head) map of the workgroup ids (A/B: attn_xcd_map; -1 % per launch, bit-neutral)
 static std::atomic<int> g_attn_kvp = 1;                               // fp32, both products split: K / V^T pre-split by the QKV epilogue (A/B: attn_kv_planes)
@@ -900,7 +903,7 @@ bool attn_set_option(const char* key, long v) {
     attn_env_once();
     const std::string k(key);
     if (k == "attn_f32_x3") g_attn_x3 = (int)std::max(0L, std::min(2L, v));
-    else if (k == "attn_split") g_attn_split = v != 0;
+    else if (k == "attn_split") g_attn_split = (int)std::max(0L, std::min(2L, v));
     else if (k == "attn_xcd_map") g_attn_xmap = v != 0;
     else if (k == "attn_kv_planes") g_attn_kvp = v != 0;
     else if (k == "attn_f32_planes") { if (v != 2 && v != 3) return false; g_attn_np = (int)v; }
@@ -945,8 +948,9 @@ void launch_attention(const void* q, const void* k, const void* v, void* o, int 
     // workgroup, + 6 % per extra slice for the prologue and the merge (measured, fp32, one utterance = 576 units:
     // Z = 1 / 2 / 3 / 4 -> 135 / 122 / 121 / 126 us in round 2; 62.1 / 58.8 / 60.8 / 60.7 us with the fp16-pair kernel of
     // round 3, whose slices are shorter against the same merge: + 9 % for fp32)
-    auto pick_z = [&](int zlimit16) -> int {
-        const long units = (long)((N + 63) / 64) * BH;
+    auto pick_z = [&](int zlimit16, bool wide = false) -> int {
+        const long units = (long)(wide ? (N + 127) / 128 : (N + 63) / 64) * BH;
+        const long slot = wide ? 4 * (32 * 64 + 64 * 2) : 2 * 32 * 64 + 2 * 64 * 2;
         const int nstage = (N + 63) / 64;
         int dev = 0, cus = 256;
         MI_HIP(hipGetDevice(&dev));
@@ -956,12 +960,12 @@ void launch_attention(const void* q, const void* k, const void* v, void* o, int 
             cus = cu_count[dev & 15];
         }
         if (g_attn_zforce > 0)
-            return (ws && cnt && units * g_attn_zforce * (2 * 32 * 64 + 2 * 64 * 2) <= ws_floats && units <= cnt_n) ? (int)g_attn_zforce : 1;
+            return (ws && cnt && units * g_attn_zforce * slot <= ws_floats && units <= cnt_n) ? (int)g_attn_zforce : 1;
         int Z = 1;
         double best = 1e30;
         const int zm = dtype == MI_F32 ? zmax : std::min(zmax, zlimit16);
         for (int z = 1; z <= zm; ++z) {
-            if (z > 1 && (!ws || !cnt || units * z * (2 * 32 * 64 + 2 * 64 * 2) > ws_floats || units > cnt_n || nstage < 2 * z)) break;
+            if (z > 1 && (!ws || !cnt || units * z * slot > ws_floats || units > cnt_n || nstage < 2 * z)) break;
             const double cost = (double)((units * z + cus - 1) / cus) / z * (1.0 + (dtype == MI_F32 ? 0.09 : 0.06) * (z - 1));
             if (cost < best - 1e-9) { best = cost; Z = z; }
         }
@@ -969,11 +973,18 @@ void launch_attention(const void* q, const void* k, const void* v, void* o, int 
     };
     const int z16 = g_attn_z16;
     if (dtype == MI_F32) {
-        // few 128-query workgroups (one or two utterances): halve them along the keys, see attn_kernel
+        // few 128-query workgroups (one or two utterances): halve them along the keys, see attn_kernel — or (attn_split = 2, the
+        // default for the pre-split fp16-pair kernel, round 4) keep the 128-query workgroups, whose four waves share every K / V
+        // stage and multiply two tiles per barrier pair, and cut only the key range into slices: 288 x 3 workgroups for one
+        // utterance, 56.3 against 60.0 us per launch on the same box (step 177.8 -> 174.3 ms)
         if (g_attn_split && (long)((N + 127) / 128) * BH < 1024 && N >= 64) {
             // ... and cut the key range into Z slices when that evens out the workgroups per CU
-            const int Z = pick_z(1);
-            if (opt_attn_x3() == 2) {
+            const bool wide = g_attn_split == 2 && opt_attn_x3() == 2 && kv_planes == 2;
+            const int Z = pick_z(1, wide);
+            if (wide) {
+                prof_set_kernel("attn_x3f_kernel<false, pre-split K V, fp16 pairs> + key slices", "", "");
+                hipLaunchKernelGGL((attn_x3f_kernel<false, true, 2>), dim3((N + 127) / 128, BH, Z), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt, (unsigned char*)o_planes, o_np, xm);
+            } else if (opt_attn_x3() == 2) {
                 if (kv_planes == 2) {
                     prof_set_kernel("attn_x3f_kernel<true, pre-split K V, fp16 pairs>", "", "");
                     hipLaunchKernelGGL((attn_x3f_kernel<true, true, 2>), dim3((N + 63) / 64, BH, Z), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt, (unsigned char*)o_planes, o_np, xm);
