@@ -684,25 +684,33 @@ __global__ __launch_bounds__(256, NP == 2 ? 3 : 2) void attn_x3f_kernel(const fl
                 else
                     split8p(float4{p[8 * s2], p[8 * s2 + 1], p[8 * s2 + 2], p[8 * s2 + 3]},
                             float4{p[8 * s2 + 4], p[8 * s2 + 5], p[8 * s2 + 6], p[8 * s2 + 7]}, pf[0], pf[1]);
+                // the two head-dim halves alternate: an MFMA that waits for the previous one's accumulator costs 52 cycles instead
+                // of 32 (tools/ubench/mfma_valu_coexec.hip); the order inside each accumulator is unchanged (bit-identical).
+                // (The same for the two score tiles of a stage in the 128-query form was measured too: 27 spilled registers and
+                // the stage loads issued one tile later cost more than the chains gain, 56.9 -> 70.8 us.)
+                Frag vf[2][NP];
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    Frag vf[NP];
+                for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
                     for (int pl = 0; pl < NP; ++pl) {
                         const bf16* row = Vs + pl * VPL + (dt * 32 + lr) * LDV + kt * 32 + 16 * s2 + 4 * hi;
                         uint2 a2[2];
                         a2[0] = *reinterpret_cast<const uint2*>(row);
                         a2[1] = *reinterpret_cast<const uint2*>(row + 8);
-                        vf[pl] = __builtin_bit_cast(Frag, x3_u4{a2[0].x, a2[0].y, a2[1].x, a2[1].y});
+                        vf[dt][pl] = __builtin_bit_cast(Frag, x3_u4{a2[0].x, a2[0].y, a2[1].x, a2[1].y});
                     }
-                    if constexpr (NP == 3) {
+                if constexpr (NP == 3) {
 #pragma unroll
-                        for (int t = 0; t < 6; ++t) oacc[dt] = MF::mma(vf[TA[t]], pf[TB[t]], oacc[dt]);
-                    } else {
-                        oacc[dt] = MF::mma(vf[1], pf[0], oacc[dt]);
-                        oacc[dt] = MF::mma(vf[0], pf[1], oacc[dt]);
-                        oacc[dt] = MF::mma(vf[0], pf[0], oacc[dt]);
-                    }
+                    for (int t = 0; t < 6; ++t)
+#pragma unroll
+                        for (int dt = 0; dt < 2; ++dt) oacc[dt] = MF::mma(vf[dt][TA[t]], pf[TB[t]], oacc[dt]);
+                } else {
+                    oacc[0] = MF::mma(vf[0][1], pf[0], oacc[0]);
+                    oacc[1] = MF::mma(vf[1][1], pf[0], oacc[1]);
+                    oacc[0] = MF::mma(vf[0][0], pf[1], oacc[0]);
+                    oacc[1] = MF::mma(vf[1][0], pf[1], oacc[1]);
+                    oacc[0] = MF::mma(vf[0][0], pf[0], oacc[0]);
+                    oacc[1] = MF::mma(vf[1][0], pf[0], oacc[1]);
                 }
             }
         };
