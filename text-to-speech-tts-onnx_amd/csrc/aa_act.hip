@@ -141,7 +141,10 @@ __global__ __launch_bounds__(256) void aa_act_kernel(const T* __restrict__ x, T*
 
 template <typename T>
 static void launch_t(const AAAct& p, hipStream_t s) {
-    constexpr int R = 16;
+    // run length per work item.  16-bit storage: 8 (152 VGPRs = three waves per SIMD; with 16 the kernel holds 204 = two, and a
+    // single wave issues at most one VALU instruction per 8 cycles, tools/ubench/mfma_valu_coexec.hip: 44.5 -> 42.6 us per launch
+    // although a run of 8 recomputes more of the up-sampled halo); fp32: 16
+    constexpr int R = sizeof(T) == 2 ? 8 : 16;
     constexpr int VEC = 16 / (int)sizeof(T);
     MI_REQUIRE(p.C % VEC == 0, "aa_act: C must be a multiple of the 16-byte vector");
     int CT = p.C;
