@@ -461,6 +461,13 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const T* __restrict__ q, c
 // operands of attention are of order one, their residuals stay above fp16's subnormal floor where it matters) and Q / P are
 // split the same way: three partial products per block, small terms first, into the one accumulator — half the MFMAs of the
 // three-plane form, 4 instead of 6 bytes per K / V element, no second accumulator set.
+#if defined(MI355TTS_ATTN_TRACE)      // tuning only: s_memtime stamps at the phase boundaries of one wave (tools/dbg/attn_trace.sh)
+#define TSTAMP(v) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define TACC(k, t1, t0) tr_[k] += (t1) - (t0)
+#else
+#define TSTAMP(v) do { } while (0)
+#define TACC(k, t1, t0) do { } while (0)
+#endif
 template <bool SPLIT2, bool KVP = false, int NP = 3>
 __global__ __launch_bounds__(256, NP == 2 ? 3 : 2) void attn_x3f_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                        const float* __restrict__ v, float* __restrict__ o, int H, int N,
@@ -608,6 +615,10 @@ __global__ __launch_bounds__(256, NP == 2 ? 3 : 2) void attn_x3f_kernel(const fl
 #pragma unroll
     for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.f; oacc[1][r] = 0.f; }
     float m_run = -INFINITY, l_run = 0.f;
+#if defined(MI355TTS_ATTN_TRACE)
+    unsigned long long tr_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ta_ = 0, tb_ = 0, tc_ = 0, td_ = 0, te_ = 0, tk_ = 0;
+    TSTAMP(tk_);
+#endif
 
     const int nstage_all = (N + KT - 1) / KT;
     const int st0 = (int)((long)blockIdx.z * nstage_all / gridDim.z);            // key slices (gridDim.z > 1): see the merge below
@@ -622,6 +633,7 @@ __global__ __launch_bounds__(256, NP == 2 ? 3 : 2) void attn_x3f_kernel(const fl
         if (st + 1 < nstage) load_regs((st + 1) * KT);
         auto tile = [&](int kt) {
             const int key0 = st * KT + kt * 32;
+            TSTAMP(ta_);
             // ---- S^T tile: 32 keys x 32 queries, six partial products per k16 step ---------------------------------------
             f32x16 sacc;
 #pragma unroll
@@ -652,6 +664,10 @@ __global__ __launch_bounds__(256, NP == 2 ? 3 : 2) void attn_x3f_kernel(const fl
 #pragma unroll
             for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, sacc[r]);
             mloc = xor32_max(mloc);
+#if defined(MI355TTS_ATTN_TRACE)
+            { const float keep_ = mloc; asm volatile("" :: "v"(keep_)); }
+#endif
+            TSTAMP(tb_); TACC(0, tb_, ta_);            // K fragment reads + score MFMAs + tile maximum
             float alpha = 1.f;
             if (!__all(mloc - m_run <= 8.0f)) {
                 const float m_new = fmaxf(m_run, mloc);
@@ -674,6 +690,10 @@ __global__ __launch_bounds__(256, NP == 2 ? 3 : 2) void attn_x3f_kernel(const fl
             float lsum = ls2.x + ls2.y;
             lsum = xor32_sum(lsum);
             l_run = l_run * alpha + lsum;
+#if defined(MI355TTS_ATTN_TRACE)
+            { const float keep_ = l_run + p[0] + p[15]; asm volatile("" :: "v"(keep_)); }
+#endif
+            TSTAMP(tc_); TACC(1, tc_, tb_);            // exponentials + row sum
             // ---- O^T += V^T P^T: the probabilities a lane holds are the B operand (keys in accumulator-row order) ------------
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
@@ -713,6 +733,7 @@ __global__ __launch_bounds__(256, NP == 2 ? 3 : 2) void attn_x3f_kernel(const fl
                     oacc[1] = MF::mma(vf[1][0], pf[0], oacc[1]);
                 }
             }
+            TSTAMP(td_); TACC(2, td_, tc_);            // P split + V fragment reads + P V MFMAs (issued)
         };
         if constexpr (SPLIT2) {
             if (st * KT + (wave & 1) * 32 < N) tile(wave & 1);
@@ -723,12 +744,22 @@ __global__ __launch_bounds__(256, NP == 2 ? 3 : 2) void attn_x3f_kernel(const fl
                 if (key0 < N) tile(kt);
             }
         }
+        TSTAMP(ta_);
         __syncthreads();
+        TSTAMP(tb_); TACC(3, tb_, ta_);                // barrier 1 (includes the tail of the P V MFMAs)
         if (st + 1 < nstage) {
             store_lds();
+            TSTAMP(tc_); TACC(4, tc_, tb_);            // wait for the stage loads + LDS stores
             __syncthreads();
+            TSTAMP(te_); TACC(5, te_, tc_);            // barrier 2
         }
     }
+#if defined(MI355TTS_ATTN_TRACE)
+    TSTAMP(te_);
+    if (blockIdx.x == 3 && blockIdx.y == 5 && (threadIdx.x & 63) == 0)
+        printf("ATTN_TRACE z %d wave %d stages %d total %llu | S+max %llu exp %llu PV %llu bar1 %llu store %llu bar2 %llu\n", (int)blockIdx.z, wave, nstage - st0,
+               te_ - tk_, tr_[0], tr_[1], tr_[2], tr_[3], tr_[4], tr_[5]);
+#endif
     bool owner = true;                                              // this wave holds a finished 32-query result
     constexpr int NG = SPLIT2 ? 2 : 4;                              // 32-query groups of the workgroup
     int grp = wave;
