@@ -235,7 +235,10 @@ void        mi_indextts_cond_destroy(mi_cond* h);
 int         mi_indextts_cond_run(mi_cond* h, const int16_t* audio, int64_t L, float* conds, float* conds_latent, float* mel,
                                  int mem);
 
-/* Process-wide tuning / A-B switches (tools, tests).  The arithmetic of an fp32 F5 engine is NOT one of them any more: it is a
+/* Process-wide tuning / A-B switches (tools, tests).  Thread safety: every other entry point of this header runs under the shared side of
+ * one reader-writer lock and mi_set_option under its exclusive side — a change waits for the calls in flight on other threads and is
+ * seen as a whole by the calls that start after it; it never alters the dispatch of a call that is running.
+ *  The arithmetic of an fp32 F5 engine is NOT one of them any more: it is a
  * property of the engine (config int 21, F5Config.f32_arithmetic; mi_f5_info reports what runs) — the four arithmetic keys below
  * only set the default of engines created without one.
  *   arithmetic defaults: "gemm_f32_x3" (1: fp32 linear layers from 16-bit partial products, 0: native v_mfma_f32_32x32x2_f32),

@@ -226,3 +226,75 @@ def test_device_blob_broadcast_in_place_and_job_level_utterance_slices():
     # all 64 utterances of the 8-GPU job are distinct and covered exactly once
     cover = [i for r in range(8) for i in range(*S.shard_range(64, 8, r))]
     assert cover == list(range(64))
+
+
+def _world8_worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "text-to-speech-tts-onnx_amd")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench_common as C
+    from mi355tts.config import F5Config
+    cfg = F5Config.small()
+    # the one collective of the path: the packed blob, rank 0 -> all, in place on the tensor the engine is created from
+    raw = W.synth_state(W.f5_spec(cfg), 9527) if rank == 0 else None
+    nparam = sum(int(np.prod(sh)) for _, sh, _ in W.f5_packed_spec(cfg))
+    blob_t = torch.from_numpy(W.pack_f5(cfg, raw)) if rank == 0 else torch.empty(nparam, dtype=torch.float32)
+    got = C.bcast_device_blob(torch, dist, blob_t)
+    same_tensor = got.data_ptr() == blob_t.data_ptr()
+    checksum = float(blob_t.double().abs().sum())
+    # configs[3]: 64 utterances, 8 per rank, cut from ONE job-level list exactly as bench.F5Bench.measure does
+    U = 8
+    lo, hi = S.shard_range(world * U, world, rank)
+    _, _, N, noise = W.f5_synthetic_inputs(cfg, U, rank, L=8192, first=lo)
+    dt = 0.100 + 0.001 * rank                                   # a stand-in for this rank's timed region (seconds)
+    rank_dt = C.per_rank_times(torch, dist, world, dt, "cpu")
+    mx = C.max_over_ranks(torch, dist, world, dt, "cpu")
+    info = [None] * world
+    dist.all_gather_object(info, (lo, hi, float(noise[0, 0, 0]), float(noise[-1, 0, 0]), checksum, bool(same_tensor)))
+    if rank == 0:
+        steps, audio_s = 1, U * 1.0
+        line = {"metric": "audio_seconds_per_second", "value": world * audio_s * steps / mx, "unit": "audio-s/s", "n_gpus": world,
+                "steps": steps, "warmup": 0, "ms_per_step": mx / steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                "config": {"workload": C.f5_workload_name("bf16", U, N), "utterances_per_gpu": U, "utterances_total": world * U,
+                           "utterance_seeds": [9527, 9527 + world * U - 1], "per_rank_ms": [t / steps * 1e3 for t in rank_dt],
+                           "rank_devices": [f"host:0000:{i:02x}:00.0" for i in range(world)], "collective_backend": dist.get_backend()},
+                "roofline": None}
+        q.put((info, rank_dt, mx, C.compact_line(line)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_world8_configs3_partition_broadcast_and_line():
+    """configs[3] at its stated width on CPU: EIGHT gloo ranks — 64 job-level seeds -> 8 x 8 contiguous slices,
+    the device-form blob broadcast in place, the per-rank / max-over-ranks reductions bench.py uses, and the compact line with
+    eight per-rank entries — so the first run on an 8-GPU node is not also the first run of world = 8."""
+    import json
+    world, port = 8, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_world8_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    info, rank_dt, mx, line = q.get(timeout=500)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [(i[0], i[1]) for i in info] == [(8 * r, 8 * r + 8) for r in range(8)]
+    assert len({i[4] for i in info}) == 1 and all(i[5] for i in info)          # same weights everywhere, filled in place
+    from mi355tts.config import F5Config
+    cfg = F5Config.small()
+    N = W.f5_synthetic_inputs(cfg, 1, 0, L=8192)[2]
+    for r, i in enumerate(info):                                               # rank r's first / last utterance = job utterances 8 r / 8 r + 7
+        assert i[2] == float(W.synth_normal(9527 + 8 * r, "noise", (N, cfg.mel_dim))[0, 0])
+        assert i[3] == float(W.synth_normal(9527 + 8 * r + 7, "noise", (N, cfg.mel_dim))[0, 0])
+    assert len(rank_dt) == 8 and rank_dt == pytest.approx([0.100 + 0.001 * r for r in range(8)]) and mx == pytest.approx(0.107)
+    s = json.dumps(line, allow_nan=False)
+    assert len(s) < 4096
+    assert line["n_gpus"] == 8 and line["config"]["utterances_total"] == 64 and line["config"]["utterance_seeds"] == [9527, 9590]
+    assert len(line["config"]["per_rank_ms"]) == 8 and len(line["config"]["rank_devices"]) == 8
+    assert max(line["config"]["per_rank_ms"]) == pytest.approx(line["ms_per_step"]) and line["config"]["collective_backend"] == "gloo"
+    assert line["value"] == pytest.approx(64.0 / 0.107)

@@ -369,3 +369,111 @@ def test_example_script_runs(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     wav, rate = audio_io.read_wav(out)
     assert rate == 24000 and wav.shape[1] == 1 and wav.shape[0] > 1000 and "RTF" in r.stdout
+
+
+def _f5_sessions(tmp_path, cfg, dtype="f32"):
+    wfile = tmp_path / "f5_weights.npy"
+    np.save(wfile, W.pack_f5(cfg, W.synth_state(W.f5_spec(cfg), 9527)))
+    paths = {k: onnxruntime.save_model(str(tmp_path / f"{k}.mi355.json"), k, cfg, str(wfile), dtype)
+             for k in ("F5_Preprocess", "F5_Transformer", "F5_Decode")}
+    return [onnxruntime.InferenceSession(paths[k]) for k in ("F5_Preprocess", "F5_Transformer", "F5_Decode")]
+
+
+def test_f5_driver_io_binding_branch_device_resident(tmp_path, golden_dir):
+    """The reference's `if device_type:` branch (F5-TTS-ONNX-Inference.py:256-288), line for line: graph A's outputs become
+    DEVICE OrtValues (`ortvalue_from_numpy(x, 'cuda', DEVICE_ID)`), outputs 0 / 1 of graph B are bound onto inputs 0 / 7, the
+    loop is `run_with_iobinding`, the result comes back with `OrtValue.numpy(io_binding.get_outputs()[0])`.  The façade keeps
+    those values in HBM and hands device pointers to the C-ABI (round 5; the round-4 OrtValue was a host array whatever the
+    device type).  Against the fixture AND bit-equal to the host-numpy loop."""
+    import torch
+    g = np.load(os.path.join(golden_dir, "f5_small.npz"))
+    cfg = F5Config.small()
+    ort_session_A, ort_session_B, ort_session_C = _f5_sessions(tmp_path, cfg)
+    in_A, out_A = [a.name for a in ort_session_A.get_inputs()], [a.name for a in ort_session_A.get_outputs()]
+    in_name_B, out_name_B = ort_session_B.get_inputs(), ort_session_B.get_outputs()
+    NFE_STEP, FUSE_NFE, DEVICE_ID, device_type = cfg.nfe_step, 1, 0, "cuda"
+    audio = g["pre_audio"].reshape(1, 1, -1)
+    text_ids = g["pre_text_ids"].reshape(1, -1)
+    max_duration = np.array([int(g["pre_N"])], dtype=np.int64)
+    time_step = np.array([0], dtype=np.int32)
+    noise, rope_cos_q, rope_sin_q, rope_cos_k, rope_sin_k, cat_mel_text, cat_mel_text_drop, ref_signal_len = ort_session_A.run(
+        out_A, {in_A[0]: audio, in_A[1]: text_ids, in_A[2]: max_duration})
+    noise = g["dit_noise"][None].copy()                          # the fixture's noise from here on
+    host_noise, host_ts = noise.copy(), time_step.copy()
+    inputs = [
+        onnxruntime.OrtValue.ortvalue_from_numpy(noise, device_type, DEVICE_ID),
+        onnxruntime.OrtValue.ortvalue_from_numpy(rope_cos_q, device_type, DEVICE_ID),
+        onnxruntime.OrtValue.ortvalue_from_numpy(rope_sin_q, device_type, DEVICE_ID),
+        onnxruntime.OrtValue.ortvalue_from_numpy(rope_cos_k, device_type, DEVICE_ID),
+        onnxruntime.OrtValue.ortvalue_from_numpy(rope_sin_k, device_type, DEVICE_ID),
+        onnxruntime.OrtValue.ortvalue_from_numpy(cat_mel_text, device_type, DEVICE_ID),
+        onnxruntime.OrtValue.ortvalue_from_numpy(cat_mel_text_drop, device_type, DEVICE_ID),
+        onnxruntime.OrtValue.ortvalue_from_numpy(time_step, device_type, DEVICE_ID)
+    ]
+    assert all(v.is_device() and v.device_name() == "cuda" for v in inputs)
+    assert inputs[1].shape() == list(rope_cos_q.shape) and inputs[3].shape() == list(rope_cos_k.shape)
+    assert inputs[1]._t.untyped_storage().nbytes() == rope_cos_q.shape[2] * rope_cos_q.shape[3] * 4     # the broadcast axes did not cross PCIe
+    outputs = [inputs[0], inputs[-1]]
+    io_binding = ort_session_B.io_binding()
+    for i in range(len(inputs)):
+        io_binding.bind_ortvalue_input(name=in_name_B[i].name, ortvalue=inputs[i])
+    for i in range(len(outputs)):
+        io_binding.bind_ortvalue_output(name=out_name_B[i].name, ortvalue=outputs[i])
+    ptr0 = inputs[0].data_ptr()
+    for i in range(0, NFE_STEP - 1, FUSE_NFE):
+        ort_session_B.run_with_iobinding(io_binding)
+    assert io_binding.get_outputs()[0] is inputs[0] and inputs[0].data_ptr() == ptr0          # advanced in place, as bound
+    assert int(onnxruntime.OrtValue.numpy(io_binding.get_outputs()[1])[0]) == NFE_STEP - 1
+    assert int(inputs[-1]._t.cpu()[0]) == NFE_STEP - 1                                       # the device value itself, not just the mirror
+    noise_dev = onnxruntime.OrtValue.numpy(io_binding.get_outputs()[0])
+    # the `else:` branch on the same inputs (host numpy through run): same engine, same steps -> the same bits
+    for i in range(0, NFE_STEP - 1, FUSE_NFE):
+        host_noise, host_ts = ort_session_B.run([out_name_B[0].name, out_name_B[1].name], {
+            in_name_B[0].name: host_noise, in_name_B[1].name: rope_cos_q, in_name_B[2].name: rope_sin_q, in_name_B[3].name: rope_cos_k,
+            in_name_B[4].name: rope_sin_k, in_name_B[5].name: cat_mel_text, in_name_B[6].name: cat_mel_text_drop, in_name_B[7].name: host_ts})
+    assert np.array_equal(noise_dev, host_noise)
+    generated_signal = ort_session_C.run([ort_session_C.get_outputs()[0].name], {
+        ort_session_C.get_inputs()[0].name: noise_dev, ort_session_C.get_inputs()[1].name: ref_signal_len})[0]
+    err = np.sqrt(np.mean(((generated_signal[0, 0].astype(np.float64) - g["e2e_i16"]) / 32767.0) ** 2))
+    assert err < 5e-4, err
+    # run_with_ort_values on device values without bound outputs: the inputs stay untouched, the outputs are new device values
+    fresh = onnxruntime.OrtValue.ortvalue_from_numpy(g["dit_noise"][None].copy(), device_type, DEVICE_ID)
+    ts0 = onnxruntime.OrtValue.ortvalue_from_numpy(np.array([0], dtype=np.int32), device_type, DEVICE_ID)
+    feed = {in_name_B[i].name: inputs[i] for i in range(1, 7)}
+    feed[in_name_B[0].name], feed[in_name_B[7].name] = fresh, ts0
+    den, ts1 = ort_session_B.run_with_ort_values([o.name for o in out_name_B], feed)
+    assert den.is_device() and den is not fresh and np.array_equal(fresh.numpy(), g["dit_noise"][None])
+    assert int(ts1.numpy()[0]) == 1 and int(ts0.numpy()[0]) == 0
+    one_host, _ = ort_session_B.run([o.name for o in out_name_B], {
+        in_name_B[0].name: g["dit_noise"][None].copy(), in_name_B[1].name: rope_cos_q, in_name_B[2].name: rope_sin_q,
+        in_name_B[3].name: rope_cos_k, in_name_B[4].name: rope_sin_k, in_name_B[5].name: cat_mel_text,
+        in_name_B[6].name: cat_mel_text_drop, in_name_B[7].name: np.array([0], dtype=np.int32)})
+    assert np.array_equal(den.numpy(), one_host)
+    # a RoPE value that is not graph A's table is refused on the device path too; wrong dtype as well
+    bad = dict(feed)
+    bad[in_name_B[1].name] = onnxruntime.OrtValue.ortvalue_from_numpy(np.ascontiguousarray(rope_cos_q) * 0.5, device_type, DEVICE_ID)
+    with pytest.raises(onnxruntime.InvalidArgument):
+        ort_session_B.run_with_ort_values(None, bad)
+    bad = dict(feed)
+    bad[in_name_B[0].name] = onnxruntime.OrtValue._from_tensor(fresh._t.double())
+    with pytest.raises(onnxruntime.InvalidArgument):
+        ort_session_B.run_with_ort_values(None, bad)
+    del torch
+
+
+def test_bigvgan_run_with_ort_values_on_a_device_value(tmp_path, golden_dir):
+    """Export_BigVGAN.py:160-170 with device_type = 'cuda': the dummy mel is a device OrtValue, the waveform comes back as one."""
+    g = np.load(os.path.join(golden_dir, "bigvgan_small.npz"))
+    cfg = BigVGANConfig.small()
+    wfile = tmp_path / "bv.npy"
+    np.save(wfile, W.pack_bigvgan(cfg, W.synth_state(W.bigvgan_spec(cfg), 9527)))
+    path = onnxruntime.save_model(str(tmp_path / "BigVGAN.mi355.json"), "BigVGAN", cfg, str(wfile), "f32")
+    ort_session_A = onnxruntime.InferenceSession(path, sess_options=onnxruntime.SessionOptions(), providers=[], provider_options=None)
+    test_dummy = onnxruntime.OrtValue.ortvalue_from_numpy(np.ones((1, ort_session_A._inputs_meta[0].shape[1], 12), dtype=np.float32), "cuda", 0)
+    output = ort_session_A.run_with_ort_values([ort_session_A.get_outputs()[0].name], {ort_session_A.get_inputs()[0].name: test_dummy})
+    assert output[0].is_device() and output[0].data_type() == "tensor(int16)"
+    w = onnxruntime.OrtValue.numpy(output[0])
+    assert np.abs(w.astype(np.int32) - g["gen_i16_ones"].astype(np.int32)).max() <= 1
+    host = ort_session_A.run_with_ort_values([ort_session_A.get_outputs()[0].name], {
+        ort_session_A.get_inputs()[0].name: onnxruntime.OrtValue.ortvalue_from_numpy(np.ones((1, cfg.num_mels, 12), dtype=np.float32), "cpu", 0)})
+    assert np.array_equal(host[0].numpy(), w)

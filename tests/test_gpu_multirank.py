@@ -40,6 +40,8 @@ def test_bench_two_ranks_on_one_gpu_equals_single_process(tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout                                   # exactly one JSON line, from rank 0
+    assert r.stdout.strip() == lines[0] and len(lines[0]) < 4096       # round 5: stdout is that line and nothing else, compact
+    assert "BENCH_DETAIL {" in r.stderr                                # the full record travels on stderr / bench_detail.json
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0 and line["dtype"] == "f32"
     assert "PLUMBING TEST ONLY" in line["config"]["workload"] and line["config"]["utterances_per_gpu"] == 3

@@ -301,8 +301,8 @@ static void launch_t(const AAConv& q, hipStream_t s) {
 #define LAUNCH(BMv, TNv)                                                                                         \
     do {                                                                                                         \
         auto kfn = aa_conv_kernel<T, BMv, TNv>;                                                                  \
-        static bool big_lds = false;           /* once per instantiation: allow the whole 160 KB */                 \
-        if (lds > 64 * 1024 && !big_lds) { MI_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); big_lds = true; } \
+        /* the opt-in is per DEVICE and cheap: set whenever needed (a process-wide flag would skip device 1) */ \
+        if (lds > 64 * 1024) MI_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
         prof_set_kernel("aa_conv_kernel<T, " #BMv ", " #TNv ">", type_label<T>());                                \
         hipLaunchKernelGGL(kfn, grid, dim3(256), lds, s, d);                                                     \
     } while (0)

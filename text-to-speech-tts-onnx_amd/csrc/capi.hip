@@ -17,8 +17,15 @@ struct mi_f5 { F5* impl; std::mutex mu; };
 struct mi_gpt { Gpt* impl; std::mutex mu; };
 struct mi_cond { Cond* impl; std::mutex mu; };
 
-template <typename F> static int guard(F&& f) {
+// Every C-ABI entry runs under the SHARED side of the option lock; mi_set_option takes the exclusive side.  The dispatch options
+// stay process-wide (tools, A/B runs, tests), but a change can never land in the middle of a call on another thread: it waits for
+// the calls in flight, and calls that start afterwards see the whole new table (the header's promise that
+// different handles may be driven from different threads holds with mi_set_option in the picture).
+template <typename F> static int guard(F&& f, bool exclusive = false) {
     try {
+        std::shared_lock<std::shared_mutex> rd(option_lock(), std::defer_lock);
+        std::unique_lock<std::shared_mutex> wr(option_lock(), std::defer_lock);
+        if (exclusive) wr.lock(); else rd.lock();
         f();
         return MI_OK;
     } catch (const mi::Error& e) {
@@ -42,6 +49,14 @@ template <typename F> static void f5_run_checked(F5& e, F&& body) {
         ++e.sat_events;
         e.set_arith(ARITH_BF16X3);
         ArithScope sc(e.arith);          // (the caller's scope still holds the pair override)
+        body();
+        (void)e.take_saturation();
+    } else if (e.dtype == MI_F16 && e.fold_built && e.cfg.ln_fold != 0 && e.take_saturation()) {
+        // f16 engine: the AdaLN fold's A operand (the unnormalised residual row o (1 + scale)) left the fp16 range — the row-norm
+        // path's operand LN(x) (1 + scale) + shift is bounded by the norm: fold off for this engine, permanently, and run again
+        ++e.sat_events;
+        e.cfg.ln_fold = 0;
+        e.drop_graphs();
         body();
         (void)e.take_saturation();
     }
@@ -263,7 +278,7 @@ int64_t mi_f5_info(mi_f5* h, const char* key) {
         const std::string k(key);
         if (k == "f32_arithmetic") v = e.dtype != MI_F32 ? -1 : !gemm_x3_enabled() ? ARITH_NATIVE : (gemm_x3p_enabled() ? e.np : ARITH_BF16X3);
         else if (k == "saturation_events") v = e.sat_events;
-        else if (k == "adaln_fold") v = e.fold_built ? 1 : 0;
+        else if (k == "adaln_fold") v = (e.fold_built && e.cfg.ln_fold != 0) ? 1 : 0;
         else MI_REQUIRE(false, "mi_f5_info: unknown key");
     });
     return rc == MI_OK ? v : (int64_t)rc;
@@ -818,7 +833,7 @@ int mi_set_option(const char* key, int64_t value) {
         MI_REQUIRE(gemm_set_option(key, (long)value) || gpt_set_option(key, (long)value) || aa_conv_set_option(key, (long)value) ||
                        attn_set_option(key, (long)value) || bigvgan_set_option(key, (long)value), "mi_set_option: unknown key");
         option_epoch_bump();
-    });
+    }, /*exclusive=*/true);
 }
 
 int mi_device_pci_bus_id(int device, char* buf, int cap) {

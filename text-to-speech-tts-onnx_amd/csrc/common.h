@@ -10,6 +10,7 @@
 #include <vector>
 #include <stdexcept>
 #include <map>
+#include <shared_mutex>
 
 #include "../../include/mi355tts.h"
 
@@ -26,6 +27,8 @@ void set_last_error(const std::string& m);
 // bumped by every mi_set_option: handles drop their captured hipGraphs when it moved (a graph bakes the dispatch in)
 long option_epoch();
 void option_epoch_bump();
+// shared: every C-ABI call; exclusive: mi_set_option (capi.hip guard)
+std::shared_mutex& option_lock();
 
 #define MI_HIP(expr)                                                                              \
     do {                                                                                          \
@@ -177,7 +180,7 @@ struct ConvGemm {
     // u = LN(x) * (1 + sc) + sh through W is  rstd * W(x o (1 + sc)) - rstd * mean * (W (1 + sc)) + (W sh + b): the LayerNorm
     // never needs a pass of its own.  PRODUCER (the O / FF2 projections: res + gate epilogue, fp32 rows out): after
     // x_new = res + gate * (acc + bias) it also writes  ln_out = x_new o (1 + ln_scale)  — panel planes of ln_out_np planes
-    // (fp32 engines) or rows [M][N] of the engine dtype — and  ln_stats_out[row][N / 32][2] = (sum, sum of squares) of x_new
+    // (fp32 engines) or rows [M][N] of the engine dtype — and  ln_stats_out[row][N / 32][2] = (sum, M2 about the block mean: wave_reduce.h) of x_new
     // over each 32-column block (plain stores, fixed order: bit-reproducible).  CONSUMER (QKV / FF1): with ln_stats_in set,
     // v = rstd * acc - (mean * rstd) * ln_p[col] + ln_c[col] replaces acc + bias (ln_p = W (1 + sc), ln_c = W sh + b per
     // (step, block), built at load time); mean / rstd over ln_dim columns with ln_eps, biased variance.

@@ -72,7 +72,7 @@ struct F5 {
     // ---- AdaLN fold (dit_eval; gemm_epilogue.h) ----
     bool fold_built = false; // the load-time vectors exist (dim >= 1024, dim % 128 == 0, cfg.ln_fold != 0)
     DevBuf ApN;              // fp32 engines: x o (1 + scale) of the residual row as panel planes (16-bit engines: rows in Ub)
-    DevBuf ln_stats;         // [rows][dim / 32][2] partial (sum, sum of squares) per residual row
+    DevBuf ln_stats;         // [rows][dim / 32][2] partial (sum, M2 about the block mean) per residual row
     DevBuf ln_fin;           // 16-bit engines: [rows][2] finished (rstd, mean * rstd) (launch_ln_finalize: one tiny launch per norm)
     DevBuf ln_tab;           // [nfe][depth][ W_qkv (1 + sc_a) : 3d | W_qkv sh_a + b : 3d | W_ff1 (1 + sc_m) : ff | W_ff1 sh_m + b : ff ]
     long ln_ld = 0, ln_blk = 0;

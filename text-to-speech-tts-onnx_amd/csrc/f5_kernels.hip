@@ -9,6 +9,7 @@
 //   Vocos head       exp/clip magnitude, phase -> re/im           vocos/heads.py:55-59, STFT_Process.py:160-163
 //   ISTFT OLA        overlap-add + envelope + clamp + int16       STFT_Process.py:164-166, Export_F5.py:203
 //   CFG/Euler        x += (p + (p - p1)*cfg) * dt[k]              Export_F5.py:179-180
+#include <type_traits>
 #include "wave_reduce.h"
 #include "common.h"
 #include "f5_kernels.h"
@@ -166,7 +167,7 @@ void launch_rownorm_x3p(const float* x, void* planes, const float* a, const floa
 
 // AdaLN fold, first block of an evaluation (the row's producer is the position convolution, whose epilogue has no fold): what
 // the O / FF2 epilogues do for every later norm (gemm_epilogue.h gemm_epilogue_resid_ln) as a pass of its own — the rows
-// o (1 + scale) as the QKV GEMM's A operand (panel planes, or rows of TA) plus the per-row partial (sum, sum of squares) over
+// o (1 + scale) as the QKV GEMM's A operand (panel planes, or rows of TA) plus the per-row partial (sum, M2 about the block mean) over
 // 32-column blocks.  A lane holds 8 consecutive columns and a quad of lanes one block: the same partials, bit for bit, as the
 // GEMM epilogues write for the same x.
 template <typename TA, int MAXP, int NP>
@@ -185,10 +186,8 @@ __global__ __launch_bounds__(256) void ln_prologue_kernel(const float* __restric
             const float4 v0 = *reinterpret_cast<const float4*>(xr + c), v1 = *reinterpret_cast<const float4*>(xr + c + 4);
             const float4 a0 = *reinterpret_cast<const float4*>(scale + c), a1 = *reinterpret_cast<const float4*>(scale + c + 4);
             float o[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-            float s1 = ((o[0] + o[1]) + (o[2] + o[3])) + ((o[4] + o[5]) + (o[6] + o[7]));
-            float s2 = ((o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3])) + ((o[4] * o[4] + o[5] * o[5]) + (o[6] * o[6] + o[7] * o[7]));
-            s1 += dpp_mov<0xB1>(s1); s2 += dpp_mov<0xB1>(s2);
-            s1 += dpp_mov<0x4E>(s1); s2 += dpp_mov<0x4E>(s2);
+            float s1, s2;
+            ln_block_stats(o, s1, s2);
             if ((lane & 3) == 0) *reinterpret_cast<float2*>(stats + (row * nb + (c >> 5)) * 2) = make_float2(s1, s2);
             const float g[8] = {1.f + a0.x, 1.f + a0.y, 1.f + a0.z, 1.f + a0.w, 1.f + a1.x, 1.f + a1.y, 1.f + a1.z, 1.f + a1.w};
 #pragma unroll
@@ -204,10 +203,11 @@ __global__ __launch_bounds__(256) void ln_prologue_kernel(const float* __restric
 #pragma unroll
                 for (int k = 0; k < 8; ++k) pk.v[k] = from_f32<TA>(o[k]);
                 *reinterpret_cast<Pk*>((TA*)aout + row * D + c) = pk;
+                if constexpr (std::is_same<TA, f16>::value) sat |= f16_range_word(o);      // (see gemm_epilogue_resid_ln)
             }
         }
     }
-    if constexpr (sizeof(TA) == 4 && NP == 2) sat_publish(satp, sat);
+    if constexpr ((sizeof(TA) == 4 && NP == 2) || std::is_same<TA, f16>::value) sat_publish(satp, sat);
 }
 
 void launch_ln_prologue(const float* x, void* aout, int a_dtype, int np, float* stats, const float* scale, long rows, int D, int* sat,
@@ -227,32 +227,32 @@ void launch_ln_prologue(const float* x, void* aout, int a_dtype, int np, float* 
     MI_HIP(hipGetLastError());
 }
 
-// AdaLN fold, 16-bit engines: the partial (sum, sum of squares) pairs of every row summed ONCE into (rstd, mean * rstd) — the
+// AdaLN fold, 16-bit engines: the partial (sum, M2) pairs of every row merged ONCE into (rstd, mean * rstd) — the
 // order of gemm_epilogue.h ln_rows32 (low half of the blocks in index order, then the high half, then low + high), so the result
 // is the one a consumer epilogue would have formed itself.  One thread per row; 4.6 MB in, 144 KB out at 8 utterances.
 __global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restrict__ part, float2* __restrict__ fin, long rows, int nb,
-                                                          float inv_d, float eps) {
+                                                          float eps) {
     const long row = (long)blockIdx.x * 256 + threadIdx.x;
     if (row >= rows) return;
-    const float4* sp = reinterpret_cast<const float4*>(part + row * (long)(nb * 2));
-    float h1[2] = {0.f, 0.f}, h2[2] = {0.f, 0.f};
+    const float* rowp = part + row * (long)(nb * 2);
+    const float m0 = rowp[0] * (1.0f / 32.0f);
+    const float4* sp = reinterpret_cast<const float4*>(rowp);
+    LnMerge h[2];
     for (int hf = 0; hf < 2; ++hf)
         for (int i = 0; i < (nb >> 2); ++i) {
             const float4 t = sp[hf * (nb >> 2) + i];
-            h1[hf] += t.x; h2[hf] += t.y; h1[hf] += t.z; h2[hf] += t.w;
+            ln_merge_add(h[hf], t.x, t.y, m0);
+            ln_merge_add(h[hf], t.z, t.w, m0);
         }
-    const float mean = (h1[0] + h1[1]) * inv_d;
-    float var = (h2[0] + h2[1]) * inv_d - mean * mean;
-    var = var > 0.f ? var : 0.f;
-    const float rstd = 1.0f / sqrtf(var + eps);
-    fin[row] = make_float2(rstd, mean * rstd);
+    float rstd, mrstd;
+    ln_merge_finish(h[0], h[1], m0, nb, eps, rstd, mrstd);
+    fin[row] = make_float2(rstd, mrstd);
 }
 void launch_ln_finalize(const float* partials, float* fin, long rows, int D, float eps, hipStream_t s) {
     MI_REQUIRE(D % 128 == 0, "ln_finalize: D must be a multiple of 128");
     ProfScope ps(FAM_NORM, s, (double)rows * (D / LN_BLK * 8.0 + 8.0), 2.0 * rows * (D / LN_BLK));
     prof_set_kernel("ln_finalize_kernel (AdaLN fold: partial row statistics -> rstd, mean * rstd)", "", "");
-    hipLaunchKernelGGL(ln_finalize_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, partials, (float2*)fin, rows, D / LN_BLK,
-                       1.0f / (float)D, eps);
+    hipLaunchKernelGGL(ln_finalize_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, partials, (float2*)fin, rows, D / LN_BLK, eps);
     MI_HIP(hipGetLastError());
 }
 

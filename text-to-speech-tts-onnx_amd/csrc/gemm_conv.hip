@@ -602,6 +602,10 @@ static void dispatch_tiles(const ConvGemmDev& d, int B, hipStream_t s) {
         MI_LAUNCH((conv_gemm_kernel<T, TO, 128, 64, 2, 2, KC>), T, TO, grid, blk, 0, s, d);
     } else {
         dim3 grid((d.M + 127) / 128, (d.N + 127) / 128, B * d.G);
+        // a launch that carries the AdaLN fold (gemm_ln_fold_ok said yes) skips the 16-bit kernels without fold epilogues (dma3<192 |
+        // 256 | 128>, 16-bit stream-K) instead of refusing in the middle of an inference: e.g. dim = 1152 at ~4 utterances would
+        // otherwise land O / FF2 on dma3<192>; the fold kernels (ph8, conv_gemm_dma) take every shape those take
+        const bool fold = d.ln_stats_in || d.ln_stats_out;
         if constexpr (sizeof(T) == 2) {
             // many row tiles (a batch of utterances): the 8-wave 256x256 eight-phase main loop
             const long tiles256 = (long)((d.M + 255) / 256) * ((d.N + 255) / 256);
@@ -635,7 +639,7 @@ static void dispatch_tiles(const ConvGemmDev& d, int B, hipStream_t s) {
             // plain linear layer (one tap, one group, one M axis, whole K chunks): stream-K over persistent workgroups
             constexpr int KCB = 128 / (int)sizeof(T);
             const long tiles = (long)((d.M + 127) / 128) * ((d.N + 127) / 128);
-            if (g_sk >= (sizeof(T) == 4 ? 1 : 2) && d.sk_ws && d.sk_slots >= 256 && B == 1 && d.G == 1 && d.K == d.Cin && d.Cin % KCB == 0 &&
+            if (!(sizeof(T) == 2 && fold) && g_sk >= (sizeof(T) == 4 ? 1 : 2) && d.sk_ws && d.sk_slots >= 256 && B == 1 && d.G == 1 && d.K == d.Cin && d.Cin % KCB == 0 &&
                 (d.epi == EPI_PLAIN || (d.epi == EPI_QKV_ROPE && (sizeof(T) == 2 || g_sk_qkv32))) && buf_ok(d, (int)sizeof(T)) && d.M > 128 && tiles >= g_sk_min_tiles && tiles <= g_sk_max_tiles && d.pad == 0) {
                 ConvGemmDev e = d;
                 e.Tm = (d.M + 127) / 128; e.Tn = (d.N + 127) / 128; e.RT = e.Tm;
@@ -655,7 +659,7 @@ static void dispatch_tiles(const ConvGemmDev& d, int B, hipStream_t s) {
             const long rt256 = (long)B * ((d.M + 255) / 256);
             const long rounds192 = (rt256 * (d.N / 192) + 255) / 256, rounds256 = (rt256 * ((d.N + 255) / 256) + 255) / 256;
             const bool n192_wins = d.N % 256 != 0 || (d.K > g_k_min && rounds192 * 192 < rounds256 * 256);
-            if (g_use_dma3 && g_n192 && buf_ok(d) && d.K % d.Cin == 0 && d.M > 128 && d.N % 192 == 0 && n192_wins &&
+            if (!fold && g_use_dma3 && g_n192 && buf_ok(d) && d.K % d.Cin == 0 && d.M > 128 && d.N % 192 == 0 && n192_wins &&
                 d.K >= 576 && (long)B * ((d.M + 255) / 256) * (d.N / 192) >= g_n192_min) {
                 // N = 192 / 384 (BigVGAN stages 2 and 1): a 192-wide tile has no padded columns (128-wide tiles waste 25 %
                 // of the MFMAs and DMA bytes at N = 192) and the fewest DMA bytes per useful flop after 256x256
@@ -666,7 +670,7 @@ static void dispatch_tiles(const ConvGemmDev& d, int B, hipStream_t s) {
                 MI_HIP(hipGetLastError());
                 return;
             }
-            if (g_use_dma3 && d.Cin % 8 == 0 && d.K % d.Cin == 0 && d.M > 128 && d.K > g_k_min) {
+            if (!fold && g_use_dma3 && d.Cin % 8 == 0 && d.K % d.Cin == 0 && d.M > 128 && d.K > g_k_min) {
                 ConvGemmDev e = d;
                 e.RC = 0;
                 const long blocks_128 = (long)B * ((d.M + 127) / 128) * ((d.N + 127) / 128);
@@ -847,8 +851,7 @@ bool gemm_ln_fold_ok(const ConvGemm& p) {
     if (p.epi != EPI_PLAIN && p.epi != EPI_QKV_ROPE) return false;
     if (p.dtype == MI_F32) return gemm_x3p_would_run(p) && lds_epi_for(p, odt, true);
     if (!lds_epi_for(p, odt, false) || !g_use_dma || p.Cin % 64 != 0 || p.N <= 64) return false;
-    if (g_sk >= 2) return false;                                        // 16-bit stream-K (opt-in) has no fold epilogue
-    if (g_use_dma3 && p.Cin > g_k_min) return false;                    // K > 2048: the 256-row dma3 kernels
+    if (g_use_dma3 && p.Cin > g_k_min) return false;                    // K > 2048: the 256-row dma3 kernels are the faster choice (a preference, not a constraint: dispatch_tiles keeps fold launches off the kernels without fold epilogues)
     return true;
 }
 

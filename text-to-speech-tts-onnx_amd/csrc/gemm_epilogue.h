@@ -2,6 +2,7 @@
 // (gemm_conv.hip: register-staged and LDS-DMA kernels; gemm_dma3.hip: the 8-wave 256-row kernels).
 #pragma once
 #include "common.h"
+#include <type_traits>
 #include "mfma.h"
 #include "x3_split.h"
 #include "wave_reduce.h"
@@ -297,8 +298,8 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x16 (&acc)[TM][TN], const C
 // ---------------------------------------------------------------------------------------------------------------------------
 // AdaLN fold (ConvGemm::ln_* in common.h; AdaLayerNorm.forward modules.py:301-305, DiTBlock.forward :599-613).
 // The LayerNorm between the residual stream and the QKV / FF1 projections has no launch of its own: the producer of the
-// residual row (O / FF2 epilogue) leaves x o (1 + scale) as the next GEMM's A operand plus per-row partial (sum, sum of squares)
-// over 32-column blocks; the consumer's epilogue finishes  rstd * acc - (mean * rstd) * (W (1 + scale)) + (W shift + b).
+// residual row (O / FF2 epilogue) leaves x o (1 + scale) as the next GEMM's A operand plus per-row partial (sum, M2 about the block mean)
+// over 32-column blocks (merged Chan-style, wave_reduce.h: no E[x^2] - mean^2 cancellation); the consumer's epilogue finishes  rstd * acc - (mean * rstd) * (W (1 + scale)) + (W shift + b).
 // Every partial is a plain store and every sum runs in a fixed order: results are bit-reproducible and do not depend on
 // which kernel (tile shape) produced the partials.
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -314,21 +315,19 @@ __device__ __forceinline__ void ln_rows32(const ConvGemmDev& p, long row0, long 
         rstd = t.x; mrstd = t.y;
         return;
     }
-    const float4* sp = reinterpret_cast<const float4*>(p.ln_stats_in + row * (long)(nb * 2)) + lk * (nb >> 2);
-    float s1 = 0.f, s2 = 0.f;
+    const float* rowp = p.ln_stats_in + row * (long)(nb * 2);
+    const float m0 = rowp[0] * (1.0f / 32.0f);               // reference point of the merge: the first block's mean (wave_reduce.h)
+    const float4* sp = reinterpret_cast<const float4*>(rowp) + lk * (nb >> 2);
+    LnMerge t;
     for (int i = 0; i < (nb >> 2); ++i) {
-        const float4 t = sp[i];
-        s1 += t.x; s2 += t.y; s1 += t.z; s2 += t.w;
+        const float4 v = sp[i];
+        ln_merge_add(t, v.x, v.y, m0);
+        ln_merge_add(t, v.z, v.w, m0);
     }
-    const float o1 = __shfl_xor(s1, 32), o2 = __shfl_xor(s2, 32);
-    const float t1 = lk ? o1 + s1 : s1 + o1;                 // low half + high half on both lanes
-    const float t2 = lk ? o2 + s2 : s2 + o2;
-    const float inv_d = 1.0f / (float)p.ln_dim;
-    const float mean = t1 * inv_d;
-    float var = t2 * inv_d - mean * mean;                    // biased variance
-    var = var > 0.f ? var : 0.f;
-    rstd = 1.0f / sqrtf(var + p.ln_eps);
-    mrstd = mean * rstd;
+    LnMerge o;
+    o.a = __shfl_xor(t.a, 32); o.b = __shfl_xor(t.b, 32); o.c = __shfl_xor(t.c, 32);
+    if (lk) ln_merge_finish(o, t, m0, nb, p.ln_eps, rstd, mrstd);     // low half + high half on both lanes
+    else ln_merge_finish(t, o, m0, nb, p.ln_eps, rstd, mrstd);
 }
 
 // LDS-staged variant of the fused QKV epilogue for the 128x128 DMA kernel (head_dim 64, one (q|k|v, head) slice per
@@ -659,7 +658,7 @@ __device__ __forceinline__ void gemm_epilogue_ln_in(f32x16 (&acc)[TM][TN], const
 
 // PRODUCER (O / FF2 projections): x_new = res + gate * (acc + bias) -> fp32 rows in p.out (the residual stream); the same rows
 // o (1 + ln_scale) -> the next GEMM's A operand (TA = float: panel planes of NP planes; else rows of TA, [M][N]); partial
-// (sum, sum of squares) of x_new per 32-column block -> ln_stats_out.  Wave tile as above.
+// (sum, M2 about the block mean) of x_new per 32-column block -> ln_stats_out (wave_reduce.h).  Wave tile as above.
 template <typename TA, int TM, int TN, int NP>
 __device__ __forceinline__ void gemm_epilogue_resid_ln(f32x16 (&acc)[TM][TN], const ConvGemmDev& p, int mw, int nc0, int lr, int lk, float* stage) {
     constexpr int WN = 32 * TN, LPR = WN / 8, RPI = 64 / LPR, NIT = 32 / RPI;
@@ -714,10 +713,8 @@ __device__ __forceinline__ void gemm_epilogue_resid_ln(f32x16 (&acc)[TM][TN], co
                 *reinterpret_cast<float4*>(outp + ix[it] + 4) = make_float4(x[4], x[5], x[6], x[7]);
             }
             // partial statistics of the 32-column block this lane's quad covers (8 columns per lane, 4 lanes): fixed order
-            float s1 = ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
-            float s2 = ((x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3])) + ((x[4] * x[4] + x[5] * x[5]) + (x[6] * x[6] + x[7] * x[7]));
-            s1 += dpp_mov<0xB1>(s1); s2 += dpp_mov<0xB1>(s2);      // lane ^ 1
-            s1 += dpp_mov<0x4E>(s1); s2 += dpp_mov<0x4E>(s2);      // lane ^ 2
+            float s1, s2;
+            ln_block_stats(x, s1, s2);                             // (sum, M2 about the block mean): wave_reduce.h
             if (ok[it] && (lane & 3) == 0)
                 *reinterpret_cast<float2*>(p.ln_stats_out + ((long)m * nb + (col >> 5)) * 2) = make_float2(s1, s2);
 #pragma unroll
@@ -735,12 +732,16 @@ __device__ __forceinline__ void gemm_epilogue_resid_ln(f32x16 (&acc)[TM][TN], co
 #pragma unroll
                 for (int q = 0; q < 8; ++q) o.v[q] = from_f32<TA>(x[q]);
                 if (ok[it]) *reinterpret_cast<Pk*>((TA*)p.ln_out + (long)m * p.N + col) = o;
+                // f16 engines: the fold's A operand is the UNNORMALISED residual row o (1 + scale) — not bounded by ~sqrt(d) like
+                // LN(x) (1 + scale) + shift is.  A value beyond the fp16 range raises the engine's flag: the call is re-run on the
+                // row-norm path (capi.hip f5_run_checked)
+                if constexpr (std::is_same<TA, f16>::value) sat |= ok[it] ? f16_range_word(x) : 0u;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-    if constexpr (sizeof(TA) == 4 && NP == 2) sat_publish(p.sat, sat);
+    if constexpr ((sizeof(TA) == 4 && NP == 2) || std::is_same<TA, f16>::value) sat_publish(p.sat, sat);
 }
 
 typedef __attribute__((address_space(3))) void lds_void;

@@ -13,6 +13,7 @@ const std::string& last_error() { return g_err; }
 static std::atomic<long> g_option_epoch{0};
 long option_epoch() { return g_option_epoch.load(); }
 void option_epoch_bump() { g_option_epoch.fetch_add(1); }
+std::shared_mutex& option_lock() { static std::shared_mutex m; return m; }
 
 void upload_f32(DevBuf& dst, const float* src, size_t n, hipStream_t s) {
     dst.ensure(n * 4);

@@ -61,6 +61,12 @@ __device__ __forceinline__ unsigned x2_sat_word(unsigned ph) { return ((ph & 0x7
 __device__ __forceinline__ void sat_publish(int* flag, unsigned sat) {
     if (flag && sat) atomicOr(flag, 1);          // only lanes that saw a saturated operand get here: rare by construction
 }
+// non-zero if one of eight fp32 values does not fit fp16 (|v| > 65504 or inf): the range watch of the f16 engines' fold operand
+__device__ __forceinline__ unsigned f16_range_word(const float (&v)[8]) {
+    const float m = fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))),
+                          fmaxf(fmaxf(fabsf(v[4]), fabsf(v[5])), fmaxf(fabsf(v[6]), fabsf(v[7]))));
+    return m > 65504.0f ? 1u : 0u;              // (a NaN operand is not a range event: it propagates and the parity gates see it)
+}
 // eight consecutive values -> the 16-byte slot of each plane
 template <int NP> __device__ __forceinline__ void xnp_split8(const float (&v)[8], x3_u4 (&pl)[NP]) {
     unsigned w[NP][4];

@@ -155,6 +155,23 @@ class F5Engine:
                                                       _lib.i32p(ts), fuse, _lib.MI_HOST), "mi_f5_transformer_step")
         return x, ts
 
+    def transformer_step_device(self, x, cat_mel_text, cat_mel_text_drop, k: int, fuse: int = 1) -> int:
+        """ort_session_B.run_with_iobinding with every operand in HBM: float32 CUDA tensors x (U,N,100) — advanced IN PLACE —,
+        cat_mel_text(_drop) (U,N,612); `k` = the grid index *time_step holds.  Returns k + fuse."""
+        import torch
+        for t in (x, cat_mel_text, cat_mel_text_drop):
+            if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.device.index == self.device):
+                raise ValueError("operands must be contiguous float32 CUDA tensors on the engine's device")
+        U, N, M = x.shape
+        cd = self.cfg.mel_dim + self.cfg.text_dim
+        if M != self.cfg.mel_dim or tuple(cat_mel_text.shape) != (U, N, cd) or tuple(cat_mel_text_drop.shape) != (U, N, cd):
+            raise ValueError(f"x must be (U, N, {self.cfg.mel_dim}), cat_mel_text(_drop) (U, N, {cd})")
+        torch.cuda.current_stream(x.device).synchronize()
+        ts = C.c_int32(int(k))
+        _lib.check(_lib.load().mi_f5_transformer_step(self._h, x.data_ptr(), cat_mel_text.data_ptr(), cat_mel_text_drop.data_ptr(),
+                                                      U, N, C.byref(ts), int(fuse), _lib.MI_DEVICE), "mi_f5_transformer_step")
+        return int(ts.value)
+
     def sample(self, noise, cat_mel_text, cat_mel_text_drop, k0: int = 0, n_steps: Optional[int] = None):
         noise, cmt, cmtd, U, N = self._cond(noise, cat_mel_text, cat_mel_text_drop)
         x = noise.copy()
@@ -273,15 +290,22 @@ class F5Engine:
         N = int(max_duration)
         R = cfg.ref_frames(Ln)
         n = (N - R - 1) * cfg.hop_length
+        if n < 0:
+            raise ValueError("max_duration leaves no generated frames")
         if out is None:
             out = torch.empty((U, 1, n), dtype=torch.int16, device=audio.device)
         assert audio.is_cuda and audio.dtype == torch.int16 and audio.is_contiguous()
         assert text_ids.is_cuda and text_ids.dtype == torch.int32 and text_ids.is_contiguous()
+        assert out.is_cuda and out.dtype == torch.int16 and out.is_contiguous() and out.numel() == U * n
         if noise is not None:
             assert noise.is_cuda and noise.dtype == torch.float32 and noise.is_contiguous()
         torch.cuda.current_stream(audio.device).synchronize()
         ln = C.c_int64(0)
+        # one generated frame -> an empty waveform like graph C (and like synthesize()): an empty tensor has no storage, so the
+        # library (which requires a destination) gets a one-sample scratch buffer it writes nothing to
+        dst = out if n > 0 else torch.empty((1,), dtype=torch.int16, device=audio.device)
         _lib.check(_lib.load().mi_f5_synthesize(self._h, U, audio.data_ptr(), Ln, text_ids.data_ptr(), text_ids.shape[1], N,
-                                                None if noise is None else noise.data_ptr(), seed, out.data_ptr(),
+                                                None if noise is None else noise.data_ptr(), seed, dst.data_ptr(),
                                                 C.byref(ln), _lib.MI_DEVICE), "mi_f5_synthesize")
+        assert ln.value == n
         return out

@@ -5,24 +5,31 @@
 #   tools/measure.sh bench [bench.py args]      one bench line (+ a short readable summary)
 #   tools/measure.sh ab '<args A>' '<args B>' [n]   same-box A/B of two bench.py command lines, n alternations (default 2)
 #   tools/measure.sh layers [bench.py args]     average time of the four DiT linear layers (rocprofv3 --kernel-trace + tools/x3p_by_shape.py)
-#   tools/measure.sh cpu-full                   the CPU baseline with all 31 evaluations at 8 and min(nproc, 32) threads (no GPU work)
+#   tools/measure.sh cpu-full                   the CPU baseline with all 31 evaluations at 8 threads (no GPU work)
 #   tools/measure.sh final                      the round-end set: GPU tests, default line (PMC traffic, host I/O, CPU baseline, secondaries),
 #                                               rocprofv3 kernel stats of the three F5 / BigVGAN configs, PMC passes, plumbing run of --gpus 2
 #
 # Replaces the 44 one-off tools/r3/call*.sh and the per-round rN_final.sh scripts.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-ROUND=${ROUND:-r4}
+ROUND=${ROUND:-r5}
 WHAT=${1:-bench}; shift || true
 O=$ROOT/gpurun_out/$ROUND/$WHAT; mkdir -p $O
 cd $ROOT
 B="python $ROOT/bench.py"
 Q="--no-secondary --no-cpu-baseline --no-pmc"
 R="rocprofv3 --kernel-trace --stats --output-format csv"
+# runb NAME [bench args]: stdout (the ONE compact line) -> $O/NAME.json, stderr -> $O/NAME.err, the full record -> $O/NAME_detail.json
+runb() { local n=$1; shift; rm -f $ROOT/bench_detail.json; timeout 1500 $B "$@" > $O/$n.json 2> $O/$n.err; [ -f $ROOT/bench_detail.json ] && cp $ROOT/bench_detail.json $O/${n}_detail.json; summary $O/$n.json; }
 summary() { python - "$1" <<'PY'
-import json, sys
+import json, os, sys
 try:
-    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    line = open(sys.argv[1]).read().strip().splitlines()[-1]
+    d = json.loads(line)
+    print(f"{sys.argv[1].split('/')[-1]}: compact line {len(line)} bytes")
+    det = sys.argv[1][:-5] + "_detail.json"
+    if os.path.exists(det):
+        d = json.loads(open(det).read())
 except Exception as e:
     print(sys.argv[1], "no JSON line:", e); sys.exit(0)
 r = d.get("roofline") or {}
@@ -35,19 +42,19 @@ for n, v in (d.get("secondary") or {}).items():
     print(f"   secondary {n}: {v.get('ms_per_step', v.get('ms_per_round_of_two', 0)):.2f} ms  {v['value']:.1f}")
 c = d.get("cpu_baseline")
 if c:
-    print("   cpu_baseline", round(c["value"], 4), "cores", c["cores"], {k: round(c[k]["value"], 4) for k in ("t8", "tN") if k in c})
+    print("   cpu_baseline", round(c["value"], 4), "cores", c["cores"], "evaluations", c.get("evaluations_run"))
 PY
 }
 case $WHAT in
 tests)
     timeout 2700 python -m pytest tests -m gpu -q -x -rA --timeout 900 "$@" > $O/tests_gpu_rA.log 2>&1; tail -12 $O/tests_gpu_rA.log ;;
 bench)
-    timeout 1500 $B "$@" > $O/bench.json 2> $O/bench.err; summary $O/bench.json ;;
+    runb bench "$@" ;;
 ab)
     A=$1; Bb=$2; N=${3:-2}
     for i in $(seq 1 $N); do
-        timeout 900 $B $Q $A > $O/a_$i.json 2>> $O/err.log; summary $O/a_$i.json
-        timeout 900 $B $Q $Bb > $O/b_$i.json 2>> $O/err.log; summary $O/b_$i.json
+        runb a_$i $Q $A
+        runb b_$i $Q $Bb
     done ;;
 layers)
     cd /tmp; export TMPDIR=/tmp
@@ -58,11 +65,10 @@ cpu-full)
     timeout 2400 $B --cpu-baseline-only --cpu-baseline-full > $O/cpu_baseline_full.json 2> $O/err.log; tail -c 300 $O/cpu_baseline_full.json ;;
 final)
     timeout 2700 python -m pytest tests -m gpu -q -x -rA --timeout 900 > $O/tests_gpu_rA.log 2>&1; tail -3 $O/tests_gpu_rA.log
-    timeout 1500 $B --steps 10 --warmup 3 > $O/bench_default.json 2> $O/bench_default.err; summary $O/bench_default.json
-    timeout 600 $B --workload bigvgan > $O/bench_bigvgan_f16_b8.json 2>/dev/null; summary $O/bench_bigvgan_f16_b8.json
-    timeout 600 $B --workload indextts --no-cpu-baseline > $O/bench_indextts.json 2>/dev/null; summary $O/bench_indextts.json
-    MI355TTS_BENCH_BACKEND=gloo MI355TTS_BENCH_ONE_GPU=1 MI355TTS_BENCH_SMALL=1 timeout 600 $B --gpus 2 --steps 2 --warmup 1 > $O/bench_gpus2_selflaunch_plumbing.json 2> $O/bench_gpus2.err
-    summary $O/bench_gpus2_selflaunch_plumbing.json
+    runb bench_default --steps 20 --warmup 5
+    runb bench_bigvgan_f16_b8 --workload bigvgan
+    runb bench_indextts --workload indextts --no-cpu-baseline
+    MI355TTS_BENCH_BACKEND=gloo MI355TTS_BENCH_ONE_GPU=1 MI355TTS_BENCH_SMALL=1 runb bench_gpus2_selflaunch_plumbing --gpus 2 --steps 2 --warmup 1
     cd /tmp; export TMPDIR=/tmp
     timeout 600 $R -d $O/t_f5_f32_u1 -- $B $Q --steps 3 --warmup 2 2>/dev/null | tail -1 > $O/bench_f5_f32_under_rocprof.json
     timeout 600 $R -d $O/t_f5_bf16_u8 -- $B $Q --dtype bf16 --batch 8 --steps 2 --warmup 2 2>/dev/null | tail -1 > $O/bench_f5_bf16_u8_under_rocprof.json
