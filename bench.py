@@ -33,7 +33,7 @@ import time
 import numpy as np
 
 from bench_common import (ROOT, USER_OPTIONS, MFMA_F16_PEAK_TF, MFMA_F32_PEAK_TF, f5_flops_per_eval, merge_instantiations,
-                          dominant_kernel_roofline, bcast_device_blob, per_rank_times, max_over_ranks, f5_workload_name, emit)
+                          dominant_kernel_roofline, bcast_device_blob, per_rank_times, max_over_ranks, f5_workload_name, emit, claim_stdout)
 
 
 def cpu_baseline_f5_run(cfg, st, audio, ids, N, noise, threads: int, evals):
@@ -348,6 +348,7 @@ def main():
                                                          full=args.cpu_baseline_full, threads=args.cpu_threads)}), flush=True)
         return
 
+    claim_stdout()          # (after the self-launch above: the parent passes its children's stdout through)
     import torch
     import torch.distributed as dist
 

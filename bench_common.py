@@ -174,6 +174,19 @@ def compact_line(line: dict) -> dict:
     return out
 
 
+_LINE_FD = None
+
+
+def claim_stdout() -> None:
+    """stdout belongs to the ONE result line: from here on everything else this process (and the native libraries it loads: gloo
+    announces its ranks on stdout, RCCL can be told to) writes to fd 1 lands on stderr; emit() writes the line to the real stdout."""
+    global _LINE_FD
+    if _LINE_FD is None:
+        sys.stdout.flush()
+        _LINE_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
 def emit(line: dict) -> str:
     """Write the full record to bench_detail.json (+ gpurun_out/ if present, + stderr) and print the compact line as the ONE stdout line."""
     import json
@@ -196,5 +209,9 @@ def emit(line: dict) -> str:
         c["config"] = {k: v for k, v in c["config"].items() if not isinstance(v, (str, list)) or k == "workload"}
         s = json.dumps(c, allow_nan=False)
     assert len(s) < COMPACT_LIMIT, len(s)
-    print(s, flush=True)
+    if _LINE_FD is not None:
+        sys.stdout.flush()
+        os.write(_LINE_FD, (s + "\n").encode())
+    else:
+        print(s, flush=True)
     return s

@@ -117,7 +117,8 @@ class OrtValue:
             return OrtValue(arr, "cpu", device_id)
         import torch
         base = _unbroadcast(arr)
-        t = torch.from_numpy(np.ascontiguousarray(base)).to(torch.device("cuda", int(device_id)))
+        base = np.ascontiguousarray(base) if base.flags.writeable else np.array(base, order="C")     # (torch refuses read-only views)
+        t = torch.from_numpy(base).to(torch.device("cuda", int(device_id)))
         if base.shape != arr.shape:
             t = t.expand(*arr.shape)
         v = OrtValue(None, "cuda", int(device_id), tensor=t)
