@@ -646,6 +646,37 @@ def test_adaln_fold_against_rownorm_path_and_oracle(dtype, tol_paths, tol_oracle
         e_fold.close(); e_rows.close()
 
 
+@pytest.mark.parametrize("offset", [20.0, 100.0])
+def test_adaln_fold_rows_with_a_dc_offset(offset):
+    """nn.LayerNorm is two-pass; the fold's row statistics were E[x^2] - mean^2 over fp32 partial sums, whose cancellation
+    error grows as eps * mean^2 / var — invisible on the synthetic weights (row means ~ 0).  The statistics now travel as (sum, M2
+    about the block mean) pairs merged Chan-style (wave_reduce.h).  Here the residual stream carries a common offset of `offset`
+    standard deviations (input_embed.proj.bias shifted): the fold must still agree with the row-norm path and the oracle.  (At
+    offset 100 the old formula's variance error alone was 6e-8 * 1e4 = 6e-4.)"""
+    import dataclasses
+    cfg = _mid_cfg()
+    raw = dict(W.synth_state(W.f5_spec(cfg), 7))
+    raw["transformer.input_embed.proj.bias"] = raw["transformer.input_embed.proj.bias"] + np.float32(offset)
+    st = W.fold_f5(cfg, raw)
+    tables = O.time_tables(cfg, st)
+    e_fold = F5Engine(cfg, raw, dtype="f32")
+    e_rows = F5Engine(dataclasses.replace(cfg, adaln_fold=False), raw, dtype="f32")
+    try:
+        U, N = 1, 500
+        noise, cmt, cmtd = _mid_inputs(cfg, U, N)
+        a = e_fold.dit_eval(noise, cmt, cmtd, 2)
+        b = e_rows.dit_eval(noise, cmt, cmtd, 2)
+        cos, sin = O.rope_tables(N, 64)
+        ref = O.dit_forward(cfg, st, noise[0], cmt[0], cmtd[0], tables[2][2], cos, sin)
+        e_ab, e_ao, e_bo = rms(a - b) / rms(b), rms(a[:2] - ref) / rms(ref), rms(b[:2] - ref) / rms(ref)
+        print(f"AdaLN fold with a DC offset of {offset}: fold vs row-norm {e_ab:.2e}, fold vs oracle {e_ao:.2e}, row-norm vs oracle {e_bo:.2e}")
+        assert np.isfinite(a).all() and e_fold.info()["saturation_events"] == 0
+        # what remains is the fold's own rounding: operands rounded relative to |x| (22 bits) instead of |x - mean|
+        assert e_ab < 2e-7 * max(offset, 10.0) and e_ao < 2e-7 * max(offset, 10.0) + 5e-6, (offset, e_ab, e_ao, e_bo)
+    finally:
+        e_fold.close(); e_rows.close()
+
+
 def test_two_engines_with_different_fp32_arithmetic_coexist():
     """The fp32 arithmetic is a property of the engine (F5Config.f32_arithmetic), not of the process: an fp16-pair engine, a
     three-plane bf16 engine and a native-fp32-MFMA engine alive at once, called alternately, each give exactly what they give

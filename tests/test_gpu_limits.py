@@ -128,6 +128,38 @@ def test_one_and_two_generated_frames():
         eng.close()
 
 
+def test_a_bad_device_text_id_fails_once_and_the_handle_recovers():
+    """device-resident text ids are validated by the kernel (a flag the engine reads at its next synchronisation).  The
+    flag used to stay raised: after ONE failed call every later call on the handle — with valid inputs — failed with the same
+    "text id out of range".  Now the flag is cleared when it is reported (and by F5::recover), and the one-generated-frame request
+    returns an empty tensor on the torch path like the numpy path (it used to be refused: an empty tensor has no storage)."""
+    import torch
+    cfg = F5Config.small()
+    raw = W.synth_state(W.f5_spec(cfg), 9527)
+    audio = _audio(31 * 256)
+    R = 32
+    N = R + 6
+    ids = np.arange(6, dtype=np.int32)
+    noise = W.synth_normal(5, "nrec", (N, cfg.mel_dim))
+    eng = F5Engine(cfg, raw, dtype="f32")
+    try:
+        dev = torch.device("cuda", 0)
+        t_audio, t_noise = torch.from_numpy(audio[None]).to(dev), torch.from_numpy(noise[None]).to(dev)
+        good = eng.synthesize_torch(t_audio, torch.from_numpy(ids[None]).to(dev), N, noise=t_noise).cpu().numpy()
+        bad = ids.copy(); bad[3] = cfg.text_num_embeds + 7
+        with pytest.raises(_lib.MiError, match="text id out of range"):
+            eng.synthesize_torch(t_audio, torch.from_numpy(bad[None]).to(dev), N, noise=t_noise)
+        again = eng.synthesize_torch(t_audio, torch.from_numpy(ids[None]).to(dev), N, noise=t_noise).cpu().numpy()
+        assert np.array_equal(good, again)                       # same handle, valid ids: no inherited error, same waveform
+        assert np.array_equal(eng.synthesize(audio[None], ids[None], N, noise=noise[None]), good)
+        empty = eng.synthesize_torch(t_audio, torch.from_numpy(ids[None]).to(dev), R + 1, noise=torch.from_numpy(W.synth_normal(5, "n1", (1, R + 1, cfg.mel_dim))).to(dev))
+        assert tuple(empty.shape) == (1, 1, 0)
+        with pytest.raises(ValueError):
+            eng.synthesize_torch(t_audio, torch.from_numpy(ids[None]).to(dev), R, noise=None)
+    finally:
+        eng.close()
+
+
 @pytest.mark.timeout(900)
 def test_workspace_grows_and_shrinks_in_one_handle():
     """One handle: 300 frames -> 4096 frames x 2 utterances -> 300 frames again -> other dtype-independent shapes; every result equals
