@@ -206,9 +206,12 @@ def test_indextts_a_session_like_the_reference_call(tmp_path, golden_dir):
         ort_session_A.run(out_name_A, {in_name_A0: g["r_audio"].astype(np.float32).reshape(1, 1, -1)})
 
 
-def test_indextts_gpt_driver_loop_through_facade(tmp_path, golden_dir):
+@pytest.mark.parametrize("device_type", ["cpu", "cuda"])
+def test_indextts_gpt_driver_loop_through_facade(tmp_path, golden_dir, device_type):
     """Inference_IndexTTS_ONNX.py:619-800 for one sentence with sessions B, C, D, E: same variable names and feed
-    bookkeeping as the reference driver; out_key/out_value OrtValues are fed straight back as in_key/in_value."""
+    bookkeeping as the reference driver; out_key/out_value OrtValues are fed straight back as in_key/in_value.
+    device_type 'cuda' (round 5): every `ortvalue_from_numpy(x, device_type, DEVICE_ID)` of the driver is a device-resident value
+    (the sessions of this model read them back through `.numpy()`: same tokens, same hidden states)."""
     from mi355tts.config import IndexGPTConfig
     g = np.load(os.path.join(golden_dir, "indextts_gpt.npz"))
     cfg = IndexGPTConfig.small()
@@ -216,7 +219,7 @@ def test_indextts_gpt_driver_loop_through_facade(tmp_path, golden_dir):
     np.save(wfile, W.pack_gpt(cfg, W.synth_state(W.gpt_spec(cfg), 9527)))
     paths = {k: onnxruntime.save_model(str(tmp_path / f"{k}.mi355.json"), k, cfg, str(wfile), "f32")
              for k in ("IndexTTS_B", "IndexTTS_C", "IndexTTS_D", "IndexTTS_E")}
-    device_type, DEVICE_ID = "cpu", 0
+    DEVICE_ID = 0
     REPEAT_PENALITY, PENALITY_RANGE = float(g["gen_params"][0]), int(g["gen_params"][1])
     STOP_TOKEN = [cfg.stop_mel_token]
     ort_session_B = onnxruntime.InferenceSession(paths["IndexTTS_B"])

@@ -206,7 +206,7 @@ __global__ __launch_bounds__(512, 1) void linear_x3p_kernel(const ConvGemmDev p)
     // three-stage ring that measured the same as four) into the stage of chunk c-1 — read two bodies ago, i.e. always behind a
     // barrier.  Same MFMAs in the same order on the same fragments: bit-identical results (checked: int16 waveforms array_equal).
     // Same-box A/B (tools/dbg/ab_bar2.sh, profiles/r4/x3p_bar2_ab.txt): 51.5 -> 50.35 us per launch, step 182.8 -> 178.8 ms.
-    constexpr bool BAR2 = (X3P_BAR2 != 0) && NP == 2 && DBG == 0;
+    constexpr bool BAR2 = (X3P_BAR2 != 0) && NP == 2;             // (round 5: the tuning instantiations run the product loop too)
     constexpr int NST = NP == 3 ? 3 : (BAR2 ? 5 : X3P_NST2);
     constexpr int CHB = NP * X3P_PLANE;                         // bytes of one operand chunk
     constexpr int STAGE = 2 * CHB;                              // 48 | 32 KB: A chunk then B chunk
@@ -362,6 +362,7 @@ __global__ __launch_bounds__(512, 1) void linear_x3p_kernel(const ConvGemmDev p)
             const int coff = chunk_off(cb + c + (BAR2 ? NST - 1 : NST));
             const unsigned ldsd = __builtin_amdgcn_readfirstlane(smem_lds + (unsigned)(st_free * STAGE) + lds_part);
             auto boundary = [&]() __attribute__((always_inline)) {
+                if constexpr (DBG & 32) return;                 // tuning: no waits, no barriers in the loop (wrong numbers, right MFMA stream)
                 // chunk c+2 has landed (this wave's PER pieces of chunk c+3 may stay in flight), the fragments of chunk c+1 are
                 // in registers (its stage is free); for NP = 3 the last six MFMAs run behind the barrier
                 x3p_wait_vm<(BAR2 ? 1 : NST - 2) * PER>();
@@ -567,7 +568,8 @@ void launch_linear_x3p(const ConvGemmDev& e_in, hipStream_t s) {
     if (e.np == 2) {
 #if defined(MI355TTS_TUNING)
 #define X2_TUNE(D, LABEL) case D: prof_set_kernel("linear_x3p_kernel<float, true, 2, " LABEL ">", "", ""); hipLaunchKernelGGL((linear_x3p_kernel<float, true, 2, D>), grid, dim3(512), 0, s, e); MI_HIP(hipGetLastError()); return;
-        if (e.lds_epi) switch (e.dbg & 27) {
+        if (e.lds_epi) switch (e.dbg & 59) {
+            X2_TUNE(48, "MFMA on real operands only, no loop barriers") X2_TUNE(34, "no LDS reads, no loop barriers") X2_TUNE(32, "no loop barriers")
             X2_TUNE(1, "noDMA") X2_TUNE(2, "noLDSread") X2_TUNE(3, "noDMA noLDSread") X2_TUNE(8, "noMFMA") X2_TUNE(9, "noDMA noMFMA") X2_TUNE(10, "noLDSread noMFMA") X2_TUNE(16, "MFMA on real operands only")
             default: break;
         }

@@ -8,7 +8,7 @@ IT=${1:-40}
 for sh in "2 1126 1024 3072" "2 1126 1024 1024" "2 1126 1024 2048" "2 1126 2048 1024"; do
   set -- $sh
   echo "== f32 B$1 T$2 K$3 N$4"
-  for d in 0 4 1 5 2 6 3 7 8 12 9 13 10 14 16 20; do
+  for d in ${DBGS:-0 4 1 5 2 6 3 7 8 12 9 13 10 14 16 20 36 52 38}; do
     printf "dbg %2d: " $d
     MI355TTS_GEMM_DBG=$d ITERS=$IT timeout 120 python tools/gemm_bench.py custom f32 $1 $2 $3 $4 1 1 | sed 's/custom *//'
   done
