@@ -374,6 +374,43 @@ def test_example_script_runs(tmp_path):
     assert rate == 24000 and wav.shape[1] == 1 and wav.shape[0] > 1000 and "RTF" in r.stdout
 
 
+@pytest.mark.parametrize("device_type", ["cpu", "cuda"])
+def test_indextts_example_script_runs(tmp_path, device_type):
+    """examples/indextts_infer.py: Inference_IndexTTS_ONNX.py:578-805 end to end (all six sessions, sentence loop, WAVEX write) on
+    the reduced models; the host and the device-resident OrtValue forms of the driver must write the same file."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from mi355tts import audio_io
+    prompt = str(tmp_path / "prompt.wav")
+    t = np.arange(30000)
+    audio_io.write_wavex(prompt, (8000 * np.sin(2 * np.pi * 330 * t / 24000)).astype(np.int16), 24000)
+    out = str(tmp_path / f"gen_{device_type}.wav")
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "indextts_infer.py"), "--small", "--dtype", "f32", "--prompt", prompt,
+                        "--text", "hello there. how are you today?", "--out", out, "--device-type", device_type, "--ignore-stop",
+                        "--max-generate-length", "70"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    wav, rate = audio_io.read_wav(out)
+    assert rate == 24000 and wav.shape[1] == 1 and wav.shape[0] > 4800 and "RTF" in r.stdout and "Decode Speed" in r.stdout
+    ref = tmp_path / "gen_cpu.wav"
+    if device_type == "cuda" and ref.exists():
+        assert np.array_equal(audio_io.read_wav(str(ref))[0], wav)
+
+
+def test_bigvgan_example_script_runs(tmp_path):
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from mi355tts import audio_io
+    outs = []
+    for device_type in ("cpu", "cuda"):
+        out = str(tmp_path / f"bv_{device_type}.wav")
+        r = subprocess.run([sys.executable, os.path.join(root, "examples", "bigvgan_infer.py"), "--small", "--dtype", "f32", "--out", out,
+                            "--device-type", device_type], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "RTF" in r.stdout, r.stderr[-2000:]
+        outs.append(audio_io.read_wav(out)[0])
+    assert outs[0].shape[0] == 512 * 8 + 30 and np.array_equal(outs[0], outs[1])
+
+
 def _f5_sessions(tmp_path, cfg, dtype="f32"):
     wfile = tmp_path / "f5_weights.npy"
     np.save(wfile, W.pack_f5(cfg, W.synth_state(W.f5_spec(cfg), 9527)))

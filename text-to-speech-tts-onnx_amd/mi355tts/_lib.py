@@ -36,6 +36,16 @@ def load() -> C.CDLL:
     if not os.path.exists(_LIB_PATH):
         raise MiError(f"{_LIB_PATH} is missing: build it with `python text-to-speech-tts-onnx_amd/build.py` "
                       f"(or __graft_entry__.build()); there is no CPU fallback")
+    # torch-ROCm ships its own copy of the HIP runtime.  If this library's copy initialises first, a later
+    # `torch.cuda` initialisation in the same process reports "No HIP GPUs are available" (seen with the device-resident
+    # OrtValues of ort_compat in a script that opened its sessions before touching torch); the other order works.  So when
+    # torch is installed it goes first (MI355TTS_NO_TORCH=1 skips this for pure-numpy users who never hand over torch tensors).
+    if os.environ.get("MI355TTS_NO_TORCH") != "1":
+        try:
+            import torch
+            torch.cuda.is_available()
+        except ImportError:
+            pass
     L = C.CDLL(_LIB_PATH)
     i32p, f32p = C.POINTER(C.c_int32), C.POINTER(C.c_float)
     vp = C.c_void_p
