@@ -359,6 +359,51 @@ def test_handles_are_thread_safe(golden_dir):
     a.close(); b.close()
 
 
+def test_set_option_while_other_threads_run_calls():
+    """include/mi355tts.h: "different handles may be used concurrently from different threads" — with mi_set_option in the picture
+    (VERDICT r4 #10).  Every entry point holds the shared side of one reader-writer lock, mi_set_option the exclusive side: a thread
+    that flips a dispatch option (here `bigvgan_streams`, whose three settings are bit-identical by construction) while two other
+    threads run forwards on two handles must neither corrupt a result nor dead-lock, and every flip must succeed."""
+    import threading
+    from mi355tts import _lib
+    from mi355tts.bigvgan import BigVGANVocoder
+    cfg = BigVGANConfig.small()
+    st = W.synth_state(W.bigvgan_spec(cfg), 9527)
+    engs = [BigVGANVocoder(cfg, st, dtype="f32") for _ in range(2)]
+    mels = [W.synth_normal(70 + i, "mel", (1, cfg.num_mels, 64 + 16 * i), std=1.0) for i in range(4)]
+    want = [engs[0].run(m) for m in mels]
+    errs, done, flips = [], threading.Event(), [0]
+
+    def work(eng):
+        try:
+            for rep in range(25):
+                for i, m in enumerate(mels):
+                    if not np.array_equal(eng.run(m), want[i]):
+                        errs.append(("mismatch", rep, i))
+        except Exception as e:                      # pragma: no cover
+            errs.append(e)
+
+    def flip():
+        try:
+            while not done.is_set():
+                for v in (1, 2, 3):
+                    _lib.set_option("bigvgan_streams", v)
+                    flips[0] += 1
+        except Exception as e:                      # pragma: no cover
+            errs.append(e)
+    th = [threading.Thread(target=work, args=(e,)) for e in engs]
+    tf = threading.Thread(target=flip)
+    [t.start() for t in th]; tf.start()
+    [t.join(300) for t in th]
+    done.set(); tf.join(60)
+    _lib.set_option("bigvgan_streams", 3)
+    assert not any(t.is_alive() for t in th) and not tf.is_alive(), "dead-lock"
+    assert not errs, errs[:3]
+    assert flips[0] >= 3
+    for e in engs:
+        e.close()
+
+
 def test_example_script_runs(tmp_path):
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
