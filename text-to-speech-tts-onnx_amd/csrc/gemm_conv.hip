@@ -781,6 +781,8 @@ bool gemm_set_option(const char* key, long v) {
     else if (k == "gemm_f32_planes") { if (v != 2 && v != 3) return false; g_x3p_np = v; }
     else if (k == "gemm_x3p_noalign") x3p_set_option(0, v);
     else if (k == "gemm_x3p_grid") x3p_set_option(1, v);
+    else if (k == "gemm_x3d") x3d_set_option(0, v);
+    else if (k == "gemm_x3d_min_eff") x3d_set_option(1, v);
     else if (k == "gemm_ph8") g_ph8 = v;
     else if (k == "gemm_ph8_min_tiles") g_ph8_min_tiles = v;
     else if (k == "gemm_row_split") g_row_split = v;

@@ -194,7 +194,8 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], const ConvG
 // and accumulate operands are fetched with 16-byte loads in the same layout).  Wave-local: no block barrier.
 template <typename TO, int TM, int TN, int WM, int WN>
 __device__ __forceinline__ void gemm_epilogue_lds(f32x16 (&acc)[TM][TN], const ConvGemmDev& p, int m0, int n0, int b, int g,
-                                                  int wm, int wn, int lr, int lk, float* stage) {
+                                                  int wm, int wn, int lr, int lk, float* stage, int m_end = -1) {
+    const int Mlim = m_end >= 0 ? m_end : p.M;
     constexpr int CH = sizeof(TO) == 2 ? 8 : 4;            // columns per lane: one 16-byte store
     constexpr int LPR = WN / CH;                            // lanes per output row
     constexpr int RPI = 64 / LPR;                           // rows per wave instruction
@@ -252,7 +253,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x16 (&acc)[TM][TN], const C
                 const int rr = rl0 + (it0 + gi) * RPI;
                 const int m = m0 + wm * WM + i0 * 32 + rr;
                 long row = m;
-                bool ok = cok && rr < RT * 32 && m < p.M;                 // (RPI need not divide the pass: 96-wide wave tiles)
+                bool ok = cok && rr < RT * 32 && m < Mlim;                // (RPI need not divide the pass: 96-wide wave tiles)
                 if (p.epi == EPI_CONVT) { row = (long)m * p.u + cph - p.padT; ok = ok && row >= 0 && row < p.T_out; }
                 okv[gi] = ok;
                 ixv[gi] = ok ? row * p.out_rstride + ccol : 0;       // masked lanes read element 0 (always there) and store nothing
@@ -342,7 +343,9 @@ __device__ __forceinline__ void ln_rows32(const ConvGemmDev& p, long row0, long 
 template <typename TO, int TMQ = 2, bool LN = false, bool PRE = false>
 __device__ __forceinline__ void gemm_epilogue_qkv_lds(f32x16 (&acc)[TMQ][2], const ConvGemmDev& p, int m0, int n0, int b,
                                                       int wm, int wn, int lr, int lk, float* stage,
-                                                      const float* pre_rs = nullptr, const float* pre_mr = nullptr) {
+                                                      const float* pre_rs = nullptr, const float* pre_mr = nullptr, int m_end = -1) {
+    // m_end >= 0: rows of this launch at or beyond m_end are not this caller's (gemm_x3d.hip: a 144-row tile ends inside a 32-row block)
+    const int Mlim = m_end >= 0 ? m_end : p.M;
     const int lane = lk * 32 + lr;
     const int dm = p.heads * 64;
     const int nbase = n0 + wn * 64;
@@ -396,7 +399,7 @@ __device__ __forceinline__ void gemm_epilogue_qkv_lds(f32x16 (&acc)[TMQ][2], con
 #pragma unroll
             for (int gi = 0; gi < GRP; ++gi) {
                 const int rr = (lane >> 3) + (it0 + gi) * 8;
-                okv[gi] = mrow + rr < p.M;
+                okv[gi] = mrow + rr < Mlim;
                 int m = mloc0 + rr, bi = bi0;
                 if (m >= Mb) { m -= Mb; ++bi; }
                 if (!okv[gi]) { m = 0; bi = bi0; }
@@ -512,7 +515,7 @@ __device__ __forceinline__ void gemm_epilogue_qkv_lds(f32x16 (&acc)[TMQ][2], con
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             const int rr = i * 32 + row;
-            const bool ok = mrow + rr < p.M;
+            const bool ok = mrow + rr < Mlim;
             int m = mloc0 + rr, bi = bi0;
             if (m >= Mb) { m -= Mb; ++bi; }
             TO* dst = base + (((long)b + bi) * p.heads + hh) * 64 * p.v_ld + m;
@@ -593,7 +596,8 @@ template <typename TO> __device__ __forceinline__ void ln_act8(float (&x)[8], in
 // engines: p.out) or as panel planes of NP planes (fp32 engines: p.out_planes), one 16-byte store per lane and plane.
 template <typename TO, int TM, int TN, int NP, bool PRE = false>
 __device__ __forceinline__ void gemm_epilogue_ln_in(f32x16 (&acc)[TM][TN], const ConvGemmDev& p, int mw, int nc0, int lr, int lk, float* stage,
-                                                    const float* pre_rs = nullptr, const float* pre_mr = nullptr) {
+                                                    const float* pre_rs = nullptr, const float* pre_mr = nullptr, int m_end = -1) {
+    const int Mlim = m_end >= 0 ? m_end : p.M;
     constexpr int WN = 32 * TN, LPR = WN / 8, RPI = 64 / LPR, NIT = 32 / RPI;
     const int lane = lk * 32 + lr;
     const int c8 = (lane % LPR) * 8, rl0 = lane / LPR;
@@ -638,7 +642,7 @@ __device__ __forceinline__ void gemm_epilogue_ln_in(f32x16 (&acc)[TM][TN], const
             if constexpr (sizeof(TO) == 4) {
                 x3_u4 pl[NP];
                 xnp_split8_sat<NP>(x, pl, sat);
-                if (m < p.M) {
+                if (m < Mlim) {
                     unsigned char* dst = (unsigned char*)p.out_planes + x3p_slot_offset(m, col >> 3, p.N >> 5, NP);
 #pragma unroll
                     for (int q = 0; q < NP; ++q) *reinterpret_cast<x3_u4*>(dst + q * X3P_PLANE) = pl[q];
@@ -647,7 +651,7 @@ __device__ __forceinline__ void gemm_epilogue_ln_in(f32x16 (&acc)[TM][TN], const
                 Pk o;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) o.v[q] = from_f32<TO>(x[q]);
-                if (m < p.M) *reinterpret_cast<Pk*>((TO*)p.out + (long)m * p.out_rstride + col) = o;
+                if (m < Mlim) *reinterpret_cast<Pk*>((TO*)p.out + (long)m * p.out_rstride + col) = o;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -660,7 +664,8 @@ __device__ __forceinline__ void gemm_epilogue_ln_in(f32x16 (&acc)[TM][TN], const
 // o (1 + ln_scale) -> the next GEMM's A operand (TA = float: panel planes of NP planes; else rows of TA, [M][N]); partial
 // (sum, M2 about the block mean) of x_new per 32-column block -> ln_stats_out (wave_reduce.h).  Wave tile as above.
 template <typename TA, int TM, int TN, int NP>
-__device__ __forceinline__ void gemm_epilogue_resid_ln(f32x16 (&acc)[TM][TN], const ConvGemmDev& p, int mw, int nc0, int lr, int lk, float* stage) {
+__device__ __forceinline__ void gemm_epilogue_resid_ln(f32x16 (&acc)[TM][TN], const ConvGemmDev& p, int mw, int nc0, int lr, int lk, float* stage, int m_end = -1) {
+    const int Mlim = m_end >= 0 ? m_end : p.M;
     constexpr int WN = 32 * TN, LPR = WN / 8, RPI = 64 / LPR, NIT = 32 / RPI;
     const int lane = lk * 32 + lr;
     const int c8 = (lane % LPR) * 8, rl0 = lane / LPR;
@@ -695,7 +700,7 @@ __device__ __forceinline__ void gemm_epilogue_resid_ln(f32x16 (&acc)[TM][TN], co
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int m = mw + i * 32 + rl0 + it * RPI;
-            ok[it] = m < p.M;
+            ok[it] = m < Mlim;
             ix[it] = ok[it] ? (long)m * p.out_rstride + col : 0;
             r0[it] = *reinterpret_cast<const float4*>(resp + ix[it]);
             r1[it] = *reinterpret_cast<const float4*>(resp + ix[it] + 4);
@@ -744,6 +749,60 @@ __device__ __forceinline__ void gemm_epilogue_resid_ln(f32x16 (&acc)[TM][TN], co
     if constexpr ((sizeof(TA) == 4 && NP == 2) || std::is_same<TA, f16>::value) sat_publish(p.sat, sat);
 }
 
+// Epilogue with the OUTPUT as panel planes of the [M][N] result (the A operand of the next linear layer; FF1 -> FF2):
+// bias + activation on the accumulators, the 64x64 wave tile through LDS, then every lane takes 8 consecutive columns of
+// a row (one 16-byte k-slot of the next GEMM), splits them three ways and stores 16 bytes per plane.
+template <int TM, int TN, int NP>
+__device__ __forceinline__ void x3p_epilogue_planes(f32x16 (&acc)[TM][TN], const ConvGemmDev& p, int m0, int n0, int wm, int wn,
+                                                    int lr, int lk, float* stage, int m_end = -1) {
+    const int Mlim = m_end >= 0 ? m_end : p.M;
+    const int lane = lk * 32 + lr;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const float bv = p.bias ? p.bias[n0 + wn * 64 + j * 32 + lr] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r] + bv;
+            switch (p.act) {
+                case ACT_GELU_TANH: act16<ACT_GELU_TANH, true>(v); break;      // x * sigmoid(2t): see ln_act8 (gemm_epilogue.h)
+                case ACT_GELU_ERF: act16<ACT_GELU_ERF>(v); break;
+                case ACT_MISH: act16<ACT_MISH>(v); break;
+                case ACT_SILU: act16<ACT_SILU>(v); break;
+                default: break;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) stage[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * 64 + j * 32 + lr] = v[r];
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int nch_out = p.N >> 5;
+    const int c8 = (lane & 7) * 8;
+    const int s8 = (n0 + wn * 64 + c8) >> 3;
+    unsigned char* planes = (unsigned char*)p.out_planes;
+    unsigned sat = 0;
+#pragma unroll
+    for (int it = 0; it < 4 * TM; ++it) {
+        const int rr = (lane >> 3) + it * 8;
+        const int m = m0 + wm * (32 * TM) + rr;                 // wm counts (32 * TM)-row blocks
+        const float4 t0 = *reinterpret_cast<const float4*>(&stage[rr * 64 + c8]);
+        const float4 t1 = *reinterpret_cast<const float4*>(&stage[rr * 64 + c8 + 4]);
+        const float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+        x3_u4 pl[NP];
+        xnp_split8_sat<NP>(v, pl, sat);
+        if (m < Mlim) {
+            unsigned char* dst = planes + x3p_slot_offset(m, s8, nch_out, NP);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) *reinterpret_cast<x3_u4*>(dst + q * X3P_PLANE) = pl[q];
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if constexpr (NP == 2) sat_publish(p.sat, sat);
+}
+
 typedef __attribute__((address_space(3))) void lds_void;
 
 // gemm_dma3.hip: the 8-wave 256-row kernels (bn = 192 / 256: buffer-descriptor DMA, bn = 128: three-stage ring)
@@ -756,6 +815,10 @@ void launch_linear_x3(const ConvGemmDev& e, hipStream_t s);
 template <typename T, typename TO> void launch_linear_ph8(const ConvGemmDev& e, hipStream_t s);
 void launch_linear_x3p(const ConvGemmDev& e, hipStream_t s);
 void x3p_set_option(int which, long v);
+// gemm_x3d.hip: exact-fit data-parallel form of linear_x3p (np = 2) — taken by launch_linear_x3p when x3d_plan finds a tiling
+bool x3d_plan(const ConvGemmDev& e, int cus, int& tw, int& rgn, int& cgn, int& band);
+void launch_linear_x3d(const ConvGemmDev& e, int tw, int rgn, int cgn, int band, hipStream_t s);
+void x3d_set_option(int which, long v);
 void ph8_set_split_max(long v);
 void ph8_set_split_min_nk(long v);
 

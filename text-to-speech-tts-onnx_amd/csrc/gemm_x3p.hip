@@ -98,59 +98,6 @@ __device__ __forceinline__ void x3p_dma16(RSRC rsrc, int voff, unsigned lds_dst)
 #endif
 }
 
-// Epilogue with the OUTPUT as panel planes of the [M][N] result (the A operand of the next linear layer; FF1 -> FF2):
-// bias + activation on the accumulators, the 64x64 wave tile through LDS, then every lane takes 8 consecutive columns of
-// a row (one 16-byte k-slot of the next GEMM), splits them three ways and stores 16 bytes per plane.
-template <int TM, int TN, int NP>
-__device__ __forceinline__ void x3p_epilogue_planes(f32x16 (&acc)[TM][TN], const ConvGemmDev& p, int m0, int n0, int wm, int wn,
-                                                    int lr, int lk, float* stage) {
-    const int lane = lk * 32 + lr;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const float bv = p.bias ? p.bias[n0 + wn * 64 + j * 32 + lr] : 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            float v[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r] + bv;
-            switch (p.act) {
-                case ACT_GELU_TANH: act16<ACT_GELU_TANH, true>(v); break;      // x * sigmoid(2t): see ln_act8 (gemm_epilogue.h)
-                case ACT_GELU_ERF: act16<ACT_GELU_ERF>(v); break;
-                case ACT_MISH: act16<ACT_MISH>(v); break;
-                case ACT_SILU: act16<ACT_SILU>(v); break;
-                default: break;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) stage[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * 64 + j * 32 + lr] = v[r];
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const int nch_out = p.N >> 5;
-    const int c8 = (lane & 7) * 8;
-    const int s8 = (n0 + wn * 64 + c8) >> 3;
-    unsigned char* planes = (unsigned char*)p.out_planes;
-    unsigned sat = 0;
-#pragma unroll
-    for (int it = 0; it < 4 * TM; ++it) {
-        const int rr = (lane >> 3) + it * 8;
-        const int m = m0 + wm * (32 * TM) + rr;                 // wm counts (32 * TM)-row blocks
-        const float4 t0 = *reinterpret_cast<const float4*>(&stage[rr * 64 + c8]);
-        const float4 t1 = *reinterpret_cast<const float4*>(&stage[rr * 64 + c8 + 4]);
-        const float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-        x3_u4 pl[NP];
-        xnp_split8_sat<NP>(v, pl, sat);
-        if (m < p.M) {
-            unsigned char* dst = planes + x3p_slot_offset(m, s8, nch_out, NP);
-#pragma unroll
-            for (int q = 0; q < NP; ++q) *reinterpret_cast<x3_u4*>(dst + q * X3P_PLANE) = pl[q];
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if constexpr (NP == 2) sat_publish(p.sat, sat);
-}
-
 // the same with an instruction offset OFF (0 / 1024 / 2048 / 3072): it advances the global address AND the LDS address, and the
 // operand chunk is laid out in LDS exactly as in memory, so four consecutive 1 KB pieces share one M0 value
 template <int OFF, typename RSRC>
@@ -541,6 +488,11 @@ void launch_linear_x3p(const ConvGemmDev& e_in, hipStream_t s) {
         static int cu_count[16] = {0};
         if (!cu_count[dev & 15]) { hipDeviceProp_t pr; MI_HIP(hipGetDeviceProperties(&pr, dev)); cu_count[dev & 15] = pr.multiProcessorCount; }
         cus = cu_count[dev & 15];
+    }
+    // exact-fit data-parallel tiling (gemm_x3d.hip) when the output divides into whole rounds of the CUs; else stream-K below
+    if (!(e.dbg & ~4)) {
+        int tw, rgn, cgn, band;
+        if (x3d_plan(e, cus, tw, rgn, cgn, band)) { launch_linear_x3d(e, tw, rgn, cgn, band, s); return; }
     }
     e.Tm = (e.M + 127) / 128; e.Tn = (e.N + 127) / 128;
     // XCD bands: GR x GC = 8.  Fabric-side bytes ~ GC * |A| + GR * |B|; the bands must also balance the tile counts
