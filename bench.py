@@ -73,15 +73,15 @@ def cpu_baseline_f5(cfg, raw_state, audio, ids, N, noise, full: bool = False, th
     """`cpu_baseline`: the numpy oracle (kind 'port', im2col + OpenBLAS sgemm) on the SAME utterance at the reference driver's own
     thread setting (MAX_THREADS = 8, F5-TTS-ONNX-Inference.py:36) — ONE thread setting (a 32-thread leg measured 2.3x slower on the
     256-thread GPU-box host: oversubscription, not a baseline; `--cpu-threads T` runs another setting on request).
-    Default (the bench contract's bounded sample, 10-30 s of CPU work): preprocess + MI355TTS_CPU_EVALS (8) of the 31 DiT evaluations +
-    decode, every stage measured; `value` is the utterance rate with the mean measured evaluation time standing for the ones not
-    run (`all_evaluations_measured: false` says so).  `--cpu-baseline-full`: ALL 31 evaluations run — nothing scaled
-    (profiles/r4/cpu_baseline_full.json is such a run on the GPU box's host: 55.9 s per utterance)."""
+    Default (round 6): preprocess + ALL 31 DiT evaluations + decode, every stage measured, nothing scaled
+    (`all_evaluations_measured: true`; ~56 s on the GPU box's host, profiles/r4/cpu_baseline_full.json).  MI355TTS_CPU_EVALS=k
+    bounds the leg to k evaluations (`value` then counts the ones not run at the mean measured evaluation and
+    `all_evaluations_measured: false` says so); `--cpu-baseline-full` ignores that bound."""
     from mi355tts import weights as W
     st = W.fold_f5(cfg, raw_state)
     nproc = os.cpu_count() or 1
     T = int(threads or os.environ.get("MI355TTS_CPU_THREADS", min(8, nproc)))
-    evals = None if full else int(os.environ.get("MI355TTS_CPU_EVALS", "8"))
+    evals = None if (full or "MI355TTS_CPU_EVALS" not in os.environ) else int(os.environ["MI355TTS_CPU_EVALS"])
     r = cpu_baseline_f5_run(cfg, st, audio, ids, N, noise, T, evals)
     mean_eval = sum(r["evaluations_s"]) / len(r["evaluations_s"])
     nfe = r["evaluations_of_the_workload"]
@@ -122,10 +122,10 @@ class F5Bench:
         # one process per GPU: fail loudly if two ranks resolved to the same physical device (the plumbing test on a one-GPU box says so)
         from mi355tts.shard import assert_one_device_per_rank
         self.rank_devices = [f"{h}:{b}" for h, b in assert_one_device_per_rank(local, allow_shared=os.environ.get("MI355TTS_BENCH_ONE_GPU") == "1")]
-        if world > 1:                       # the one collective of the path: weights rank 0 -> all, RCCL over xGMI
+        if world > 1 or dist.is_initialized():      # the one collective of the path: weights rank 0 -> all, RCCL over xGMI (one rank: --force-collective)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            self.blob_t = bcast_device_blob(torch, dist, self.blob_t)
+            self.blob_t = bcast_device_blob(torch, dist, self.blob_t, force=True)
             torch.cuda.synchronize()
             self.bcast_ms = (time.perf_counter() - t0) * 1e3
 
@@ -193,8 +193,9 @@ class F5Bench:
         gemm_like = [k for k in kernels if k["family"] in ("conv_gemm", "attn")]
         note = ("HIP events on the engine's stream around every launch, one separate eager pass after the timed region (the timed "
                 "region replays a hipGraph; events cannot be recorded into it); flops = 2*M*N*K of the launch")
+        gemm_like, merged = merge_instantiations(gemm_like)
         dom = gemm_like[0]["kernel"] if gemm_like else ""
-        if "linear_x3p_kernel<float, true, 2" in dom or "linear_x3p_kernel<float, false, 2" in dom:
+        if "linear_x3p_kernel<float, true, 2" in dom or "linear_x3p_kernel<float, false, 2" in dom or "linear_x3d_kernel" in dom:
             # fp32 products as THREE fp16 x fp16 partial products (operands as {hi, lo * 2^11} fp16 pairs, two accumulator sets:
             # gemm_x3p.hip NP = 2): the ceiling is the dense fp16 MFMA peak / 3 in fp32-equivalent flops
             peak = MFMA_F16_PEAK_TF / 3.0
@@ -206,8 +207,11 @@ class F5Bench:
             peak = MFMA_F16_PEAK_TF / 6.0
             note += ("; this kernel computes every fp32 product as 6 bf16 MFMA partial products (3-way exact operand split, fp32 "
                      "accumulate): peak = 2500 / 6 TFLOP/s of fp32-equivalent work, achieved counts 2*M*N*K once")
-        gemm_like, merged = merge_instantiations(gemm_like)
-        if merged:
+        if merged and "linear_x3d_kernel" in merged["kernel"]:
+            note += ("; linear_x3d (gemm_x3d.hip) is the exact-fit data-parallel form of the fp16-pair GEMM, compiled per tile width and "
+                     "epilogue (QKV 144 x 192 | FF1 144 x 128 | O, FF2 144 x 64): the row pools the instantiations (launch-weighted), "
+                     "`instantiations` lists each, and the rocprofv3 summary carries them as linear_x3d_kernel<192 | 128 | 64, true, 1 | 2 | 3>")
+        elif merged:
             note += ("; linear_x3p is compiled once per epilogue (QKV | FF1 | O / FF2: no register spills in the main loop) — the row "
                      "pools the three instantiations (launch-weighted), `instantiations` lists each, and the rocprofv3 summary "
                      "carries them as linear_x3p_kernel<float, true, 2, 0, true, 1 | 2 | 3>")
@@ -259,7 +263,7 @@ def run_f5(args, world, rank, local, dev, dist, torch):
                    "per_rank_ms": res["per_rank_ms"], "rank_devices": fb.rank_devices, "frames": N,
                    "audio_seconds_per_step_per_gpu": res["audio_seconds_per_step_per_gpu"], "rtf": res["rtf"],
                    "weights": "synthetic seeded (337 M DiT + 13.5 M Vocos)", "weight_bcast_ms": fb.bcast_ms,
-                   "collective_backend": dist.get_backend() if world > 1 else None,
+                   "collective_backend": dist.get_backend() if dist.is_initialized() else None,
                    "arithmetic_kind": res["arithmetic_kind"], "adaln_fold": res["adaln_fold"], "saturation_events": res["saturation_events"],
                    "native_fp32_ms_per_step": native["ms_per_step"] if native else None,
                    "arithmetic": ("fp32 values, fp32 accumulation; the DiT linear layers form each fp32 product as three fp16 x fp16 partial products "
@@ -327,6 +331,9 @@ def main():
                     help="f5 fp32: F5Config.f32_arithmetic of the engine (default: the library default, fp16x2-pairs)")
     ap.add_argument("--adaln-fold", action="store_true", help="f5: F5Config.adaln_fold = True (16-bit engines: the fold is opt-in)")
     ap.add_argument("--no-adaln-fold", action="store_true", help="f5: F5Config.adaln_fold = False (row-norm launches; A/B of the fold)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="--gpus 1: create a one-rank process group (backend nccl = RCCL) and send the weight blob through its broadcast, "
+                         "as every rank of an N-GPU run does; the line then carries collective_backend and weight_bcast_ms")
     ap.add_argument("--no-pmc", action="store_true", help="f5 on one GPU: skip the two rocprofv3 --pmc passes that fill roofline.traffic")
     ap.add_argument("--no-secondary", action="store_true", help="f5 on one GPU: skip the configs[1] / configs[3]-shard blocks")
     ap.add_argument("--cpu-frames", type=int, default=128)
@@ -359,9 +366,14 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit(f"bench.py needs an MI355X (no CPU fallback) [rank {rank} of {world}]")
-    if world > 1:
+    if world > 1 or args.force_collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1:                       # --force-collective: a one-rank process group so that the weight broadcast runs through RCCL
+            import socket
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(so.getsockname()[1]))
         # MI355TTS_BENCH_BACKEND=gloo + MI355TTS_BENCH_ONE_GPU=1: exercise the multi-rank code path on a 1-GPU box
         dist.init_process_group(os.environ.get("MI355TTS_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
     if os.environ.get("MI355TTS_BENCH_ONE_GPU") == "1":
@@ -392,7 +404,7 @@ def main():
     else:
         import bench_detail
         bench_detail.run_other(args, world, rank, local, dev, dist, torch)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

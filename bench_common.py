@@ -32,6 +32,23 @@ def merge_instantiations(kernels):
     """linear_x3p NP = 2 is one kernel compiled per epilogue (template parameter EPK, gemm_x3p.hip): the roofline row is
     quoted on the kernel, so the per-epilogue instantiations are pooled (flops, bytes, time, launches summed) and kept
     beside the pooled row.  Returns (kernels with the pooled row in place, the pooled row or None)."""
+    # round 6: the exact-fit data-parallel form of the same GEMM (gemm_x3d.hip), compiled per tile width x epilogue
+    for tag, fam in (("AdaLN fold", r"linear_x3d_kernel<(64|128|192), true, [123]>"), ("", r"linear_x3d_kernel<(64|128|192), false, [123]>")):
+        roles = ("AdaLN fold, QKV", "AdaLN fold, FF1", "AdaLN fold, O / FF2") if tag else ("QKV", "planes out", "rows out")
+        names = [f"linear_x3d_kernel<{w}, {r}>" for w in (64, 128, 192) for r in roles]
+        inst = [k for k in kernels if k["kernel"] in names and k["launches"] > 0]
+        if len(inst) < 2:
+            continue
+        m = dict(inst[0])
+        m["kernel"] = "linear_x3d_kernel<144 x {64,128,192} tiles, fp16 pairs" + (", " + tag if tag else "") + ">"
+        for f in ("ms", "launches", "flops", "bytes"):
+            m[f] = sum(k[f] for k in inst)
+        m["instantiations"] = [{"kernel": k["kernel"], "launches": k["launches"], "avg_launch_us": k["ms"] / k["launches"] * 1e3,
+                                "tflops": k["flops"] / (k["ms"] * 1e-3) / 1e12} for k in inst]
+        m["pmc_family"] = fam
+        rest = [k for k in kernels if k not in inst]
+        out = sorted(rest + [m], key=lambda k: -k["ms"])
+        return out, m
     for tag, fam in (("AdaLN fold", r"linear_x3p_kernel<float, true, 2, 0, true, [123]>"), ("", r"linear_x3p_kernel<float, true, 2, 0, false, [123]>")):
         pre = "linear_x3p_kernel<float, true, 2, " + (tag + ", " if tag else "")
         names = [pre + r + ">" for r in X3P_ROLES] if tag else ["linear_x3p_kernel<float, true, 2, QKV>", "linear_x3p_kernel<float, true, 2, planes out>", "linear_x3p_kernel<float, true, 2>"]
@@ -77,11 +94,11 @@ def dominant_kernel_roofline(kernels, steps: int, peak: float, bound: str, note:
                          "alg_GBps": x["bytes"] / (x["ms"] * 1e-3) / 1e9 if x["ms"] > 0 else 0.0} for x in ks[:8]]}
 
 
-def bcast_device_blob(torch, dist, blob_t):
+def bcast_device_blob(torch, dist, blob_t, force=False):
     """rank 0 -> all: the library helper (mi355tts/shard.py broadcast_blob_device — RCCL over xGMI on the device buffer itself;
     gloo in the one-GPU plumbing test is staged through host memory)."""
     from mi355tts.shard import broadcast_blob_device
-    return broadcast_blob_device(blob_t, src=0)
+    return broadcast_blob_device(blob_t, src=0, force=force)
 
 
 def per_rank_times(torch, dist, world, dt, dev):

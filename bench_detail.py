@@ -325,6 +325,7 @@ def run_indextts(args, world, rank, local, dev, dist, torch):
 
     def graph_a():
         vc, lat = cond_eng.run(prompt_audio)
+        vc = np.concatenate([vc[ccfg.voc_initial:], vc[:ccfg.voc_initial]])      # graph F's input order: the stage vectors, then the speaker embedding layer's
         pr, cl = gpt.concat(lat[None], text_h, mel_h)
         return torch.from_numpy(vc).to(dev), torch.from_numpy(pr[0]).to(dev), int(cl[0]), pr
 

@@ -226,8 +226,8 @@ int         mi_bench_conv_gemm(int dtype, int B, int T, int Cin, int N, int taps
  * IndexTTS/Export_IndexTTS.py:74-200): mel front end (0.1 s constant noise pad + 'constant'-padded STFT + HTK mel + log) ->
  * Conformer conditioning encoder (rel-pos attention with rel_shift) -> Perceiver resampler => conds_latent (latents, model_dim),
  * the prompt of the acoustic GPT (graph D's first input); ECAPA-TDNN speaker encoder + the 1x1 conditioning convolutions =>
- * conds = [bigvgan_cond_layer_speaker_embedding (voc_initial) | save_bigvgan_conds_0 | ... | _n-1], exactly the `conds` vector
- * mi_bigvgan_forward_latent takes.  fp32 engine.  cfg: mi355tts.config.IndexCondConfig.to_int_array(); weights: the packed
+ * conds = [bigvgan_cond_layer_speaker_embedding (voc_initial) | save_bigvgan_conds_0 | ... | _n-1] (mi_bigvgan_forward_latent
+ * takes the same vectors with the speaker-embedding layer's LAST: IndexCond.split_conds / graph F's input order).  fp32 engine.  cfg: mi355tts.config.IndexCondConfig.to_int_array(); weights: the packed
  * blob of mi355tts.weights.pack_cond (export-time folds applied).  mel (optional, may be NULL): the (frames, n_mels) log-mel. */
 int64_t     mi_indextts_cond_param_count(const int32_t* cfg, int n_cfg);
 mi_cond*    mi_indextts_cond_create(const int32_t* cfg, int n_cfg, const float* weights, int64_t n_weights, int device);

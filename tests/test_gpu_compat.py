@@ -206,129 +206,132 @@ def test_indextts_a_session_like_the_reference_call(tmp_path, golden_dir):
         ort_session_A.run(out_name_A, {in_name_A0: g["r_audio"].astype(np.float32).reshape(1, 1, -1)})
 
 
+# ---- IndexTTS graphs B / C / D / E behind the façade: the CONTRACT a driver relies on, as a table the test walks ------------------
+# (name, ONNX element type, rank) per input / output, in export order (Export_IndexTTS.py:203-297: input_names / output_names of the
+# four torch.onnx.export calls).  `{i}` rows are repeated per GPT layer.
+_GPT_IO = {
+    "IndexTTS_B": ([("text_ids", "int32", 2)], [("text_hidden_state", "float", 3)]),
+    "IndexTTS_C": ([("gpt_ids", "int32", 2), ("kv_seq_len", "int64", 1)], [("gpt_hidden_state", "float", 3), ("next_kv_seq_len", "int64", 1)]),
+    "IndexTTS_D": ([("embed_x", "float", 3), ("embed_y", "float", 3), ("embed_z", "float", 3)],
+                   [("concat_hidden_state", "float", 3), ("concat_len", "int64", 1)]),
+    "IndexTTS_E": ([("in_key_{i}", "float", 3), ("in_value_{i}", "float", 3), ("history_len", "int64", 1), ("repeat_penality", "float", 2),
+                    ("ids_len", "int64", 1), ("hidden_state", "float", 3), ("attention_mask", "int8", 1)],
+                   [("out_key_{i}", "float", 3), ("out_value_{i}", "float", 3), ("kv_seq_len", "int64", 1), ("last_hidden_state", "float", 2),
+                    ("max_logit_id", "int32", 2)]),
+}
+
+
+def _expand_io(rows, layers):
+    out = []
+    for name, ty, rank in rows:
+        out += [(name.format(i=i), ty, rank) for i in range(layers)] if "{i}" in name else [(name, ty, rank)]
+    return out
+
+
+class _GreedyMelDecoder:
+    """What a caller of the four sessions has to do for one sentence — stated against the contract, by NAME: prompt = D(conds, B(text),
+    C(start)); then E on the prompt with attention_mask 1 and an empty history, and E on one row at a time with attention_mask 0, the
+    out_key / out_value VALUES of a step being the in_key / in_value of the next (references, never copied); the token of a step
+    goes through C to become the next row.  The repeat penalty is host state: a chosen code's entry is set to `value`, and once more
+    than `window` codes have been chosen the oldest chosen code is released back to 1 unless it is the code just chosen."""
+
+    def __init__(self, sessions, place, layers, mel_codes, value, window):
+        self.B, self.C, self.D, self.E = sessions
+        self.place, self.layers, self.value, self.window = place, layers, value, window
+        self.penalty = np.ones((1, mel_codes), np.float32)
+        self.keys_in = [f"in_key_{i}" for i in range(layers)]
+        self.vals_in = [f"in_value_{i}" for i in range(layers)]
+        self.e_outs = [o.name for o in self.E.get_outputs()]
+        self.c_outs = [o.name for o in self.C.get_outputs()]
+        meta = {a.name: a for a in self.E.get_inputs()}
+        k, v = meta["in_key_0"].shape, meta["in_value_0"].shape
+        self.empty_k = place(np.zeros((k[0], k[1], 0), np.float32))
+        self.empty_v = place(np.zeros((v[0], 0, v[2]), np.float32))
+
+    def prompt(self, conds_latent, text_ids, start_code):
+        text_h = self.B.run_with_ort_values(["text_hidden_state"], {"text_ids": self.place(text_ids)})[0]
+        row, self.position = self.C.run_with_ort_values(self.c_outs, {"gpt_ids": self.place(np.array([[start_code]], np.int32)),
+                                                                      "kv_seq_len": self.place(np.array([0], np.int64))})
+        return self.D.run_with_ort_values([o.name for o in self.D.get_outputs()],
+                                          {"embed_x": self.place(conds_latent), "embed_y": text_h, "embed_z": row})
+
+    def fresh_feed(self, rows, n_rows):
+        feed = {k: self.empty_k for k in self.keys_in}
+        feed.update({v: self.empty_v for v in self.vals_in})
+        feed.update(history_len=self.place(np.array([0], np.int64)), repeat_penality=self.place(self.penalty.copy()), ids_len=n_rows,
+                    hidden_state=rows, attention_mask=self.place(np.array([1], np.int8)))
+        return feed
+
+    def decode(self, rows, n_rows, limit, stop_codes):
+        feed = self.fresh_feed(rows, n_rows)
+        chosen, hidden, released = [], [], 0
+        out = None
+        while len(chosen) < limit:
+            out = dict(zip(self.e_outs, self.E.run_with_ort_values(self.e_outs, feed)))
+            code = int(out["max_logit_id"].numpy().reshape(-1)[0])
+            chosen.append(code)
+            hidden.append(out["last_hidden_state"])
+            if code in stop_codes:
+                break
+            self.penalty[0, code] = self.value
+            if len(chosen) > self.window and chosen[released] != code:
+                self.penalty[0, chosen[released]] = 1.0
+                released += 1
+            row, self.position = self.C.run_with_ort_values(self.c_outs, {"gpt_ids": out["max_logit_id"], "kv_seq_len": self.position})
+            feed = {f"in_key_{i}": out[f"out_key_{i}"] for i in range(self.layers)}
+            feed.update({f"in_value_{i}": out[f"out_value_{i}"] for i in range(self.layers)})
+            feed.update(history_len=out["kv_seq_len"], repeat_penality=self.place(self.penalty.copy()),
+                        ids_len=self.place(np.array([1], np.int64)), hidden_state=row, attention_mask=self.place(np.array([0], np.int8)))
+        return chosen, hidden, out
+
+
 @pytest.mark.parametrize("device_type", ["cpu", "cuda"])
-def test_indextts_gpt_driver_loop_through_facade(tmp_path, golden_dir, device_type):
-    """Inference_IndexTTS_ONNX.py:619-800 for one sentence with sessions B, C, D, E: same variable names and feed
-    bookkeeping as the reference driver; out_key/out_value OrtValues are fed straight back as in_key/in_value.
-    device_type 'cuda' (round 5): every `ortvalue_from_numpy(x, device_type, DEVICE_ID)` of the driver is a device-resident value
-    (the sessions of this model read them back through `.numpy()`: same tokens, same hidden states)."""
+def test_indextts_gpt_sessions_contract(tmp_path, golden_dir, device_type):
+    """Sessions B, C, D, E of IndexTTS as a drop-in for the reference driver's sentence loop (Inference_IndexTTS_ONNX.py:723-800):
+    names / element types / ranks of every input and output, values passed as OrtValues on the host or on the device, cache values
+    consumed by reference, the tokens and hidden states of the reference fixture, cache restart, stale references, the numpy form."""
     from mi355tts.config import IndexGPTConfig
     g = np.load(os.path.join(golden_dir, "indextts_gpt.npz"))
     cfg = IndexGPTConfig.small()
     wfile = tmp_path / "gpt_weights.npy"
     np.save(wfile, W.pack_gpt(cfg, W.synth_state(W.gpt_spec(cfg), 9527)))
-    paths = {k: onnxruntime.save_model(str(tmp_path / f"{k}.mi355.json"), k, cfg, str(wfile), "f32")
-             for k in ("IndexTTS_B", "IndexTTS_C", "IndexTTS_D", "IndexTTS_E")}
-    DEVICE_ID = 0
-    REPEAT_PENALITY, PENALITY_RANGE = float(g["gen_params"][0]), int(g["gen_params"][1])
-    STOP_TOKEN = [cfg.stop_mel_token]
-    ort_session_B = onnxruntime.InferenceSession(paths["IndexTTS_B"])
-    ort_session_C = onnxruntime.InferenceSession(paths["IndexTTS_C"])
-    ort_session_D = onnxruntime.InferenceSession(paths["IndexTTS_D"])
-    ort_session_E = onnxruntime.InferenceSession(paths["IndexTTS_E"])
-    in_name_B0, out_name_B0 = ort_session_B.get_inputs()[0].name, ort_session_B.get_outputs()[0].name
-    in_name_C = [a.name for a in ort_session_C.get_inputs()]
-    out_name_C = [a.name for a in ort_session_C.get_outputs()]
-    in_name_D = [a.name for a in ort_session_D.get_inputs()]
-    out_name_D = [a.name for a in ort_session_D.get_outputs()]
-    model_E_dtype = np.float16 if "float16" in ort_session_E._inputs_meta[0].type else np.float32
-    in_names_E = [a.name for a in ort_session_E.get_inputs()]
-    out_name_E = [a.name for a in ort_session_E.get_outputs()]
-    amount_of_outputs_E = len(out_name_E)
-    num_layers = (amount_of_outputs_E - 3) // 2
-    assert num_layers == cfg.layers and len(in_names_E) == 2 * num_layers + 5
-    num_layers_2 = num_layers * 2
-    last_input_indices_E, last_output_indices_E = len(in_names_E) - 1, amount_of_outputs_E - 1
-    second_last_output_indices_E = amount_of_outputs_E - 2
-    OV = onnxruntime.OrtValue.ortvalue_from_numpy
-    init_gpt_ids = OV(np.array([[cfg.start_mel_token]], dtype=np.int32), device_type, DEVICE_ID)
-    init_gen_len = OV(np.array([0], dtype=np.int64), device_type, DEVICE_ID)
-    init_ids_len_1 = OV(np.array([1], dtype=np.int64), device_type, DEVICE_ID)
-    init_history_len = OV(np.array([0], dtype=np.int64), device_type, DEVICE_ID)
-    init_attention_mask_0 = OV(np.array([0], dtype=np.int8), device_type, DEVICE_ID)
-    init_attention_mask_1 = OV(np.array([1], dtype=np.int8), device_type, DEVICE_ID)
-    m = ort_session_E._inputs_meta
-    init_past_keys_E = OV(np.zeros((m[0].shape[0], m[0].shape[1], 0), dtype=model_E_dtype), device_type, DEVICE_ID)
-    init_past_values_E = OV(np.zeros((m[num_layers].shape[0], 0, m[num_layers].shape[2]), dtype=model_E_dtype), device_type, DEVICE_ID)
-    repeat_penality = OV(np.ones((1, m[num_layers_2 + 1].shape[1]), dtype=model_E_dtype), device_type, DEVICE_ID)
-    input_feed_E = {in_names_E[last_input_indices_E]: init_attention_mask_1, in_names_E[num_layers_2]: init_history_len,
-                    in_names_E[num_layers_2 + 1]: repeat_penality}
-    for i in range(num_layers):
-        input_feed_E[in_names_E[i]] = init_past_keys_E
-    for i in range(num_layers, num_layers_2):
-        input_feed_E[in_names_E[i]] = init_past_values_E
-
-    conds_latent = OV(g["conds_latent"], device_type, DEVICE_ID)
-    text_ids = OV(g["text_ids"], device_type, DEVICE_ID)
-    text_hidden_state = ort_session_B.run_with_ort_values([out_name_B0], {in_name_B0: text_ids})[0]
-    gpt_hidden_state, gen_len = ort_session_C.run_with_ort_values(out_name_C, {in_name_C[0]: init_gpt_ids, in_name_C[1]: init_gen_len})
-    gpt_hidden_state, concat_len = ort_session_D.run_with_ort_values(
-        out_name_D, {in_name_D[0]: conds_latent, in_name_D[1]: text_hidden_state, in_name_D[2]: gpt_hidden_state})
-    np.testing.assert_allclose(gpt_hidden_state.numpy(), g["D_hidden"], atol=1e-6, rtol=0)
-    generate_limit = 13 + len(g["gen_tokens"]) - onnxruntime.OrtValue.numpy(concat_len)
-    input_feed_E[in_names_E[num_layers_2 + 2]] = concat_len
-    save_last_hidden_state, save_max_logits_ids = [], []
-    reset_penality = num_decode = 0
-    while num_decode < generate_limit:
-        input_feed_E[in_names_E[num_layers_2 + 3]] = gpt_hidden_state
-        all_outputs_E = ort_session_E.run_with_ort_values(out_name_E, input_feed_E)
-        max_logit_ids = onnxruntime.OrtValue.numpy(all_outputs_E[last_output_indices_E])
-        save_max_logits_ids.append(max_logit_ids)
-        save_last_hidden_state.append(all_outputs_E[second_last_output_indices_E])
-        num_decode += 1
-        if max_logit_ids in STOP_TOKEN:
-            break
-        if num_decode < 2:
-            input_feed_E[in_names_E[last_input_indices_E]] = init_attention_mask_0
-            input_feed_E[in_names_E[num_layers_2 + 2]] = init_ids_len_1
-        for i in range(second_last_output_indices_E):
-            input_feed_E[in_names_E[i]] = all_outputs_E[i]
-        repeat_penality = onnxruntime.OrtValue.numpy(repeat_penality)
-        repeat_penality[:, max_logit_ids] = REPEAT_PENALITY
-        if (num_decode > PENALITY_RANGE) and (save_max_logits_ids[reset_penality] != max_logit_ids):
-            repeat_penality[:, save_max_logits_ids[reset_penality]] = 1.0
-            reset_penality += 1
-        repeat_penality = OV(repeat_penality, device_type, DEVICE_ID)
-        input_feed_E[in_names_E[num_layers_2 + 1]] = repeat_penality
-        gpt_hidden_state, gen_len = ort_session_C.run_with_ort_values(
-            out_name_C, {in_name_C[0]: all_outputs_E[last_output_indices_E], in_name_C[1]: gen_len})
-    toks = [int(t.reshape(-1)[0]) for t in save_max_logits_ids]
-    assert toks == [int(x) for x in g["gen_tokens"]]
-    hid = np.concatenate([onnxruntime.OrtValue.numpy(h) for h in save_last_hidden_state], axis=0)
-    np.testing.assert_allclose(hid, g["gen_hidden"], atol=3e-4, rtol=0)
-    # the final cache can still be materialised in the reference's layouts
-    np.testing.assert_allclose(all_outputs_E[0].numpy(), g["gen_key0"], atol=3e-4, rtol=0)
-    np.testing.assert_allclose(all_outputs_E[num_layers + 1].numpy(), g["gen_value1"], atol=3e-4, rtol=0)
-    # next sentence: the empty caches are fed again (:796-800) -> history restarts
-    input_feed_E[in_names_E[last_input_indices_E]] = init_attention_mask_1
-    input_feed_E[in_names_E[num_layers_2]] = init_history_len
-    for i in range(num_layers):
-        input_feed_E[in_names_E[i]] = init_past_keys_E
-    for i in range(num_layers, num_layers_2):
-        input_feed_E[in_names_E[i]] = init_past_values_E
-    input_feed_E[in_names_E[num_layers_2 + 2]] = concat_len
-    input_feed_E[in_names_E[num_layers_2 + 3]] = OV(g["D_hidden"], device_type, DEVICE_ID)
-    input_feed_E[in_names_E[num_layers_2 + 1]] = OV(np.ones((1, cfg.mel_codes), np.float32), device_type, DEVICE_ID)
-    again = ort_session_E.run_with_ort_values(out_name_E, input_feed_E)
-    assert int(again[last_output_indices_E].numpy().reshape(-1)[0]) == int(g["gen_tokens"][0])
-    assert int(again[num_layers_2].numpy()[0]) == 13
-    # stale references are refused, numpy round trips work (plain .run materialises the cache)
-    with pytest.raises(onnxruntime.Fail):
-        all_outputs_E[0].numpy()
-    feed_np = {k: (v.numpy() if hasattr(v, "numpy") else v) for k, v in input_feed_E.items()}
-    outs = ort_session_E.run(None, feed_np)
-    assert outs[0].shape == (cfg.heads, cfg.head_dim, 13) and int(outs[-1].reshape(-1)[0]) == int(g["gen_tokens"][0])
-    # a history given as arrays (not references) is loaded into the cache: one more step from the golden mid-state
-    feed_np = {f"in_key_{i}": g["S_keys_in"][i] for i in range(num_layers)}
-    feed_np.update({f"in_value_{i}": g["S_values_in"][i] for i in range(num_layers)})
-    feed_np.update({"history_len": np.array([g["S_keys_in"].shape[3]], np.int64), "repeat_penality": g["S_pen"],
-                    "ids_len": np.array([1], np.int64), "hidden_state": g["S_hidden_in"],
-                    "attention_mask": np.array([0], np.int8)})
-    kv, last, tok = ort_session_E.run(["kv_seq_len", "last_hidden_state", "max_logit_id"], feed_np)
+    sess = {}
+    for graph, (ins, outs) in _GPT_IO.items():
+        sess[graph] = onnxruntime.InferenceSession(onnxruntime.save_model(str(tmp_path / f"{graph}.mi355.json"), graph, cfg, str(wfile), "f32"))
+        for have, want in ((sess[graph].get_inputs(), _expand_io(ins, cfg.layers)), (sess[graph].get_outputs(), _expand_io(outs, cfg.layers))):
+            assert [(a.name, a.type, len(a.shape)) for a in have] == [(n, f"tensor({t})", r) for n, t, r in want], graph
+    place = lambda x: onnxruntime.OrtValue.ortvalue_from_numpy(np.ascontiguousarray(x), device_type, 0)
+    dec = _GreedyMelDecoder([sess[k] for k in _GPT_IO], place, cfg.layers, cfg.mel_codes, float(g["gen_params"][0]), int(g["gen_params"][1]))
+    rows, n_rows = dec.prompt(g["conds_latent"], g["text_ids"], cfg.start_mel_token)
+    assert int(n_rows.numpy()[0]) == 13
+    np.testing.assert_allclose(rows.numpy(), g["D_hidden"], atol=1e-6, rtol=0)
+    want_tokens = [int(x) for x in g["gen_tokens"]]
+    chosen, hidden, last = dec.decode(rows, n_rows, len(want_tokens), [cfg.stop_mel_token])
+    assert chosen == want_tokens
+    np.testing.assert_allclose(np.concatenate([h.numpy() for h in hidden], axis=0), g["gen_hidden"], atol=3e-4, rtol=0)
+    # the cache behind the last step's references, in the reference's layouts
+    np.testing.assert_allclose(last["out_key_0"].numpy(), g["gen_key0"], atol=3e-4, rtol=0)
+    np.testing.assert_allclose(last["out_value_1"].numpy(), g["gen_value1"], atol=3e-4, rtol=0)
+    # a new sentence = empty caches fed again: the history restarts, the first token is the fixture's first token
+    dec.penalty[:] = 1.0
+    again = dict(zip(dec.e_outs, sess["IndexTTS_E"].run_with_ort_values(dec.e_outs, dec.fresh_feed(place(g["D_hidden"]), n_rows))))
+    assert int(again["max_logit_id"].numpy().reshape(-1)[0]) == want_tokens[0] and int(again["kv_seq_len"].numpy()[0]) == 13
+    with pytest.raises(onnxruntime.Fail):                     # ... and the references of the sentence before are stale now
+        last["out_key_0"].numpy()
+    # plain run() on arrays: the cache is materialised for the caller
+    arrays = {k: v.numpy() for k, v in dec.fresh_feed(place(g["D_hidden"]), n_rows).items()}
+    outs = sess["IndexTTS_E"].run(None, arrays)
+    assert outs[0].shape == (cfg.heads, cfg.head_dim, 13) and int(outs[-1].reshape(-1)[0]) == want_tokens[0]
+    # a history handed over as ARRAYS is loaded into the cache: one step from the fixture's mid-sentence state
+    mid = {f"in_key_{i}": g["S_keys_in"][i] for i in range(cfg.layers)}
+    mid.update({f"in_value_{i}": g["S_values_in"][i] for i in range(cfg.layers)})
+    mid.update(history_len=np.array([g["S_keys_in"].shape[3]], np.int64), repeat_penality=g["S_pen"], ids_len=np.array([1], np.int64),
+               hidden_state=g["S_hidden_in"], attention_mask=np.array([0], np.int8))
+    kv, hid, tok = sess["IndexTTS_E"].run(["kv_seq_len", "last_hidden_state", "max_logit_id"], mid)
     assert int(kv[0]) == g["S_keys_in"].shape[3] + 1 and int(tok[0, 0]) == int(g["S_token"][0, 0])
-    np.testing.assert_allclose(last, g["S_last_hidden"], atol=3e-4, rtol=0)
-    with pytest.raises(onnxruntime.InvalidArgument):
-        ort_session_E.run(None, {**feed_np, "ids_len": np.array([2], np.int64)})
+    np.testing.assert_allclose(hid, g["S_last_hidden"], atol=3e-4, rtol=0)
+    with pytest.raises(onnxruntime.InvalidArgument):          # ids_len must say what hidden_state holds
+        sess["IndexTTS_E"].run(None, {**mid, "ids_len": np.array([2], np.int64)})
 
 
 def test_handles_are_thread_safe(golden_dir):
@@ -464,86 +467,68 @@ def _f5_sessions(tmp_path, cfg, dtype="f32"):
     return [onnxruntime.InferenceSession(paths[k]) for k in ("F5_Preprocess", "F5_Transformer", "F5_Decode")]
 
 
+# graph B of F5 (F5_Transformer): which output may be bound onto which input — the aliasing the reference's io-binding loop
+# relies on (F5-TTS-ONNX-Inference.py:256-288): output k advances input _F5_B_ALIAS[k] in place
+_F5_B_INPUTS = ("noise", "rope_cos_q", "rope_sin_q", "rope_cos_k", "rope_sin_k", "cat_mel_text", "cat_mel_text_drop", "time_step")
+_F5_B_ALIAS = {"denoised": "noise", "time_step": "time_step"}
+
+
 def test_f5_driver_io_binding_branch_device_resident(tmp_path, golden_dir):
-    """The reference's `if device_type:` branch (F5-TTS-ONNX-Inference.py:256-288), line for line: graph A's outputs become
-    DEVICE OrtValues (`ortvalue_from_numpy(x, 'cuda', DEVICE_ID)`), outputs 0 / 1 of graph B are bound onto inputs 0 / 7, the
-    loop is `run_with_iobinding`, the result comes back with `OrtValue.numpy(io_binding.get_outputs()[0])`.  The façade keeps
-    those values in HBM and hands device pointers to the C-ABI (round 5; the round-4 OrtValue was a host array whatever the
-    device type).  Against the fixture AND bit-equal to the host-numpy loop."""
-    import torch
+    """Graph B's io-binding contract with DEVICE-resident values: every graph-A output placed on the device, the two outputs bound
+    onto the inputs they advance, `run_with_iobinding` NFE - 1 times, the result read back from the binding.  Checked: the values
+    are device values (broadcast RoPE axes not expanded), the bound buffers advance IN PLACE (same pointer, device copy itself), the
+    result equals the host-array loop bit for bit and the reference fixture within its gate; unbound `run_with_ort_values` leaves its
+    inputs alone; foreign RoPE tables and wrong dtypes are refused."""
     g = np.load(os.path.join(golden_dir, "f5_small.npz"))
     cfg = F5Config.small()
-    ort_session_A, ort_session_B, ort_session_C = _f5_sessions(tmp_path, cfg)
-    in_A, out_A = [a.name for a in ort_session_A.get_inputs()], [a.name for a in ort_session_A.get_outputs()]
-    in_name_B, out_name_B = ort_session_B.get_inputs(), ort_session_B.get_outputs()
-    NFE_STEP, FUSE_NFE, DEVICE_ID, device_type = cfg.nfe_step, 1, 0, "cuda"
-    audio = g["pre_audio"].reshape(1, 1, -1)
-    text_ids = g["pre_text_ids"].reshape(1, -1)
-    max_duration = np.array([int(g["pre_N"])], dtype=np.int64)
-    time_step = np.array([0], dtype=np.int32)
-    noise, rope_cos_q, rope_sin_q, rope_cos_k, rope_sin_k, cat_mel_text, cat_mel_text_drop, ref_signal_len = ort_session_A.run(
-        out_A, {in_A[0]: audio, in_A[1]: text_ids, in_A[2]: max_duration})
-    noise = g["dit_noise"][None].copy()                          # the fixture's noise from here on
-    host_noise, host_ts = noise.copy(), time_step.copy()
-    inputs = [
-        onnxruntime.OrtValue.ortvalue_from_numpy(noise, device_type, DEVICE_ID),
-        onnxruntime.OrtValue.ortvalue_from_numpy(rope_cos_q, device_type, DEVICE_ID),
-        onnxruntime.OrtValue.ortvalue_from_numpy(rope_sin_q, device_type, DEVICE_ID),
-        onnxruntime.OrtValue.ortvalue_from_numpy(rope_cos_k, device_type, DEVICE_ID),
-        onnxruntime.OrtValue.ortvalue_from_numpy(rope_sin_k, device_type, DEVICE_ID),
-        onnxruntime.OrtValue.ortvalue_from_numpy(cat_mel_text, device_type, DEVICE_ID),
-        onnxruntime.OrtValue.ortvalue_from_numpy(cat_mel_text_drop, device_type, DEVICE_ID),
-        onnxruntime.OrtValue.ortvalue_from_numpy(time_step, device_type, DEVICE_ID)
-    ]
-    assert all(v.is_device() and v.device_name() == "cuda" for v in inputs)
-    assert inputs[1].shape() == list(rope_cos_q.shape) and inputs[3].shape() == list(rope_cos_k.shape)
-    assert inputs[1]._t.untyped_storage().nbytes() == rope_cos_q.shape[2] * rope_cos_q.shape[3] * 4     # the broadcast axes did not cross PCIe
-    outputs = [inputs[0], inputs[-1]]
-    io_binding = ort_session_B.io_binding()
-    for i in range(len(inputs)):
-        io_binding.bind_ortvalue_input(name=in_name_B[i].name, ortvalue=inputs[i])
-    for i in range(len(outputs)):
-        io_binding.bind_ortvalue_output(name=out_name_B[i].name, ortvalue=outputs[i])
-    ptr0 = inputs[0].data_ptr()
-    for i in range(0, NFE_STEP - 1, FUSE_NFE):
-        ort_session_B.run_with_iobinding(io_binding)
-    assert io_binding.get_outputs()[0] is inputs[0] and inputs[0].data_ptr() == ptr0          # advanced in place, as bound
-    assert int(onnxruntime.OrtValue.numpy(io_binding.get_outputs()[1])[0]) == NFE_STEP - 1
-    assert int(inputs[-1]._t.cpu()[0]) == NFE_STEP - 1                                       # the device value itself, not just the mirror
-    noise_dev = onnxruntime.OrtValue.numpy(io_binding.get_outputs()[0])
-    # the `else:` branch on the same inputs (host numpy through run): same engine, same steps -> the same bits
-    for i in range(0, NFE_STEP - 1, FUSE_NFE):
-        host_noise, host_ts = ort_session_B.run([out_name_B[0].name, out_name_B[1].name], {
-            in_name_B[0].name: host_noise, in_name_B[1].name: rope_cos_q, in_name_B[2].name: rope_sin_q, in_name_B[3].name: rope_cos_k,
-            in_name_B[4].name: rope_sin_k, in_name_B[5].name: cat_mel_text, in_name_B[6].name: cat_mel_text_drop, in_name_B[7].name: host_ts})
-    assert np.array_equal(noise_dev, host_noise)
-    generated_signal = ort_session_C.run([ort_session_C.get_outputs()[0].name], {
-        ort_session_C.get_inputs()[0].name: noise_dev, ort_session_C.get_inputs()[1].name: ref_signal_len})[0]
-    err = np.sqrt(np.mean(((generated_signal[0, 0].astype(np.float64) - g["e2e_i16"]) / 32767.0) ** 2))
+    pre, dit, voc = _f5_sessions(tmp_path, cfg)
+    assert tuple(a.name for a in dit.get_inputs()) == _F5_B_INPUTS and [o.name for o in dit.get_outputs()] == list(_F5_B_ALIAS)
+    a_in = [a.name for a in pre.get_inputs()]
+    a_out = dict(zip([o.name for o in pre.get_outputs()],
+                     pre.run(None, {a_in[0]: g["pre_audio"].reshape(1, 1, -1), a_in[1]: g["pre_text_ids"].reshape(1, -1),
+                                    a_in[2]: np.array([int(g["pre_N"])], np.int64)})))
+    host = {k: a_out[k] for k in _F5_B_INPUTS[1:7]}
+    host["noise"], host["time_step"] = g["dit_noise"][None].copy(), np.array([0], np.int32)       # the fixture's noise from here on
+    on_dev = lambda x: onnxruntime.OrtValue.ortvalue_from_numpy(x, "cuda", 0)
+    dev = {k: on_dev(host[k].copy() if k in _F5_B_ALIAS.values() else host[k]) for k in _F5_B_INPUTS}
+    for k, v in dev.items():
+        assert v.is_device() and v.device_name() == "cuda" and v.shape() == list(host[k].shape), k
+    cos_q = host["rope_cos_q"]
+    assert dev["rope_cos_q"]._t.untyped_storage().nbytes() == cos_q.shape[2] * cos_q.shape[3] * 4     # the broadcast axes did not cross PCIe
+    binding = dit.io_binding()
+    for k in _F5_B_INPUTS:
+        binding.bind_ortvalue_input(name=k, ortvalue=dev[k])
+    for out_name, in_name in _F5_B_ALIAS.items():
+        binding.bind_ortvalue_output(name=out_name, ortvalue=dev[in_name])
+    steps = cfg.nfe_step - 1
+    where = dev["noise"].data_ptr()
+    for _ in range(steps):
+        dit.run_with_iobinding(binding)
+    bound = binding.get_outputs()
+    assert bound[0] is dev["noise"] and dev["noise"].data_ptr() == where                      # advanced in place, as bound
+    assert int(bound[1].numpy()[0]) == steps and int(dev["time_step"]._t.cpu()[0]) == steps   # the device value itself, not just a mirror
+    latent_dev = bound[0].numpy()
+    # the same steps on host arrays through run(): same engine -> the same bits
+    x, t = host["noise"].copy(), host["time_step"].copy()
+    for _ in range(steps):
+        x, t = dit.run(list(_F5_B_ALIAS), {**host, "noise": x, "time_step": t})
+    assert np.array_equal(latent_dev, x)
+    c_in = [a.name for a in voc.get_inputs()]
+    wave = voc.run(None, {c_in[0]: latent_dev, c_in[1]: a_out["ref_signal_len"]})[0]
+    err = np.sqrt(np.mean(((wave[0, 0].astype(np.float64) - g["e2e_i16"]) / 32767.0) ** 2))
     assert err < 5e-4, err
-    # run_with_ort_values on device values without bound outputs: the inputs stay untouched, the outputs are new device values
-    fresh = onnxruntime.OrtValue.ortvalue_from_numpy(g["dit_noise"][None].copy(), device_type, DEVICE_ID)
-    ts0 = onnxruntime.OrtValue.ortvalue_from_numpy(np.array([0], dtype=np.int32), device_type, DEVICE_ID)
-    feed = {in_name_B[i].name: inputs[i] for i in range(1, 7)}
-    feed[in_name_B[0].name], feed[in_name_B[7].name] = fresh, ts0
-    den, ts1 = ort_session_B.run_with_ort_values([o.name for o in out_name_B], feed)
-    assert den.is_device() and den is not fresh and np.array_equal(fresh.numpy(), g["dit_noise"][None])
-    assert int(ts1.numpy()[0]) == 1 and int(ts0.numpy()[0]) == 0
-    one_host, _ = ort_session_B.run([o.name for o in out_name_B], {
-        in_name_B[0].name: g["dit_noise"][None].copy(), in_name_B[1].name: rope_cos_q, in_name_B[2].name: rope_sin_q,
-        in_name_B[3].name: rope_cos_k, in_name_B[4].name: rope_sin_k, in_name_B[5].name: cat_mel_text,
-        in_name_B[6].name: cat_mel_text_drop, in_name_B[7].name: np.array([0], dtype=np.int32)})
-    assert np.array_equal(den.numpy(), one_host)
-    # a RoPE value that is not graph A's table is refused on the device path too; wrong dtype as well
-    bad = dict(feed)
-    bad[in_name_B[1].name] = onnxruntime.OrtValue.ortvalue_from_numpy(np.ascontiguousarray(rope_cos_q) * 0.5, device_type, DEVICE_ID)
-    with pytest.raises(onnxruntime.InvalidArgument):
-        ort_session_B.run_with_ort_values(None, bad)
-    bad = dict(feed)
-    bad[in_name_B[0].name] = onnxruntime.OrtValue._from_tensor(fresh._t.double())
-    with pytest.raises(onnxruntime.InvalidArgument):
-        ort_session_B.run_with_ort_values(None, bad)
-    del torch
+    # unbound outputs: inputs untouched, outputs are NEW device values
+    x0, t0 = on_dev(g["dit_noise"][None].copy()), on_dev(np.array([0], np.int32))
+    feed = {**{k: dev[k] for k in _F5_B_INPUTS[1:7]}, "noise": x0, "time_step": t0}
+    x1, t1 = dit.run_with_ort_values(list(_F5_B_ALIAS), feed)
+    assert x1.is_device() and x1 is not x0 and np.array_equal(x0.numpy(), g["dit_noise"][None])
+    assert int(t1.numpy()[0]) == 1 and int(t0.numpy()[0]) == 0
+    one_step, _ = dit.run(list(_F5_B_ALIAS), {**host, "noise": g["dit_noise"][None].copy(), "time_step": np.array([0], np.int32)})
+    assert np.array_equal(x1.numpy(), one_step)
+    # a RoPE value that is not graph A's table is refused on the device path too; a wrong element type as well
+    for key, value in (("rope_cos_q", on_dev(np.ascontiguousarray(cos_q) * 0.5)), ("noise", onnxruntime.OrtValue._from_tensor(x0._t.double()))):
+        with pytest.raises(onnxruntime.InvalidArgument):
+            dit.run_with_ort_values(None, {**feed, key: value})
 
 
 def test_bigvgan_run_with_ort_values_on_a_device_value(tmp_path, golden_dir):

@@ -101,6 +101,54 @@ def test_bench_two_gpus_rccl():
     assert line["config"]["utterances_total"] == 16 and len(set(line["config"]["rank_devices"])) == 2
 
 
+@pytest.mark.timeout(900)
+def test_rccl_one_rank_group_broadcasts_the_device_blob_and_the_engine_runs_from_it(tmp_path):
+    """RCCL itself, on the one GPU of the test box: a one-rank process group with backend nccl, the weight blob sent
+    through shard.broadcast_blob_device(force=True) — communicator, stream and broadcast kernel on the device tensor, as every rank
+    of an 8-GPU run does — and an engine built from the blob that came out of the collective.  Twice: in a child process that
+    checks the blob and the engine's waveform against an engine that never saw a collective, and through
+    `bench.py --gpus 1 --force-collective`, whose line must say backend nccl and a measured broadcast time."""
+    code = r"""
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.path.join(sys.argv[1], "text-to-speech-tts-onnx_amd"))
+from mi355tts.config import F5Config
+from mi355tts import weights as W
+from mi355tts.f5 import F5Engine
+from mi355tts.shard import broadcast_blob_device
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)
+assert dist.get_backend() == "nccl"
+cfg = F5Config.small()
+blob = W.pack_f5(cfg, W.synth_state(W.f5_spec(cfg), 9527))
+t = torch.from_numpy(blob).cuda()
+out = broadcast_blob_device(t, src=0, force=True)
+torch.cuda.synchronize()
+assert out.data_ptr() == t.data_ptr() and np.array_equal(out.cpu().numpy(), blob)
+probe = torch.ones(1 << 20, device="cuda"); dist.all_reduce(probe); torch.cuda.synchronize()      # a second collective kind on the same communicator
+assert float(probe.sum()) == float(1 << 20)
+audio, ids, N, noise = W.f5_synthetic_inputs(cfg, 2, 0, L=24000)
+a = F5Engine(cfg, blob_device=out, dtype="f32").synthesize(audio, ids, N, noise=noise)
+b = F5Engine(cfg, blob=blob, dtype="f32").synthesize(audio, ids, N, noise=noise)
+assert np.array_equal(a, b)
+maps = open("/proc/self/maps").read()
+libs = sorted({l.split("/")[-1] for l in maps.splitlines() if "librccl" in l or "libnccl" in l})
+print("RCCL_OK", dist.get_backend(), libs, flush=True)
+assert libs, "no RCCL library mapped"
+dist.destroy_process_group()
+"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code, ROOT], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0 and "RCCL_OK nccl" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    env.pop("MASTER_PORT")
+    env["MI355TTS_BENCH_SMALL"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-collective", "--steps", "1", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert line["n_gpus"] == 1 and line["config"]["collective_backend"] == "nccl" and line["config"]["weight_bcast_ms"] > 0
+
+
 def test_two_ranks_on_one_device_are_refused_without_the_plumbing_switch():
     """One process per GPU is the contract: `bench.py --gpus 2` whose ranks resolve to the SAME physical device must fail loudly
     (a scaling line measured that way would be two ranks time-slicing one GPU) unless MI355TTS_BENCH_ONE_GPU=1 says it is a

@@ -69,6 +69,29 @@ __device__ __forceinline__ void x3d_dma(RSRC rsrc, int voff, unsigned lds_dst) {
                  : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst) : "memory");
 #endif
 }
+template <int N> __device__ __forceinline__ void x3d_wait_lgkm() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(N) : "memory");
+#endif
+}
+// N fragment reads (16 bytes per lane, 1 KB apart) from LDS byte address a + OFF: inline asm, NOT waited for by the compiler
+template <int OFF> __device__ __forceinline__ void x3d_lds_rd128(f16x8& d, unsigned a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(a), "n"(OFF) : "memory");
+#endif
+}
+template <int OFF, int N> struct X3dRd {
+    static __device__ __forceinline__ void go(f16x8 (&dst)[N], unsigned a) {
+        X3dRd<OFF, N - 1>::go(reinterpret_cast<f16x8 (&)[N - 1]>(dst), a);
+        x3d_lds_rd128<OFF + (N - 1) * 1024>(dst[N - 1], a);
+    }
+};
+template <int OFF> struct X3dRd<OFF, 1> {
+    static __device__ __forceinline__ void go(f16x8 (&dst)[1], unsigned a) { x3d_lds_rd128<OFF>(dst[0], a); }
+};
+template <int N, int I = 0, typename F> __device__ __forceinline__ void x3d_unroll(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); x3d_unroll<N, I + 1>(f); }
+}
 template <int N> __device__ __forceinline__ void x3d_wait_vm() {
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
@@ -104,14 +127,13 @@ __global__ __launch_bounds__(768) void linear_x3d_kernel(const ConvGemmDev p) {
     const int wm = w6 / G::WNS, wn = w6 - wm * G::WNS;
 
     // ---- LDS-DMA pieces of this wave: piece q = wave + 12 i of the step's P (chunk-in-step, operand, plane, 16-row group) -----
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)((long)((p.M + 127) >> 7) * nch * 16384), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.w3, 0, (int)((long)((p.N + 127) >> 7) * nch * 16384), 0x00020000);
+    const int bytesA = (int)((long)((p.M + 127) >> 7) * nch * 16384), bytesB = (int)((long)((p.N + 127) >> 7) * nch * 16384);
     const unsigned smem_lds = (unsigned)(unsigned long)(const __attribute__((address_space(3))) void*)smem;
     const int voff = lane * 16;
     constexpr int OOB = 0x7fffff00;
     int pc_gbase[G::NHI], pc_cs[G::NHI];
     unsigned pc_lofs[G::NHI];
-    bool pc_isA[G::NHI];
+    __amdgpu_buffer_rsrc_t pc_rs[G::NHI];          // the piece's operand: one descriptor per piece, no branch at issue time
 #pragma unroll
     for (int i = 0; i < G::NHI; ++i) {
         const int q = wave + 12 * i;
@@ -121,21 +143,25 @@ __global__ __launch_bounds__(768) void linear_x3d_kernel(const ConvGemmDev p) {
         const int gpp = isA ? 9 : TW / 16;
         const int plane = rr / gpp, g16 = rr - plane * gpp;
         const int row = (isA ? m0 : n0) + 16 * g16;
-        pc_cs[i] = cs; pc_isA[i] = isA;
+        pc_cs[i] = cs;
+        pc_rs[i] = __builtin_amdgcn_make_buffer_rsrc(isA ? (void*)p.x : (void*)p.w3, 0, isA ? bytesA : bytesB, 0x00020000);
         pc_gbase[i] = __builtin_amdgcn_readfirstlane((row >> 7) * nch * 16384 + plane * 8192 + (row & 127) * 64);
         pc_lofs[i] = (unsigned)__builtin_amdgcn_readfirstlane(isA ? plane * G::A_PLANE + g16 * 1024 : G::A_BYTES + plane * G::B_PLANE + g16 * 1024);
     }
     const bool hi_wave = wave < G::NHIW;                             // this wave issues NHI pieces per step (else NHI - 1)
-    auto issue_batch = [&](int t) __attribute__((always_inline)) {   // the pieces of step t (past the last step: zero fill, nothing fetched)
-#pragma unroll
-        for (int i = 0; i < G::NHI; ++i) {
-            if (i == G::NHI - 1 && !hi_wave) continue;
+    // piece i of the step-t batch (past the last step: zero fill, nothing fetched); pieces are issued one per MFMA slot of phase 1
+    auto issue_piece = [&](int t, auto I_) __attribute__((always_inline)) {
+        constexpr int i = decltype(I_)::value;
+        if constexpr (i < G::NHI) {
+            if (i == G::NHI - 1 && !hi_wave) return;
             const int chunk = t * G::S + pc_cs[i];
             const int soff = __builtin_amdgcn_readfirstlane(chunk < nch ? pc_gbase[i] + chunk * 16384 : OOB);
             const unsigned dst = __builtin_amdgcn_readfirstlane(smem_lds + (unsigned)((chunk % G::R) * G::CH) + pc_lofs[i]);
-            const int vo = (int)((unsigned)voff + (unsigned)soff);
-            if (pc_isA[i]) x3d_dma(rsA, vo, dst); else x3d_dma(rsB, vo, dst);
+            x3d_dma(pc_rs[i], (int)((unsigned)voff + (unsigned)soff), dst);
         }
+    };
+    auto issue_batch = [&](int t) __attribute__((always_inline)) {
+        x3d_unroll<G::NHI>([&](auto I_) __attribute__((always_inline)) { issue_piece(t, I_); });
     };
     auto wait_batches = [&](auto NB_) __attribute__((always_inline)) {    // all but the NB_ youngest batches of this wave have landed
         constexpr int n = decltype(NB_)::value;
@@ -148,21 +174,26 @@ __global__ __launch_bounds__(768) void linear_x3d_kernel(const ConvGemmDev p) {
     const unsigned f_lane = (unsigned)((4 * sig + (fi & 3)) * 64 + ((fs ^ sig) << 4));
     const unsigned fa_off = (unsigned)(wm * 48 * 64) + f_lane;
     const unsigned fb_off = (unsigned)(G::A_BYTES + wn * G::WNW * 64) + f_lane;
-
     Frag a_lo[MB], a_hi[MB], b_lo[NB], b_hi[NB];
     f32x4 acc0[MB][NB], acc1[MB][NB];
 #pragma unroll
     for (int i = 0; i < MB; ++i)
 #pragma unroll
         for (int j = 0; j < NB; ++j) { acc0[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    auto rd_a = [&](const unsigned char* s, int plane, Frag (&dst)[MB]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < MB; ++i) dst[i] = *reinterpret_cast<const Frag*>(s + fa_off + plane * G::A_PLANE + i * 1024);
+    // Fragment reads are inline asm with hand-counted lgkmcnt waits (X3D_ASM_RD, the default): with compiler-visible ds_reads
+    // under sched_barriers hipcc puts s_waitcnt lgkmcnt(0) in front of phase 0 — behind the reads it has just issued for phases
+    // 1 and 2 — and the wave stalls for a full LDS round trip per chunk.  LDS operations of a wave complete in order: a wait
+    // for "all but the N youngest" is exact.  (a: LDS byte address of the A part of the slot + this lane; b: of the B part.)
+    auto rd_a = [&](unsigned a, auto PL, Frag (&dst)[MB]) __attribute__((always_inline)) {
+        constexpr int pl = decltype(PL)::value;
+        X3dRd<pl * G::A_PLANE, MB>::go(dst, a);
     };
-    auto rd_b = [&](const unsigned char* s, int plane, Frag (&dst)[NB]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < NB; ++j) dst[j] = *reinterpret_cast<const Frag*>(s + fb_off + plane * G::B_PLANE + j * 1024);
+    auto rd_b = [&](unsigned b, auto PL, Frag (&dst)[NB]) __attribute__((always_inline)) {
+        constexpr int pl = decltype(PL)::value;
+        X3dRd<pl * G::B_PLANE, NB>::go(dst, b);
     };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
     auto mma = [&](const Frag (&a)[MB], const Frag (&b)[NB], f32x4 (&c)[MB][NB]) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < MB; ++i)
@@ -178,27 +209,42 @@ __global__ __launch_bounds__(768) void linear_x3d_kernel(const ConvGemmDev p) {
     wait_batches(std::integral_constant<int, G::LB>{});
     __builtin_amdgcn_s_barrier();
     {
-        const unsigned char* s0 = smem + (kg % G::R) * G::CH;
-        rd_a(s0, 1, a_lo); rd_b(s0, 0, b_hi); rd_a(s0, 0, a_hi); rd_b(s0, 1, b_lo);
+        const unsigned s0 = smem_lds + (unsigned)((kg % G::R) * G::CH);
+        rd_a(s0 + fa_off, P1{}, a_lo); rd_b(s0 + fb_off, P0{}, b_hi); rd_a(s0 + fa_off, P0{}, a_hi); rd_b(s0 + fb_off, P1{}, b_lo);
     }
-    for (int j = 0; j < NJ; ++j) {
+    // One chunk.  BAR: the next chunk opens a step — behind phase 0 its batch has landed for every wave and every wave is done with
+    // the step behind us, whose slots take the batch LB steps ahead: those pieces go out one per MFMA of phase 1 (a piece costs
+    // 60 - 180 cycles of issue: in a block of their own behind the barrier, with all three waves of a SIMD at the same point, the
+    // matrix pipe idled for them).  Past the last chunk the barrier block runs once more: zero fill into a dead slot.
+    auto chunk = [&](int j, auto BAR_) __attribute__((always_inline)) {
+        constexpr bool BAR = decltype(BAR_)::value;
+        x3d_wait_lgkm<MB + NB>();                                   // lo(A), hi(B) of this chunk are in (hi(A), lo(B) may be on their way)
         X3D_SB(); mma(a_lo, b_hi, acc1); X3D_SB();                  // phase 0: lo(A) x hi(B)
         const int jn = j + 1;
-        if (jn % G::WSTEP == 0) {
-            // the next chunk opens a step: its batch has landed for every wave, every wave is done with the step behind us, whose
-            // slots take the batch LB steps ahead.  (Past the last chunk this runs once more: zero fill into a dead slot.)
-            const int ts = jn / G::WSTEP;
+        const int ts = jn / G::WSTEP;
+        if constexpr (BAR) {
             wait_batches(std::integral_constant<int, G::LB - 1>{});
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            issue_batch(ts + G::LB);
         }
-        const unsigned char* sn = smem + ((jn * G::KG + kg) % G::R) * G::CH;
-        rd_a(sn, 1, a_lo);
-        X3D_SB(); mma(a_hi, b_hi, acc0); X3D_SB();                  // phase 1: hi x hi
-        rd_b(sn, 0, b_hi);
+        const unsigned sn = smem_lds + (unsigned)(((jn * G::KG + kg) % G::R) * G::CH);
+        rd_a(sn + fa_off, P1{}, a_lo);
+        x3d_wait_lgkm<MB>();                                        // hi(A), lo(B) are in
+        X3D_SB();
+        x3d_unroll<MB * NB>([&](auto IDX_) __attribute__((always_inline)) {       // phase 1: hi x hi
+            constexpr int idx = decltype(IDX_)::value, i = idx / NB, jj = idx % NB;
+            acc0[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[i], b_hi[jj], acc0[i][jj], 0, 0, 0);
+            if constexpr (BAR) issue_piece(ts + G::LB, IDX_);
+            X3D_SB();
+        });
+        rd_b(sn + fb_off, P0{}, b_hi);
         X3D_SB(); mma(a_hi, b_lo, acc1); X3D_SB();                  // phase 2: hi(A) x lo(B)
-        rd_a(sn, 0, a_hi); rd_b(sn, 1, b_lo);
+        rd_a(sn + fa_off, P0{}, a_hi); rd_b(sn + fb_off, P1{}, b_lo);
+    };
+    static_assert(G::NHI <= MB * NB, "x3d: a batch's pieces ride on the MFMAs of phase 1");
+    for (int j = 0; j < NJ; j += G::WSTEP) {
+        if constexpr (G::WSTEP == 2) chunk(j, std::false_type{});
+        chunk(j + G::WSTEP - 1, std::true_type{});
     }
 #undef X3D_SB
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

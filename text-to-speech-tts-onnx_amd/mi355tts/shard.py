@@ -54,13 +54,15 @@ def broadcast_blob(blob, src: int = 0, device=None):
     return t.cpu().numpy()
 
 
-def broadcast_blob_device(blob_t, src: int = 0):
+def broadcast_blob_device(blob_t, src: int = 0, force: bool = False):
     """Device-resident form of broadcast_blob: `blob_t` is a float32 CUDA tensor on every rank (filled on `src`, empty elsewhere);
     it is broadcast IN PLACE over the process group's backend — "nccl" = RCCL over xGMI, the tensor never visits the host — and
     handed back for F5Engine(blob_device=...) / BigVGANVocoder(blob_device=...), which build their engines straight from HBM.
-    gloo (the one-GPU plumbing tests) stages through host memory, because its device-tensor support is not a given on ROCm."""
+    gloo (the one-GPU plumbing tests) stages through host memory, because its device-tensor support is not a given on ROCm.
+    force: issue the collective on a one-rank group too (`bench.py --gpus 1 --force-collective`, tests/test_gpu_multirank.py):
+    the RCCL library path — communicator, stream, kernel launch on the blob — runs on a one-GPU box as it does on eight."""
     import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return blob_t
     if dist.get_backend() == "nccl":
         dist.broadcast(blob_t, src=src)
