@@ -235,9 +235,11 @@ void        mi_indextts_cond_destroy(mi_cond* h);
 int         mi_indextts_cond_run(mi_cond* h, const int16_t* audio, int64_t L, float* conds, float* conds_latent, float* mel,
                                  int mem);
 
-/* Process-wide tuning / A-B switches (tools, tests).  Thread safety: every other entry point of this header runs under the shared side of
- * one reader-writer lock and mi_set_option under its exclusive side — a change waits for the calls in flight on other threads and is
- * seen as a whole by the calls that start after it; it never alters the dispatch of a call that is running.
+/* Process-wide tuning / A-B switches (tools, tests).  Thread safety: every entry point that DISPATCHES KERNELS (create / run / step /
+ * generate / forward ...) holds the shared side of one reader-writer lock for its duration and mi_set_option the exclusive side — a
+ * change waits for the calls in flight on other threads (under sustained concurrent inference that wait is unbounded: the lock
+ * prefers readers; set options before serving) and is seen as a whole by the calls that start after it; it never alters the dispatch
+ * of a call that is running.  mi_*_destroy, mi_last_error, mi_device_count and mi_version read no option and take no lock.
  *  The arithmetic of an fp32 F5 engine is NOT one of them any more: it is a
  * property of the engine (config int 21, F5Config.f32_arithmetic; mi_f5_info reports what runs) — the four arithmetic keys below
  * only set the default of engines created without one.

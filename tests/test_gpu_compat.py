@@ -93,6 +93,20 @@ def test_f5_fp16_transformer_export_through_facade(tmp_path, golden_dir):
     with pytest.raises(onnxruntime.InvalidArgument):
         B.run(None, {in_B[0]: noise.astype(np.float32), in_B[1]: cq, in_B[2]: sq, in_B[3]: ck, in_B[4]: sk, in_B[5]: cmt, in_B[6]: cmtd,
                      in_B[7]: time_step})
+    # the same export through io-binding on DEVICE values: outputs 0 / 1 bound onto inputs 0 / 7 must ADVANCE them —
+    # a session that hands back fresh values instead would recompute step 0 thirty-one times
+    dev = [onnxruntime.OrtValue.ortvalue_from_numpy(x, "cuda", 0) for x in
+           (g["dit_noise"][None].astype(np.float16), cq, sq, ck, sk, cmt, cmtd, np.array([0], dtype=np.int32))]
+    binding = B.io_binding()
+    for name, v in zip(in_B, dev):
+        binding.bind_ortvalue_input(name=name, ortvalue=v)
+    binding.bind_ortvalue_output(name=out_B[0], ortvalue=dev[0])
+    binding.bind_ortvalue_output(name=out_B[1], ortvalue=dev[7])
+    for i in range(cfg.nfe_step - 1):
+        B.run_with_iobinding(binding)
+    assert binding.get_outputs()[0] is dev[0] and dev[0].is_device() and dev[0].data_type() == "tensor(float16)"
+    assert int(dev[7].numpy()[0]) == cfg.nfe_step - 1
+    assert np.array_equal(dev[0].numpy(), noise)                                        # the host loop above, bit for bit
 
 
 def test_f5_facade_fuse_nfe_seed_and_rope_inputs(tmp_path, golden_dir):

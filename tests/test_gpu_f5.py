@@ -751,6 +751,35 @@ def test_fp16_pair_range_watch_heavy_tailed_operands():
         e.close()
 
 
+def test_f16_adaln_fold_range_watch_falls_back_to_the_row_norm_path():
+    """an f16 engine's AdaLN fold multiplies the UNNORMALISED residual row o (1 + scale) — not bounded by the norm like
+    LN(x)(1 + scale) + shift.  A residual column pushed beyond 65504 (an output bias of 1e7 in block 0's O projection: biases and
+    the residual stream are fp32 in every engine) must raise the engine's flag (gemm_epilogue_resid_ln: f16_range_word), the call
+    is re-run with the fold off for that engine (capi.hip f5_run_checked), permanently, and the answer agrees with an engine that
+    never folded.  The unmodified weights leave the fold on."""
+    import dataclasses
+    cfg = _mid_cfg()
+    raw = W.synth_state(W.f5_spec(cfg), 7)
+    noise, cmt, cmtd = _mid_inputs(cfg, 1, 500)
+    hot = {k: v.copy() for k, v in raw.items()}
+    hot["transformer.transformer_blocks.0.attn.to_out.0.bias"][5] = 1e7
+    e_plain = F5Engine(dataclasses.replace(cfg, adaln_fold=True), raw, dtype="f16")
+    e_fold = F5Engine(dataclasses.replace(cfg, adaln_fold=True), hot, dtype="f16")
+    e_rows = F5Engine(dataclasses.replace(cfg, adaln_fold=False), hot, dtype="f16")
+    try:
+        e_plain.dit_eval(noise, cmt, cmtd, 1)
+        assert e_plain.info()["adaln_fold"] is True and e_plain.info()["saturation_events"] == 0
+        assert e_fold.info()["adaln_fold"] is True and e_rows.info()["adaln_fold"] is False
+        got, ref = e_fold.dit_eval(noise, cmt, cmtd, 1), e_rows.dit_eval(noise, cmt, cmtd, 1)
+        info = e_fold.info()
+        assert info["saturation_events"] == 1 and info["adaln_fold"] is False, info
+        assert np.isfinite(ref).all() and np.isfinite(got).all() and rms(got - ref) <= 1e-6 * rms(ref), rms(got - ref) / rms(ref)
+        again = e_fold.dit_eval(noise, cmt, cmtd, 1)                         # permanent: no second event, same answer
+        assert np.array_equal(again, got) and e_fold.info()["saturation_events"] == 1
+    finally:
+        e_plain.close(); e_fold.close(); e_rows.close()
+
+
 def test_bigvgan_type_mel_front_end_against_reference_fixture(golden_dir):
     """The prompt features of the F5 *_bigvgan checkpoints (VERDICT r3 missing #1): get_bigvgan_mel_spectrogram
     (modeling_modified/F5/modules.py:30-72 — librosa/slaney mel basis, reflect pad (n_fft - hop) / 2, center=False,

@@ -40,11 +40,13 @@ def load() -> C.CDLL:
     # `torch.cuda` initialisation in the same process reports "No HIP GPUs are available" (seen with the device-resident
     # OrtValues of ort_compat in a script that opened its sessions before touching torch); the other order works.  So when
     # torch is installed it goes first (MI355TTS_NO_TORCH=1 skips this for pure-numpy users who never hand over torch tensors).
+    # A torch install that cannot even be imported (missing, or broken: OSError / RuntimeError from a mismatched build) must not
+    # make THIS library unloadable: numpy-only callers never need it.
     if os.environ.get("MI355TTS_NO_TORCH") != "1":
         try:
             import torch
             torch.cuda.is_available()
-        except ImportError:
+        except Exception:
             pass
     L = C.CDLL(_LIB_PATH)
     i32p, f32p = C.POINTER(C.c_int32), C.POINTER(C.c_float)

@@ -436,8 +436,12 @@ class InferenceSession:
                 if tgt.is_device():
                     if list(tgt._t.shape) == list(o.shape):
                         tgt.update_inplace(o)
-                        binding._results.append(tgt)
-                        continue
+                    else:                               # a device-bound output of another shape is re-allocated ON the device (it stays a device value)
+                        import torch
+                        tgt._t = torch.from_numpy(np.ascontiguousarray(o)).to(tgt._t.device)
+                        tgt._mirror = np.array(o, copy=True) if o.size <= 16 else None
+                    binding._results.append(tgt)
+                    continue
                 elif tgt._host.shape == o.shape and tgt._host.dtype == o.dtype:
                     tgt._host[...] = o
                     binding._results.append(tgt)
@@ -477,8 +481,23 @@ class InferenceSession:
         import torch
         e, cfg = self._eng, self._cfg
         if getattr(cfg, "ref_fp16_attn", False):      # the float16-I/O export keeps its host path (values are rounded at the graph edges)
+            # ... but the io-binding contract holds here too: a BOUND output is written in place (the reference binds outputs 0 / 1
+            # onto inputs 0 / 7 and relies on exactly that to advance the sampler, F5-TTS-ONNX-Inference.py:268-288)
             outs = self.run(None, {k: v.numpy() for k, v in feed.items()})
-            return {o.name: OrtValue.ortvalue_from_numpy(a, "cuda", e.device) for o, a in zip(self._outputs, outs)}
+            res = {}
+            for o, a in zip(self._outputs, outs):
+                tgt = bound_out.get(o.name)
+                if tgt is None:
+                    res[o.name] = OrtValue.ortvalue_from_numpy(a, "cuda", e.device)
+                    continue
+                if tgt._t is None or list(tgt._t.shape) != list(a.shape) or str(tgt._t.dtype).replace("torch.", "") != str(a.dtype):
+                    tgt._t = torch.from_numpy(np.ascontiguousarray(a)).to(torch.device("cuda", e.device))
+                    tgt._host, tgt._device = None, "cuda"
+                    tgt._mirror = np.array(a, copy=True) if a.size <= 16 else None
+                else:
+                    tgt.update_inplace(a)
+                res[o.name] = tgt
+            return res
         noise = self._dev_tensor(feed["noise"], "noise", torch.float32, 3)
         cmt = self._dev_tensor(feed["cat_mel_text"], "cat_mel_text", torch.float32, 3)
         cmtd = self._dev_tensor(feed["cat_mel_text_drop"], "cat_mel_text_drop", torch.float32, 3)
@@ -529,6 +548,10 @@ class InferenceSession:
         mel = feed["mel_features"]._t
         if mel.dtype not in (torch.float32, torch.float16) or mel.dim() != 3:
             raise InvalidArgument("mel_features must be a rank-3 float tensor")
+        if mel.device.index != self._eng.device:
+            raise InvalidArgument(f"mel_features lives on cuda:{mel.device.index}, the session runs on cuda:{self._eng.device}")
+        if mel.shape[1] != self._cfg.num_mels or mel.shape[2] < 1:
+            raise InvalidArgument(f"mel_features must be (B, {self._cfg.num_mels}, frames >= 1), got {tuple(mel.shape)}")
         out = self._eng.run_torch(mel.float().contiguous())
         return {"generated_wav": OrtValue._from_tensor(out)}
 
@@ -647,9 +670,11 @@ class InferenceSession:
                     raise InvalidArgument(f"Invalid rank for input: {n}")
                 want = self._rope_table(N, "cos" in n)
                 got = a[0, 0] if n.endswith("_q") else a[0, 0].T
-                # the loop feeds the same table 31 times: a buffer recognised once is re-checked on its last row only
-                key = (n, a.ctypes.data, a.shape, a.strides, a.dtype.str)
-                if self._rope_seen.get(n) == key and got.shape == want.shape and np.array_equal(got[-1].astype(np.float32), want[-1]):
+                # the loop feeds the same table 31 times: a buffer recognised once is re-checked by a checksum over ALL of it (one
+                # pass over 288 KB; buffer identity + the last row would miss an in-place edit elsewhere in the table: ADVICE r5)
+                key = (n, a.ctypes.data, a.shape, a.strides, a.dtype.str, float(np.asarray(got, dtype=np.float32).sum(dtype=np.float64)),
+                       float(np.abs(np.asarray(got, dtype=np.float32)).sum(dtype=np.float64)))
+                if self._rope_seen.get(n) == key and got.shape == want.shape:
                     continue
                 self._rope_seen[n] = key
                 if got.shape != want.shape or np.abs(got.astype(np.float32) - want).max() > 2e-3:
