@@ -19,6 +19,8 @@
 //                 per instruction are two contiguous 8-byte LDS reads.
 #include <atomic>
 #include "common.h"
+#include <functional>
+#include <map>
 #include <mutex>
 #include "mfma.h"
 #include "f5_kernels.h"
@@ -472,7 +474,8 @@ template <bool SPLIT2, bool KVP = false, int NP = 3>
 __global__ __launch_bounds__(256, NP == 2 ? 3 : 2) void attn_x3f_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                        const float* __restrict__ v, float* __restrict__ o, int H, int N,
                                                        float* __restrict__ ws, int* __restrict__ cnt,
-                                                       unsigned char* __restrict__ o_planes, int o_np, int xmap = 0) {
+                                                       unsigned char* __restrict__ o_planes, int o_np, int xmap = 0,
+                                                       int cut1 = 0, int cut2 = 0, int cut3 = 0) {
     ATTN_XCD_MAP
     // o_planes != null: the output leaves as gemm_x3p.hip panel planes of the [B * N][H * 64] matrix (the A operand of the O
     // projection), split here (o_np = 3 bf16 planes | 2 fp16 planes), instead of fp32 rows in o
@@ -621,8 +624,15 @@ __global__ __launch_bounds__(256, NP == 2 ? 3 : 2) void attn_x3f_kernel(const fl
 #endif
 
     const int nstage_all = (N + KT - 1) / KT;
-    const int st0 = (int)((long)blockIdx.z * nstage_all / gridDim.z);            // key slices (gridDim.z > 1): see the merge below
-    const int nstage = (int)((long)(blockIdx.z + 1) * nstage_all / gridDim.z);
+    // key slices (gridDim.z > 1): see the merge below.  cut1 > 0 (round 6): UNEVEN slices [0, cut1), [cut1, cut2), ... chosen by the
+    // launcher so that the z-major dispatch order is longest-piece-first on the 3 x CUs slots (attn_pick_slices)
+    int st0 = (int)((long)blockIdx.z * nstage_all / gridDim.z);
+    int nstage = (int)((long)(blockIdx.z + 1) * nstage_all / gridDim.z);
+    if (cut1 > 0) {
+        const int zz = (int)blockIdx.z, ZZ = (int)gridDim.z;
+        st0 = zz == 0 ? 0 : zz == 1 ? cut1 : zz == 2 ? cut2 : cut3;
+        nstage = zz + 1 == ZZ ? nstage_all : zz == 0 ? cut1 : zz == 1 ? cut2 : cut3;
+    }
     if (st0 < nstage) {
         load_regs(st0 * KT);
         store_lds();
@@ -916,6 +926,7 @@ static std::atomic<int> g_attn_np = 2;                                // format 
 static std::atomic<int> g_attn_split = 2;                             // small grids: 1 = 64-query workgroups with the keys split between wave pairs (+ key slices) ; 2 = fp32 pairs kernel: 128-query workgroups + key slices
 static std::atomic<int> g_attn_zmax = 4, g_attn_z16 = 1, g_attn_zforce = 0;      // zforce (tests): exactly that many slices, even empty ones
 static std::atomic<int> g_attn_xmap = 1;                              // XCD-aware (query tile, head) map of the workgroup ids (A/B: attn_xcd_map; -1 % per launch, bit-neutral)
+static std::atomic<int> g_attn_lpt = 1;                               // fp32 128-query kernel: uneven key slices, longest first (A/B: attn_lpt)
 static std::atomic<int> g_attn_kvp = 1;                               // fp32, both products split: K / V^T pre-split by the QKV epilogue (A/B: attn_kv_planes)
 // The MI355TTS_ATTN_* environment overrides are read ONCE, before the first use of any of the globals above by ANY of the
 // three entry points: F5::dit_eval asks attention_v_ld() for the V layout of the QKV epilogue before the first
@@ -931,6 +942,7 @@ static void attn_env_once() {
         if (const char* z = std::getenv("MI355TTS_ATTN_X3")) g_attn_x3 = std::max(0, std::min(2, std::atoi(z)));
         if (const char* z = std::getenv("MI355TTS_ATTN_Z16")) g_attn_z16 = std::max(1, std::min(4, std::atoi(z)));
         if (const char* z = std::getenv("MI355TTS_ATTN_KVP")) g_attn_kvp = std::atoi(z) != 0;
+        if (const char* z = std::getenv("MI355TTS_ATTN_LPT")) g_attn_lpt = std::atoi(z) != 0;
         if (const char* z = std::getenv("MI355TTS_ATTN_PLANES")) g_attn_np = std::atoi(z) == 3 ? 3 : 2;
     });
 }
@@ -945,6 +957,7 @@ bool attn_set_option(const char* key, long v) {
     else if (k == "attn_split") g_attn_split = (int)std::max(0L, std::min(2L, v));
     else if (k == "attn_xcd_map") g_attn_xmap = v != 0;
     else if (k == "attn_kv_planes") g_attn_kvp = v != 0;
+    else if (k == "attn_lpt") g_attn_lpt = v != 0;
     else if (k == "attn_f32_planes") { if (v != 2 && v != 3) return false; g_attn_np = (int)v; }
     else if (k == "attn_z_force") g_attn_zforce = (int)std::max(0L, std::min(4L, v));
     else return false;
@@ -963,6 +976,59 @@ bool attention_can_write_planes(int N, int BH, int dtype) {
     attn_env_once();
     (void)N; (void)BH;
     return dtype == MI_F32 && opt_attn_x3() == 2;
+}
+
+// Key slices of the 128-query fp32 kernel, sized for the dispatch order (round 6).  The launch is (query tiles x heads) units x Z
+// slices on 3 x CUs workgroup slots, dispatched z-major.  Equal slices make 288 x 3 = 864 workgroups for one utterance: a full
+// round of 768 and an eighth of a second one, which costs as much as half a round (the second round's workgroups run alone on their
+// SIMDs: ~18 of the launch's 50 us).  With slices of 7, 7 and 4 stages the long pieces start first and the short ones fill the slots
+// they free: list scheduling, makespan 8 stage times instead of 12.  The search simulates that for every non-increasing split of the
+// stages into 1 .. zmax slices (identical pieces handled in bulk: a few map operations per split) and keeps the best.
+struct AttnSlices { int Z = 1, cut[3] = {0, 0, 0}; };
+static AttnSlices attn_pick_slices(long units, int S, int slots, int zmax) {
+    AttnSlices best;
+    double best_t = 1e30;
+    auto makespan = [&](const int* len, int Z) -> double {
+        std::map<double, long> free_at;                          // time -> slots that become free then
+        free_at[0.0] = slots;
+        double end = 0.0;
+        for (int z = 0; z < Z; ++z) {
+            const double cost = len[z] + (Z > 1 ? 0.6 : 0.3);      // stages + prologue / publish / merge (in stage times)
+            long left = units;
+            while (left > 0) {
+                auto it = free_at.begin();
+                const long take = std::min(left, it->second);
+                const double t = it->first + cost;
+                it->second -= take;
+                if (it->second == 0) free_at.erase(it);
+                free_at[t] += take;
+                end = std::max(end, t);
+                left -= take;
+            }
+        }
+        return end;
+    };
+    int len[4];
+    for (int Z = 1; Z <= zmax; ++Z) {
+        if (S < 2 * Z && Z > 1) break;
+        // non-increasing len[0] >= ... >= len[Z-1] >= 1 with sum S
+        std::function<void(int, int, int)> rec = [&](int i, int left, int cap) {
+            if (i == Z - 1) {
+                if (left < 1 || left > cap) return;
+                len[i] = left;
+                const double t = makespan(len, Z);
+                if (t < best_t - 1e-9) {
+                    best_t = t; best.Z = Z;
+                    int acc = 0;
+                    for (int c = 0; c < 3; ++c) { acc += c < Z ? len[c] : 0; best.cut[c] = c + 1 < Z ? acc : S; }
+                }
+                return;
+            }
+            for (int a = std::min(cap, left - (Z - 1 - i)); a >= (left + (Z - i) - 1) / (Z - i); --a) { len[i] = a; rec(i + 1, left - a, a); }
+        };
+        rec(0, S, S);
+    }
+    return best;
 }
 
 void launch_attention(const void* q, const void* k, const void* v, void* o, int BH, int H, int N, int dtype, hipStream_t s,
@@ -1021,8 +1087,38 @@ void launch_attention(const void* q, const void* k, const void* v, void* o, int 
             const bool wide = g_attn_split == 2 && opt_attn_x3() == 2 && kv_planes == 2;
             const int Z = pick_z(1, wide);
             if (wide) {
+                // uneven slices, longest first (attn_pick_slices): cached per (N, BH)
+                AttnSlices sl;
+                sl.Z = Z;
+                if (g_attn_lpt && g_attn_zforce == 0 && Z >= 1 && ws && cnt) {
+                    static std::mutex mu;
+                    static std::map<std::pair<int, int>, AttnSlices> cache;
+                    std::lock_guard<std::mutex> lk(mu);
+                    auto key = std::make_pair(N, BH);
+                    auto it = cache.find(key);
+                    if (it == cache.end()) {
+                        int dev = 0, cus = 256;
+                        MI_HIP(hipGetDevice(&dev));
+                        hipDeviceProp_t pr; MI_HIP(hipGetDeviceProperties(&pr, dev)); cus = pr.multiProcessorCount;
+                        const long units = (long)((N + 127) / 128) * BH;
+                        const long slot = 4 * (32 * 64 + 64 * 2);
+                        int zm = std::min((int)g_attn_zmax, 4);
+                        while (zm > 1 && (units * zm * slot > ws_floats || units > cnt_n)) --zm;
+                        it = cache.emplace(key, attn_pick_slices(units, (N + 63) / 64, 3 * cus, zm)).first;
+                    }
+                    sl = it->second;
+                    if (const char* e = std::getenv("MI355TTS_ATTN_CUTS")) {          // experiments: "7,14" = slices of stages [0,7) [7,14) [14,S)
+                        const int S = (N + 63) / 64;
+                        int c[3] = {S, S, S}, n = std::sscanf(e, "%d,%d,%d", &c[0], &c[1], &c[2]);
+                        const long units = (long)((N + 127) / 128) * BH;
+                        if (n >= 1 && c[0] > 0 && c[0] < S && units * (n + 1) * 4 * (32 * 64 + 64 * 2) <= ws_floats && units <= cnt_n) {
+                            sl.Z = n + 1; sl.cut[0] = c[0]; sl.cut[1] = n >= 2 ? c[1] : S; sl.cut[2] = n >= 3 ? c[2] : S;
+                        }
+                    }
+                }
                 prof_set_kernel("attn_x3f_kernel<false, pre-split K V, fp16 pairs> + key slices", "", "");
-                hipLaunchKernelGGL((attn_x3f_kernel<false, true, 2>), dim3((N + 127) / 128, BH, Z), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt, (unsigned char*)o_planes, o_np, xm);
+                hipLaunchKernelGGL((attn_x3f_kernel<false, true, 2>), dim3((N + 127) / 128, BH, sl.Z), dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, H, N, ws, cnt, (unsigned char*)o_planes, o_np, xm,
+                                   sl.Z > 1 ? sl.cut[0] : 0, sl.cut[1], sl.cut[2]);
             } else if (opt_attn_x3() == 2) {
                 if (kv_planes == 2) {
                     prof_set_kernel("attn_x3f_kernel<true, pre-split K V, fp16 pairs>", "", "");

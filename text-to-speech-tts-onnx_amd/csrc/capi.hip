@@ -763,7 +763,7 @@ int mi_bench_conv_gemm(int dtype, int B, int T, int Cin, int N, int taps, int di
         skw.ensure(1024, s);
         skw.attach(p);
         DevBuf w3;
-        if (dtype == MI_F32 && taps == 1 && gemm_x3_enabled() && nsets <= 1) {      // the bf16x3 kernel needs the weight planes
+        if (dtype == MI_F32 && taps == 1 && gemm_x3_enabled()) {      // the bf16x3 kernel needs the weight planes
             w3.ensure((size_t)3 * nw * 2);
             split3_planes((const float*)w.p, w3.p, (long)nw, s);
             p.w3 = w3.p;
@@ -776,12 +776,20 @@ int mi_bench_conv_gemm(int dtype, int B, int T, int Cin, int N, int taps, int di
             x3p_split_rows((const float*)w.p, Cin, w3p.p, N, Cin, s, np);
             p.xp = xp.p; p.w3p = w3p.p; p.np = np;
         }
+        // panel-plane launches with MI355TTS_BENCH_WSETS: n copies of the weight PLANES (the kernel never reads p.w)
+        DevBuf w3psets;
+        const size_t w3pb = p.w3p ? (size_t)x3p_bytes(N, Cin, p.np) : 0;
+        if (nsets > 1 && p.w3p) {
+            w3psets.ensure((size_t)nsets * w3pb);
+            for (int i = 0; i < nsets; ++i) MI_HIP(hipMemcpyAsync((char*)w3psets.p + (size_t)i * w3pb, w3p.p, w3pb, hipMemcpyDeviceToDevice, s));
+        }
         for (int i = 0; i < 3; ++i) launch_conv_gemm(p, s);
         hipEvent_t e0, e1;
         MI_HIP(hipEventCreate(&e0)); MI_HIP(hipEventCreate(&e1));
         MI_HIP(hipEventRecord(e0, s));
         for (int i = 0; i < iters; ++i) {
             if (nsets > 1) p.w = (char*)wsets.p + (size_t)(i % nsets) * nw * es;
+            if (nsets > 1 && p.w3p) p.w3p = (char*)w3psets.p + (size_t)(i % nsets) * w3pb;
             launch_conv_gemm(p, s);
         }
         MI_HIP(hipEventRecord(e1, s));

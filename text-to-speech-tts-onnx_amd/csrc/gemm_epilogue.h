@@ -819,6 +819,10 @@ void x3p_set_option(int which, long v);
 bool x3d_plan(const ConvGemmDev& e, int cus, int& tw, int& rgn, int& cgn, int& band);
 void launch_linear_x3d(const ConvGemmDev& e, int tw, int rgn, int cgn, int band, hipStream_t s);
 void x3d_set_option(int which, long v);
+// gemm_x1d.hip: exact-fit data-parallel 16-bit linear layers (288 x 256 tiles) — taken in front of linear_ph8 / the row split when x1d_plan says so
+bool x1d_plan(int M, int N, int K, int cus, int& rgn, int& cgn, int& band);
+template <typename T, typename TO> void launch_linear_x1d(const ConvGemmDev& e, int rgn, int cgn, int band, hipStream_t s);
+void x1d_set_option(int which, long v);
 void ph8_set_split_max(long v);
 void ph8_set_split_min_nk(long v);
 

@@ -266,15 +266,6 @@ __global__ __launch_bounds__(768) void linear_x3d_kernel(const ConvGemmDev p) {
 
     // ---- the tile into LDS as 32 x 64 blocks [row block][column block][32][64] (+ pad): acc0 + 2^-11 acc1 ---------------------
     float* stg = reinterpret_cast<float*>(smem);
-    // QKV role: V leaves transposed, [b * H + h][plane][d][key] fp16 {hi, lo}.  The per-block epilogue writes it as 2-byte stores (64
-    // store instructions per 32 x 64 block: the tiles made of V heads ran ~3x the store instructions of the q / k tiles and set the
-    // launch's duration); with the whole 144-row tile in LDS a lane takes (d, eight consecutive keys) and leaves with one 16-byte
-    // store per plane.  V column blocks are staged with a row stride of 65 floats for that (column reads, no bank conflicts).
-    const int dm_qkv = p.heads * 64;
-    const int Mb_qkv = p.Mb > 0 ? p.Mb : p.M;
-    const bool vfast = EPK == 1 && p.kv_planes == 2 && p.v_ld > 0 && (p.v_ld & 7) == 0 && Mb_qkv >= 2 * G::TM && p.head_dim == 64 &&
-                       (!FOLD || p.ln_stats_in) && !(p.dbg & 64);
-    auto is_v_block = [&](int cb) __attribute__((always_inline)) -> bool { return vfast && (n0 + cb * 64) / dm_qkv == 2; };
     {
         const int rq = 4 * ((0x1320 >> (4 * (lane >> 4))) & 3);                        // tile row of register 0 inside the 16-row block
         const int cq = 4 * ((0x1320 >> (4 * ((lane & 15) >> 2))) & 3) + (lane & 3);    // tile column inside the 16-column block
@@ -285,12 +276,11 @@ __global__ __launch_bounds__(768) void linear_x3d_kernel(const ConvGemmDev p) {
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
                     const int col = wn * G::WNW + j * 16 + cq;
-                    const int rs_ = (EPK == 1 && is_v_block(col >> 6)) ? 65 : 64;      // wave-uniform per j
-                    float* d = stg + ((row >> 5) * G::NCB + (col >> 6)) * G::BLK + (row & 31) * rs_ + (col & 63);
+                    float* d = stg + ((row >> 5) * G::NCB + (col >> 6)) * G::BLK + (row & 31) * 64 + (col & 63);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float v = __builtin_fmaf(acc1[i][j][r], 0x1p-11f, acc0[i][j][r]);
-                        d[r * rs_] = add ? d[r * rs_] + v : v;
+                        d[r * 64] = add ? d[r * 64] + v : v;
                     }
                 }
             }
@@ -305,10 +295,32 @@ __global__ __launch_bounds__(768) void linear_x3d_kernel(const ConvGemmDev p) {
     // ---- blocks -> waves -> the per-role epilogues of gemm_epilogue.h (32x32 accumulator layout, wave-private staging) ---------
     const int lr = lane & 31, lk = lane >> 5;
     const int m_end = min(p.M, m0 + G::TM);                        // rows 144 .. 159 of the last row block belong to the next tile
+    constexpr bool HALVES = EPK == 3 && (G::NRB * G::NCB * G::BLK + 12 * 1024) * 4 <= G::LNT;      // (room for the wave-private staging: TW = 64 | 128)
+    if constexpr (HALVES) {
+        // O / FF2 (and plain row outputs): 32 x 32 half blocks, so that a 144 x 64 tile keeps ten waves busy instead of five — the
+        // epilogue of these launches is a chain of LDS hops, residual loads and stores per wave, not a byte count (measured in the
+        // model with MI355TTS_GEMM_DBG=4: 8.8 us per launch for 28 MB)
+        float* half_stage = stg + G::NRB * G::NCB * G::BLK;            // wave-private 32 x 32 staging behind the tile (inside the dead ring)
+        for (int u = wave; u < G::NRB * G::NCB * 2; u += 12) {
+            const int b = u >> 1, hf = u & 1;
+            const int rb = b / G::NCB, cb = b - rb * G::NCB;
+            if (m0 + rb * 32 >= m_end) continue;
+            const float* blk = stg + b * G::BLK + hf * 32;
+            f32x16 h1[1][1];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float t = blk[((r & 3) + 8 * (r >> 2) + 4 * lk) * 64 + lr];
+                h1[0][0][r] = (rb == G::NRB - 1 && r >= 8) ? 0.f : t;     // (rows 144 .. 159 were never staged: see below)
+            }
+            float* st = half_stage + wave * 1024;
+            if constexpr (FOLD) gemm_epilogue_resid_ln<float, 1, 1, 2>(h1, p, m0 + rb * 32, n0 + cb * 64 + hf * 32, lr, lk, st, m_end);
+            else gemm_epilogue_lds<float, 1, 1, 32, 32>(h1, p, m0, n0, 0, 0, rb, cb * 2 + hf, lr, lk, st, m_end);
+        }
+        return;
+    }
     for (int b = wave; b < G::NRB * G::NCB; b += 12) {
         const int rb = b / G::NCB, cb = b - rb * G::NCB;
         if (m0 + rb * 32 >= m_end) continue;
-        if (EPK == 1 && is_v_block(cb)) continue;                  // the tile-level V^T path below
         float* blk = stg + b * G::BLK;
         float prs[1] = {0.f}, pmr[1] = {0.f};
         if constexpr (CONSUMER) { prs[0] = lnt[rb * 32 + lr]; pmr[0] = lnt[160 + rb * 32 + lr]; }
@@ -316,7 +328,12 @@ __global__ __launch_bounds__(768) void linear_x3d_kernel(const ConvGemmDev p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) h[0][j][r] = blk[((r & 3) + 8 * (r >> 2) + 4 * lk) * 64 + j * 32 + lr];
+            for (int r = 0; r < 16; ++r) {
+                // the last row block holds 16 staged rows (144 = 4 x 32 + 16): rows 16 .. 31 of its LDS block were never written — whatever
+                // the operand ring left there must not reach the epilogue's range watch (their stores are masked anyway)
+                const float t = blk[((r & 3) + 8 * (r >> 2) + 4 * lk) * 64 + j * 32 + lr];
+                h[0][j][r] = (rb == G::NRB - 1 && r >= 8) ? 0.f : t;
+            }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if constexpr (FOLD) {
@@ -327,64 +344,6 @@ __global__ __launch_bounds__(768) void linear_x3d_kernel(const ConvGemmDev p) {
             if constexpr (EPK == 1) gemm_epilogue_qkv_lds<float, 1>(h, p, m0, n0, 0, rb, cb, lr, lk, blk, nullptr, nullptr, m_end);
             else if constexpr (EPK == 2) x3p_epilogue_planes<1, 2, 2>(h, p, m0, n0, rb, cb, lr, lk, blk, m_end);
             else gemm_epilogue_lds<float, 1, 2, 32, 64>(h, p, m0, n0, 0, 0, rb, cb, lr, lk, blk, m_end);
-        }
-    }
-    if constexpr (EPK == 1) {
-        if (vfast) {
-            int nv = 0;                                             // V heads of this tile
-#pragma unroll
-            for (int q = 0; q < G::NCB; ++q) nv += is_v_block(q) ? 1 : 0;
-            const int rows = m_end - m0;                            // valid rows of the tile
-            const int grow0 = p.m_off + m0;                         // tile row 0 on the flattened [batch item][token] axis
-            const int bi0 = grow0 / Mb_qkv;
-            const int r_split = min(rows, (bi0 + 1) * Mb_qkv - grow0);     // rows [0, r_split) belong to item bi0, the rest to bi0 + 1 (Mb >= 288: at most two)
-            unsigned sat = 0;
-            const int d = lane;
-            for (int seg = 0; seg < 2; ++seg) {
-                const int ra = seg ? r_split : 0, rbnd = seg ? rows : r_split;
-                if (ra >= rbnd || nv == 0) continue;
-                const int bi = bi0 + seg;
-                const int ma = grow0 + ra - bi * Mb_qkv, mb = ma + (rbnd - ra);      // keys [ma, mb) of item bi
-                const int g0 = ma >> 3, ng = ((mb + 7) >> 3) - g0;                  // key groups of eight
-                for (int it = wave; it < nv * ng; it += 12) {
-                    const int vi = it / ng, g = g0 + it - vi * ng;
-                    int cb = 0, seen = 0;                           // the vi-th V column block
-#pragma unroll
-                    for (int q = 0; q < G::NCB; ++q) { if (is_v_block(q)) { cb = seen == vi ? q : cb; ++seen; } }
-                    const int nbase = n0 + cb * 64;
-                    const int hh = (nbase - 2 * dm_qkv) >> 6;
-                    float lp = 0.f, lc = 0.f;
-                    if constexpr (FOLD) { lp = p.ln_p[nbase + d]; lc = p.ln_c[nbase + d]; }
-                    else lc = p.bias ? p.bias[nbase + d] : 0.f;
-                    const int k0 = g * 8;
-                    float v[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        int row = ra + (k0 + j - ma);
-                        row = row < ra ? ra : (row >= rbnd ? rbnd - 1 : row);
-                        const float a = stg[((row >> 5) * G::NCB + cb) * G::BLK + (row & 31) * 65 + d];
-                        if constexpr (FOLD) v[j] = __builtin_fmaf(lnt[row], a, __builtin_fmaf(-lnt[160 + row], lp, lc));
-                        else v[j] = a + lc;
-                    }
-                    unsigned wh[4], wl[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) { x2u_split_pair(v[2 * q], v[2 * q + 1], wh[q], wl[q]); sat |= x2_sat_word(wh[q]); }
-                    const long pstride = 64 * p.v_ld;
-                    unsigned short* dst = (unsigned short*)p.out3 + ((long)bi * p.heads + hh) * 2 * pstride + (long)d * p.v_ld + k0;
-                    if (k0 >= ma && k0 + 8 <= mb) {
-                        *reinterpret_cast<x3_u4*>(dst) = x3_u4{wh[0], wh[1], wh[2], wh[3]};
-                        *reinterpret_cast<x3_u4*>(dst + pstride) = x3_u4{wl[0], wl[1], wl[2], wl[3]};
-                    } else {                                        // a group cut by the tile's or the batch item's end: key by key
-#pragma unroll
-                        for (int j = 0; j < 8; ++j)
-                            if (k0 + j >= ma && k0 + j < mb) {
-                                dst[j] = (unsigned short)(wh[j >> 1] >> (16 * (j & 1)));
-                                dst[pstride + j] = (unsigned short)(wl[j >> 1] >> (16 * (j & 1)));
-                            }
-                    }
-                }
-            }
-            sat_publish(p.sat, sat);
         }
     }
 #endif

@@ -490,7 +490,7 @@ void launch_linear_x3p(const ConvGemmDev& e_in, hipStream_t s) {
         cus = cu_count[dev & 15];
     }
     // exact-fit data-parallel tiling (gemm_x3d.hip) when the output divides into whole rounds of the CUs; else stream-K below
-    if (!(e.dbg & ~(4 | 64))) {            // (tuning bits 4: no epilogue, 64: no tile-level V^T path)
+    if (!(e.dbg & ~4)) {
         int tw, rgn, cgn, band;
         if (x3d_plan(e, cus, tw, rgn, cgn, band)) { launch_linear_x3d(e, tw, rgn, cgn, band, s); return; }
     }

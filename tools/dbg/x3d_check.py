@@ -9,7 +9,7 @@ from mi355tts import _lib, bigvgan
 _lib.init(0)
 rng = np.random.default_rng(7)
 bad = 0
-for T, Cin, Cout in [(2252, 1024, 1024), (2252, 1024, 2048), (2252, 1024, 3072), (2252, 2048, 1024), (2100, 1024, 1024),
+for T, Cin, Cout in [] if os.environ.get("X3D_TIMING_ONLY") == "1" else [(2252, 1024, 1024), (2252, 1024, 2048), (2252, 1024, 3072), (2252, 2048, 1024), (2100, 1024, 1024),
                      (2304, 1024, 3072), (4504, 1024, 2048), (9008, 1024, 1024), (1126, 1024, 3072)]:
     x = rng.standard_normal((1, Cin, T)).astype(np.float32)
     w = (rng.standard_normal((Cout, Cin, 1)) / np.sqrt(Cin)).astype(np.float32)
