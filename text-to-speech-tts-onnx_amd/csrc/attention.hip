@@ -522,8 +522,8 @@ __global__ __launch_bounds__(256, NP == 2 ? 3 : 2) void attn_x3f_kernel(const fl
     // the probabilities: in [0, 1] by construction, no range clamp
     auto split8p = [&](const float4 a, const float4 b, Frag& f1, Frag& f2) __attribute__((always_inline)) {
         unsigned h[4], l[4];
-        x2u_split_pair_raw(a.x, a.y, h[0], l[0]); x2u_split_pair_raw(a.z, a.w, h[1], l[1]);
-        x2u_split_pair_raw(b.x, b.y, h[2], l[2]); x2u_split_pair_raw(b.z, b.w, h[3], l[3]);
+        x2u_split_pair_raw_mix(a.x, a.y, h[0], l[0]); x2u_split_pair_raw_mix(a.z, a.w, h[1], l[1]);
+        x2u_split_pair_raw_mix(b.x, b.y, h[2], l[2]); x2u_split_pair_raw_mix(b.z, b.w, h[3], l[3]);
         f1 = __builtin_bit_cast(Frag, x3_u4{h[0], h[1], h[2], h[3]});
         f2 = __builtin_bit_cast(Frag, x3_u4{l[0], l[1], l[2], l[3]});
     };

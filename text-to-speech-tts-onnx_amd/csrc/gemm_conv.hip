@@ -609,15 +609,6 @@ static void dispatch_tiles(const ConvGemmDev& d, int B, hipStream_t s) {
         if constexpr (sizeof(T) == 2) {
             // many row tiles (a batch of utterances): the 8-wave 256x256 eight-phase main loop
             const long tiles256 = (long)((d.M + 255) / 256) * ((d.N + 255) / 256);
-            if (g_ph8 && B == 1 && d.G == 1 && d.K == d.Cin && d.Cin % 64 == 0 && d.pad == 0 && d.N % 256 == 0 && buf_ok(d, 2) &&
-                d.lds_epi && (d.epi == EPI_PLAIN || d.epi == EPI_QKV_ROPE) && tiles256 >= g_ph8_min_tiles) {
-                // exact-fit 288 x 256 tiling (gemm_x1d.hip) when the rows x columns divide into whole rounds of the CUs
-                int rgn, cgn, band, dev = 0;
-                MI_HIP(hipGetDevice(&dev));
-                static int cu_count[16] = {0};
-                if (!cu_count[dev & 15]) { hipDeviceProp_t pr; MI_HIP(hipGetDeviceProperties(&pr, dev)); cu_count[dev & 15] = pr.multiProcessorCount; }
-                if (x1d_plan(d.M, d.N, d.K, cu_count[dev & 15], rgn, cgn, band)) { launch_linear_x1d<T, TO>(d, rgn, cgn, band, s); return; }
-            }
             if (g_ph8 && B == 1 && d.G == 1 && d.K == d.Cin && d.Cin % 64 == 0 && d.pad == 0 && d.N % 64 == 0 && buf_ok(d, 2) &&
                 d.lds_epi && (d.epi == EPI_PLAIN || d.epi == EPI_QKV_ROPE) && tiles256 >= g_ph8_min_tiles) {
                 ConvGemmDev e = d;
@@ -792,8 +783,6 @@ bool gemm_set_option(const char* key, long v) {
     else if (k == "gemm_x3p_grid") x3p_set_option(1, v);
     else if (k == "gemm_x3d") x3d_set_option(0, v);
     else if (k == "gemm_x3d_min_eff") x3d_set_option(1, v);
-    else if (k == "gemm_x1d") x1d_set_option(0, v);
-    else if (k == "gemm_x1d_min_eff") x1d_set_option(1, v);
     else if (k == "gemm_ph8") g_ph8 = v;
     else if (k == "gemm_ph8_min_tiles") g_ph8_min_tiles = v;
     else if (k == "gemm_row_split") g_row_split = v;
@@ -900,9 +889,7 @@ void launch_conv_gemm(const ConvGemm& p_in, hipStream_t s) {
         const long r = (p.M / 256) / rstep * rstep;               // N = 1024 / 2048 / 3072 on 256 CUs: multiples of 64 / 32 / 64
         const long rem = p.M - 256 * r;
         const long rem_tiles = (rem + 255) / 256 * ntn;
-        int x1_rg, x1_cg, x1_band;
-        const bool exact_fit = p.Cin % 64 == 0 && x1d_plan(p.M, p.N, p.taps * p.Cin, cus, x1_rg, x1_cg, x1_band);     // one launch of 288 x 256 tiles instead
-        if (!exact_fit && r >= 1 && rem > 0 && rem_tiles * 2 < cus && r * ntn >= g_ph8_min_tiles) {
+        if (r >= 1 && rem > 0 && rem_tiles * 2 < cus && r * ntn >= g_ph8_min_tiles) {
             ConvGemm a = p, b = p;
             a.M = a.T_in = (int)(256 * r);
             b.M = b.T_in = (int)rem;
@@ -938,7 +925,8 @@ void launch_conv_gemm(const ConvGemm& p_in, hipStream_t s) {
     d.act = p.act; d.alpha = p.alpha; d.accumulate = p.accumulate; d.epi = p.epi;
     d.u = p.u; d.Cout = p.Cout; d.padT = p.padT; d.T_out = p.T_out;
     d.rope_cos = p.rope_cos; d.rope_sin = p.rope_sin; d.rope_pack = p.rope_pack; d.heads = p.heads; d.head_dim = p.head_dim;
-    d.out2 = p.out2; d.out3 = p.out3; d.v_ld = p.v_ld; d.Mb = p.rows_per_item; d.m_off = p.m_off;
+    d.out2 = p.out2; d.out3 = p.out3; d.v_ld = p.v_ld; d.Mb = p.rows_per_item; d.m_off = p.m_off; d.qkv_il = p.qkv_il;
+    MI_REQUIRE(!p.qkv_il || (p.epi == EPI_QKV_ROPE && p.head_dim == 64), "conv_gemm: head-interleaved QKV columns need head_dim 64");
     MI_REQUIRE(p.m_off == 0 || (p.epi == EPI_QKV_ROPE && p.rows_per_item >= 32), "conv_gemm: a row offset needs the flattened QKV epilogue");
     d.kv_planes = p.kv_planes; d.k_ld = p.k_ld;
     d.sk_ws = p.sk_ws; d.sk_flags = p.sk_flags; d.sk_slots = p.sk_slots;

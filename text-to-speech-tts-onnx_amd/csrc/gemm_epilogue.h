@@ -34,6 +34,7 @@ struct ConvGemmDev {
     int u, Cout, padT, T_out;
     const float* rope_cos; const float* rope_sin; const void* rope_pack; int heads, head_dim; void* out2; void* out3;
     long v_ld; int Mb;
+    int qkv_il = 0;  // EPI_QKV_ROPE: head-interleaved columns (ConvGemm::qkv_il)
     int m_off = 0;   // EPI_QKV_ROPE: this launch's row 0 is row m_off of the flattened [batch item][token] axis (launch_conv_gemm's row split)
     const void* zero;      // >= 16 bytes of zeros: source for out-of-range / K-tail vectors of the LDS-DMA path
     int dbg;               // tuning only: 1 = no DMA in the main loop, 2 = no ds_read/MFMA in the main loop
@@ -97,9 +98,10 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], const ConvG
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + wn * WN + j * 32 + lr;        // N % 32 == 0 is required: no lane drops out
-            const int which = n / dm;
+            int which = n / dm;
             const int rem = n - which * dm;
-            const int hh = rem / p.head_dim, dd = rem - hh * p.head_dim;
+            int hh = rem / p.head_dim, dd = rem - hh * p.head_dim;
+            if (p.qkv_il) { const int cblk = n / p.head_dim; hh = cblk / 3; which = cblk - hh * 3; dd = n - cblk * p.head_dim; }
             const float bv = p.bias ? p.bias[n] : 0.f;
             const float sgn = (dd & 1) ? 1.f : -1.f;
             const bool vt = which == 2 && p.v_ld > 0;         // V transposed: [bh][d][key]
@@ -349,7 +351,8 @@ __device__ __forceinline__ void gemm_epilogue_qkv_lds(f32x16 (&acc)[TMQ][2], con
     const int lane = lk * 32 + lr;
     const int dm = p.heads * 64;
     const int nbase = n0 + wn * 64;
-    const int which = nbase / dm, hh = (nbase - which * dm) >> 6;           // wave-uniform
+    int which = nbase / dm, hh = (nbase - which * dm) >> 6;                 // wave-uniform
+    if (p.qkv_il) { hh = (nbase >> 6) / 3; which = (nbase >> 6) - hh * 3; }
     const int Mb = p.Mb > 0 ? p.Mb : p.M;
     const int mrow = m0 + wm * (32 * TMQ);                                   // row of this launch
     const int mbase = mrow + p.m_off;                                        // ... of the flattened [batch item][token] axis
@@ -819,10 +822,6 @@ void x3p_set_option(int which, long v);
 bool x3d_plan(const ConvGemmDev& e, int cus, int& tw, int& rgn, int& cgn, int& band);
 void launch_linear_x3d(const ConvGemmDev& e, int tw, int rgn, int cgn, int band, hipStream_t s);
 void x3d_set_option(int which, long v);
-// gemm_x1d.hip: exact-fit data-parallel 16-bit linear layers (288 x 256 tiles) — taken in front of linear_ph8 / the row split when x1d_plan says so
-bool x1d_plan(int M, int N, int K, int cus, int& rgn, int& cgn, int& band);
-template <typename T, typename TO> void launch_linear_x1d(const ConvGemmDev& e, int rgn, int cgn, int band, hipStream_t s);
-void x1d_set_option(int which, long v);
 void ph8_set_split_max(long v);
 void ph8_set_split_min_nk(long v);
 

@@ -49,6 +49,22 @@ __device__ __forceinline__ void x2u_split_pair_raw(float x, float y, unsigned& p
     const x2_h2 l = __builtin_convertvector(x3_f2{x - (float)h.x, y - (float)h.y}, x2_h2);
     pl = __builtin_bit_cast(unsigned, l);
 }
+// The same values with the residuals formed by v_fma_mix_f32 (an FMA whose first operand is read as one fp16 HALF of a register):
+// x - (float)h.x is one instruction instead of a v_cvt_f32_f16 and a subtraction — per pair 4 VALU issues instead of 6, in the loop
+// whose limit is VALU issue (attention.hip: the probabilities of every 32 x 32 tile).  Exact as before: bit-identical pieces.
+__device__ __forceinline__ void x2u_split_pair_raw_mix(float x, float y, unsigned& ph, unsigned& pl) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const x2_h2 h = __builtin_convertvector(x3_f2{x, y}, x2_h2);
+    ph = __builtin_bit_cast(unsigned, h);
+    float rx, ry;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(rx) : "v"(ph), "v"(x));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(ry) : "v"(ph), "v"(y));
+    const x2_h2 l = __builtin_convertvector(x3_f2{rx, ry}, x2_h2);
+    pl = __builtin_bit_cast(unsigned, l);
+#else
+    x2u_split_pair_raw(x, y, ph, pl);
+#endif
+}
 __device__ __forceinline__ void x2u_split_pair(float x, float y, unsigned& ph, unsigned& pl) {
     x = x > 65504.f ? 65504.f : x; x = x < -65504.f ? -65504.f : x;
     y = y > 65504.f ? 65504.f : y; y = y < -65504.f ? -65504.f : y;

@@ -7,6 +7,7 @@ cd /tmp; export TMPDIR=/tmp
 env $ENVS ITERS=5 timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_WAIT_INST_LDS --output-format csv -d $O/p1 -- python $ROOT/tools/gemm_bench.py custom "$@" > $O/log1.txt 2>&1
 env $ENVS ITERS=5 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/p3 -- python $ROOT/tools/gemm_bench.py custom "$@" > $O/log3.txt 2>&1
 env $ENVS ITERS=5 timeout 300 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d $O/p4 -- python $ROOT/tools/gemm_bench.py custom "$@" > $O/log4.txt 2>&1
+env $ENVS ITERS=5 timeout 300 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL --output-format csv -d $O/p5 -- python $ROOT/tools/gemm_bench.py custom "$@" > $O/log5.txt 2>&1
 env $ENVS ITERS=5 timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE GRBM_COUNT --output-format csv -d $O/p2 -- python $ROOT/tools/gemm_bench.py custom "$@" > $O/log2.txt 2>&1
 python - <<PY
 import csv,glob,collections
