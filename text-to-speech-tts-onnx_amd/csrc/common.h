@@ -163,10 +163,6 @@ struct ConvGemm {
     int rows_per_item = 0;        // EPI_QKV_ROPE with the batch flattened into M: tokens per batch item (0: M)
     int m_off = 0;                // ... and the flattened row this launch's row 0 stands for (row split inside launch_conv_gemm)
     long v_ld = 0;                // > 0: V is written transposed, [b*H + h][head_dim][v_ld] (keys contiguous)
-    // EPI_QKV_ROPE, round 6: the weight rows are stored head-INTERLEAVED — 64-column block c of the output is (q | k | v)[c % 3] of head
-    // c / 3 instead of block c = which * heads + head — so that every 192-column tile of the GEMM holds one q, one k and one V head: the
-    // V^T blocks (2-byte stores, ~3x the store instructions of a q / k block) are spread over all CUs instead of filling a third of them
-    int qkv_il = 0;
     // fp32 + LDS-staged QKV epilogue only: K and V^T leave as the three bf16 planes of x3_split.h (the attention kernel then
     // stages them without splitting): out2 = [b*H + h][3][k_ld][64], out3 = [b*H + h][3][64][v_ld]; q stays fp32
     int kv_planes = 0; long k_ld = 0;

@@ -70,7 +70,6 @@ struct F5 {
     int arith_kind = ARITH_DEFAULT;
     DevBuf Ap, Ap2;          // fp32 engines: the A operand of the big linear layers as panel planes (gemm_x3p.hip): dim / ff columns
     // ---- AdaLN fold (dit_eval; gemm_epilogue.h) ----
-    int qkv_il = 0;          // the QKV weight rows are stored head-interleaved (ConvGemm::qkv_il)
     bool fold_built = false; // the load-time vectors exist (dim >= 1024, dim % 128 == 0, cfg.ln_fold != 0)
     DevBuf ApN;              // fp32 engines: x o (1 + scale) of the residual row as panel planes (16-bit engines: rows in Ub)
     DevBuf ln_stats;         // [rows][dim / 32][2] partial (sum, M2 about the block mean) per residual row

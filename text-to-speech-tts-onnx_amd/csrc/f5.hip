@@ -198,17 +198,9 @@ F5::F5(const F5Cfg& c, const float* w, int64_t nw, int dt, int dev, int mem) : c
         mod_gemm(mw, mb, 6 * d, (long)i * 6 * d);
         bk.qkv.n = 3 * d; bk.qkv.k = d;                              // q | k | v rows stacked into one GEMM weight
         bk.qkv.w.ensure((size_t)3 * d * d * dtype_size(dt)); bk.qkv.b.ensure((size_t)3 * d * 4);
-        // head-interleaved rows (ConvGemm::qkv_il, head_dim 64): 64-row block c = (q | k | v)[c % 3] of head c / 3
-        qkv_il = c.dim_head == 64 ? 1 : 0;
         for (int t3 = 0; t3 < 3; ++t3) {
             const float* wt = take((size_t)d * d); const float* bt = take(d);
-            if (qkv_il) {
-                for (int h = 0; h < c.heads; ++h) {
-                    const size_t blk = (size_t)h * 3 + t3;
-                    R.put(bk.qkv.w, wt + (size_t)h * 64 * d, (size_t)64 * d, dt, blk == 0 ? 0 : blk * 64 * d);
-                    R.put(bk.qkv.b, bt + (size_t)h * 64, 64, MI_F32, blk == 0 ? 0 : blk * 64);
-                }
-            } else if (t3 == 0) { R.put(bk.qkv.w, wt, (size_t)d * d, dt, 0); R.put(bk.qkv.b, bt, d, MI_F32, 0); }
+            if (t3 == 0) { R.put(bk.qkv.w, wt, (size_t)d * d, dt, 0); R.put(bk.qkv.b, bt, d, MI_F32, 0); }
             else { R.put(bk.qkv.w, wt, (size_t)d * d, dt, (size_t)t3 * d * d); R.put(bk.qkv.b, bt, d, MI_F32, (size_t)t3 * d); }
         }
         const float* wo = take((size_t)d * d); const float* bo = take(d);
@@ -741,7 +733,6 @@ void F5::dit_eval(int U, int N, int k) {
         g.out2 = kb.p; g.out3 = vb.p; g.rows_per_item = N;           // batch flattened into M
         g.epi = EPI_QKV_ROPE; g.rope_cos = rope_cos.as<float>(); g.rope_sin = rope_sin.as<float>(); g.rope_pack = rope_pack.p; g.heads = H; g.head_dim = D;
         g.v_ld = attention_v_ld(N, dtype);
-        g.qkv_il = qkv_il;
         return g;
     };
     const int kvp_fmt = attention_kv_planes_format();       // K / V^T pre-split for the attention kernel: 2 fp16 planes or 3 bf16 planes

@@ -925,8 +925,7 @@ void launch_conv_gemm(const ConvGemm& p_in, hipStream_t s) {
     d.act = p.act; d.alpha = p.alpha; d.accumulate = p.accumulate; d.epi = p.epi;
     d.u = p.u; d.Cout = p.Cout; d.padT = p.padT; d.T_out = p.T_out;
     d.rope_cos = p.rope_cos; d.rope_sin = p.rope_sin; d.rope_pack = p.rope_pack; d.heads = p.heads; d.head_dim = p.head_dim;
-    d.out2 = p.out2; d.out3 = p.out3; d.v_ld = p.v_ld; d.Mb = p.rows_per_item; d.m_off = p.m_off; d.qkv_il = p.qkv_il;
-    MI_REQUIRE(!p.qkv_il || (p.epi == EPI_QKV_ROPE && p.head_dim == 64), "conv_gemm: head-interleaved QKV columns need head_dim 64");
+    d.out2 = p.out2; d.out3 = p.out3; d.v_ld = p.v_ld; d.Mb = p.rows_per_item; d.m_off = p.m_off;
     MI_REQUIRE(p.m_off == 0 || (p.epi == EPI_QKV_ROPE && p.rows_per_item >= 32), "conv_gemm: a row offset needs the flattened QKV epilogue");
     d.kv_planes = p.kv_planes; d.k_ld = p.k_ld;
     d.sk_ws = p.sk_ws; d.sk_flags = p.sk_flags; d.sk_slots = p.sk_slots;

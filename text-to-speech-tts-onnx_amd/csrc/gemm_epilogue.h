@@ -34,7 +34,6 @@ struct ConvGemmDev {
     int u, Cout, padT, T_out;
     const float* rope_cos; const float* rope_sin; const void* rope_pack; int heads, head_dim; void* out2; void* out3;
     long v_ld; int Mb;
-    int qkv_il = 0;  // EPI_QKV_ROPE: head-interleaved columns (ConvGemm::qkv_il)
     int m_off = 0;   // EPI_QKV_ROPE: this launch's row 0 is row m_off of the flattened [batch item][token] axis (launch_conv_gemm's row split)
     const void* zero;      // >= 16 bytes of zeros: source for out-of-range / K-tail vectors of the LDS-DMA path
     int dbg;               // tuning only: 1 = no DMA in the main loop, 2 = no ds_read/MFMA in the main loop
@@ -98,10 +97,9 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], const ConvG
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + wn * WN + j * 32 + lr;        // N % 32 == 0 is required: no lane drops out
-            int which = n / dm;
+            const int which = n / dm;
             const int rem = n - which * dm;
-            int hh = rem / p.head_dim, dd = rem - hh * p.head_dim;
-            if (p.qkv_il) { const int cblk = n / p.head_dim; hh = cblk / 3; which = cblk - hh * 3; dd = n - cblk * p.head_dim; }
+            const int hh = rem / p.head_dim, dd = rem - hh * p.head_dim;
             const float bv = p.bias ? p.bias[n] : 0.f;
             const float sgn = (dd & 1) ? 1.f : -1.f;
             const bool vt = which == 2 && p.v_ld > 0;         // V transposed: [bh][d][key]
@@ -351,8 +349,7 @@ __device__ __forceinline__ void gemm_epilogue_qkv_lds(f32x16 (&acc)[TMQ][2], con
     const int lane = lk * 32 + lr;
     const int dm = p.heads * 64;
     const int nbase = n0 + wn * 64;
-    int which = nbase / dm, hh = (nbase - which * dm) >> 6;                 // wave-uniform
-    if (p.qkv_il) { hh = (nbase >> 6) / 3; which = (nbase >> 6) - hh * 3; }
+    const int which = nbase / dm, hh = (nbase - which * dm) >> 6;           // wave-uniform
     const int Mb = p.Mb > 0 ? p.Mb : p.M;
     const int mrow = m0 + wm * (32 * TMQ);                                   // row of this launch
     const int mbase = mrow + p.m_off;                                        // ... of the flattened [batch item][token] axis
