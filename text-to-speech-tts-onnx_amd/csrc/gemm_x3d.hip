@@ -45,8 +45,11 @@ template <int TW> struct X3dGeom {
     static constexpr int KG = TW == 64 ? 2 : 1;                   // k-groups (alternate chunks)
     static constexpr int WNS = KG == 2 ? 2 : 4;                   // waves along N
     static constexpr int WNW = TW / WNS, NB = WNW / 16;           // 32 | 32 | 48 columns per wave
-    static constexpr int S = TW == 192 ? 1 : 2;                   // chunks per step (between barriers)
-    static constexpr int WSTEP = TW == 128 ? 2 : 1;               // ... of which one wave multiplies
+#ifndef X3D_S128
+#define X3D_S128 2          // TW = 128: chunks per step (2: a barrier per two chunks, DMA one step ahead; 1: a barrier per chunk, three chunks ahead)
+#endif
+    static constexpr int S = TW == 192 ? 1 : TW == 128 ? X3D_S128 : 2;       // chunks per step (between barriers)
+    static constexpr int WSTEP = TW == 128 ? X3D_S128 : 1;        // ... of which one wave multiplies
     static constexpr int R = TW == 64 ? 6 : TW == 128 ? 4 : 3;    // ring slots (chunks)
     static constexpr int LB = R / S - 1;                          // batches in flight behind the one being waited for: 2 | 1 | 2
     static constexpr int A_PLANE = TM * 64, B_PLANE = TW * 64;
