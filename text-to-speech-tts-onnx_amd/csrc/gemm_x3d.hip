@@ -23,8 +23,8 @@
 // Per chunk and wave: phase 0 lo x hi, phase 1 hi x hi, phase 2 hi x lo (acc1 | acc0 | acc1: same order of the partial
 // products as gemm_x3p.hip); ONE fragment register set: each fragment group is re-read for the next chunk right behind
 // the phase that used it last (lo(A) after phase 0, hi(B) after 1, hi(A) + lo(B) after 2) and is next needed one to two
-// phases later.  The ring: 6 | 4 | 3 chunk slots, one barrier per step (= per chunk; TW = 128: per two chunks), the DMA
-// of a step is issued two (TW = 128: one) steps ahead right behind that barrier.
+// phases later.  The ring: 6 | 4 | 3 chunk slots, one barrier per step (TW = 64: a step is the two k-groups' chunks), the DMA
+// pieces of a step ride on the MFMAs of phase 1 two (TW = 128: three) steps ahead.
 // Epilogue: the tile is staged in LDS as 32 x 64 blocks in the 32x32 accumulator layout's order, each wave takes blocks and
 // runs gemm_epilogue.h's per-role epilogues unchanged (QKV + RoPE + V^T | FF1 planes + GELU | gated residual + AdaLN fold).
 #include <atomic>
@@ -46,7 +46,8 @@ template <int TW> struct X3dGeom {
     static constexpr int WNS = KG == 2 ? 2 : 4;                   // waves along N
     static constexpr int WNW = TW / WNS, NB = WNW / 16;           // 32 | 32 | 48 columns per wave
 #ifndef X3D_S128
-#define X3D_S128 2          // TW = 128: chunks per step (2: a barrier per two chunks, DMA one step ahead; 1: a barrier per chunk, three chunks ahead)
+#define X3D_S128 1          // TW = 128: chunks per step (1: a barrier per chunk, the DMA three chunks ahead — FF1 38.3 -> 37.4 us with the layer's
+                            // weights cold in HBM, bit-identical, profiles/r6/x3d_s128_ab.txt; 2: a barrier per two chunks, one step ahead)
 #endif
     static constexpr int S = TW == 192 ? 1 : TW == 128 ? X3D_S128 : 2;       // chunks per step (between barriers)
     static constexpr int WSTEP = TW == 128 ? X3D_S128 : 1;        // ... of which one wave multiplies
