@@ -256,6 +256,7 @@ int         mi_indextts_cond_run(mi_cond* h, const int16_t* audio, int64_t L, fl
  *   attention: "attn_split" (small grids: 0 plain 128-query workgroups, 1 64-query workgroups with the keys split between wave
  *     pairs + key slices, 2 [default] fp32: 128-query workgroups + key slices, 16-bit as 1), "attn_kv_planes" (0: the fp32 kernel splits K / V itself), "attn_z_force" (key slices, tests),
  *     "attn_xcd_map" (1: a head's query tiles on one XCD; bit-identical either way),
+ *     "attn_lpt" (1 [default]: the fp32 128-query kernel's key slices are uneven, longest first — attention.hip attn_pick_slices),
  *     "gemm_x3d" (1 [default]: fp32 linear layers on the exact-fit data-parallel kernel gemm_x3d.hip when the output divides into whole rounds
  *     of the CUs), "gemm_x3d_min_eff" (per cent of useful tile area from which it is taken, default 90)
  *   "gpt_mfma_min" (sentences from which mi_gpt_generate_batch runs its linears on MFMA; default 9)

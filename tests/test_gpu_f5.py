@@ -249,6 +249,38 @@ def test_fp32_attention_split_products_match_native():
         eng.close()
 
 
+def test_attention_uneven_key_slices_longest_first():
+    """Round 6: the fp32 128-query attention launch cuts the 64-key stages into UNEVEN slices, longest first (attn_pick_slices: the
+    z-major dispatch order is then list scheduling on the 3 x CUs workgroup slots; N = 1126: 7 + 7 + 2 + 2 stages instead of 6 + 6 + 6).
+    Same merge as the even slices: against the oracle, against the even slices (attn_lpt = 0) and identical run to run, at lengths whose
+    stage counts split differently."""
+    from mi355tts import _lib
+    cfg = F5Config(dim=256, depth=1, heads=4, dim_head=64, text_dim=64, text_num_embeds=40, conv_layers=1,
+                   pos_conv_groups=4, vocos_dim=64, vocos_intermediate=128, vocos_layers=1, nfe_step=4)
+    raw = W.synth_state(W.f5_spec(cfg), 7)
+    st = W.fold_f5(cfg, raw)
+    eng = F5Engine(cfg, raw, dtype="f32")
+    tables = O.time_tables(cfg, st)
+    try:
+        for N in (257, 700, 1126):
+            noise = W.synth_normal(3, f"n{N}", (N, cfg.mel_dim))
+            cmt = W.synth_normal(4, f"c{N}", (N, cfg.mel_dim + cfg.text_dim), std=0.7)
+            cmtd = W.synth_normal(5, f"d{N}", (N, cfg.mel_dim + cfg.text_dim), std=0.7)
+            cos, sin = O.rope_tables(N, 64)
+            ref = O.dit_forward(cfg, st, noise, cmt, cmtd, tables[2][1], cos, sin)
+            _lib.set_option("attn_lpt", 0)
+            even = eng.dit_eval(noise[None], cmt[None], cmtd[None], 1)
+            _lib.set_option("attn_lpt", 1)
+            a = eng.dit_eval(noise[None], cmt[None], cmtd[None], 1)
+            for _ in range(3):
+                assert np.array_equal(a, eng.dit_eval(noise[None], cmt[None], cmtd[None], 1)), N
+            np.testing.assert_allclose(a, ref, atol=3e-4)
+            assert np.abs(a - even).max() < 1e-4, N
+    finally:
+        _lib.set_option("attn_lpt", 1)
+        eng.close()
+
+
 @pytest.mark.parametrize("dtype,tol,split", [("f32", 3e-4, 1), ("f32", 3e-4, 2), ("f16", 1.5e-2, 1)])
 def test_attention_key_slices_agree(dtype, tol, split):
     """Key-sliced attention (gridDim.z slices of the 64-key stages, last-arriver merge in slice order): every slice count,
