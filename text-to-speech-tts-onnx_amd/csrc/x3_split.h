@@ -50,17 +50,16 @@ __device__ __forceinline__ void x2u_split_pair_raw(float x, float y, unsigned& p
     pl = __builtin_bit_cast(unsigned, l);
 }
 // The same values with the residuals formed by v_fma_mix_f32 (an FMA whose first operand is read as one fp16 HALF of a register):
-// x - (float)h.x is one instruction instead of a v_cvt_f32_f16 and a subtraction — per pair 4 VALU issues instead of 6, in the loop
+// x - (float)h.x is one instruction instead of a v_cvt_f32_f16 and a subtraction — per pair 3 VALU issues instead of 6, in the loop
 // whose limit is VALU issue (attention.hip: the probabilities of every 32 x 32 tile).  Exact as before: bit-identical pieces.
 __device__ __forceinline__ void x2u_split_pair_raw_mix(float x, float y, unsigned& ph, unsigned& pl) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const x2_h2 h = __builtin_convertvector(x3_f2{x, y}, x2_h2);
     ph = __builtin_bit_cast(unsigned, h);
-    float rx, ry;
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(rx) : "v"(ph), "v"(x));
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(ry) : "v"(ph), "v"(y));
-    const x2_h2 l = __builtin_convertvector(x3_f2{rx, ry}, x2_h2);
-    pl = __builtin_bit_cast(unsigned, l);
+    // v_fma_mixlo / mixhi_f16: fma(fp16 half of ph, -1, fp32) rounded straight into one half of the destination — the exact residual
+    // x - hi with ONE rounding to fp16, the same value as cvt(x - (float)hi); the pair costs 3 VALU issues (v_cvt_pk + these two)
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(pl) : "v"(ph), "v"(x), "v"(y));
 #else
     x2u_split_pair_raw(x, y, ph, pl);
 #endif
