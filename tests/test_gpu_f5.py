@@ -515,6 +515,45 @@ def test_full_size_fp32_other_lengths_default_forms_against_native(full, N):
     assert rms(a[:2] - a1) / rms(a1) < 3e-6                    # one utterance alone: other tile counts, same values
 
 
+def test_fp32_input_projection_padded_to_whole_chunks(full, monkeypatch):
+    """fp32 engines pad K of the input projection (2 * mel + text_dim = 712, dit.py InputEmbedding.proj) to 768 with zero
+    weight columns and a zeroed tail of the cat buffer's rows, so that the layer runs on the panel-plane kernel (csrc/f5.hip,
+    F5::cat_ld).  Against the unpadded engine (MI355TTS_CAT_PAD=0 at construction: the native fp32 small-tile kernel): the same
+    evaluation to fp32 round-off, for one and for two utterances, and the padded engine's profile shows the layer on
+    linear_x3d_kernel<64, rows out> (two launches per evaluation: this one and the last block's FF2)."""
+    from mi355tts import _lib
+    cfg, raw, audio, ids, _, _ = full
+    N = 1126
+    noise = np.stack([W.synth_normal(5 + u, "noise_pad", (N, cfg.mel_dim)) for u in range(2)])
+    outs, kernels = {}, {}
+    for pad in ("1", "0"):
+        monkeypatch.setenv("MI355TTS_CAT_PAD", pad)
+        eng = F5Engine(cfg, raw, dtype="f32")
+        try:
+            o = [eng.preprocess(audio[u].reshape(1, 1, -1), ids[u].reshape(1, -1), np.array([N]), noise=noise[u]) for u in range(2)]
+            cmt = np.concatenate([x["cat_mel_text"] for x in o]); cmtd = np.concatenate([x["cat_mel_text_drop"] for x in o])
+            one = eng.dit_eval(noise[:1], cmt[:1], cmtd[:1], 5)
+            _lib.prof_reset(); _lib.prof_enable(["conv_gemm"])
+            try:
+                again = eng.dit_eval(noise[:1], cmt[:1], cmtd[:1], 5)
+            finally:
+                _lib.prof_enable(())
+            kernels[pad] = {k["kernel"]: k["launches"] for k in _lib.prof_kernels()}
+            assert np.array_equal(one, again)
+            outs[pad] = (one, eng.dit_eval(noise, cmt, cmtd, 5))
+            assert eng.info()["saturation_events"] == 0
+        finally:
+            eng.close()
+    for a, b in zip(outs["1"], outs["0"]):
+        assert a.shape == b.shape and np.isfinite(a).all()
+        e = rms(a - b) / rms(b)
+        print(f"padded against unpadded input projection: rel rms {e:.2e}")
+        assert e < 3e-6, e
+    rows_out = [n for k, n in kernels["1"].items() if "linear_x3d_kernel<64, rows out>" in k]
+    assert rows_out == [2], kernels["1"]
+    assert [n for k, n in kernels["0"].items() if "linear_x3d_kernel<64, rows out>" in k] == [1], kernels["0"]
+
+
 @pytest.mark.parametrize("dtype,gate", [("bf16", 1.5e-3), ("f16", 3e-4)])        # achieved (profiles/r3): 2.5e-4 / 3.4e-5
 def test_full_size_lowp_u8_against_reference_fixture(full, gfull, dtype, gate):
     """configs[3] shard: 8 utterances per GPU in one batch, 16-bit DiT operands.  Utterance 0 is the reference fixture's

@@ -31,6 +31,10 @@ struct F5 {
 
     // ---- DiT (engine dtype) ----
     Lin in_proj, gconv1, gconv2, proj_out;
+    // row stride of the cat(x, cond, text) buffer = K of in_proj: fp32 engines pad it to whole 64-deep chunks (zero columns)
+    // (MI355TTS_CAT_PAD=0 at construction: unpadded, the A/B switch)
+    int cat_pad = 0;
+    int cat_ld() const { return cfg.cat_dim() + cat_pad; }
     struct Block { Lin qkv, o, ff1, ff2; };
     std::vector<Block> blocks;
     DevBuf mod;             // fp32 [nfe][depth*6d + 2d]  AdaLN modulation, hoisted out of the loop

@@ -96,6 +96,10 @@ F5::F5(const F5Cfg& c, const float* w, int64_t nw, int dt, int dev, int mem) : c
     d_sat.ensure(64);
     MI_HIP(hipMemsetAsync(d_sat.p, 0, 64, s));
     const int d = c.dim, td = c.text_dim, ff = c.ff(), ti = td * c.conv_mult, cin = c.cat_dim();
+    {
+        const char* e = std::getenv("MI355TTS_CAT_PAD");
+        if (dt == MI_F32 && !(e && e[0] == '0')) cat_pad = rup(cin, 64) - cin;
+    }
     const float* p = w;
     auto take = [&](size_t n) { const float* r = p; p += n; return r; };          // blob ranges (host or device memory)
     BlobReader R(mem, s);
@@ -162,7 +166,17 @@ F5::F5(const F5Cfg& c, const float* w, int64_t nw, int dt, int dev, int mem) : c
     // ---- input embedding -------------------------------------------------------------------------------
     {
         const float* pw = take((size_t)d * cin); const float* pb = take(d);
-        put_lin(R, in_proj, pw, pb, d, cin, dt);
+        if (cat_ld() == cin) put_lin(R, in_proj, pw, pb, d, cin, dt);
+        else {
+            // fp32 engines: K = 2 * mel + text_dim (712) padded with zero columns to whole 64-deep chunks (768), the row stride of
+            // the cat buffer with it (its pad columns are zeroed once, ensure_workspace): the layer then runs on the panel-plane
+            // kernel like the block matrices instead of the native-fp32 small-tile kernel (46.9 -> ~25 us per evaluation)
+            const int kp = cat_ld();
+            const float* hw = R.host(pw, (size_t)d * cin); const float* hb = R.host(pb, d);
+            std::vector<float> wp((size_t)d * kp, 0.f);
+            for (int o = 0; o < d; ++o) std::copy(hw + (size_t)o * cin, hw + (size_t)(o + 1) * cin, wp.begin() + (size_t)o * kp);
+            up_lin(in_proj, wp.data(), hb, d, kp, dt, s);
+        }
         const int cg = d / c.pos_g;
         const size_t gw = (size_t)d * cg * c.pos_k;                 // the k31 grouped convs are re-laid out by host code
         const float* w1 = R.host(take(gw), gw); const float* b1 = R.host(take(d), d);
@@ -407,12 +421,14 @@ void F5::set_arith(int kind) {
     drop_graphs();
     if (dtype != MI_F32) return;
     const bool planes = gemm_x3p_enabled();
+    auto build_planes = [&](Lin* L) {
+        if (!planes || L->n % 128 != 0 || L->k % 32 != 0) { L->w3p.release(); return; }
+        L->w3p.ensure((size_t)x3p_bytes(L->n, L->k, np));
+        x3p_split_rows(L->w.as<float>(), L->k, L->w3p.p, L->n, L->k, stream, np);
+    };
     for (Block& bk : blocks)
-        for (Lin* L : {&bk.qkv, &bk.o, &bk.ff1, &bk.ff2}) {
-            if (!planes || L->n % 128 != 0 || L->k % 32 != 0) { L->w3p.release(); continue; }
-            L->w3p.ensure((size_t)x3p_bytes(L->n, L->k, np));
-            x3p_split_rows(L->w.as<float>(), L->k, L->w3p.p, L->n, L->k, stream, np);
-        }
+        for (Lin* L : {&bk.qkv, &bk.o, &bk.ff1, &bk.ff2}) build_planes(L);
+    build_planes(&in_proj);
     if (ws_U > 0) {       // the activation planes are sized by the format
         const long rows = (long)2 * ws_U * ws_N;
         Ap.ensure((size_t)x3p_bytes(rows, cfg.dim, np)); Ap2.ensure((size_t)x3p_bytes(rows, cfg.ff(), np)); ApN.ensure((size_t)x3p_bytes(rows, cfg.dim, np));
@@ -483,7 +499,10 @@ void F5::ensure_workspace(int U, int N) {
     d_noise.ensure((size_t)Um * Nm * c.mel * 4);
     d_cmt.ensure((size_t)Um * Nm * c.cond_dim() * 4);
     d_cmtd.ensure((size_t)Um * Nm * c.cond_dim() * 4);
-    cat.ensure(rows * c.cat_dim() * es);
+    if (rows * cat_ld() * es > cat.bytes) {
+        cat.ensure(rows * cat_ld() * es);
+        if (cat_ld() != c.cat_dim()) MI_HIP(hipMemsetAsync(cat.p, 0, cat.bytes, stream));      // the pad columns stay zero
+    }
     h32.ensure(rows * c.dim * 4); hT.ensure(rows * c.dim * es); c1.ensure(rows * c.dim * es);
     X.ensure(rows * c.dim * 4); Ub.ensure(rows * c.dim * es);
     qb.ensure(rows * c.dim * es); Ob.ensure(rows * c.dim * es);
@@ -679,7 +698,7 @@ void F5::load_cond(const float* noise, const float* cmt, const float* cmtd, int 
 void F5::build_cat_cond(int U, int N) {
     const F5Cfg& c = cfg;
     const size_t es = dtype_size(dtype);
-    const int cd = c.cond_dim(), ld = c.cat_dim();
+    const int cd = c.cond_dim(), ld = cat_ld();
     for (int u = 0; u < U; ++u)
         for (int br = 0; br < 2; ++br) {
             const float* src = (br == 0 ? d_cmt.as<float>() : d_cmtd.as<float>()) + (size_t)u * N * cd;
@@ -692,7 +711,7 @@ void F5::dit_eval(int U, int N, int k) {
     const F5Cfg& c = cfg;
     MI_REQUIRE(k >= 0 && k < c.nfe, "f5: time step out of range");
     hipStream_t s = stream;
-    const int B = 2 * U, d = c.dim, ld = c.cat_dim(), ff = c.ff(), H = c.heads, D = c.dim_head;
+    const int B = 2 * U, d = c.dim, ld = cat_ld(), ff = c.ff(), H = c.heads, D = c.dim_head;
     const long rows = (long)B * N;
     const float* modk = mod.as<float>() + (size_t)k * mod_ld;
     // ---- input embedding: proj(cat(x, cond)) ; + Mish(GConv(Mish(GConv(.)))) ---------------------------
