@@ -515,6 +515,39 @@ def test_full_size_fp32_other_lengths_default_forms_against_native(full, N):
     assert rms(a[:2] - a1) / rms(a1) < 3e-6                    # one utterance alone: other tile counts, same values
 
 
+@pytest.mark.parametrize("N", [1126, 333])
+def test_fp32_position_convolution_weights_split_at_load(full, N):
+    """ConvPositionEmbedding (modules.py:167-190: two grouped k = 31 convolutions + Mish) on fp16 pairs: the round-6 kernel takes its
+    weights pre-split at load and keeps two taps in flight per workgroup (gconv_pairs2_kernel); the round-3 kernel re-splits them
+    per launch (option gconv_two_taps = 0).  Same operands, same products, another summation order (even taps + odd taps): the
+    evaluations agree to fp32 round-off, at the bench length and at one whose last row tile is cut (333 = 192 + 141)."""
+    from mi355tts import _lib
+    cfg, raw, audio, ids, _, _ = full
+    noise = np.stack([W.synth_normal(31 + u, "noise_gc", (N, cfg.mel_dim)) for u in range(2)])
+    eng = F5Engine(cfg, raw, dtype="f32")
+    outs, kernels = {}, {}
+    try:
+        o = [eng.preprocess(audio[u].reshape(1, 1, -1)[..., :24000 * 2], ids[u].reshape(1, -1)[:, :40], np.array([N]), noise=noise[u]) for u in range(2)]
+        cmt = np.concatenate([x["cat_mel_text"] for x in o]); cmtd = np.concatenate([x["cat_mel_text_drop"] for x in o])
+        for on in (1, 0):
+            _lib.set_option("gconv_two_taps", on)
+            _lib.prof_reset(); _lib.prof_enable(["conv_gemm"])
+            try:
+                outs[on] = eng.dit_eval(noise, cmt, cmtd, 9)
+            finally:
+                _lib.prof_enable(())
+            kernels[on] = [k["kernel"] for k in _lib.prof_kernels()]
+        assert eng.info()["saturation_events"] == 0
+    finally:
+        _lib.set_option("gconv_two_taps", 1)
+        eng.close()
+    assert any("gconv_pairs2_kernel" in k for k in kernels[1]) and not any("gconv_pairs2_kernel" in k for k in kernels[0]), kernels
+    assert any("gconv_pairs_kernel" in k for k in kernels[0]), kernels[0]
+    e = rms(outs[1] - outs[0]) / rms(outs[0])
+    print(f"N = {N}: position convolution, weights split at load against per launch: rel rms {e:.2e}")
+    assert np.isfinite(outs[1]).all() and e < 2e-6, e
+
+
 def test_fp32_input_projection_padded_to_whole_chunks(full, monkeypatch):
     """fp32 engines pad K of the input projection (2 * mel + text_dim = 712, dit.py InputEmbedding.proj) to 768 with zero
     weight columns and a zeroed tail of the cat buffer's rows, so that the layer runs on the panel-plane kernel (csrc/f5.hip,

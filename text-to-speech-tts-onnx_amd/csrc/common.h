@@ -173,6 +173,7 @@ struct ConvGemm {
     const void* w3 = nullptr;
     // gemm_x3p.hip (round 3): both operands as pre-split, pre-tiled "panel planes" (x3p_split_rows): xp replaces x, w3p replaces w3
     const void* xp = nullptr; const void* w3p = nullptr; int np = 3;        // np: planes per operand (3 bf16 | 2 fp16), both operands alike
+    const void* gcp_w = nullptr;    // gconv_pairs.hip: the grouped convolution's weights pre-split at load (gconv_pairs_split_weights); null: split per launch
     // ... and its output as panel planes too (the A operand of the NEXT linear layer: FF1 -> FF2), instead of rows in `out`;
     // plain epilogue only: bias + activation, no residual / gate / accumulate
     void* out_planes = nullptr;
@@ -209,6 +210,9 @@ __host__ __device__ inline long x3p_slot_offset(long row, int s8, int nch, int n
 }
 long x3p_bytes(long rows, long K, int np = 3);                                        // bytes of the panel planes of a [rows][K] matrix
 void x3p_split_rows(const float* x, long ld, void* planes, int rows, int K, hipStream_t s, int np = 3, int* sat = nullptr);   // sat: range watch (x3_split.h)
+// gconv_pairs.hip: fp16 {hi, lo} images of a grouped convolution's fp32 weights [G][64][taps][64], one per (group, tap), built once at load
+size_t gconv_pairs_planes_bytes(int G, int taps);
+void gconv_pairs_split_weights(const float* w, void* wp, int G, int taps, hipStream_t s);
 int x3p_planes();                                  // option "gemm_f32_planes": the format new planes are built in (3 or 2)
 bool gemm_x3p_enabled();
 bool gemm_x3p_would_run(const ConvGemm& p);        // p.xp / p.w3p set: will launch_conv_gemm(p) take the panel-plane kernel?

@@ -185,6 +185,13 @@ F5::F5(const F5Cfg& c, const float* w, int64_t nw, int dt, int dev, int mem) : c
         const float* w2 = R.host(take(gw), gw); const float* b2 = R.host(take(d), d);
         auto r2 = relayout(w2, d, cg, c.pos_k);
         up_lin(gconv2, r2.data(), b2, d, cg * c.pos_k, dt, s);
+        if (dt == MI_F32 && cg == 64 && c.pos_k >= 8 && c.pos_k <= 127) {
+            // the pair-split form of the position convolution (gconv_pairs.hip) takes its weights pre-split: once here, not per launch
+            for (Lin* L : {&gconv1, &gconv2}) {
+                L->w3p.ensure(gconv_pairs_planes_bytes(c.pos_g, c.pos_k));
+                gconv_pairs_split_weights(L->w.as<float>(), L->w3p.p, c.pos_g, c.pos_k, s);
+            }
+        }
     }
     // ---- DiT blocks + hoisted AdaLN modulation table -------------------------------------------------
     mod_ld = (long)c.depth * 6 * d + 2 * d;
@@ -724,9 +731,9 @@ void F5::dit_eval(int U, int N, int k) {
         g.dtype = dtype; g.x = hin; g.w = gconv1.w.p; g.bias = gconv1.b.as<float>(); g.out = c1.p;
         g.B = B; g.G = c.pos_g; g.T_in = N; g.M = N; g.N = d / c.pos_g; g.Cin = d / c.pos_g; g.taps = c.pos_k; g.pad = c.pos_k / 2;
         g.x_bstride = (long)N * d; g.x_rstride = d; g.x_goff = d / c.pos_g; g.out_bstride = (long)N * d; g.out_rstride = d;
-        g.act = ACT_MISH; g.sat = d_sat.as<int>();
+        g.act = ACT_MISH; g.sat = d_sat.as<int>(); g.gcp_w = gconv1.w3p.p;
         launch_conv_gemm(g, s);
-        g.x = c1.p; g.w = gconv2.w.p; g.bias = gconv2.b.as<float>(); g.out = X.p; g.out_dtype = MI_F32; g.res = h32.p;
+        g.x = c1.p; g.w = gconv2.w.p; g.bias = gconv2.b.as<float>(); g.out = X.p; g.out_dtype = MI_F32; g.res = h32.p; g.gcp_w = gconv2.w3p.p;
         launch_conv_gemm(g, s);
     }
     // ---- transformer blocks ----------------------------------------------------------------------------------

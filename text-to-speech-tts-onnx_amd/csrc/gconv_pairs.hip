@@ -21,6 +21,8 @@
 #include "gemm_epilogue.h"
 #include "mfma.h"
 #include "x3_split.h"
+#include <atomic>
+#include <cstdlib>
 
 namespace mi {
 
@@ -187,6 +189,169 @@ __global__ __launch_bounds__(256, BM <= 128 ? 2 : 1) void gconv_pairs_kernel(con
     }
 }
 
+// -----------------------------------------------------------------------------------------------------------------------------
+// Round 6: the same convolution with the weights split ONCE PER ENGINE (gconv_pairs_split_weights at load: fp16 {hi, lo} planes
+// per (group, tap) in the LDS image, [plane][co][72] with the pad columns zero) and two taps in flight per workgroup.
+// The kernel above re-splits every tap's weights in registers (16 values per thread per tap behind two barriers) and runs one wave
+// per SIMD, so every LDS round trip and every barrier is an idle matrix pipe: 55 us per launch where the MFMAs alone want ~17.
+// Here: eight waves = two tap-parity groups of 2 (rows) x 2 (channels) waves; group kg multiplies taps 2 j + kg, so a SIMD always
+// holds two waves at different points of their k-steps.  The weight planes of taps 2 j + 2, 2 j + 3 arrive by LDS-DMA (a straight
+// copy of 36 contiguous 1 KB pieces) while taps 2 j, 2 j + 1 are multiplied: one barrier per tap PAIR, no VALU on the weight side.
+// The two groups' partial sums meet in the LDS staging of the epilogue (fixed order: even taps + odd taps).
+// -----------------------------------------------------------------------------------------------------------------------------
+constexpr int GCP_WTAP = 2 * GCP_C * GCP_S;        // fp16 elements of one (group, tap) weight image: hi plane, lo plane
+size_t gconv_pairs_planes_bytes(int G, int taps) { return (size_t)G * ((taps + 1) / 2 * 2) * GCP_WTAP * sizeof(f16); }
+
+__global__ __launch_bounds__(256) void gconv_split_weights_kernel(const float* __restrict__ w, f16* __restrict__ wp, int G, int taps, int tp) {
+    // one thread per (g, tap, co, 8 input channels); w is [g][co][tap][ci]
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long n = (long)G * taps * GCP_C * 8;
+    if (i >= n) return;
+    const int c8 = (int)(i & 7), co = (int)((i >> 3) & 63);
+    const long gt = i >> 9;
+    const int t = (int)(gt % taps), g = (int)(gt / taps);
+    const float* src = w + (((long)g * GCP_C + co) * taps + t) * GCP_C + c8 * 8;
+    x3_u4 h, l;
+    gcp_split8(*reinterpret_cast<const float4*>(src), *reinterpret_cast<const float4*>(src + 4), h, l, false);
+    f16* dst = wp + ((long)g * tp + t) * GCP_WTAP + co * GCP_S + c8 * 8;
+    *reinterpret_cast<x3_u4*>(dst) = h;
+    *reinterpret_cast<x3_u4*>(dst + GCP_C * GCP_S) = l;
+}
+
+// wp: gconv_pairs_planes_bytes(G, taps) bytes; w: fp32 [G][64 co][taps][64 ci] (the layout launch_conv_gemm takes)
+void gconv_pairs_split_weights(const float* w, void* wp, int G, int taps, hipStream_t s) {
+    const int tp = (taps + 1) / 2 * 2;
+    MI_HIP(hipMemsetAsync(wp, 0, gconv_pairs_planes_bytes(G, taps), s));          // pad columns and the pad tap of an odd count
+    const long n = (long)G * taps * GCP_C * 8;
+    hipLaunchKernelGGL(gconv_split_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, (f16*)wp, G, taps, tp);
+    MI_HIP(hipGetLastError());
+}
+
+template <int BM>
+__global__ __launch_bounds__(512, 1) void gconv_pairs2_kernel(const GConvPairsDev p, const f16* __restrict__ wplanes) {
+    using MH = Mfma<f16>;
+    using FH = typename MH::Frag;
+    constexpr int S = GCP_S;
+    constexpr int WM = BM / 2, TM = WM / 32;                        // per tap-parity group: 2 (rows) x 2 (channels) waves, WM x 32 per wave
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
+    const int rows_a = BM + p.taps - 1;
+    const int a_el = ((rows_a * S + 511) / 512) * 512;              // plane size rounded to 1 KB: the weight slots stay 1 KB-aligned
+    f16* AH = reinterpret_cast<f16*>(smem_raw);
+    f16* AL = AH + a_el;
+    f16* WS = AL + a_el;                                            // four tap slots: slot = 2 * (pair & 1) + parity
+    float* OUT = reinterpret_cast<float*>(smem_raw);                // 2 x BM x 64 fp32 (one per tap-parity group), aliases everything after the main loop
+
+    const int tid = threadIdx.x, lane = tid & 63, lr = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kg = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+    const int m0 = blockIdx.x * BM, g = blockIdx.y, b = blockIdx.z;
+    const float* xb = p.x + (long)b * p.x_bstride + (long)g * p.x_goff;
+    const int tp = (p.taps + 1) & ~1, npair = tp >> 1;
+    const f16* wg = wplanes + (long)g * tp * GCP_WTAP;
+
+    // one tap pair = 2 * GCP_WTAP halfs = 36 pieces of 1 KB (64 lanes x 16 B), contiguous in HBM and in LDS
+    constexpr int NPIECE = 2 * GCP_WTAP * (int)sizeof(f16) / 1024;
+    static_assert(NPIECE * 1024 == 2 * GCP_WTAP * (int)sizeof(f16), "a tap pair is whole 1 KB pieces");
+    auto wdma = [&](int pair) {
+        const char* src = reinterpret_cast<const char*>(wg + (long)pair * 2 * GCP_WTAP) + lane * 16;
+        char* dst = reinterpret_cast<char*>(WS + (pair & 1) * 2 * GCP_WTAP);
+        for (int pc = wave; pc < NPIECE; pc += 8)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + pc * 1024), (lds_void*)(dst + pc * 1024), 16, 0, 0);
+    };
+    wdma(0);
+    // ---- activations: rows m0 - pad .. , split once (as above) ------------------------------------------------------------------
+    {
+        const int t_base = m0 - p.pad;
+        const int nitem = rows_a * 8;
+        unsigned sat = 0;
+        for (int v = tid; v < nitem; v += 512) {
+            const int row = v >> 3, c8 = v & 7;
+            const int t = t_base + row;
+            float4 u = float4{0.f, 0.f, 0.f, 0.f}, w2 = u;
+            if (t >= 0 && t < p.T_in) {
+                const float* src = xb + (long)t * p.x_rstride + c8 * 8;
+                u = *reinterpret_cast<const float4*>(src);
+                w2 = *reinterpret_cast<const float4*>(src + 4);
+            }
+            x3_u4 h, l;
+            gcp_split8(u, w2, h, l, true);
+            sat |= x2_sat_word(h.x) | x2_sat_word(h.y) | x2_sat_word(h.z) | x2_sat_word(h.w);
+            *reinterpret_cast<x3_u4*>(AH + row * S + c8 * 8) = h;
+            *reinterpret_cast<x3_u4*>(AL + row * S + c8 * 8) = l;
+        }
+        sat_publish(p.sat, sat);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    f32x16 acc[TM], accb[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[i][r] = 0.f; accb[i][r] = 0.f; }
+    // (fragment reads one k-step ahead in a second register set, with the pair boundary pipelined as in conv_gemm_dma3_kernel, measured
+    // the same: the SIMD's other wave already covers the LDS round trips; the loop sits at the power-limited MFMA rate)
+    for (int j = 0; j < npair; ++j) {
+        if (j + 1 < npair) wdma(j + 1);                             // into the slots of pair j - 1: every wave passed the barrier behind it
+        const int t = 2 * j + kg;
+        if (t < p.taps) {                                           // (the last pair of an odd tap count has no odd tap)
+            const f16* wt = WS + ((j & 1) * 2 + kg) * GCP_WTAP;
+            const f16* bh_row = wt + (wn * 32 + lr) * S + hi * 8;
+            const f16* bl_row = bh_row + GCP_C * S;
+            const f16* ah_row = AH + (wm * WM + lr + t) * S + hi * 8;
+            const f16* al_row = AL + (wm * WM + lr + t) * S + hi * 8;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const FH bh = *reinterpret_cast<const FH*>(bh_row + ks * 16);
+                const FH bl = *reinterpret_cast<const FH*>(bl_row + ks * 16);
+                FH ah[TM], al[TM];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    ah[i] = *reinterpret_cast<const FH*>(ah_row + i * 32 * S + ks * 16);
+                    al[i] = *reinterpret_cast<const FH*>(al_row + i * 32 * S + ks * 16);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    accb[i] = MH::mma(al[i], bh, accb[i]);
+                    accb[i] = MH::mma(ah[i], bl, accb[i]);
+                    acc[i] = MH::mma(ah[i], bh, acc[i]);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's pieces of pair j + 1 (a whole pair period to land)
+        __syncthreads();                                            // ... and every wave is done with pair j's slots (and, at the end, with the planes)
+    }
+    // ---- accumulators -> LDS (one image per tap-parity group) -> summed in the coalesced epilogue ---------------------------------
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            OUT[(kg * BM + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * GCP_C + wn * 32 + lr] = __builtin_fmaf(accb[i][r], 0x1p-11f, acc[i][r]);
+    __syncthreads();
+    {
+        float* ob = p.out + (long)b * p.out_bstride + (long)g * GCP_C;
+        const float* rb = p.res ? p.res + (long)b * p.out_bstride + (long)g * GCP_C : nullptr;
+        const float* bias = p.bias ? p.bias + g * GCP_C : nullptr;
+        for (int v = tid; v < BM * 16; v += 512) {
+            const int row = v >> 4, c4 = v & 15;
+            const int m = m0 + row;
+            if (m >= p.M) continue;
+            float4 o = *reinterpret_cast<const float4*>(OUT + row * GCP_C + c4 * 4);
+            const float4 o1 = *reinterpret_cast<const float4*>(OUT + (BM + row) * GCP_C + c4 * 4);
+            o.x += o1.x; o.y += o1.y; o.z += o1.z; o.w += o1.w;                // even taps + odd taps
+            if (bias) { const float4 bv = *reinterpret_cast<const float4*>(bias + c4 * 4); o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w; }
+            if (p.act != ACT_NONE) { o.x = gcp_act(o.x, p.act); o.y = gcp_act(o.y, p.act); o.z = gcp_act(o.z, p.act); o.w = gcp_act(o.w, p.act); }
+            const long gi = (long)m * p.out_rstride + c4 * 4;
+            if (rb) { const float4 rv = *reinterpret_cast<const float4*>(rb + gi); o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w; }
+            *reinterpret_cast<float4*>(ob + gi) = o;
+        }
+    }
+}
+
+// option gconv_two_taps (mi_set_option; MI355TTS_GCONV2=0 at start-up): 0 = the per-launch split kernel even when the planes exist (A/B, tests)
+static std::atomic<bool> g_two_taps{[] { const char* e = std::getenv("MI355TTS_GCONV2"); return !(e && e[0] == '0'); }()};
+void gconv_pairs_set_option(long v) { g_two_taps = v != 0; }
+
 // true: launched.  false: not this kernel's shape (the caller goes on to its other kernels).
 bool launch_gconv_pairs(const ConvGemm& p, hipStream_t s) {
     const int odt = p.out_dtype < 0 ? p.dtype : p.out_dtype;
@@ -226,6 +391,22 @@ bool launch_gconv_pairs(const ConvGemm& p, hipStream_t s) {
         prof_set_kernel("gconv_pairs_kernel<" #BMv "> (fp32 grouped conv, fp16 pairs split once per workgroup)", "", "");      \
         hipLaunchKernelGGL(kfn, grid, dim3(256), lds, s, d);                                                                  \
     } while (0)
+    if (p.gcp_w && g_two_taps) {
+        // weights pre-split at load (gconv_pairs_split_weights): 192 rows, eight waves, two taps in flight
+        constexpr int BM2 = 192;
+        const int ra = BM2 + p.taps - 1;
+        const size_t a_el = ((size_t)ra * GCP_S + 511) / 512 * 512;
+        size_t lds2 = (2 * a_el + (size_t)4 * GCP_WTAP) * sizeof(f16);
+        lds2 = std::max(lds2, (size_t)2 * BM2 * GCP_C * 4);
+        if (lds2 <= 160 * 1024) {
+            auto kfn = gconv_pairs2_kernel<BM2>;
+            MI_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            prof_set_kernel("gconv_pairs2_kernel<192> (fp32 grouped conv, fp16 pairs, weights split at load, two taps in flight)", "", "");
+            hipLaunchKernelGGL(kfn, dim3((p.M + BM2 - 1) / BM2, p.G, p.B), dim3(512), lds2, s, d, (const f16*)p.gcp_w);
+            MI_HIP(hipGetLastError());
+            return true;
+        }
+    }
     if (BM == 192) GCP_LAUNCH(192); else GCP_LAUNCH(128);
 #undef GCP_LAUNCH
     MI_HIP(hipGetLastError());

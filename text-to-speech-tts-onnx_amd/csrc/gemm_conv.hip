@@ -521,6 +521,7 @@ static std::atomic<long> g_x3 = 1;
 static std::atomic<long> g_x3p = 1;
 static std::atomic<long> g_f32_gconv = 1;         // ... and, when the shape allows, with each operand split once per workgroup (gconv_pairs.hip)
 bool launch_gconv_pairs(const ConvGemm& p, hipStream_t s);
+void gconv_pairs_set_option(long v);
 static std::atomic<long> g_f32_n64_pairs = 1;     // fp32 N = 64 convolutions with >= 8 taps: fp16 pairs split in registers (conv_gemm_dma_kernel PAIRS)
 // number format of the panel planes built from now on: 3 = three bf16 planes (six products), 2 = fp16 {hi, lo} planes (three products)
 static std::atomic<long> g_x3p_np = 0;          // 0: not set by mi_set_option -> MI355TTS_F32_PLANES, else 2
@@ -765,6 +766,7 @@ bool gemm_set_option(const char* key, long v) {
     else if (k == "gemm_use_dma") g_use_dma = v != 0;
     else if (k == "gemm_big_tiles") g_big_tiles = v != 0;
     else if (k == "gemm_n192") g_n192 = v != 0;
+    else if (k == "gconv_two_taps") gconv_pairs_set_option(v);
     else if (k == "gemm_f32_dma") g_f32_dma = v != 0;
     else if (k == "gemm_ring4") g_ring4 = v != 0;
     else if (k == "gemm_buf") g_buf = v != 0;
