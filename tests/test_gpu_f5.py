@@ -548,6 +548,35 @@ def test_fp32_position_convolution_weights_split_at_load(full, N):
     assert np.isfinite(outs[1]).all() and e < 2e-6, e
 
 
+def test_fp32_output_projection_in_k_slices(full, monkeypatch):
+    """proj_out (dit.py: Linear(dim, mel) behind AdaLN-final) runs on fp32 engines as four K slices — a grouped launch whose partial
+    sums lie side by side and are added in slice order by the consumers (cfg_update_kernel inside the loop, F5::pred_rows for
+    mi_f5_dit_eval).  Against an engine built with MI355TTS_PROJ_PARTS=1 (one slice): the evaluation and four Euler steps of the loop
+    agree to fp32 round-off."""
+    cfg, raw, audio, ids, _, _ = full
+    N = 600
+    noise = np.stack([W.synth_normal(41 + u, "noise_pp", (N, cfg.mel_dim)) for u in range(2)])
+    outs = {}
+    for parts in ("4", "1"):
+        monkeypatch.setenv("MI355TTS_PROJ_PARTS", parts)
+        eng = F5Engine(cfg, raw, dtype="f32")
+        try:
+            o = [eng.preprocess(audio[u].reshape(1, 1, -1)[..., :72000], ids[u].reshape(1, -1), np.array([N]), noise=noise[u]) for u in range(2)]
+            cmt = np.concatenate([x["cat_mel_text"] for x in o]); cmtd = np.concatenate([x["cat_mel_text_drop"] for x in o])
+            pred = eng.dit_eval(noise, cmt, cmtd, 2)
+            x = noise.copy()
+            for k in range(4):
+                x, _ = eng.transformer_step(x, cmt, cmtd, k)
+            outs[parts] = (pred, np.asarray(x))
+        finally:
+            eng.close()
+    for a, b in zip(outs["4"], outs["1"]):
+        assert a.shape == b.shape and np.isfinite(a).all()
+        e = rms(a - b) / rms(b)
+        print(f"proj_out in four K slices against one: rel rms {e:.2e}")
+        assert e < 2e-6, e
+
+
 def test_fp32_input_projection_padded_to_whole_chunks(full, monkeypatch):
     """fp32 engines pad K of the input projection (2 * mel + text_dim = 712, dit.py InputEmbedding.proj) to 768 with zero
     weight columns and a zeroed tail of the cat buffer's rows, so that the layer runs on the panel-plane kernel (csrc/f5.hip,

@@ -354,7 +354,7 @@ int mi_f5_dit_eval(mi_f5* h, const float* noise, const float* cmt, const float* 
             e.dit_eval(U, (int)N, k);
             MI_HIP(hipStreamSynchronize(e.stream));
         });
-        copy_out(pred, e.pred.p, (size_t)2 * U * N * e.cfg.mel * 4, mem, e.stream);
+        copy_out(pred, e.pred_rows(U, (int)N), (size_t)2 * U * N * e.cfg.mel * 4, mem, e.stream);
         MI_HIP(hipStreamSynchronize(e.stream));
         e.finish_call();
     });

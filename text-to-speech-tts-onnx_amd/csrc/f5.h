@@ -32,6 +32,11 @@ struct F5 {
     // ---- DiT (engine dtype) ----
     Lin in_proj, gconv1, gconv2, proj_out;
     // row stride of the cat(x, cond, text) buffer = K of in_proj: fp32 engines pad it to whole 64-deep chunks (zero columns)
+    // proj_out (dim -> mel = 100 columns: 72 tiles of 64 x 64 at one utterance, each walking all of K with one wave per SIMD) as
+    // proj_parts K slices = a grouped launch ([slice][mel][dim / parts] weights, partial sums side by side in `pred`, summed in a fixed
+    // order by their consumers): fp32 engines, 4 slices (MI355TTS_PROJ_PARTS=1 at construction: one slice, the A/B switch)
+    Lin proj_out_k; int proj_parts = 1; DevBuf pred_sum;
+    const float* pred_rows(int U, int N);               // pred as [2U][N][mel] rows (sums the slices when there are any)
     // (MI355TTS_CAT_PAD=0 at construction: unpadded, the A/B switch)
     int cat_pad = 0;
     int cat_ld() const { return cfg.cat_dim() + cat_pad; }

@@ -273,6 +273,21 @@ F5::F5(const F5Cfg& c, const float* w, int64_t nw, int dt, int dev, int mem) : c
         mod_gemm(mw, mb, 2 * d, (long)c.depth * 6 * d);
         const float* pw = take((size_t)c.mel * d); const float* pb = take(c.mel);
         put_lin(R, proj_out, pw, pb, c.mel, d, dt);
+        {
+            const char* e = std::getenv("MI355TTS_PROJ_PARTS");
+            const int parts = e ? std::atoi(e) : 4;
+            if (dt == MI_F32 && parts > 1 && parts <= 8 && d % (parts * 32) == 0) {
+                proj_parts = parts;
+                const int kq = d / parts;
+                const float* hw = R.host(pw, (size_t)c.mel * d); const float* hb = R.host(pb, c.mel);
+                std::vector<float> wq((size_t)c.mel * d), bq((size_t)parts * c.mel, 0.f);
+                for (int q = 0; q < parts; ++q)
+                    for (int o = 0; o < c.mel; ++o)
+                        std::copy(hw + (size_t)o * d + (size_t)q * kq, hw + (size_t)o * d + (size_t)(q + 1) * kq, wq.begin() + ((size_t)q * c.mel + o) * kq);
+                std::copy(hb, hb + c.mel, bq.begin());              // the bias rides on slice 0
+                up_lin(proj_out_k, wq.data(), bq.data(), parts * c.mel, kq, dt, s);
+            }
+        }
     }
     // ---- RoPE tables, rounded through fp16 (Export_F5.py:107-112) --------------------------------------
     {
@@ -529,7 +544,8 @@ void F5::ensure_workspace(int U, int N) {
         if (fold_built) ApN.ensure((size_t)x3p_bytes((long)rows, c.dim, np));
     }
     if (fold_built) { ln_stats.ensure((rows + 128) * (size_t)(c.dim / LN_BLK) * 2 * 4); if (dtype != MI_F32) ln_fin.ensure((rows + 128) * 8); }
-    pred.ensure(rows * c.mel * 4);
+    pred.ensure(rows * c.mel * 4 * proj_parts);
+    if (proj_parts > 1) pred_sum.ensure(rows * c.mel * 4);
     // preprocess temporaries
     const int ti = c.text_dim * c.conv_mult;
     p_ids.ensure((size_t)Um * Nm * 4);
@@ -884,13 +900,27 @@ void F5::dit_eval(int U, int N, int k) {
     // ---- AdaLN-final (scale, shift order: modules.py:323) + proj_out ------------------------------------------
     const float* mf = modk + (size_t)c.depth * 6 * d;
     launch_rownorm(NORM_LN_MOD, X.as<float>(), Ub.p, dtype, mf, mf + d, rows, d, 1e-6f, s);
-    gemm(dtype, Ub.p, (long)N * d, d, d, proj_out, pred.p, MI_F32, (long)N * c.mel, c.mel, B, N);
+    if (proj_parts > 1) {
+        ConvGemm g;                                              // K slices as groups: slice q multiplies columns [q d / parts, ...) of every row
+        g.dtype = dtype; g.out_dtype = MI_F32; g.x = Ub.p; g.w = proj_out_k.w.p; g.bias = proj_out_k.b.as<float>(); g.out = pred.p;
+        g.B = 1; g.G = proj_parts; g.T_in = (int)rows; g.M = (int)rows; g.N = c.mel; g.Cin = d / proj_parts; g.taps = 1;
+        g.x_bstride = rows * d; g.x_rstride = d; g.x_goff = d / proj_parts;
+        g.out_bstride = rows * proj_parts * c.mel; g.out_rstride = (long)proj_parts * c.mel;
+        launch_conv_gemm(g, s);
+    } else
+        gemm(dtype, Ub.p, (long)N * d, d, d, proj_out, pred.p, MI_F32, (long)N * c.mel, c.mel, B, N);
+}
+
+const float* F5::pred_rows(int U, int N) {
+    if (proj_parts <= 1) return pred.as<float>();
+    launch_sum_parts(pred.as<float>(), pred_sum.as<float>(), (long)2 * U * N, cfg.mel, proj_parts, stream);
+    return pred_sum.as<float>();
 }
 
 void F5::steps_eager(int U, int N, int k0, int nsteps) {
     for (int k = k0; k < k0 + nsteps; ++k) {
         dit_eval(U, N, k);
-        launch_cfg_update(d_noise.as<float>(), pred.as<float>(), U, N, cfg.mel, cfg.cfg_strength, delta_t.as<float>(), k, stream);
+        launch_cfg_update(d_noise.as<float>(), pred.as<float>(), U, N, cfg.mel, cfg.cfg_strength, delta_t.as<float>(), k, stream, proj_parts);
     }
 }
 

@@ -34,7 +34,8 @@ void launch_vocos_head(const float* sp, float* c, long rows, int nb, int ldc, hi
 void launch_istft_ola(const float* frames, const float* wsi, int U, int F, int nfft, int hop, float* out_f,
                       int16_t* out_i, hipStream_t s);
 void launch_cat_noise(const float* noise, void* cat, int U, int N, int M, int ldc, int dtype, hipStream_t s);
-void launch_cfg_update(float* noise, const float* pred, int U, int N, int M, float cfg, const float* dt, int k, hipStream_t s);
+void launch_cfg_update(float* noise, const float* pred, int U, int N, int M, float cfg, const float* dt, int k, hipStream_t s, int parts = 1);
+void launch_sum_parts(const float* in, float* out, long rows, int M, int parts, hipStream_t s);
 
 // attention.hip: softmax_fp32(q k^T) v, no mask, no scale (q/k are pre-scaled): modules.py:467
 //   q,k [BH][N][64], v [BH][N][64] (fp32, native / q.k-split kernels) or transposed [BH][64][v_ld] (16-bit, and the fp32

@@ -604,18 +604,39 @@ void launch_cat_noise(const float* noise, void* cat, int U, int N, int M, int ld
     MI_HIP(hipGetLastError());
 }
 
-// noise[u,n,m] += (p_c + (p_c - p_u) * cfg) * dt ; pred layout [(2u+br)][N][M]
+// noise[u,n,m] += (p_c + (p_c - p_u) * cfg) * dt ; pred layout [(2u+br)][N][parts][M]: the K slices of proj_out side by side (F5::proj_parts),
+// summed here in slice order
 __global__ __launch_bounds__(256) void cfg_update_kernel(float* __restrict__ noise, const float* __restrict__ pred,
-                                                         long NM, long total, float cfg, const float* __restrict__ dt, int k) {
+                                                         long NM, int M, int parts, long total, float cfg, const float* __restrict__ dt, int k) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const long u = i / NM, r = i - u * NM;
-    const float pc = pred[(2 * u) * NM + r], pu = pred[(2 * u + 1) * NM + r];
+    const long n = r / M; const int m = (int)(r - n * M);
+    const float* c = pred + ((2 * u) * NM + n * M) * parts + m;
+    const float* un = c + NM * parts;
+    float pc = c[0], pu = un[0];
+    for (int q = 1; q < parts; ++q) { pc += c[(long)q * M]; pu += un[(long)q * M]; }
     noise[i] += (pc + (pc - pu) * cfg) * dt[k];
 }
-void launch_cfg_update(float* noise, const float* pred, int U, int N, int M, float cfg, const float* dt, int k, hipStream_t s) {
+void launch_cfg_update(float* noise, const float* pred, int U, int N, int M, float cfg, const float* dt, int k, hipStream_t s, int parts) {
     const long total = (long)U * N * M;
-    hipLaunchKernelGGL(cfg_update_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, noise, pred, (long)N * M, total, cfg, dt, k);
+    hipLaunchKernelGGL(cfg_update_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, noise, pred, (long)N * M, M, parts, total, cfg, dt, k);
+    MI_HIP(hipGetLastError());
+}
+
+// out[row][m] = sum over the slices of in[row][q][m], in slice order (the export of F5::pred_rows)
+__global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict__ in, float* __restrict__ out, long total, int M, int parts) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const long row = i / M; const int m = (int)(i - row * M);
+    const float* p = in + row * M * parts + m;
+    float v = p[0];
+    for (int q = 1; q < parts; ++q) v += p[(long)q * M];
+    out[i] = v;
+}
+void launch_sum_parts(const float* in, float* out, long rows, int M, int parts, hipStream_t s) {
+    const long total = rows * M;
+    hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, total, M, parts);
     MI_HIP(hipGetLastError());
 }
 
