@@ -357,17 +357,30 @@ void launch_dwconv7(const float* x, float* y, const float* w, const float* bias,
 // out = gamma * (y * Nx) + beta + y.   Kernel 1: per-(b,c) sum of squares (fp32, fixed order);
 // kernel 2: each workgroup re-derives mean_c Gx (C <= 4096) and applies the elementwise map.
 // -----------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void grn_sumsq_kernel(const float* __restrict__ y, float* __restrict__ ss, int T, int C) {
-    __shared__ float red[4][64];
+// (sixteen time slices per workgroup with four independent loads in flight per lane: the first form walked T / 4 dependent strided
+// loads per lane on 32 workgroups — 83 us for a 2 x 1126 x 1024 tensor)
+__global__ __launch_bounds__(1024) void grn_sumsq_kernel(const float* __restrict__ y, float* __restrict__ ss, int T, int C) {
+    constexpr int P = 16;
+    __shared__ float red[P][64];
     const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
-    float acc = 0.f;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     if (c < C) {
         const float* yb = y + (long)b * T * C + c;
-        for (int t = part; t < T; t += 4) { const float v = yb[(long)t * C]; acc = fmaf(v, v, acc); }
+        int t = part;
+        for (; t + 3 * P < T; t += 4 * P) {
+            const float v0 = yb[(long)t * C], v1 = yb[(long)(t + P) * C], v2 = yb[(long)(t + 2 * P) * C], v3 = yb[(long)(t + 3 * P) * C];
+            a0 = fmaf(v0, v0, a0); a1 = fmaf(v1, v1, a1); a2 = fmaf(v2, v2, a2); a3 = fmaf(v3, v3, a3);
+        }
+        for (; t < T; t += P) { const float v = yb[(long)t * C]; a0 = fmaf(v, v, a0); }
     }
-    red[part][threadIdx.x & 63] = acc;
+    red[part][threadIdx.x & 63] = (a0 + a1) + (a2 + a3);
     __syncthreads();
-    if (part == 0 && c < C) ss[(long)b * C + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (part == 0 && c < C) {
+        float r = 0.f;
+#pragma unroll
+        for (int q = 0; q < P; ++q) r += red[q][threadIdx.x];          // fixed order
+        ss[(long)b * C + c] = r;
+    }
 }
 
 __global__ __launch_bounds__(256) void grn_apply_kernel(float* __restrict__ y, const float* __restrict__ ss,
@@ -396,7 +409,7 @@ __global__ __launch_bounds__(256) void grn_apply_kernel(float* __restrict__ y, c
 
 void launch_grn(float* y, float* ss_scratch, const float* gamma, const float* beta, int B, int T, int C, hipStream_t s) {
     ProfScope ps(FAM_OTHER, s, 12.0 * B * T * C, 6.0 * B * T * C);
-    hipLaunchKernelGGL(grn_sumsq_kernel, dim3((C + 63) / 64, B), dim3(256), 0, s, y, ss_scratch, T, C);
+    hipLaunchKernelGGL(grn_sumsq_kernel, dim3((C + 63) / 64, B), dim3(1024), 0, s, y, ss_scratch, T, C);
     const long n = (long)T * C;
     const int blocks = (int)std::min<long>((n + 255) / 256, 1024);
     hipLaunchKernelGGL(grn_apply_kernel, dim3(blocks, B), dim3(256), 0, s, y, ss_scratch, gamma, beta, T, C);
