@@ -19,6 +19,7 @@
 // result goes back through LDS so the HBM store is again 16-byte coalesced.
 #include "common.h"
 #include "aa_math.h"
+#include <algorithm>
 #include <cstdlib>
 
 namespace mi {
@@ -139,6 +140,109 @@ __global__ __launch_bounds__(256) void aa_act_kernel(const T* __restrict__ x, T*
     }
 }
 
+// -----------------------------------------------------------------------------------------------------------------------------
+// Round 6: the same tile, software-pipelined inside a persistent workgroup (16-bit storage).
+// The kernel above is one tile per workgroup: load -> barrier -> compute -> barrier -> store.  A launch is only two or three rounds
+// of workgroups, all started together, so the whole chip loads at the same time, computes at the same time and stores at the
+// same time: its time is the SUM of the HBM phase and the VALU phase (C = 384, T = 8192, B = 8: 20 us of traffic + 28 us of VALU
+// issue = the 48 us measured), not their maximum.  Here a workgroup walks tiles: the input of tile i + 1 arrives by LDS-DMA
+// (buffer_load ... lds: no VGPR staging, rows outside [0, T) zero-filled by the descriptor's range check) while tile i is
+// computed, and the stores of tile i leave while tile i + 1 is computed.  Same arithmetic per element: bit-identical outputs.
+// -----------------------------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void aa_lds_void;
+
+template <typename T, int R>
+__global__ __launch_bounds__(256) void aa_act_pipe_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ alpha,
+                                                          const float* __restrict__ inv_beta, int Tlen, int C, int CT, int TT,
+                                                          int shift, int ext, int ntt, int nct, int ntiles, int xsp) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    static_assert(sizeof(T) == 2, "16-bit storage");
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];
+    T* const xs0 = reinterpret_cast<T*>(lds_raw);         // two input buffers of xsp elements ((TT + 10) x CT, rounded up to whole 1 KB DMA writes)
+    T* const ys = xs0 + 2 * xsp;                          // TT x CT
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int Tout = Tlen + 2 * shift;
+    const int cvn = CT / VEC, nvec = (TT + 10) * cvn, nout = TT * cvn;
+    const AATaps tp = aa_make_taps(c_h);
+    const int lo = -ext, hi = 2 * Tlen + ext;
+    struct alignas(2 * sizeof(T)) Pair { T a, b; };
+    const int CP = CT >> 1;
+    const int nitems = CP * (TT / R);
+
+    auto decode = [&](int t, int& o0, int& c0, int& b) {   // time tiles fastest: neighbours share their halo rows in L2
+        const int ti = t % ntt, r = t / ntt;
+        const int ci = r % nct;
+        b = r / nct; o0 = ti * TT; c0 = ci * CT;
+    };
+    // input rows [o0 - shift - 5, + TT + 10) x channels [c0, c0 + CT) of batch item b -> xs[buf], 64 lanes x 16 bytes per instruction
+    auto dma = [&](int t, int buf) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        int o0, c0, b;
+        decode(t, o0, c0, b);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (long)b * Tlen * C), 0, (int)((long)Tlen * C * (long)sizeof(T)), 0x00020000);
+        T* dst = xs0 + buf * xsp;
+        for (int v = tid; v < xsp / VEC; v += 256) {
+            const int row = v / cvn, cv = v - row * cvn;
+            // rows before 0: a negative offset = a huge unsigned one, zero-filled like rows >= Tlen; lanes past the tile: into the pad
+            const int off = v < nvec ? (int)(((long)(o0 - shift - 5 + row) * C + c0 + cv * VEC) * (long)sizeof(T)) : 0x7fffff00;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (aa_lds_void*)(dst + (v - lane) * VEC), 16, off, 0, 0, 0);
+        }
+#endif
+    };
+    auto store = [&](int t) {
+        int o0, c0, b;
+        decode(t, o0, c0, b);
+        T* yb = y + (long)b * Tout * C;
+        for (int v = tid; v < nout; v += 256) {
+            const int row = v / cvn, cv = v - row * cvn;
+            const int o = o0 + row;
+            if (o < Tout)
+                *reinterpret_cast<uint4*>(yb + (long)o * C + c0 + cv * VEC) = *reinterpret_cast<const uint4*>(ys + row * CT + cv * VEC);
+        }
+    };
+
+    int t = blockIdx.x;
+    if (t >= ntiles) return;
+    dma(t, 0);
+    int buf = 0, tprev = -1;
+    for (; t < ntiles; t += gridDim.x) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this tile's rows have landed (this wave's share); the stores before them too
+        __syncthreads();
+        if (tprev >= 0) store(tprev);                         // the previous tile leaves while this one is computed
+        __syncthreads();                                      // ys is free again
+        if (t + (int)gridDim.x < ntiles) dma(t + gridDim.x, buf ^ 1);      // that buffer's tile was computed before the first barrier
+        int o0, c0, b;
+        decode(t, o0, c0, b);
+        const int mp0 = o0 - shift;
+        const bool edge = (2 * (mp0 - 3) - 1 < lo) || (2 * (mp0 + TT + 3) >= hi);      // workgroup-uniform
+        const T* xs = xs0 + buf * xsp;
+        for (int it = tid; it < nitems; it += 256) {
+            const int run = it / CP, c = 2 * (it - run * CP);
+            const int ml = run * R;
+            const float s0 = 0.15915494309189535f;
+            const aa_f2 al = aa_f2{alpha[c0 + c] * s0, alpha[c0 + c + 1] * s0};
+            const aa_f2 ib = aa_f2{inv_beta[c0 + c], inv_beta[c0 + c + 1]};
+            aa_f2 xv[R + 10], acc[R];
+#pragma unroll
+            for (int j = 0; j < R + 10; ++j) {
+                const Pair pr = *reinterpret_cast<const Pair*>(xs + (ml + j) * CT + c);
+                xv[j] = aa_f2{to_f32(pr.a), to_f32(pr.b)};
+            }
+            if (edge) aa_run<R, true, true>(xv, acc, tp, al, ib, mp0 + ml, lo, hi);
+            else aa_run<R, true, false>(xv, acc, tp, al, ib, mp0 + ml, lo, hi);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                Pair pr;
+                pr.a = from_f32<T>(acc[r].x); pr.b = from_f32<T>(acc[r].y);
+                *reinterpret_cast<Pair*>(ys + (ml + r) * CT + c) = pr;
+            }
+        }
+        tprev = t; buf ^= 1;
+    }
+    __syncthreads();
+    store(tprev);
+}
+
 template <typename T>
 static void launch_t(const AAAct& p, hipStream_t s) {
     // run length per work item.  16-bit storage: 8 (152 VGPRs = three waves per SIMD; with 16 the kernel holds 204 = two, and a
@@ -166,6 +270,34 @@ static void launch_t(const AAAct& p, hipStream_t s) {
     const double bytes = (double)p.B * p.C * ((double)p.T + Tout) * sizeof(T);
     const double flops = (double)p.B * p.C * Tout * 60.0;
     ProfScope ps(FAM_AA, s, bytes, flops);
+    if constexpr (sizeof(T) == 2) {
+        static const bool pipe = [] { const char* e = std::getenv("MI355TTS_AA_PIPE"); return !(e && e[0] == '0'); }();
+        const long in_bytes = (long)p.T * p.C * (long)sizeof(T);
+        if (pipe && in_bytes < 0x7fff0000L && TT % R == 0) {
+            // persistent workgroups walking tiles, input by LDS-DMA one tile ahead (aa_act_pipe_kernel)
+            const int ntt = (Tout + TT - 1) / TT, nct = p.C / CT;
+            const long ntiles = (long)ntt * nct * p.B;
+            const int nvec = (TT + 10) * CT / VEC;
+            const int xsp = (nvec + 63) / 64 * 64 * VEC;
+            const size_t lds2 = ((size_t)2 * xsp + (size_t)TT * CT) * sizeof(T);
+            int dev = 0, cus = 256;
+            MI_HIP(hipGetDevice(&dev));
+            {
+                static int cu_count[16] = {0};
+                if (!cu_count[dev & 15]) { hipDeviceProp_t pr; MI_HIP(hipGetDeviceProperties(&pr, dev)); cu_count[dev & 15] = pr.multiProcessorCount; }
+                cus = cu_count[dev & 15];
+            }
+            const int per_cu = (int)std::min<size_t>(3, (size_t)(160 * 1024) / lds2);
+            if (per_cu >= 1 && lds2 <= 64 * 1024 && ntiles < 0x7fffffffL) {
+                const int grid_p = (int)std::min<long>(ntiles, (long)cus * per_cu);
+                prof_set_kernel("aa_act_pipe_kernel<T>", type_label<T>());
+                hipLaunchKernelGGL((aa_act_pipe_kernel<T, R>), dim3(grid_p), dim3(256), lds2, s, (const T*)p.x, (T*)p.y, p.alpha, p.inv_beta,
+                                   p.T, p.C, CT, TT, shift, ext, ntt, nct, (int)ntiles, xsp);
+                MI_HIP(hipGetLastError());
+                return;
+            }
+        }
+    }
     prof_set_kernel("aa_act_kernel<T>", type_label<T>());
     hipLaunchKernelGGL((aa_act_kernel<T, R>), grid, dim3(256), lds, s, (const T*)p.x, (T*)p.y, p.alpha, p.inv_beta,
                        p.T, p.C, CT, TT, shift, ext);
