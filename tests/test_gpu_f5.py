@@ -548,6 +548,56 @@ def test_fp32_position_convolution_weights_split_at_load(full, N):
     assert np.isfinite(outs[1]).all() and e < 2e-6, e
 
 
+@pytest.mark.parametrize("x3d", [0, 1])
+def test_two_fp32_handles_on_two_threads_stream_k_and_exact_fit(full, x3d):
+    """the stream-K fix-up of linear_x3p_kernel (x3d = 0: owners spin, bounded, on their contributors' flags) rests
+    on the workgroups of ONE launch being dispatched in order — with two handles on two streams two such grids share the chip.
+    Two full-width fp32 engines, each driven by its own thread through three evaluations and three Euler steps at once: no watchdog
+    trip (f5_run_checked raises on one), no dead-lock, and every result equal, bit for bit, to what the same handle computes alone.
+    x3d = 1: the same with the exact-fit kernels, which have no cross-workgroup hand-off at all."""
+    import threading
+    from mi355tts import _lib
+    cfg, raw, audio, ids, _, _ = full
+    N = 1126
+    engs = [F5Engine(cfg, raw, dtype="f32") for _ in range(2)]
+    _lib.set_option("gemm_x3d", x3d)
+    try:
+        inputs = []
+        for u, eng in enumerate(engs):
+            noise = W.synth_normal(61 + u, "noise_2h", (1, N, cfg.mel_dim))
+            o = eng.preprocess(audio[u].reshape(1, 1, -1), ids[u].reshape(1, -1), np.array([N]), noise=noise[0])
+            inputs.append((noise, o["cat_mel_text"], o["cat_mel_text_drop"]))
+
+        def run(eng, inp):
+            noise, cmt, cmtd = inp
+            outs = [eng.dit_eval(noise, cmt, cmtd, k) for k in (0, 7, 30)]
+            x = noise.copy()
+            for k in range(3):
+                x, _ = eng.transformer_step(x, cmt, cmtd, k)
+            return outs + [np.asarray(x)]
+        want = [run(e, i) for e, i in zip(engs, inputs)]           # each handle alone
+        got, errs = [None, None], []
+
+        def work(j):
+            try:
+                for _ in range(2):
+                    got[j] = run(engs[j], inputs[j])
+            except Exception as e:                      # pragma: no cover
+                errs.append(e)
+        th = [threading.Thread(target=work, args=(j,)) for j in range(2)]
+        [t.start() for t in th]
+        [t.join(600) for t in th]
+        assert not any(t.is_alive() for t in th), "dead-lock"
+        assert not errs, errs
+        for j in range(2):
+            for a, b in zip(got[j], want[j]):
+                assert np.array_equal(a, b)
+            assert engs[j].info()["saturation_events"] == 0
+    finally:
+        _lib.set_option("gemm_x3d", 1)
+        for e in engs: e.close()
+
+
 def test_fp32_output_projection_in_k_slices(full, monkeypatch):
     """proj_out (dit.py: Linear(dim, mel) behind AdaLN-final) runs on fp32 engines as four K slices — a grouped launch whose partial
     sums lie side by side and are added in slice order by the consumers (cfg_update_kernel inside the loop, F5::pred_rows for
