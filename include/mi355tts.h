@@ -248,7 +248,8 @@ int         mi_indextts_cond_run(mi_cond* h, const int16_t* audio, int64_t L, fl
  *     planes, exact), "attn_f32_x3" (2: both attention products split, 1: q.k only, 0: native), "attn_f32_planes" (2 | 3);
  *     "gemm_f32_x3p" (0: the round-2 kernel gemm_x3.hip instead of the panel-plane kernel), "gemm_f32_n64_pairs" /
  *     "gemm_f32_gconv" (the position convolution on fp16 pairs / with each operand split once per workgroup),
- *     "gconv_two_taps" (0: re-split the position convolution's weights per launch instead of using the planes split at load)
+ *     "gconv_two_taps" (0: re-split the position convolution's weights per launch instead of using the planes split at load),
+ *     "gconv16" (0: the 16-bit engines' position convolution on the generic tile kernel instead of gconv16.hip)
  *   dispatch thresholds of the implicit-GEMM launcher: "gemm_big_tile_min", "gemm_n192_min", "gemm_mid_tile_min",
  *     "gemm_dma3_k_min", "gemm_use_dma3", "gemm_use_dma", "gemm_big_tiles", "gemm_n192", "gemm_f32_dma", "gemm_ring4",
  *     "gemm_ring4_max", "gemm_buf", "gemm_f32_small", "gemm_f32_small_max", "gemm_small16_max", "gemm_sk" (stream-K: 0 off, 1 fp32,

@@ -627,6 +627,37 @@ def test_fp32_output_projection_in_k_slices(full, monkeypatch):
         assert e < 2e-6, e
 
 
+@pytest.mark.parametrize("dtype,tol", [("bf16", 6e-3), ("f16", 8e-4)])
+def test_16bit_position_convolution_from_weight_images(full, dtype, tol):
+    """ConvPositionEmbedding on the 16-bit engines (csrc/gconv16.hip: weight images built at load, input rows staged once, two taps in
+    flight) against the generic tile kernel it replaces (option gconv16 = 0): the same 16-bit operands and fp32 accumulation in another
+    order, so the DiT evaluation differs by the roundings of the 16-bit intermediates only; two utterances, a cut last row tile."""
+    from mi355tts import _lib
+    cfg, raw, audio, ids, _, _ = full
+    N = 700
+    noise = np.stack([W.synth_normal(71 + u, "noise_g16", (N, cfg.mel_dim)) for u in range(2)])
+    eng = F5Engine(cfg, raw, dtype=dtype)
+    outs, kernels = {}, {}
+    try:
+        o = [eng.preprocess(audio[u].reshape(1, 1, -1)[..., :96000], ids[u].reshape(1, -1), np.array([N]), noise=noise[u]) for u in range(2)]
+        cmt = np.concatenate([x["cat_mel_text"] for x in o]); cmtd = np.concatenate([x["cat_mel_text_drop"] for x in o])
+        for on in (1, 0):
+            _lib.set_option("gconv16", on)
+            _lib.prof_reset(); _lib.prof_enable(["conv_gemm"])
+            try:
+                outs[on] = eng.dit_eval(noise, cmt, cmtd, 4)
+            finally:
+                _lib.prof_enable(())
+            kernels[on] = [k["kernel"] for k in _lib.prof_kernels()]
+    finally:
+        _lib.set_option("gconv16", 1)
+        eng.close()
+    assert any("gconv16_kernel" in k for k in kernels[1]) and not any("gconv16_kernel" in k for k in kernels[0]), kernels
+    e = rms(outs[1] - outs[0]) / rms(outs[0])
+    print(f"{dtype}: position convolution from weight images against the tile kernel: rel rms {e:.2e}")
+    assert np.isfinite(outs[1]).all() and e < tol, e
+
+
 def test_fp32_input_projection_padded_to_whole_chunks(full, monkeypatch):
     """fp32 engines pad K of the input projection (2 * mel + text_dim = 712, dit.py InputEmbedding.proj) to 768 with zero
     weight columns and a zeroed tail of the cat buffer's rows, so that the layer runs on the panel-plane kernel (csrc/f5.hip,

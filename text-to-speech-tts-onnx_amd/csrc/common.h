@@ -173,7 +173,7 @@ struct ConvGemm {
     const void* w3 = nullptr;
     // gemm_x3p.hip (round 3): both operands as pre-split, pre-tiled "panel planes" (x3p_split_rows): xp replaces x, w3p replaces w3
     const void* xp = nullptr; const void* w3p = nullptr; int np = 3;        // np: planes per operand (3 bf16 | 2 fp16), both operands alike
-    const void* gcp_w = nullptr;    // gconv_pairs.hip: the grouped convolution's weights pre-split at load (gconv_pairs_split_weights); null: split per launch
+    const void* gcp_w = nullptr;    // gconv_pairs.hip / gconv16.hip: the grouped position convolution's weights as LDS images built at load (fp32: fp16 pairs, gconv_pairs_split_weights; 16-bit: gconv16_build_weights); null: the per-launch kernels
     // ... and its output as panel planes too (the A operand of the NEXT linear layer: FF1 -> FF2), instead of rows in `out`;
     // plain epilogue only: bias + activation, no residual / gate / accumulate
     void* out_planes = nullptr;
@@ -213,6 +213,9 @@ void x3p_split_rows(const float* x, long ld, void* planes, int rows, int K, hipS
 // gconv_pairs.hip: fp16 {hi, lo} images of a grouped convolution's fp32 weights [G][64][taps][64], one per (group, tap), built once at load
 size_t gconv_pairs_planes_bytes(int G, int taps);
 void gconv_pairs_split_weights(const float* w, void* wp, int G, int taps, hipStream_t s);
+// gconv16.hip: the same convolution on 16-bit engines: weight images [G][taps][64][72] of the engine's type, built once at load
+size_t gconv16_image_bytes(int G, int taps);
+void gconv16_build_weights(const void* w, int dtype, void* img, int G, int taps, hipStream_t s);
 int x3p_planes();                                  // option "gemm_f32_planes": the format new planes are built in (3 or 2)
 bool gemm_x3p_enabled();
 bool gemm_x3p_would_run(const ConvGemm& p);        // p.xp / p.w3p set: will launch_conv_gemm(p) take the panel-plane kernel?

@@ -185,6 +185,13 @@ F5::F5(const F5Cfg& c, const float* w, int64_t nw, int dt, int dev, int mem) : c
         const float* w2 = R.host(take(gw), gw); const float* b2 = R.host(take(d), d);
         auto r2 = relayout(w2, d, cg, c.pos_k);
         up_lin(gconv2, r2.data(), b2, d, cg * c.pos_k, dt, s);
+        if (dt != MI_F32 && cg == 64 && c.pos_k >= 8 && c.pos_k <= 127) {
+            // 16-bit engines: the same convolution from weight images in the engine's type (gconv16.hip)
+            for (Lin* L : {&gconv1, &gconv2}) {
+                L->w3p.ensure(gconv16_image_bytes(c.pos_g, c.pos_k));
+                gconv16_build_weights(L->w.p, dt, L->w3p.p, c.pos_g, c.pos_k, s);
+            }
+        }
         if (dt == MI_F32 && cg == 64 && c.pos_k >= 8 && c.pos_k <= 127) {
             // the pair-split form of the position convolution (gconv_pairs.hip) takes its weights pre-split: once here, not per launch
             for (Lin* L : {&gconv1, &gconv2}) {

@@ -522,6 +522,8 @@ static std::atomic<long> g_x3p = 1;
 static std::atomic<long> g_f32_gconv = 1;         // ... and, when the shape allows, with each operand split once per workgroup (gconv_pairs.hip)
 bool launch_gconv_pairs(const ConvGemm& p, hipStream_t s);
 void gconv_pairs_set_option(long v);
+bool launch_gconv16(const ConvGemm& p, hipStream_t s);
+void gconv16_set_option(long v);
 static std::atomic<long> g_f32_n64_pairs = 1;     // fp32 N = 64 convolutions with >= 8 taps: fp16 pairs split in registers (conv_gemm_dma_kernel PAIRS)
 // number format of the panel planes built from now on: 3 = three bf16 planes (six products), 2 = fp16 {hi, lo} planes (three products)
 static std::atomic<long> g_x3p_np = 0;          // 0: not set by mi_set_option -> MI355TTS_F32_PLANES, else 2
@@ -767,6 +769,7 @@ bool gemm_set_option(const char* key, long v) {
     else if (k == "gemm_big_tiles") g_big_tiles = v != 0;
     else if (k == "gemm_n192") g_n192 = v != 0;
     else if (k == "gconv_two_taps") gconv_pairs_set_option(v);
+    else if (k == "gconv16") gconv16_set_option(v);
     else if (k == "gemm_f32_dma") g_f32_dma = v != 0;
     else if (k == "gemm_ring4") g_ring4 = v != 0;
     else if (k == "gemm_buf") g_buf = v != 0;
@@ -1028,6 +1031,8 @@ void launch_conv_gemm(const ConvGemm& p_in, hipStream_t s) {
 
     // fp32 grouped convolutions with 64 channels per group and >= 8 taps (the DiT's position convolution): gconv_pairs.hip
     if (p.dtype == MI_F32 && opt_x3() != 0 && opt_n64_pairs() != 0 && opt_gconv() != 0 && g_use_dma && launch_gconv_pairs(p, s)) return;
+    // ... and the same shape on the 16-bit engines, weights as LDS images built at load: gconv16.hip
+    if (p.dtype != MI_F32 && p.gcp_w && g_use_dma && launch_gconv16(p, s)) return;
     if (p.dtype == MI_F32) {
         dispatch_tiles<float, float>(d, p.B, s);
     } else if (p.dtype == MI_F16) {
