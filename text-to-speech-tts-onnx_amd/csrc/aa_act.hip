@@ -222,6 +222,21 @@ __global__ __launch_bounds__(256) void aa_act_pipe_kernel(const T* __restrict__ 
             const float s0 = 0.15915494309189535f;
             const aa_f2 al = aa_f2{alpha[c0 + c] * s0, alpha[c0 + c + 1] * s0};
             const aa_f2 ib = aa_f2{inv_beta[c0 + c], inv_beta[c0 + c + 1]};
+            if constexpr (R > 8) {
+                // long runs: inputs fetched and outputs stored as the window moves (aa_math.h aa_run_stream): six live inputs whatever R
+                auto ld = [&](int j) __attribute__((always_inline)) {
+                    const Pair pr = *reinterpret_cast<const Pair*>(xs + (ml + j) * CT + c);
+                    return aa_f2{to_f32(pr.a), to_f32(pr.b)};
+                };
+                auto st = [&](int r, aa_f2 v) __attribute__((always_inline)) {
+                    Pair pr;
+                    pr.a = from_f32<T>(v.x); pr.b = from_f32<T>(v.y);
+                    *reinterpret_cast<Pair*>(ys + (ml + r) * CT + c) = pr;
+                };
+                if (edge) aa_run_stream<R, true, true>(ld, st, tp, al, ib, mp0 + ml, lo, hi);
+                else aa_run_stream<R, true, false>(ld, st, tp, al, ib, mp0 + ml, lo, hi);
+                continue;
+            }
             aa_f2 xv[R + 10], acc[R];
 #pragma unroll
             for (int j = 0; j < R + 10; ++j) {
@@ -273,8 +288,15 @@ static void launch_t(const AAAct& p, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {
         static const bool pipe = [] { const char* e = std::getenv("MI355TTS_AA_PIPE"); return !(e && e[0] == '0'); }();
         const long in_bytes = (long)p.T * p.C * (long)sizeof(T);
-        if (pipe && in_bytes < 0x7fff0000L && TT % R == 0) {
+        // outputs per work item of the pipelined kernel: 16 in the streaming form (aa_run_stream: 135 VGPRs; 21 / 16 instead of 13 / 8
+        // up-sampler + snake evaluations per output: 44.2 -> 41.4 us per launch, bit-identical; MI355TTS_AA_R=8: the A/B switch)
+        static const int run_len = [] { const char* e = std::getenv("MI355TTS_AA_R"); return e ? std::atoi(e) : 16; }();
+        const int RP = run_len == 8 ? 8 : 16;
+        if (pipe && in_bytes < 0x7fff0000L) {
             // persistent workgroups walking tiles, input by LDS-DMA one tile ahead (aa_act_pipe_kernel)
+            TT = (tt_elems / CT) / RP * RP;
+            if (TT < RP) TT = RP;
+            if (TT > 512) TT = 512;
             const int ntt = (Tout + TT - 1) / TT, nct = p.C / CT;
             const long ntiles = (long)ntt * nct * p.B;
             const int nvec = (TT + 10) * CT / VEC;
@@ -291,8 +313,12 @@ static void launch_t(const AAAct& p, hipStream_t s) {
             if (per_cu >= 1 && lds2 <= 64 * 1024 && ntiles < 0x7fffffffL) {
                 const int grid_p = (int)std::min<long>(ntiles, (long)cus * per_cu);
                 prof_set_kernel("aa_act_pipe_kernel<T>", type_label<T>());
-                hipLaunchKernelGGL((aa_act_pipe_kernel<T, R>), dim3(grid_p), dim3(256), lds2, s, (const T*)p.x, (T*)p.y, p.alpha, p.inv_beta,
-                                   p.T, p.C, CT, TT, shift, ext, ntt, nct, (int)ntiles, xsp);
+                if (RP == 16)
+                    hipLaunchKernelGGL((aa_act_pipe_kernel<T, 16>), dim3(grid_p), dim3(256), lds2, s, (const T*)p.x, (T*)p.y, p.alpha, p.inv_beta,
+                                       p.T, p.C, CT, TT, shift, ext, ntt, nct, (int)ntiles, xsp);
+                else
+                    hipLaunchKernelGGL((aa_act_pipe_kernel<T, 8>), dim3(grid_p), dim3(256), lds2, s, (const T*)p.x, (T*)p.y, p.alpha, p.inv_beta,
+                                       p.T, p.C, CT, TT, shift, ext, ntt, nct, (int)ntiles, xsp);
                 MI_HIP(hipGetLastError());
                 return;
             }

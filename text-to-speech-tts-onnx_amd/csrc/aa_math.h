@@ -92,4 +92,54 @@ __device__ __forceinline__ void aa_run(const aa_f2 (&xv)[R + 10], aa_f2 (&out)[R
     for (int r = 0; r < R; ++r) out[r] = ae[r] + ao[r];
 }
 
+// The same run with the inputs fetched and the outputs handed over AS THEY ARE NEEDED / FINISHED (ld(j) -> x pair j of the run,
+// st(r, y) <- output r): the live state is a window of six inputs and six pairs of accumulators whatever R is, so a run of 16
+// (1.31 up-sampler + snake evaluations per output instead of 1.63 at R = 8) fits the register budget of three waves per SIMD.
+// Same operations in the same order per output as aa_run: bit-identical results.
+template <int R, bool FAST, bool EDGE, typename LD, typename ST>
+__device__ __forceinline__ void aa_run_stream(LD&& ld, ST&& st, const AATaps& tp, aa_f2 al, aa_f2 ib, int mp, int lo, int hi) {
+    aa_f2 xw[6];                       // xw[k] = x[e + 5 - k] at step e
+    aa_f2 ae[6], ao[6];                // accumulators of outputs e - 5 .. e, slot = output index mod 6
+#pragma unroll
+    for (int k = 0; k < 5; ++k) xw[k + 1] = ld(4 - k);      // x[0..4]: xw[1] = x[4] ... xw[5] = x[0]
+#pragma unroll
+    for (int e = 0; e < R + 5; ++e) {
+        xw[0] = ld(e + 5);
+        aa_f2 ue = aa_f2{0.f, 0.f}, uo = aa_f2{0.f, 0.f};
+#pragma unroll
+        for (int ee = 0; ee < 6; ++ee) {
+            ue = __builtin_elementwise_fma(aa_splat(tp.ue[ee]), xw[ee], ue);
+            uo = __builtin_elementwise_fma(aa_splat(tp.uo[ee]), xw[ee], uo);
+        }
+        const aa_f2 pe = al * ue, po = al * uo;
+        aa_f2 sne, sno;
+        if constexpr (FAST) {
+            sne = aa_f2{__builtin_amdgcn_sinf(pe.x), __builtin_amdgcn_sinf(pe.y)};
+            sno = aa_f2{__builtin_amdgcn_sinf(po.x), __builtin_amdgcn_sinf(po.y)};
+        } else {
+            sne = aa_f2{sinf(pe.x), sinf(pe.y)};
+            sno = aa_f2{sinf(po.x), sinf(po.y)};
+        }
+        aa_f2 se = __builtin_elementwise_fma(sne * sne, ib, ue);
+        aa_f2 so = __builtin_elementwise_fma(sno * sno, ib, uo);
+        if constexpr (EDGE) {
+            const int ie = 2 * (mp + e - 2), io = ie - 1;
+            if (ie < lo || ie >= hi) se = aa_f2{0.f, 0.f};
+            if (io < lo || io >= hi) so = aa_f2{0.f, 0.f};
+        }
+        if (e < R) { ae[e % 6] = aa_f2{0.f, 0.f}; ao[e % 6] = aa_f2{0.f, 0.f}; }       // output e opens at step e (tap 0)
+#pragma unroll
+        for (int tt = 0; tt < 6; ++tt) {
+            const int r = e - tt;
+            if (r >= 0 && r < R) {
+                ae[r % 6] = __builtin_elementwise_fma(aa_splat(tp.de[tt]), se, ae[r % 6]);
+                ao[r % 6] = __builtin_elementwise_fma(aa_splat(tp.dO[tt]), so, ao[r % 6]);
+            }
+        }
+        if (e >= 5) st(e - 5, ae[(e - 5) % 6] + ao[(e - 5) % 6]);                       // output e - 5 closed with tap 5
+#pragma unroll
+        for (int k = 5; k > 0; --k) xw[k] = xw[k - 1];
+    }
+}
+
 }  // namespace mi
