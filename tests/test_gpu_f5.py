@@ -488,7 +488,9 @@ def test_full_size_fp32_fused_producers_are_bit_neutral(full):
         eng.close()
 
 
-@pytest.mark.parametrize("N", [701, 1015, 1280])
+# 1037 / 1152: the shortest and the longest utterance whose 2 N rows the exact-fit tiling takes in one round (>= 90 % of 16 x 144 rows);
+# 1153: one frame more, 17 row groups = 53 % of two rounds, back on the stream-K kernel
+@pytest.mark.parametrize("N", [701, 1015, 1037, 1152, 1153, 1280])
 def test_full_size_fp32_other_lengths_default_forms_against_native(full, N):
     """The full-width DiT at frame counts other than the bench's 1126 — odd ones (K / V^T plane rows, the second batch item's
     rows and the last 128-row panel all start at odd offsets), one that fills whole panels — default arithmetic (fp16-pair
